@@ -1,0 +1,293 @@
+/* oracle/oracle_impl.h -- TEST INFRASTRUCTURE ONLY (see oracle/oracle.c).
+ *
+ * Included once per elevation type with T (C type) and SUF (name suffix)
+ * defined.  Plain-C restatement of the reference algorithms; every function
+ * cites the reference file:line it follows (paths relative to
+ * /root/reference/include/richdem/).
+ */
+
+#define CAT_(a, b) a##_##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUF)
+
+/* ------------------------------------------------------------------------- */
+/* Priority-Flood (improved), depressions/Barnes2014.hpp:230-304.            */
+/* Min-heap on z + plain FIFO for pit cells.  topo = 8 or 4.                 */
+/* The filled surface is algorithm independent, so the */
+/* same function is the oracle for FillDepressions<D8> (Zhou2016.hpp:126-191)*/
+/* and FillDepressions<D4> (depressions.hpp:13-21).                          */
+/* ------------------------------------------------------------------------- */
+typedef struct { T z; int32_t x, y; } FN(hcell);
+
+static void FN(heap_push)(FN(hcell) **heap, size_t *n, size_t *cap, FN(hcell) c) {
+  if (*n == *cap) {
+    *cap = *cap ? *cap * 2 : 1024;
+    *heap = (FN(hcell) *)realloc(*heap, *cap * sizeof(FN(hcell)));
+  }
+  size_t i = (*n)++;
+  FN(hcell) *h = *heap;
+  while (i > 0) {
+    size_t p = (i - 1) / 2;
+    if (!(h[p].z > c.z)) break;  /* GridCellZ::operator> (common/grid_cell.hpp:29-38) */
+    h[i] = h[p];
+    i = p;
+  }
+  h[i] = c;
+}
+
+static FN(hcell) FN(heap_pop)(FN(hcell) *h, size_t *n) {
+  FN(hcell) top = h[0];
+  FN(hcell) last = h[--(*n)];
+  size_t i = 0, sz = *n;
+  for (;;) {
+    size_t l = 2 * i + 1, r = l + 1, m;
+    if (l >= sz) break;
+    m = (r < sz && h[l].z > h[r].z) ? r : l;
+    if (!(last.z > h[m].z)) break;
+    h[i] = h[m];
+    i = m;
+  }
+  if (sz) h[i] = last;
+  return top;
+}
+
+void FN(orc_fill)(T *dem, int w, int h, int topo) {
+  const int *dx = topo == 4 ? D4X : D8X, *dy = topo == 4 ? D4Y : D8Y;
+  const int nmax = topo == 4 ? 4 : 8;
+  size_t N = (size_t)w * h;
+  int8_t *closed = (int8_t *)calloc(N, 1);                     /* Barnes2014.hpp:248 */
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  FN(hcell) *pit = (FN(hcell) *)malloc(N * sizeof(FN(hcell))); /* each cell enters at most once */
+  size_t ph = 0, pt = 0;
+  for (int x = 0; x < w; x++) {                                /* :255-260 */
+    FN(hcell) a = {dem[x], x, 0}, b = {dem[(size_t)(h - 1) * w + x], x, h - 1};
+    FN(heap_push)(&heap, &hn, &hcap, a);
+    FN(heap_push)(&heap, &hn, &hcap, b);
+    closed[x] = 1; closed[(size_t)(h - 1) * w + x] = 1;
+  }
+  for (int y = 1; y < h - 1; y++) {                            /* :261-266 */
+    FN(hcell) a = {dem[(size_t)y * w], 0, y}, b = {dem[(size_t)y * w + w - 1], w - 1, y};
+    FN(heap_push)(&heap, &hn, &hcap, a);
+    FN(heap_push)(&heap, &hn, &hcap, b);
+    closed[(size_t)y * w] = 1; closed[(size_t)y * w + w - 1] = 1;
+  }
+  while (hn > 0 || ph < pt) {                                  /* :270-297 */
+    FN(hcell) c;
+    if (ph < pt) c = pit[ph++];
+    else c = FN(heap_pop)(heap, &hn);
+    for (int n = 1; n <= nmax; n++) {
+      int nx = c.x + dx[n], ny = c.y + dy[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      closed[ni] = 1;
+      if (dem[ni] <= c.z) {
+        if (dem[ni] < c.z) dem[ni] = c.z;                      /* overwrite only when strictly lower, :290-294 */
+        FN(hcell) p = {c.z, nx, ny};
+        pit[pt++] = p;
+      } else {
+        FN(hcell) o = {dem[ni], nx, ny};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+      }
+    }
+  }
+  free(closed); free(heap); free(pit);
+}
+
+/* ------------------------------------------------------------------------- */
+/* d8_FlowDir + d8_flow_directions, flowmet/d8_flowdirs.hpp:32-74, :96-123.  */
+/* ------------------------------------------------------------------------- */
+static int FN(d8_flowdir_cell)(const T *dem, int w, int h, int x, int y) {
+  T minimum = dem[(size_t)y * w + x];
+  int flowdir = 0; /* NO_FLOW, common/constants.hpp:80 */
+  if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {          /* :37-54 */
+    if (x == 0 && y == 0) return 2;
+    else if (x == 0 && y == h - 1) return 8;
+    else if (x == w - 1 && y == 0) return 4;
+    else if (x == w - 1 && y == h - 1) return 6;
+    else if (x == 0) return 1;
+    else if (x == w - 1) return 5;
+    else if (y == 0) return 3;
+    else if (y == h - 1) return 7;
+  }
+  for (int n = 1; n <= 8; n++) {                               /* :63-71 */
+    T e = dem[(size_t)(y + D8Y[n]) * w + (x + D8X[n])];
+    if (e < minimum || (e == minimum && flowdir > 0 && flowdir % 2 == 0 && n % 2 == 1)) {
+      minimum = e;
+      flowdir = n;
+    }
+  }
+  return flowdir;
+}
+
+void FN(orc_d8_flowdirs)(const T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) dirs[i] = 255;                     /* FLOWDIR_NO_DATA, :116-117 */
+      else dirs[i] = (uint8_t)FN(d8_flowdir_cell)(dem, w, h, x, y);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* resolve_flats_barnes, flats/flat_resolution.hpp:447-517 with              */
+/* find_flat_edges :381-418, label_this :331-355, BuildAwayGradient :152-198,*/
+/* BuildTowardsCombinedGradient :241-298.  dirs must hold d8_flow_directions */
+/* output.  mask/labels are int32 w*h, written in full.                      */
+/* ------------------------------------------------------------------------- */
+void FN(orc_resolve_flats)(const T *dem, int w, int h, const uint8_t *dirs,
+                           int32_t *mask, int32_t *labels) {
+  size_t N = (size_t)w * h;
+  memset(mask, 0, N * 4);
+  memset(labels, 0, N * 4);
+  /* find_flat_edges: column-major scan (x outer, y inner), :392-414 */
+  int32_t *low = (int32_t *)malloc(N * 4), *high = (int32_t *)malloc(N * 4);
+  size_t nlow = 0, nhigh = 0;
+  for (int x = 0; x < w; x++)
+    for (int y = 0; y < h; y++) {
+      size_t i = (size_t)y * w + x;
+      if (dirs[i] == 255) continue;
+      for (int n = 1; n <= 8; n++) {
+        int nx = x + D8X[n], ny = y + D8Y[n];
+        if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+        size_t ni = (size_t)ny * w + nx;
+        if (dirs[ni] == 255) continue;
+        if (dirs[i] != 0 && dirs[ni] == 0 && dem[ni] == dem[i]) { low[nlow++] = (int32_t)i; break; }
+        else if (dirs[i] == 0 && dem[i] < dem[ni]) { high[nhigh++] = (int32_t)i; break; }
+      }
+    }
+  if (nlow == 0) { free(low); free(high); return; }            /* :475-481 */
+
+  /* label_this for every still-unlabelled low edge, :483-487 / :331-355 */
+  int32_t *q = (int32_t *)malloc(N * 4);
+  int group = 1;
+  for (size_t k = 0; k < nlow; k++) {
+    size_t s = (size_t)low[k];
+    if (labels[s] != 0) continue;
+    T target = dem[s];
+    size_t qh = 0, qt = 0;
+    labels[s] = group; q[qt++] = (int32_t)s;
+    while (qh < qt) {
+      size_t c = (size_t)q[qh++];
+      int cx = (int)(c % w), cy = (int)(c / w);
+      for (int n = 1; n <= 8; n++) {
+        int nx = cx + D8X[n], ny = cy + D8Y[n];
+        if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+        size_t ni = (size_t)ny * w + nx;
+        if (labels[ni] > 0 || dem[ni] != target) continue;     /* same partition as the reference's
+                                                                  label-on-pop flood; labelling on
+                                                                  push only bounds the queue */
+        labels[ni] = group; q[qt++] = (int32_t)ni;
+      }
+    }
+    group++;
+  }
+  /* drop high edges of flats without outlets, :491-500 */
+  size_t nh2 = 0;
+  for (size_t k = 0; k < nhigh; k++) if (labels[high[k]] != 0) high[nh2++] = high[k];
+  nhigh = nh2;
+  int32_t *flat_height = (int32_t *)calloc((size_t)group, 4);
+
+  /* BuildAwayGradient :152-198 and BuildTowardsCombinedGradient :241-298.
+     The reference runs one FIFO with an iteration marker; all sources enter at
+     level 1, so a cell is first popped at its BFS level and later duplicates
+     are skipped (:178, :279).  A frontier array per level is equivalent. */
+  for (int pass = 0; pass < 2; pass++) {
+    const int32_t *src = pass == 0 ? high : low;
+    size_t ncur = pass == 0 ? nhigh : nlow;
+    if (pass == 1)
+      for (size_t i = 0; i < N; i++) mask[i] = -mask[i];       /* :259-262 */
+    size_t fcap = ncur > 16 ? ncur : 16, ncap = 1024;
+    int32_t *cur = (int32_t *)malloc(fcap * 4), *nxt = (int32_t *)malloc(ncap * 4);
+    memcpy(cur, src, ncur * 4);
+    int loops = 1;
+    while (ncur > 0) {
+      size_t nn = 0;
+      for (size_t k = 0; k < ncur; k++) {
+        size_t c = (size_t)cur[k];
+        if (mask[c] > 0) continue;                             /* :178 / :279 */
+        if (pass == 0) {
+          mask[c] = loops;                                     /* :180 */
+          flat_height[labels[c]] = loops;                      /* :181 */
+        } else if (mask[c] != 0) {
+          mask[c] = (flat_height[labels[c]] + mask[c]) + 2 * loops;  /* :281-282 */
+        } else {
+          mask[c] = 2 * loops;                                 /* :284 */
+        }
+        int cx = (int)(c % w), cy = (int)(c / w);
+        for (int n = 1; n <= 8; n++) {
+          int nx = cx + D8X[n], ny = cy + D8Y[n];
+          if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+          size_t ni = (size_t)ny * w + nx;
+          if (labels[ni] == labels[c] && dirs[ni] == 0) {      /* :189-192 / :289-292 */
+            if (nn == ncap) { ncap *= 2; nxt = (int32_t *)realloc(nxt, ncap * 4); }
+            nxt[nn++] = (int32_t)ni;
+          }
+        }
+      }
+      if (nn > fcap) { fcap = nn; cur = (int32_t *)realloc(cur, fcap * 4); }
+      memcpy(cur, nxt, nn * 4);
+      ncur = nn;
+      loops++;
+    }
+    free(cur); free(nxt);
+  }
+  free(low); free(high); free(q); free(flat_height);
+}
+
+/* d8_masked_FlowDir :42-65 + d8_flow_flats :96-116 */
+static void orc_d8_flow_flats(const int32_t *mask, const int32_t *labels, int w, int h, uint8_t *dirs);
+
+/* barnes_flat_resolution_d8(alter=false), flats/flat_resolution.hpp:587-605 */
+void FN(orc_flat_resolution)(const T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  size_t N = (size_t)w * h;
+  int32_t *mask = (int32_t *)malloc(N * 4), *labels = (int32_t *)malloc(N * 4);
+  FN(orc_d8_flowdirs)(dem, nodata, w, h, dirs);
+  FN(orc_resolve_flats)(dem, w, h, dirs, mask, labels);
+  orc_d8_flow_flats(mask, labels, w, h, dirs);
+  free(mask); free(labels);
+}
+
+/* ------------------------------------------------------------------------- */
+/* FM_OCallaghan<D8> = FM_D8, flowmet/OCallaghan1984.hpp:13-77, :81-84.       */
+/* props9: 9 floats per cell, index 9*i+n (common/Array3D.hpp:203-206).       */
+/* ------------------------------------------------------------------------- */
+void FN(orc_fm_d8)(const T *dem, T nodata, int w, int h, float *props9) {
+  size_t N = (size_t)w * h;
+  for (size_t i = 0; i < N * 9; i++) props9[i] = -1.0f;        /* NO_FLOW_GEN, :26 */
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) { props9[9 * i] = -2.0f; continue; }     /* NO_DATA_GEN, :37-40 */
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;    /* :42-43 */
+      T e = dem[i];
+      int lowest_n = 0;
+      T lowest = 0; int have = 0;
+      for (int n = 1; n <= 8; n++) {                                 /* :49-65 */
+        size_t ni = (size_t)(y + D8Y[n]) * w + (x + D8X[n]);
+        if (dem[ni] == nodata) continue;
+        T ne = dem[ni];
+        if (ne >= e) continue;
+        /* reference compares against numeric_limits<T>::max() initially, so a
+           neighbour equal to max() can never be chosen; it cannot be < e either
+           unless e > max(), i.e. never -- equivalent to "first strictly lowest" */
+        if (!have || ne < lowest) { lowest = ne; lowest_n = n; have = 1; }
+      }
+      if (lowest_n == 0) continue;
+      props9[9 * i] = 0.0f;                                          /* HAS_FLOW_GEN, :70 */
+      props9[9 * i + lowest_n] = 1.0f;                               /* :74 */
+    }
+}
+
+/* FA_D8, methods/flow_accumulation.hpp:27 */
+void orc_flow_accumulation_f64(const float *props9, int w, int h, double *accum);
+void FN(orc_fa_d8)(const T *dem, T nodata, int w, int h, double *accum) {
+  float *props = (float *)malloc((size_t)w * h * 9 * sizeof(float));
+  FN(orc_fm_d8)(dem, nodata, w, h, props);
+  orc_flow_accumulation_f64(props, w, h, accum);
+  free(props);
+}
+
+#undef CAT_
+#undef CAT
+#undef FN

@@ -1,0 +1,157 @@
+// oracle/ref_wrap.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// extern "C" wrappers around the UNMODIFIED reference headers under
+// /root/reference/include (never copied into this repo).  Built by
+// oracle/Makefile into oracle/_ref/libref.so when /root/reference is present
+// (-std=c++17 -O3 -fopenmp -DNDEBUG -DRICHDEM_NO_PROGRESS).
+// Used to (1) pin oracle/oracle.c against the real reference, (2) generate the
+// golden fixtures in tests/golden/, (3) optionally serve as bench.py's
+// cpu_baseline ("kind": "reference").  Never on the product path.
+//
+// Each wrapper wraps caller memory with the reference's own wrap constructor
+// Array2D(T*,w,h) (common/Array2D.hpp:344-352) so the algorithms run on exactly
+// the bytes the caller passed.
+#include <richdem/common/Array2D.hpp>
+#include <richdem/common/Array3D.hpp>
+#include <richdem/depressions/depressions.hpp>
+#include <richdem/flowmet/d8_flowdirs.hpp>
+#include <richdem/flats/flat_resolution.hpp>
+#include <richdem/methods/d8_methods.hpp>
+#include <richdem/methods/flow_accumulation.hpp>
+
+#include <cstdint>
+#include <cstring>
+#include <omp.h>
+
+using namespace richdem;
+
+namespace {
+
+template <class T>
+void ref_fill(T *dem, int w, int h, int variant) {
+  Array2D<T> a(dem, w, h);
+  switch (variant) {
+  case 0: FillDepressions<Topology::D8>(a); break;            // = PriorityFlood_Zhou2016 (depressions.hpp:13-21)
+  case 1: PriorityFlood_Barnes2014<Topology::D8>(a); break;   // depressions/Barnes2014.hpp:230
+  case 2: FillDepressions<Topology::D4>(a); break;            // = PriorityFlood_Barnes2014<D4>
+  case 3: PriorityFlood_Wei2018(a); break;                    // depressions/Wei2018.hpp:154
+  case 4: PriorityFlood_Original<Topology::D8>(a); break;     // depressions/Barnes2014.hpp:136
+  }
+}
+
+template <class T>
+void ref_d8_flowdirs(const T *dem, T nodata, int w, int h, uint8_t *out) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<uint8_t> fd;
+  d8_flow_directions(a, fd);   // flowmet/d8_flowdirs.hpp:96-123
+  std::memcpy(out, fd.data(), (size_t)w * h);
+}
+
+template <class T>
+void ref_flat_resolution(T *dem, T nodata, int w, int h, uint8_t *out, int alter) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  Array2D<uint8_t> fd;
+  barnes_flat_resolution_d8(a, fd, alter != 0);   // flats/flat_resolution.hpp:587-605
+  std::memcpy(out, fd.data(), (size_t)w * h);
+}
+
+// Exposes the intermediate flat_mask / labels of resolve_flats_barnes
+// (flats/flat_resolution.hpp:447-517) so the oracle restatement can be pinned
+// on more than the final directions.
+template <class T>
+void ref_resolve_flats(const T *dem, T nodata, int w, int h, uint8_t *dirs_out,
+                       int32_t *mask_out, int32_t *labels_out) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<uint8_t> fd;
+  d8_flow_directions(a, fd);
+  Array2D<int32_t> flat_mask, labels;
+  resolve_flats_barnes(a, fd, flat_mask, labels);
+  std::memcpy(dirs_out, fd.data(), (size_t)w * h);
+  std::memcpy(mask_out, flat_mask.data(), (size_t)w * h * 4);
+  std::memcpy(labels_out, labels.data(), (size_t)w * h * 4);
+}
+
+template <class A>
+void ref_d8_flow_accum(const uint8_t *dirs, uint8_t nodata, int w, int h, A *out) {
+  Array2D<uint8_t> fd(const_cast<uint8_t *>(dirs), w, h);
+  fd.setNoData(nodata);
+  Array2D<A> area;
+  // The reference's dependency pass does a non-atomic ++dependency under
+  // "omp parallel for" (methods/d8_methods.hpp:68-90); run it on one thread so
+  // the parity run is deterministic.
+  const int nt = omp_get_max_threads();
+  omp_set_num_threads(1);
+  d8_flow_accum(fd, area);    // methods/d8_methods.hpp:47-139
+  omp_set_num_threads(nt);
+  std::memcpy(out, area.data(), (size_t)w * h * sizeof(A));
+}
+
+template <class T>
+void ref_fa_d8(const T *dem, T nodata, int w, int h, double *accum) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<double> acc(accum, w, h);
+  FA_D8(a, acc);              // methods/flow_accumulation.hpp:27
+}
+
+template <class T>
+void ref_fm_d8(const T *dem, T nodata, int w, int h, float *props9) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array3D<float> props(a);
+  FM_D8(a, props);            // flowmet/OCallaghan1984.hpp:81-84
+  std::memcpy(props9, props.getData(), (size_t)w * h * 9 * sizeof(float));
+}
+
+} // namespace
+
+#define REF_ELEV_API(SUF, T)                                                                     \
+  extern "C" void ref_fill_##SUF(T *dem, int w, int h, int variant) { ref_fill<T>(dem, w, h, variant); } \
+  extern "C" void ref_d8_flowdirs_##SUF(const T *dem, T nodata, int w, int h, uint8_t *out) {    \
+    ref_d8_flowdirs<T>(dem, nodata, w, h, out);                                                  \
+  }                                                                                              \
+  extern "C" void ref_flat_resolution_##SUF(T *dem, T nodata, int w, int h, uint8_t *out, int alter) { \
+    ref_flat_resolution<T>(dem, nodata, w, h, out, alter);                                       \
+  }                                                                                              \
+  extern "C" void ref_resolve_flats_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs,   \
+                                          int32_t *mask, int32_t *labels) {                      \
+    ref_resolve_flats<T>(dem, nodata, w, h, dirs, mask, labels);                                 \
+  }                                                                                              \
+  extern "C" void ref_fa_d8_##SUF(const T *dem, T nodata, int w, int h, double *accum) {         \
+    ref_fa_d8<T>(dem, nodata, w, h, accum);                                                      \
+  }                                                                                              \
+  extern "C" void ref_fm_d8_##SUF(const T *dem, T nodata, int w, int h, float *props9) {         \
+    ref_fm_d8<T>(dem, nodata, w, h, props9);                                                     \
+  }
+
+REF_ELEV_API(u8, uint8_t)
+REF_ELEV_API(i16, int16_t)
+REF_ELEV_API(u16, uint16_t)
+REF_ELEV_API(i32, int32_t)
+REF_ELEV_API(u32, uint32_t)
+REF_ELEV_API(f32, float)
+REF_ELEV_API(f64, double)
+
+extern "C" void ref_d8_flow_accum_i32(const uint8_t *dirs, uint8_t nodata, int w, int h, int32_t *out) {
+  ref_d8_flow_accum<int32_t>(dirs, nodata, w, h, out);
+}
+extern "C" void ref_d8_flow_accum_f32(const uint8_t *dirs, uint8_t nodata, int w, int h, float *out) {
+  ref_d8_flow_accum<float>(dirs, nodata, w, h, out);
+}
+extern "C" void ref_d8_flow_accum_f64(const uint8_t *dirs, uint8_t nodata, int w, int h, double *out) {
+  ref_d8_flow_accum<double>(dirs, nodata, w, h, out);
+}
+
+// Generic FlowAccumulation over a caller-supplied 9-float proportions array
+// (methods/flow_accumulation_generic.hpp:33-100).  Array3D has no wrap
+// constructor, so the proportions are copied in.
+extern "C" void ref_flow_accumulation_f64(const float *props9, int w, int h, double *accum) {
+  Array2D<double> acc(accum, w, h);
+  Array3D<float> props(acc);
+  std::memcpy(props.getData(), props9, (size_t)w * h * 9 * sizeof(float));
+  props.setNoData(NO_DATA_GEN);
+  FlowAccumulation(props, acc);
+}
