@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcells/s of the Priority-Flood-equivalent fill on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S]
+
+A step = one fill (rdgpu_fill_dev_f32 through the C-ABI) of one synthetic float32 DEM, G(seed) of
+SURVEY.md section 8d, already resident in HBM when the timed region starts.  At N=1 the workload is
+BASELINE config "40000x40000 float32 DEM, Priority-Flood fill on 1 MI355X".  One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FILL_ALG_BYTES_PER_CELL = 8.0  # read z (4 B) + write W (4 B)
+DOMINANT_KERNEL = "fill.scan"
+
+
+def cpu_baseline(Z, sample: int):
+    """Times the reference's FillDepressions<D8> (or the C port) on a bounded window of the SAME DEM,
+    on this box's host cores (1 thread: the reference fill has no OpenMP).  Reported baseline only."""
+    import numpy as np
+
+    import oracle  # checker, used here only for the reported CPU baseline
+
+    s = min(sample, Z.shape[0], Z.shape[1])
+    win = Z[:s, :s].cpu().numpy().copy()
+    if oracle.ref.available:
+        be, kind, what = oracle.ref, "reference", "PriorityFlood_Zhou2016 (unmodified reference headers, oracle/_ref)"
+    else:
+        if not oracle.port.available:
+            oracle.build()
+        be, kind, what = oracle.port, "port", "oracle/oracle.c Priority-Flood (Barnes2014 improved)"
+    t0 = time.perf_counter()
+    out = be.fill(win, 8)
+    dt = time.perf_counter() - t0
+    assert out.shape == win.shape and np.isfinite(out).all()
+    return {
+        "value": round(s * s / 1e6 / dt, 3),
+        "unit": "Mcells/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"{s}x{s} top-left window of the bench DEM, {what}, {dt:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=40000, help="DEM is size x size cells")
+    ap.add_argument("--cpu-sample", type=int, default=10000, help="window edge for the CPU baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+
+    import richdem_amd as rd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from richdem_amd.sharded import bench_sharded
+
+        return bench_sharded(args, rank, world)
+
+    n = args.size
+    cells = n * n
+    Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    rd.synth_dem_dev(Z, seed=args.seed)
+    bufs = [Z.clone() for _ in range(args.steps)]   # fill is in place: one pristine copy per timed step
+    scratch = Z.clone()
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        scratch.copy_(Z)
+        rd.fill_depressions_dev(scratch)
+    torch.cuda.synchronize()
+
+    rd.profile_reset()
+    rd.profile_enable(True)   # HIP events around every kernel, on the stream the kernel is launched on
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        rd.fill_depressions_dev(bufs[k])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rd.profile_enable(False)
+    prof = rd.profile_totals()
+    stats = rd.fill_stats()
+
+    changed = float((bufs[0] != Z).float().mean())
+    ms_step = dt * 1e3 / args.steps
+    value = cells / 1e6 / (dt / args.steps)
+
+    k_ms, k_n = prof.get(DOMINANT_KERNEL, (0.0, 0))
+    total_kernel_ms = sum(v[0] for v in prof.values())
+    roofline = None
+    if k_n:
+        avg_s = k_ms / k_n / 1e3
+        achieved = cells * FILL_ALG_BYTES_PER_CELL / avg_s / 1e9
+        roofline = {
+            "bound": "hbm",
+            "kernel": DOMINANT_KERNEL,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "avg_launch_ms": round(k_ms / k_n, 4),
+            "launches_per_step": k_n / args.steps,
+            "share_of_kernel_time": round(k_ms / total_kernel_ms, 3) if total_kernel_ms else None,
+        }
+    out = {
+        "metric": "Mcells/s Priority-Flood fill, 40k x 40k f32 DEM",
+        "value": round(value, 2),
+        "unit": "Mcells/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n}x{n} float32 fractal value-noise DEM G(seed={args.seed}), FillDepressions<D8>, HBM-resident",
+            "cells": cells,
+            "basins": stats["basins"],
+            "boruvka_rounds": stats["rounds"],
+            "cells_raised_frac": round(changed, 4),
+            "parallelism": "1 GPU",
+        },
+        "roofline": roofline,
+        "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+    }
+    if args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(Z, args.cpu_sample)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""richdem_amd -- MI355X-native depression filling / flow routing behind RichDEM's API.
+
+The product is ``librdgpu.so`` (hand-written HIP for gfx950, C-ABI in ``include/rdgpu.h``) and the
+C++ header shim ``include/rdgpu/richdem_gpu.hpp`` that keeps the reference's ``Array2D<T>`` signatures.
+This Python package is thin plumbing over the same C-ABI (ctypes) for tests, ``bench.py`` and
+multi-GPU sharding with ``torch.distributed``; function names follow the reference's Python wrapper
+(``wrappers/pyrichdem/richdem/__init__.py``: ``FillDepressions``, ``FlowAccumulation``).
+
+There is NO CPU fallback: if ``librdgpu.so`` is missing or a HIP call fails, calls raise.
+"""
+from __future__ import annotations
+
+from ._lib import (  # noqa: F401
+    RdgpuError,
+    lib,
+    lib_path,
+    build,
+    fill_stats,
+    profile_enable,
+    profile_collect,
+    profile_reset,
+    profile_totals,
+)
+from .api import (  # noqa: F401
+    FillDepressions,
+    fill_depressions_dev,
+    synth_dem_dev,
+)
+
+__all__ = [
+    "RdgpuError",
+    "lib",
+    "lib_path",
+    "build",
+    "FillDepressions",
+    "fill_depressions_dev",
+    "synth_dem_dev",
+    "fill_stats",
+    "profile_enable",
+    "profile_collect",
+    "profile_reset",
+    "profile_totals",
+]

@@ -1,0 +1,151 @@
+// runtime.hip -- error state, device workspace, HIP-event profiler, runtime C-ABI entry points.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace rdgpu {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &m) { g_last_error = m; }
+
+// ---- Workspace ----------------------------------------------------------------------------
+Workspace &Workspace::get() {
+  static Workspace w;
+  return w;
+}
+
+void *Workspace::buf(const char *name, size_t bytes) {
+  Slot &s = slots_[name];
+  if (bytes > s.cap) {
+    if (s.p) RD_HIP(hipFree(s.p));
+    s.p = nullptr;
+    s.cap = 0;
+    // grow with a little slack so slightly different basin counts between calls do not realloc
+    size_t want = bytes + bytes / 16 + 256;
+    RD_HIP(hipMalloc(&s.p, want));
+    s.cap = want;
+  }
+  return s.p;
+}
+
+uint32_t *Workspace::host_words() {
+  if (!host_words_) RD_HIP(hipHostMalloc((void **)&host_words_, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  return host_words_;
+}
+
+void Workspace::release() {
+  for (auto &kv : slots_)
+    if (kv.second.p) (void)hipFree(kv.second.p);
+  slots_.clear();
+  if (host_words_) (void)hipHostFree(host_words_);
+  host_words_ = nullptr;
+}
+
+// ---- Profiler -----------------------------------------------------------------------------
+Profiler &Profiler::get() {
+  static Profiler p;
+  return p;
+}
+
+hipEvent_t Profiler::take() {
+  if (!pool_.empty()) {
+    hipEvent_t e = pool_.back();
+    pool_.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  RD_HIP(hipEventCreate(&e));
+  return e;
+}
+
+void Profiler::begin(const char *name, hipStream_t s) {
+  Pending p;
+  p.name = name;
+  p.a = take();
+  p.b = take();
+  RD_HIP(hipEventRecord(p.a, s));
+  pending_.push_back(p);
+}
+
+void Profiler::end(hipStream_t s) { RD_HIP(hipEventRecord(pending_.back().b, s)); }
+
+void Profiler::collect() {
+  for (auto &p : pending_) {
+    RD_HIP(hipEventSynchronize(p.b));
+    float ms = 0;
+    RD_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    Tot &t = totals[p.name];
+    t.ms += ms;
+    t.n += 1;
+    pool_.push_back(p.a);
+    pool_.push_back(p.b);
+  }
+  pending_.clear();
+}
+
+void Profiler::reset() {
+  collect();
+  totals.clear();
+}
+
+std::vector<std::string> Profiler::names() const {
+  std::vector<std::string> v;
+  for (auto &kv : totals) v.push_back(kv.first);
+  return v;
+}
+
+}  // namespace rdgpu
+
+using namespace rdgpu;
+
+extern "C" {
+
+const char *rdgpu_last_error(void) { return g_last_error.c_str(); }
+const char *rdgpu_version(void) { return "rdgpu 0.1 (gfx950)"; }
+
+int rdgpu_device_count(int *count) {
+  return guarded([&] {
+    if (!count) throw Error(RDGPU_ERR_ARG, "rdgpu_device_count: null pointer");
+    RD_HIP(hipGetDeviceCount(count));
+  });
+}
+
+int rdgpu_set_device(int id) {
+  return guarded([&] { RD_HIP(hipSetDevice(id)); });
+}
+
+int rdgpu_release_workspace(void) {
+  return guarded([&] { Workspace::get().release(); });
+}
+
+int rdgpu_profile_enable(int on) {
+  Profiler::get().enabled = on != 0;
+  return RDGPU_OK;
+}
+int rdgpu_profile_collect(void) {
+  return guarded([&] { Profiler::get().collect(); });
+}
+int rdgpu_profile_reset(void) {
+  return guarded([&] { Profiler::get().reset(); });
+}
+const char *rdgpu_profile_name(int index) {
+  static thread_local std::string s;
+  auto v = Profiler::get().names();
+  if (index < 0 || (size_t)index >= v.size()) return nullptr;
+  s = v[index];
+  return s.c_str();
+}
+int rdgpu_profile_get(const char *kernel, double *total_ms, uint64_t *launches) {
+  auto &t = Profiler::get().totals;
+  auto it = t.find(kernel ? kernel : "");
+  if (it == t.end()) {
+    if (total_ms) *total_ms = 0;
+    if (launches) *launches = 0;
+    return RDGPU_ERR_ARG;
+  }
+  if (total_ms) *total_ms = it->second.ms;
+  if (launches) *launches = it->second.n;
+  return RDGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""numpy model of the GPU fill algorithm (descent forest -> basins -> raster Boruvka rounds).
+Algorithm validation only; not product, not oracle."""
+import sys; sys.path.insert(0,'/root/repo')
+import numpy as np
+import oracle
+from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+SH8=[(0,-1),(-1,-1),(-1,0),(-1,1),(0,1),(1,1),(1,0),(1,-1)]  # (dy,dx) n=1..8
+SH4=[(0,-1),(-1,0),(0,1),(1,0)]
+
+def shifted(a, dy, dx, fill):
+    h,w=a.shape
+    out=np.full_like(a, fill)
+    ys=slice(max(0,-dy), min(h,h-dy)); xs=slice(max(0,-dx), min(w,w-dx))
+    ysn=slice(max(0,dy), min(h,h+dy)); xsn=slice(max(0,dx), min(w,w+dx))
+    out[ys,xs]=a[ysn,xsn]
+    return out
+
+def fill_proto(z, topo=8, roots_mask=None, verbose=False):
+    SH=SH8 if topo==8 else SH4
+    h,w=z.shape; N=h*w
+    # order preserving integer key
+    ranks=np.unique(z, return_inverse=True)[1].reshape(h,w).astype(np.int64)+1  # >=1
+    k=ranks
+    idx=np.arange(N,dtype=np.int64).reshape(h,w)
+    OUT=np.int64(N)
+    border=np.zeros((h,w),bool); border[0,:]=border[-1,:]=border[:,0]=border[:,-1]=True
+    # phase 0
+    bestk=k.copy(); besti=idx.copy()
+    BIG=np.int64(1<<60)
+    for dy,dx in SH:
+        kn=shifted(k,dy,dx,BIG); inn=shifted(idx,dy,dx,BIG)
+        better=(kn<bestk)|((kn==bestk)&(inn<besti))
+        bestk=np.where(better,kn,bestk); besti=np.where(better,inn,besti)
+    ptr=besti.copy()
+    ptr[border]=OUT
+    ptr=ptr.ravel()
+    # phase 1 jump
+    ext=np.append(ptr,OUT)
+    it=0
+    while True:
+        nxt=ext[ext]
+        it+=1
+        if (nxt==ext).all(): break
+        ext=nxt
+    ptr=ext[:N]
+    pits=np.flatnonzero(ptr==np.arange(N))
+    B=len(pits)
+    pitid=np.full(N+1,-1,np.int64); pitid[pits]=np.arange(B); pitid[N]=B   # OUT -> B
+    lab=pitid[ptr].reshape(h,w)
+    assert (lab>=0).all()
+    OUTC=B
+    cur=np.arange(B+1); acc=np.zeros(B+1,np.int64)
+    kflat=k
+    rounds=0
+    while True:
+        comp=cur[lab]
+        if (comp==OUTC).all(): break
+        rounds+=1
+        # candidates
+        cw=[];cc=[];ct=[]
+        for dy,dx in SH:
+            kn=shifted(kflat,dy,dx,-1); cn=shifted(comp,dy,dx,-1)
+            m=(cn>=0)&(cn!=comp)&(comp!=OUTC)
+            cw.append(np.maximum(kflat,kn)[m]); cc.append(comp[m]); ct.append(cn[m])
+        cw=np.concatenate(cw);cc=np.concatenate(cc);ct=np.concatenate(ct)
+        key=cw*(B+2)+ct
+        best=np.full(B+1,np.iinfo(np.int64).max,np.int64)
+        np.minimum.at(best,cc,key)
+        roots=np.flatnonzero((cur==np.arange(B+1))&(np.arange(B+1)!=OUTC))
+        bw=best[roots]//(B+2); bt=best[roots]%(B+2)
+        assert (best[roots]<np.iinfo(np.int64).max).all()
+        par=np.arange(B+1); pm=np.zeros(B+1,np.int64)
+        par[roots]=bt; pm[roots]=bw
+        # mutual pairs: smaller id stays root
+        mutual=(par[par[roots]]==roots)&(bt!=OUTC)&(roots<bt)
+        par[roots[mutual]]=roots[mutual]; pm[roots[mutual]]=0
+        # pointer jumping with max
+        while True:
+            pp=par[par]; mm=np.maximum(pm,pm[par])
+            if (pp==par).all(): break
+            par=pp; pm=mm
+        # update basins
+        c=cur.copy()
+        cur=par[c]; acc=np.maximum(acc,pm[c])
+        if verbose: print('round',rounds,'roots',len(roots),'->',int(((cur==np.arange(B+1))).sum()-1))
+    # final
+    L=acc[lab]
+    kk=np.maximum(k,L)
+    # map rank back to value
+    vals=np.unique(z)
+    out=vals[kk-1]
+    return out, dict(jump_iters=it, basins=B, rounds=rounds)
+
+if __name__=='__main__':
+    oracle.build()
+    for (w,h,seed) in [(200,150,1),(513,257,2),(64,64,3)]:
+        for mk in ('f','i','i2'):
+            z = fractal_dem(w,h,seed) if mk=='f' else fractal_dem_int(w,h,seed, 1.0 if mk=='i' else 0.05)
+            for topo in (8,4):
+                ref=oracle.port.fill(z,topo)
+                got,info=fill_proto(z,topo)
+                print(w,h,seed,mk,topo,(got==ref).all(),info, 'changed',(ref!=z).mean())
+                assert (got==ref).all()

@@ -1,0 +1,91 @@
+"""Pins oracle/oracle.c (the C restatement) against
+  (1) the reference's own golden vectors (tests/golden/ref_fixtures.npz),
+  (2) outputs of the unmodified reference headers on seeded inputs (tests/golden/ref_generated.npz),
+  (3) oracle/_ref/libref.so live, where it is present (this container; travels prebuilt to the GPU box).
+CPU only."""
+import numpy as np
+import pytest
+
+from conftest import gen_cases
+
+
+def accum_names(fixtures):
+    return sorted({k.split("/")[1] for k in fixtures.files if k.startswith("accum/")})
+
+
+def test_fill_reference_golden(orc, fixtures):
+    dem = fixtures["fill/testdem1/dem"]
+    exp = fixtures["fill/testdem1/all_out"]
+    assert np.array_equal(orc.port.fill(dem, 8), exp)  # reference tests/tests.cpp:233-271
+    if orc.ref.available:
+        for variant in (orc.ZHOU2016, orc.BARNES2014_D8, orc.WEI2018, orc.ORIGINAL_D8):
+            assert np.array_equal(orc.ref.fill(dem, 8, variant), exp)
+
+
+def test_d8_flow_accum_reference_golden(orc, fixtures):
+    names = accum_names(fixtures)
+    assert len(names) == 24  # reference tests/tests.cpp:135-146
+    for nm in names:
+        dirs, nd, exp = fixtures[f"accum/{nm}/d8"], int(fixtures[f"accum/{nm}/nodata"]), fixtures[f"accum/{nm}/out"]
+        got = orc.port.d8_flow_accum(dirs, nd, np.int32)
+        assert np.array_equal(got, exp), nm
+        if orc.ref.available:
+            assert np.array_equal(orc.ref.d8_flow_accum(dirs, nd, np.int32), exp), nm
+
+
+def test_port_matches_generated_reference_outputs(orc, generated):
+    P = orc.port
+    for name in gen_cases(generated):
+        dem, nd = generated[f"{name}/dem"], generated[f"{name}/nodata"]
+        filled = P.fill(dem, 8)
+        assert np.array_equal(filled, generated[f"{name}/fill_d8"]), name
+        assert np.array_equal(P.fill(dem, 4), generated[f"{name}/fill_d4"]), name
+        for tag, src in (("raw", dem), ("filled", filled)):
+            assert np.array_equal(P.d8_flowdirs(src, nd), generated[f"{name}/{tag}/d8_flowdirs"]), (name, tag)
+            _, mask, labels = P.resolve_flats(src, nd)
+            assert np.array_equal(mask, generated[f"{name}/{tag}/flat_mask"]), (name, tag)
+            assert np.array_equal(labels, generated[f"{name}/{tag}/flat_labels"]), (name, tag)
+            fr = P.flat_resolution(src, nd)
+            assert np.array_equal(fr, generated[f"{name}/{tag}/flat_resolved_dirs"]), (name, tag)
+            assert np.array_equal(P.d8_flow_accum(fr, 255, np.float64), generated[f"{name}/{tag}/d8_flow_accum_f64"])
+            assert np.array_equal(P.fa_d8(src, nd), generated[f"{name}/{tag}/fa_d8"]), (name, tag)
+
+
+@pytest.mark.parametrize("seed,scale,dtype", [(21, 1.0, np.float32), (22, 1.0, np.int32), (23, 0.05, np.int32),
+                                              (24, 0.2, np.int16), (25, 0.1, np.uint16), (26, 0.05, np.uint8)])
+def test_port_matches_live_reference(orc, seed, scale, dtype):
+    if not orc.ref.available:
+        pytest.skip("oracle/_ref/libref.so not built here")
+    from richdem_amd.synth import fractal_dem
+
+    z = fractal_dem(150, 110, seed)
+    dem = z if dtype == np.float32 else np.floor((z - z.min()) * scale).astype(dtype)
+    nd = dtype(0) if np.issubdtype(dtype, np.unsignedinteger) else dtype(-9999)
+    P, R = orc.port, orc.ref
+    filled = P.fill(dem, 8)
+    assert np.array_equal(filled, R.fill(dem, 8))
+    assert np.array_equal(P.fill(dem, 4), R.fill(dem, 4))
+    for src in (dem, filled):
+        assert np.array_equal(P.d8_flowdirs(src, nd), R.d8_flowdirs(src, nd))
+        for a, b in zip(P.resolve_flats(src, nd), R.resolve_flats(src, nd)):
+            assert np.array_equal(a, b)
+        fr = P.flat_resolution(src, nd)
+        assert np.array_equal(fr, R.flat_resolution(src, nd))
+        assert np.array_equal(P.d8_flow_accum(fr, 255, np.int32), R.d8_flow_accum(fr, 255, np.int32))
+        assert np.array_equal(P.fm_d8(src, nd), R.fm_d8(src, nd))
+        assert np.array_equal(P.fa_d8(src, nd), R.fa_d8(src, nd))
+        wts = np.random.default_rng(seed).random(src.shape)
+        assert np.array_equal(P.fa_d8(src, nd, wts), R.fa_d8(src, nd, wts))
+
+
+def test_zhou_barnes_wei_agree_on_random_terrain(orc):
+    """The reference's own differential pattern (tests/wei2018-test/main.cpp:55-77)."""
+    if not orc.ref.available:
+        pytest.skip("oracle/_ref/libref.so not built here")
+    from richdem_amd.synth import fractal_dem
+
+    z = fractal_dem(400, 300, 31)
+    a = orc.ref.fill(z, 8, orc.ZHOU2016)
+    assert np.array_equal(a, orc.ref.fill(z, 8, orc.BARNES2014_D8))
+    assert np.array_equal(a, orc.ref.fill(z, 8, orc.WEI2018))
+    assert np.array_equal(a, orc.port.fill(z, 8))
