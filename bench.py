@@ -145,6 +145,7 @@ def main():
             "cells": cells,
             "basins": stats["basins"],
             "boruvka_rounds": stats["rounds"],
+            "jump_passes": stats["jump_passes"],
             "cells_raised_frac": round(changed, 4),
             "parallelism": "1 GPU",
         },

@@ -44,6 +44,13 @@ def lib() -> ctypes.CDLL:
                 f"{p} is missing: the HIP extension is not built (run richdem_amd.build() / "
                 "python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback."
             )
+        # torch bundles its own HIP runtime; when both live in one process it must be the first one
+        # loaded (otherwise torch.cuda reports "No HIP GPUs are available").  torch is plumbing here:
+        # device memory, streams, torch.distributed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pure C-ABI use without torch is fine
+            pass
         L = ctypes.CDLL(p)
         L.rdgpu_last_error.restype = ctypes.c_char_p
         L.rdgpu_version.restype = ctypes.c_char_p
