@@ -69,6 +69,58 @@ typedef struct rdgpu_fill_stats {
 } rdgpu_fill_stats;
 int rdgpu_fill_get_stats(rdgpu_fill_stats *out);
 
+/* ---- d8_flow_directions(const Array2D<T>&, Array2D<uint8_t>&) ------------------------------
+ * Replaces richdem::d8_flow_directions / d8_FlowDir (include/richdem/flowmet/d8_flowdirs.hpp:96-123,
+ * :32-74).  dirs[i] in {0 = NO_FLOW, 1..8 = neighbour in the 234/105/876 numbering, 255 =
+ * FLOWDIR_NO_DATA} (common/constants.hpp:76-80).  The shim sets flowdirs.setNoData(255). */
+int rdgpu_d8_flowdirs_u8(const uint8_t *dem, uint8_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_i16(const int16_t *dem, int16_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_u16(const uint16_t *dem, uint16_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_i32(const int32_t *dem, int32_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_i32(const int32_t *d_dem, int32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_f32(const float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_f64(const double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+
+/* ---- d8_flow_accum(const Array2D<uint8_t>& flowdirs, Array2D<A>& area) ----------------------
+ * Replaces richdem::d8_flow_accum (include/richdem/methods/d8_methods.hpp:47-139): area = number of
+ * cells draining through each cell (itself included); cells whose direction equals dir_nodata get
+ * -1 (area.noData(), :64).  Exact (integer arithmetic) for every output type. */
+int rdgpu_d8_flow_accum_i32(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, int32_t *area);
+int rdgpu_d8_flow_accum_f32(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, float *area);
+int rdgpu_d8_flow_accum_f64(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, double *area);
+int rdgpu_d8_flow_accum_dev_i32(const uint8_t *d_dirs, uint8_t dir_nodata, int width, int height, int32_t *d_area, void *hip_stream);
+int rdgpu_d8_flow_accum_dev_f32(const uint8_t *d_dirs, uint8_t dir_nodata, int width, int height, float *d_area, void *hip_stream);
+int rdgpu_d8_flow_accum_dev_f64(const uint8_t *d_dirs, uint8_t dir_nodata, int width, int height, double *d_area, void *hip_stream);
+
+/* ---- FA_D8(const Array2D<T>& elevations, Array2D<double>& accum) ----------------------------
+ * Replaces richdem::FA_D8 (include/richdem/methods/flow_accumulation.hpp:27) = FM_D8
+ * (flowmet/OCallaghan1984.hpp:13-77) + FlowAccumulation (methods/flow_accumulation_generic.hpp:33-100)
+ * without materialising the 36 B/cell Array3D.  accum is in/out: on entry the flow each cell
+ * generates (1 by default in the reference's callers), on return the accumulation; NoData cells get
+ * -1 (ACCUM_NO_DATA).  Exact for integer-valued weights; for general weights the f64 summation order
+ * differs from the reference's FIFO order (results agree to f64 rounding, <= 1 ULP after an f32 cast). */
+int rdgpu_fa_d8_u8(const uint8_t *dem, uint8_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_i16(const int16_t *dem, int16_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_u16(const uint16_t *dem, uint16_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_f32(const float *dem, float nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_f64(const double *dem, double nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_i32(const int32_t *d_dem, int32_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_f32(const float *d_dem, float nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_f64(const double *d_dem, double nodata, int width, int height, double *d_accum, void *hip_stream);
+
 /* ---- synthetic input (test/bench input generator) ----------- */
 int rdgpu_synth_dem_dev_f32(float *d_dem, int width, int height, int seed, int x0, int y0,
                             float tilt, void *hip_stream);

@@ -23,6 +23,9 @@ from ._lib import (  # noqa: F401
 )
 from .api import (  # noqa: F401
     FillDepressions,
+    FlowAccumulation,
+    d8_flow_directions,
+    d8_flow_accum,
     fill_depressions_dev,
     synth_dem_dev,
 )
@@ -33,6 +36,9 @@ __all__ = [
     "lib_path",
     "build",
     "FillDepressions",
+    "FlowAccumulation",
+    "d8_flow_directions",
+    "d8_flow_accum",
     "fill_depressions_dev",
     "synth_dem_dev",
     "fill_stats",

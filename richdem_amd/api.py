@@ -20,6 +20,11 @@ _SUFFIX = {
     np.dtype(np.float32): "f32",
 }
 _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
+_CT = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "u16": ctypes.c_uint16, "i32": ctypes.c_int32,
+       "u32": ctypes.c_uint32, "f32": ctypes.c_float, "f64": ctypes.c_double}
+_ELEV_SUFFIX = dict(_SUFFIX)
+_ELEV_SUFFIX[np.dtype(np.float64)] = "f64"   # stencil/accumulation entry points also take f64 DEMs
+_ACC_SUFFIX = {np.dtype(np.int32): "i32", np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 
 
 def _suffix(dtype) -> str:
@@ -53,6 +58,65 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     fn = getattr(lib(), f"rdgpu_fill_{_suffix(out.dtype)}")
     check(fn(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology)), "rdgpu_fill")
     return None if in_place else out
+
+
+def _elev(dem, who):
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError(f"{who}: expected a 2-D numpy array")
+    dem = np.ascontiguousarray(dem)
+    try:
+        return dem, _ELEV_SUFFIX[dem.dtype]
+    except KeyError:
+        raise RdgpuError(f"{who}: unsupported elevation dtype {dem.dtype}") from None
+
+
+def d8_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
+    """uint8 D8 directions (reference d8_flow_directions, flowmet/d8_flowdirs.hpp:96-123)."""
+    dem, s = _elev(dem, "d8_flow_directions")
+    h, w = dem.shape
+    out = np.empty((h, w), np.uint8)
+    fn = getattr(lib(), f"rdgpu_d8_flowdirs_{s}")
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+          "rdgpu_d8_flowdirs")
+    return out
+
+
+def d8_flow_accum(dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.ndarray:
+    """Cells draining through each cell from uint8 D8 directions (reference d8_flow_accum,
+    methods/d8_methods.hpp:47-139)."""
+    if not isinstance(dirs, np.ndarray) or dirs.ndim != 2 or dirs.dtype != np.uint8:
+        raise RdgpuError("d8_flow_accum: expected a 2-D uint8 array of D8 directions")
+    dirs = np.ascontiguousarray(dirs)
+    h, w = dirs.shape
+    try:
+        s = _ACC_SUFFIX[np.dtype(dtype)]
+    except KeyError:
+        raise RdgpuError(f"d8_flow_accum: unsupported accumulation dtype {dtype}") from None
+    out = np.empty((h, w), dtype)
+    fn = getattr(lib(), f"rdgpu_d8_flow_accum_{s}")
+    check(fn(dirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+          "rdgpu_d8_flow_accum")
+    return out
+
+
+def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights: np.ndarray | None = None):
+    """Flow accumulation (reference ``rd.FlowAccumulation(dem, method='D8', weights=...)``,
+    wrappers/pyrichdem/richdem/__init__.py:490-597 -> FA_D8, methods/flow_accumulation.hpp:27).
+    Returns float64 accumulation; NoData cells get -1."""
+    if method != "D8":
+        raise RdgpuError(f"FlowAccumulation: method {method!r} is not part of this round's hot path (only 'D8')")
+    dem, s = _elev(dem, "FlowAccumulation")
+    h, w = dem.shape
+    if weights is None:
+        acc = np.ones((h, w), np.float64)          # __init__.py:560-563: every cell generates 1
+    else:
+        if weights.shape != dem.shape:             # flow_accumulation_generic.hpp:42-43
+            raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
+        acc = np.ascontiguousarray(weights, dtype=np.float64).copy()
+    fn = getattr(lib(), f"rdgpu_fa_d8_{s}")
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, acc.ctypes.data_as(ctypes.c_void_p)),
+          "rdgpu_fa_d8")
+    return acc
 
 
 # ---- HBM-resident variants (torch tensors on the GPU) ---------------------------------------

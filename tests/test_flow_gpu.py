@@ -1,0 +1,120 @@
+"""GPU parity tests: d8_flow_directions, d8_flow_accum, FA_D8 through the C-ABI vs the oracle/reference goldens."""
+import numpy as np
+import pytest
+
+from conftest import gen_cases
+from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+pytestmark = pytest.mark.gpu
+
+
+def test_d8_flow_accum_reference_golden(rd, fixtures):
+    names = sorted({k.split("/")[1] for k in fixtures.files if k.startswith("accum/")})
+    assert len(names) == 24  # reference tests/tests.cpp:135-146
+    for nm in names:
+        dirs, nd, exp = fixtures[f"accum/{nm}/d8"], int(fixtures[f"accum/{nm}/nodata"]), fixtures[f"accum/{nm}/out"]
+        got = rd.d8_flow_accum(dirs, nd, np.int32)
+        assert got.dtype == np.int32 and np.array_equal(got, exp), nm
+        assert np.array_equal(rd.d8_flow_accum(dirs, nd, np.float64), exp.astype(np.float64)), nm
+        assert np.array_equal(rd.d8_flow_accum(dirs, nd, np.float32), exp.astype(np.float32)), nm
+
+
+def test_generated_reference_outputs(rd, generated):
+    for name in gen_cases(generated):
+        dem, nd = generated[f"{name}/dem"], generated[f"{name}/nodata"]
+        for tag, src in (("raw", dem), ("filled", generated[f"{name}/fill_d8"])):
+            assert np.array_equal(rd.d8_flow_directions(src, nd), generated[f"{name}/{tag}/d8_flowdirs"]), (name, tag)
+            fr = generated[f"{name}/{tag}/flat_resolved_dirs"]
+            assert np.array_equal(rd.d8_flow_accum(fr, 255, np.float64), generated[f"{name}/{tag}/d8_flow_accum_f64"]), (name, tag)
+            assert np.array_equal(rd.FlowAccumulation(src, "D8", nodata=nd), generated[f"{name}/{tag}/fa_d8"]), (name, tag)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (2, 2), (3, 3), (5, 70), (16, 64), (17, 65), (130, 67), (400, 523)])
+@pytest.mark.parametrize("dtype", [np.float32, np.int32, np.uint8, np.int16, np.uint16, np.uint32, np.float64])
+def test_d8_flowdirs_shapes_dtypes(rd, orc, shape, dtype):
+    h, w = shape
+    z = fractal_dem(w, h, seed=h * 7 + w)
+    if dtype in (np.float32, np.float64):
+        dem = z.astype(dtype)
+        nd = dtype(-9999)
+    else:
+        dem = np.floor((z - z.min()) * 0.1).astype(dtype)   # quantised: many ties exercise the tie rule
+        nd = dtype(3)
+    if h > 4 and w > 4:
+        dem[h // 2, w // 3] = nd
+    got = rd.d8_flow_directions(dem, nd)
+    assert np.array_equal(got, orc.port.d8_flowdirs(dem, nd))
+
+
+def test_d8_flowdirs_tie_rule_exhaustive(rd, orc):
+    """All 3x3 neighbourhoods over a 3-letter alphabet (3^9 = 19683 cases) laid out as one raster of
+    isolated 3x3 blocks: pins the cardinal-before-diagonal tie rule of d8_FlowDir (d8_flowdirs.hpp:63-71)."""
+    n = 3 ** 9
+    cols = 192
+    rows = (n + cols - 1) // cols
+    dem = np.full((rows * 4 + 1, cols * 4 + 1), 9, np.int32)
+    for k in range(n):
+        digs = [(k // 3 ** i) % 3 for i in range(9)]
+        r, c = divmod(k, cols)
+        dem[r * 4 + 1:r * 4 + 4, c * 4 + 1:c * 4 + 4] = np.array(digs).reshape(3, 3)
+    got = rd.d8_flow_directions(dem, np.int32(-1))
+    assert np.array_equal(got, orc.port.d8_flowdirs(dem, np.int32(-1)))
+
+
+def _accum_case(rd, orc, dem, nd):
+    dirs = orc.port.flat_resolution(dem, nd)
+    for dt in (np.int32, np.float64, np.float32):
+        assert np.array_equal(rd.d8_flow_accum(dirs, 255, dt), orc.port.d8_flow_accum(dirs, 255, dt))
+    raw = orc.port.d8_flowdirs(dem, nd)   # still has NO_FLOW cells
+    assert np.array_equal(rd.d8_flow_accum(raw, 255, np.float64), orc.port.d8_flow_accum(raw, 255, np.float64))
+    assert np.array_equal(rd.FlowAccumulation(dem, "D8", nodata=nd), orc.port.fa_d8(dem, nd))
+
+
+def test_accum_fractal_and_flats(rd, orc):
+    z = fractal_dem(700, 500, seed=17)
+    _accum_case(rd, orc, z, np.float32(-9999))
+    _accum_case(rd, orc, orc.port.fill(z), np.float32(-9999))
+    zi = fractal_dem_int(400, 300, 18, 0.05)
+    _accum_case(rd, orc, orc.port.fill(zi), np.int32(-9999))
+    hole = z.copy(); hole[100:140, 200:260] = -9999.0; hole[:, :4] = -9999.0
+    _accum_case(rd, orc, hole, np.float32(-9999))
+
+
+def test_accum_direction_loops_match_reference_semantics(rd, orc):
+    """Hand-made directions with a 2-cycle and a chain hanging below it: the reference never completes
+    those cells (d8_methods.hpp:104-131); the engine must leave the same partial values."""
+    dirs = np.zeros((6, 8), np.uint8)
+    dirs[:] = 5                      # everything flows east ...
+    dirs[2, 3], dirs[2, 4] = 5, 1    # ... except a 2-cycle (2,3) <-> (2,4)
+    dirs[4, 2] = 255
+    for dt in (np.int32, np.float64):
+        assert np.array_equal(rd.d8_flow_accum(dirs, 255, dt), orc.port.d8_flow_accum(dirs, 255, dt))
+
+
+def test_fa_d8_weights(rd, orc):
+    z = fractal_dem(300, 260, seed=23)
+    rng = np.random.default_rng(1)
+    wi = rng.integers(0, 5, z.shape).astype(np.float64)         # integer-valued weights: exact
+    assert np.array_equal(rd.FlowAccumulation(z, "D8", nodata=-9999, weights=wi), orc.port.fa_d8(z, np.float32(-9999), wi))
+    wf = rng.random(z.shape)                                     # general weights: summation order differs
+    got, exp = rd.FlowAccumulation(z, "D8", nodata=-9999, weights=wf), orc.port.fa_d8(z, np.float32(-9999), wf)
+    assert np.allclose(got, exp, rtol=1e-12, atol=0)
+    # north_star tolerance: within 1 ULP after a float32 cast
+    g32, e32 = got.astype(np.float32), exp.astype(np.float32)
+    assert (np.abs(g32.view(np.int32).astype(np.int64) - e32.view(np.int32).astype(np.int64)) <= 1).all()
+    with pytest.raises(rd.RdgpuError, match="same dimensions"):
+        rd.FlowAccumulation(z, "D8", weights=np.ones((3, 3)))
+
+
+def test_large_accumulation_exact(rd, orc):
+    """3000x3000 filled DEM: long cross-XCD flow paths; exact equality with the oracle for both engines
+    (packed-u64 unit path and f64 release/acquire path)."""
+    z = fractal_dem(3000, 3000, seed=29)
+    zf = rd.FillDepressions(z)
+    nd = np.float32(-9999)
+    dirs = orc.port.flat_resolution(zf, nd)
+    exp = orc.port.d8_flow_accum(dirs, 255, np.float64)
+    assert np.array_equal(rd.d8_flow_accum(dirs, 255, np.float64), exp)
+    assert exp.max() > 1e5
+    assert np.array_equal(rd.FlowAccumulation(zf, "D8", nodata=nd), orc.port.fa_d8(zf, nd))
+    assert np.array_equal(rd.FlowAccumulation(z, "D8", nodata=nd), orc.port.fa_d8(z, nd))
