@@ -88,6 +88,45 @@ int rdgpu_d8_flowdirs_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width,
 int rdgpu_d8_flowdirs_dev_f32(const float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_d8_flowdirs_dev_f64(const double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 
+/* ---- barnes_flat_resolution_d8(Array2D<T>& elevations, Array2D<uint8_t>& flowdirs, alter=false) --
+ * Replaces richdem::barnes_flat_resolution_d8 (include/richdem/flats/flat_resolution.hpp:587-605) with
+ * alter == false: d8_flow_directions, then resolve_flats_barnes (:447-517), then d8_flow_flats
+ * (:96-116).  dirs is written in full; NO_FLOW cells of flats without an outlet stay 0.
+ * rdgpu_resolve_flats_* additionally returns the flat_mask of resolve_flats_barnes (identical to the
+ * reference's values) and the flat partition (labels[i] = 1 + lowest cell index of the cell's flat,
+ * 0 for cells outside drainable flats; the reference numbers flats in scan order instead -- only
+ * the partition is defined by the algorithm).  mask / labels may be NULL. */
+int rdgpu_flat_resolution_d8_u8(const uint8_t *dem, uint8_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_i16(const int16_t *dem, int16_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_u16(const uint16_t *dem, uint16_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_i32(const int32_t *d_dem, int32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_f32(const float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_f64(const double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_resolve_flats_u8(const uint8_t *dem, uint8_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_i16(const int16_t *dem, int16_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_u16(const uint16_t *dem, uint16_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_i32(const int32_t *dem, int32_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+
+typedef struct rdgpu_flat_stats {
+  uint64_t low_edges;      /* find_flat_edges: cells with flow next to an equal NO_FLOW cell */
+  uint64_t high_edges;     /* NO_FLOW cells next to higher terrain                           */
+  uint64_t noflow_cells;   /* cells without a local gradient                                 */
+  uint32_t away_levels;    /* BFS level launches, away-from-higher gradient (multiple of 8)  */
+  uint32_t towards_levels; /* BFS level launches, towards-lower gradient (multiple of 8)     */
+} rdgpu_flat_stats;
+int rdgpu_flat_get_stats(rdgpu_flat_stats *out);
+
 /* ---- d8_flow_accum(const Array2D<uint8_t>& flowdirs, Array2D<A>& area) ----------------------
  * Replaces richdem::d8_flow_accum (include/richdem/methods/d8_methods.hpp:47-139): area = number of
  * cells draining through each cell (itself included); cells whose direction equals dir_nodata get

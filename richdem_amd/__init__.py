@@ -26,6 +26,8 @@ from .api import (  # noqa: F401
     FlowAccumulation,
     d8_flow_directions,
     d8_flow_accum,
+    barnes_flat_resolution_d8,
+    resolve_flats,
     fill_depressions_dev,
     synth_dem_dev,
 )
@@ -39,6 +41,8 @@ __all__ = [
     "FlowAccumulation",
     "d8_flow_directions",
     "d8_flow_accum",
+    "barnes_flat_resolution_d8",
+    "resolve_flats",
     "fill_depressions_dev",
     "synth_dem_dev",
     "fill_stats",

@@ -81,6 +81,34 @@ def d8_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
     return out
 
 
+def barnes_flat_resolution_d8(dem: np.ndarray, nodata, alter: bool = False) -> np.ndarray:
+    """Flat-resolved uint8 D8 directions (reference barnes_flat_resolution_d8(elev, flowdirs, alter=false),
+    flats/flat_resolution.hpp:587-605)."""
+    if alter:
+        raise RdgpuError("barnes_flat_resolution_d8(alter=True) is not part of this round's hot path")
+    dem, s = _elev(dem, "barnes_flat_resolution_d8")
+    h, w = dem.shape
+    out = np.empty((h, w), np.uint8)
+    fn = getattr(lib(), f"rdgpu_flat_resolution_d8_{s}")
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+          "rdgpu_flat_resolution_d8")
+    return out
+
+
+def resolve_flats(dem: np.ndarray, nodata):
+    """(flat-resolved dirs, flat_mask, flat partition labels) -- exposes resolve_flats_barnes's
+    intermediate arrays (flats/flat_resolution.hpp:447-517) for parity tests."""
+    dem, s = _elev(dem, "resolve_flats")
+    h, w = dem.shape
+    dirs = np.empty((h, w), np.uint8)
+    mask = np.empty((h, w), np.int32)
+    labels = np.empty((h, w), np.int32)
+    fn = getattr(lib(), f"rdgpu_resolve_flats_{s}")
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, dirs.ctypes.data_as(ctypes.c_void_p),
+             mask.ctypes.data_as(ctypes.c_void_p), labels.ctypes.data_as(ctypes.c_void_p)), "rdgpu_resolve_flats")
+    return dirs, mask, labels
+
+
 def d8_flow_accum(dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.ndarray:
     """Cells draining through each cell from uint8 D8 directions (reference d8_flow_accum,
     methods/d8_methods.hpp:47-139)."""

@@ -1,0 +1,123 @@
+"""GPU parity tests: barnes_flat_resolution_d8(alter=false) through the C-ABI vs the oracle
+(the reference has no golden file for flat resolution -- SURVEY.md section 4; parity is pinned by the
+outputs of the unmodified reference in tests/golden/ref_generated.npz and by the oracle)."""
+import numpy as np
+import pytest
+
+from conftest import gen_cases
+from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+pytestmark = pytest.mark.gpu
+
+
+def canon(labels):
+    """Canonical partition ids: 1 + lowest cell index of each label (0 stays 0)."""
+    flat = labels.ravel()
+    out = np.zeros_like(flat)
+    ids, first = np.unique(flat, return_index=True)
+    lut = dict(zip(ids.tolist(), first.tolist()))
+    nz = flat != 0
+    out[nz] = np.vectorize(lambda v: lut[v] + 1, otypes=[flat.dtype])(flat[nz]) if nz.any() else 0
+    return out.reshape(labels.shape)
+
+
+def check(rd, orc, dem, nd):
+    got = rd.barnes_flat_resolution_d8(dem, nd)
+    exp = orc.port.flat_resolution(dem, nd)
+    if not np.array_equal(got, exp):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{len(bad)} dirs differ; first {bad[:5].tolist()} got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}")
+    dirs, mask, labels = rd.resolve_flats(dem, nd)
+    _, emask, elabels = orc.port.resolve_flats(dem, nd)
+    assert np.array_equal(dirs, exp)
+    assert np.array_equal(mask, emask), "flat_mask differs"
+    assert np.array_equal(labels, canon(elabels)), "flat partition differs"
+    return got
+
+
+def test_generated_reference_outputs(rd, generated):
+    for name in gen_cases(generated):
+        dem, nd = generated[f"{name}/dem"], generated[f"{name}/nodata"]
+        for tag, src in (("raw", dem), ("filled", generated[f"{name}/fill_d8"])):
+            got = rd.barnes_flat_resolution_d8(src, nd)
+            assert np.array_equal(got, generated[f"{name}/{tag}/flat_resolved_dirs"]), (name, tag)
+            _, mask, labels = rd.resolve_flats(src, nd)
+            assert np.array_equal(mask, generated[f"{name}/{tag}/flat_mask"]), (name, tag)
+            assert np.array_equal(labels, canon(generated[f"{name}/{tag}/flat_labels"])), (name, tag)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (3, 3), (4, 9), (16, 64), (17, 65), (100, 130), (300, 421)])
+@pytest.mark.parametrize("scale", [1.0, 0.1, 0.02])
+def test_filled_integer_dems(rd, orc, shape, scale):
+    h, w = shape
+    dem = orc.port.fill(fractal_dem_int(w, h, seed=3 * h + w, scale=scale))
+    check(rd, orc, dem, np.int32(-9999))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.uint16, np.uint8, np.uint32])
+def test_dtypes(rd, orc, dtype):
+    z = fractal_dem(260, 190, seed=41)
+    dem = np.floor((z - z.min()) * 0.08).astype(dtype)
+    dem = orc.port.fill(dem) if dtype != np.float64 else orc.port.fill(dem.astype(np.float32)).astype(np.float64)
+    nd = dtype(250) if dtype == np.uint8 else dtype(60000) if dtype in (np.uint16, np.uint32) else dtype(-9999)
+    check(rd, orc, dem, nd)
+
+
+def test_unfilled_dems_with_undrainable_flats(rd, orc):
+    """Raw (unfilled) DEMs: pits and flats without outlets must stay NO_FLOW (flat_resolution.hpp:491-500)."""
+    check(rd, orc, fractal_dem_int(300, 200, 51, 0.05), np.int32(-9999))
+    check(rd, orc, fractal_dem(200, 150, 52), np.float32(-9999))
+    rng = np.random.default_rng(5)
+    check(rd, orc, rng.integers(0, 3, (150, 170)).astype(np.int32), np.int32(-1))
+    check(rd, orc, np.zeros((40, 50), np.float32), np.float32(-1))          # one flat, drained by the edge cells
+    mesa = np.zeros((60, 60), np.int32); mesa[20:40, 20:40] = 5              # mesa: no high edges
+    check(rd, orc, mesa, np.int32(-1))
+    bowl = np.full((60, 60), 5, np.int32); bowl[20:40, 20:40] = 0             # sunken flat: no outlet
+    check(rd, orc, bowl, np.int32(-1))
+
+
+def test_reference_data_dems(rd, orc, fixtures):
+    """The reference's un-asserted flat inputs data/*.dem."""
+    names = sorted({k.split("/")[1] for k in fixtures.files if k.startswith("data/")})
+    assert "multi_flat" in names and "garbrecht" in names
+    for nm in names:
+        dem, nd = fixtures[f"data/{nm}/dem"], fixtures[f"data/{nm}/nodata"]
+        check(rd, orc, dem, nd)
+        check(rd, orc, orc.port.fill(dem), nd)
+
+
+def test_nodata_holes_and_equal_elevation_bridges(rd, orc):
+    dem = orc.port.fill(fractal_dem_int(240, 200, 61, 0.04))
+    dem[50:70, 80:120] = -9999
+    dem[:, :3] = -9999
+    check(rd, orc, dem, np.int32(-9999))
+    # two NO_FLOW pockets of one elevation joined only through cells that have flow:
+    # they share ONE label (and one flat_height) in the reference
+    d = np.full((12, 30), 9, np.int32)
+    d[3:9, 3:27] = 5
+    d[5:7, 5:10] = 5; d[5:7, 20:25] = 5
+    d[4:8, 12:18] = 4          # a lower notch in the middle gives the 5-cells around it a direction
+    d[6, 14:16] = 3; d[7:, 14] = 2
+    check(rd, orc, d, np.int32(-1))
+
+
+def test_large_lake_many_bfs_levels(rd, orc):
+    """A 1500x1100 DEM quantised so hard that lakes are hundreds of cells across."""
+    dem = orc.port.fill(fractal_dem_int(1500, 1100, 71, 0.01))
+    check(rd, orc, dem, np.int32(-9999))
+    st = rd.lib  # noqa: F841
+
+
+def test_full_pipeline_fill_dirs_accum(rd, orc):
+    """rd_flood_for_flowdirs-style chain (apps/rd_d8_flowdirs.cpp:12-25 + d8_flow_accum) entirely on the GPU path."""
+    z = fractal_dem(1200, 900, seed=81)
+    nd = np.float32(-9999)
+    filled = rd.FillDepressions(z)
+    dirs = rd.barnes_flat_resolution_d8(filled, nd)
+    area = rd.d8_flow_accum(dirs, 255, np.float64)
+    efilled = orc.port.fill(z)
+    edirs = orc.port.flat_resolution(efilled, nd)
+    assert np.array_equal(filled, efilled)
+    assert np.array_equal(dirs, edirs)
+    assert (dirs[1:-1, 1:-1] != 0).all()      # a filled DEM has no undrainable flats
+    assert np.array_equal(area, orc.port.d8_flow_accum(edirs, 255, np.float64))
