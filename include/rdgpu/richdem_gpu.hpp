@@ -1,0 +1,177 @@
+// rdgpu/richdem_gpu.hpp -- C++ shim: the reference's function names and Array2D<T> signatures over
+// the C-ABI of librdgpu.so (include/rdgpu.h).  Host code stays C++; HIP lives only behind the C-ABI.
+//
+// Every function is templated on the ARRAY type, so the same shim binds to
+//   * richdem::Array2D<T>  -- inside the reference tree (apps/rd_depressions_flood.cpp,
+//                             apps/rd_flow_accumulation.cpp, apps/rd_d8_flowdirs.cpp compile unchanged
+//                             apart from the namespace of the call), and
+//   * rdgpu::Array2D<T>    -- the stand-alone container in rdgpu/Array2D.hpp.
+// Required of the array type: data(), width(), height(), noData(), setNoData(), resize(other, val),
+// templateCopy(other) -- all present in the reference's Array2D (common/Array2D.hpp).
+//
+// Contracts kept from the reference:
+//   * all functions are void, modify / size their outputs exactly as the reference does, and report
+//     failure by throwing std::runtime_error (the C-ABI's non-zero codes are converted here);
+//   * the DEM buffer is never freed or reallocated: results are copied back into data();
+//   * works for owning and for wrapping (externally owned) arrays.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../rdgpu.h"
+
+namespace rdgpu {
+namespace detail {
+
+inline void check(int rc, const char *what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + rdgpu_last_error());
+}
+
+template <class A>
+using elem_t = typename std::remove_cv<typename std::remove_pointer<decltype(std::declval<A &>().data())>::type>::type;
+
+[[noreturn]] inline void unsupported(const char *fn) {
+  throw std::runtime_error(std::string(fn) + ": element type not supported by the MI355X engine");
+}
+
+// ---- overload sets: element type -> C-ABI entry point ---------------------------------------
+#define RDGPU_SHIM_ELEV(SUF, T)                                                                            \
+  inline int c_fill(T *p, int w, int h, int t) { return rdgpu_fill_##SUF(p, w, h, t); }
+RDGPU_SHIM_ELEV(u8, uint8_t)
+RDGPU_SHIM_ELEV(i16, int16_t)
+RDGPU_SHIM_ELEV(u16, uint16_t)
+RDGPU_SHIM_ELEV(i32, int32_t)
+RDGPU_SHIM_ELEV(u32, uint32_t)
+RDGPU_SHIM_ELEV(f32, float)
+#undef RDGPU_SHIM_ELEV
+template <class T>
+int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
+
+#define RDGPU_SHIM_STENCIL(SUF, T)                                                                         \
+  inline int c_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_d8_flowdirs_##SUF(p, nd, w, h, o); } \
+  inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
+  inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); }
+RDGPU_SHIM_STENCIL(u8, uint8_t)
+RDGPU_SHIM_STENCIL(i16, int16_t)
+RDGPU_SHIM_STENCIL(u16, uint16_t)
+RDGPU_SHIM_STENCIL(i32, int32_t)
+RDGPU_SHIM_STENCIL(u32, uint32_t)
+RDGPU_SHIM_STENCIL(f32, float)
+RDGPU_SHIM_STENCIL(f64, double)
+#undef RDGPU_SHIM_STENCIL
+template <class T>
+int c_flowdirs(const T *, T, int, int, uint8_t *) { unsupported("d8_flow_directions"); }
+template <class T>
+int c_flatres(const T *, T, int, int, uint8_t *) { unsupported("barnes_flat_resolution_d8"); }
+template <class T>
+int c_fa_d8(const T *, T, int, int, double *) { unsupported("FA_D8"); }
+
+inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, int32_t *a) { return rdgpu_d8_flow_accum_i32(d, nd, w, h, a); }
+inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, float *a) { return rdgpu_d8_flow_accum_f32(d, nd, w, h, a); }
+inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, double *a) { return rdgpu_d8_flow_accum_f64(d, nd, w, h, a); }
+template <class A>
+int c_accum(const uint8_t *, uint8_t, int, int, A *) { unsupported("d8_flow_accum"); }
+
+// Topology enumerators: richdem::Topology and rdgpu::Topology both declare {D8, D4} in this order
+// (reference common/constants.hpp:97-100).
+template <auto topo>
+constexpr int topology_code() {
+  static_assert(std::is_enum<decltype(topo)>::value, "topology must be Topology::D8 or Topology::D4");
+  return static_cast<int>(topo) == 0 ? 8 : 4;
+}
+
+}  // namespace detail
+
+// ---- depressions -------------------------------------------------------------------------------
+// richdem::PriorityFlood_Zhou2016(Array2D<T>&)            depressions/Zhou2016.hpp:126-191
+template <class A>
+void PriorityFlood_Zhou2016(A &dem) {
+  detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), 8), "PriorityFlood_Zhou2016");
+}
+
+// richdem::PriorityFlood_Barnes2014<topo>(Array2D<T>&)    depressions/Barnes2014.hpp:230-304
+template <auto topo, class A>
+void PriorityFlood_Barnes2014(A &dem) {
+  detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()),
+                "PriorityFlood_Barnes2014");
+}
+
+// richdem::FillDepressions<topo>(Array2D<T>&)             depressions/depressions.hpp:13-21
+template <auto topo, class A>
+void FillDepressions(A &dem) {
+  detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()), "FillDepressions");
+}
+
+// ---- flow directions ---------------------------------------------------------------------------
+namespace detail {
+template <class E, class F, class Fn>
+void dirs_into(const E &elevations, F &flowdirs, Fn fn, const char *who) {
+  using U = elem_t<F>;
+  flowdirs.resize(elevations);          // d8_flowdirs.hpp:107
+  flowdirs.setNoData((U)255);           // FLOWDIR_NO_DATA, d8_flowdirs.hpp:109
+  const int w = elevations.width(), h = elevations.height();
+  if (w == 0 || h == 0) return;
+  if constexpr (std::is_same<U, uint8_t>::value) {
+    check(fn(elevations.data(), elevations.noData(), w, h, flowdirs.data()), who);
+  } else {  // the reference allows any integer U: compute in u8, widen
+    std::vector<uint8_t> tmp((size_t)w * h);
+    check(fn(elevations.data(), elevations.noData(), w, h, tmp.data()), who);
+    for (size_t i = 0; i < tmp.size(); i++) flowdirs.data()[i] = (U)tmp[i];
+  }
+}
+}  // namespace detail
+
+// richdem::d8_flow_directions(const Array2D<T>&, Array2D<U>&)   flowmet/d8_flowdirs.hpp:96-123
+template <class E, class F>
+void d8_flow_directions(const E &elevations, F &flowdirs) {
+  using T = detail::elem_t<E>;
+  detail::dirs_into(elevations, flowdirs,
+                    [](const T *p, T nd, int w, int h, uint8_t *o) { return detail::c_flowdirs(p, nd, w, h, o); },
+                    "d8_flow_directions");
+}
+
+// richdem::barnes_flat_resolution_d8(Array2D<T>&, Array2D<U>&, bool alter)   flats/flat_resolution.hpp:587-605
+template <class E, class F>
+void barnes_flat_resolution_d8(E &elevations, F &flowdirs, bool alter) {
+  if (alter) throw std::runtime_error("barnes_flat_resolution_d8: alter=true is not provided by the MI355X engine yet");
+  using T = detail::elem_t<E>;
+  detail::dirs_into(elevations, flowdirs,
+                    [](const T *p, T nd, int w, int h, uint8_t *o) { return detail::c_flatres(p, nd, w, h, o); },
+                    "barnes_flat_resolution_d8");
+  flowdirs.templateCopy(elevations);    // flat_resolution.hpp:604
+}
+
+// ---- accumulation ------------------------------------------------------------------------------
+// richdem::d8_flow_accum(const Array2D<T>& flowdirs, Array2D<U>& area)   methods/d8_methods.hpp:47-139
+template <class F, class G>
+void d8_flow_accum(const F &flowdirs, G &area) {
+  static_assert(std::is_same<detail::elem_t<const F>, uint8_t>::value || std::is_same<detail::elem_t<F>, uint8_t>::value,
+                "d8_flow_accum: flow directions must be uint8_t (d8_flowdir_t)");
+  using U = detail::elem_t<G>;
+  area.resize(flowdirs, (U)0);          // d8_methods.hpp:63
+  area.setNoData((U)-1);                // d8_methods.hpp:64
+  if (flowdirs.width() == 0 || flowdirs.height() == 0) return;
+  detail::check(detail::c_accum(flowdirs.data(), flowdirs.noData(), flowdirs.width(), flowdirs.height(), area.data()),
+                "d8_flow_accum");
+}
+
+// richdem::FA_D8(const Array2D<elev_t>&, Array2D<accum_t>&)   methods/flow_accumulation.hpp:27
+// accum is in/out: pre-loaded with the flow each cell generates.
+template <class E, class G>
+void FA_D8(const E &elevations, G &accum) {
+  using T = detail::elem_t<E>;
+  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FA_D8: the accumulation array must be Array2D<double>");
+  accum.setNoData(-1.0);                // ACCUM_NO_DATA, flow_accumulation_generic.hpp:40
+  if (accum.width() != elevations.width() || accum.height() != elevations.height())   // :42-43
+    throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_fa_d8((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(),
+                                accum.data()),
+                "FA_D8");
+}
+
+}  // namespace rdgpu
