@@ -69,6 +69,50 @@ typedef struct rdgpu_fill_stats {
 } rdgpu_fill_stats;
 int rdgpu_fill_get_stats(rdgpu_fill_stats *out);
 
+/* ---- row-block shards: the tile protocol of programs/parallel_priority_flood over GPUs ---------
+ * Mirrors the reference's tiled Priority-Flood (Barnes 2016; programs/parallel_priority_flood/main.cpp:
+ * Consumer FirstRound :276-313 / SecondRound :315-330, Producer Calculations :401-547; Zhou2016pf.hpp).
+ * The DEM is cut into row blocks; one block per GPU (or one after the other on one GPU).
+ *   1. rdgpu_fill_shard_begin_<T>   local phase on the block resident in HBM: fills it against its own
+ *                                   perimeter, labels every cell with the cut-row cell ("terminal") or
+ *                                   the outside its watershed drains to, and reduces the lowest pass
+ *                                   between every pair of adjacent watersheds (the spillover graph).
+ *                                   open_top / open_bottom: the first / last row is a cut, not DEM border.
+ *   2. rdgpu_fill_shard_export      what the reference's Job1 carries (main.cpp:147-173): the cut rows'
+ *                                   elevations (as order-preserving uint32 keys) and the graph edges
+ *                                   (a, b, pass) with a/b = terminal ids (top row: x, bottom row:
+ *                                   width + x) or 0xFFFFFFFF for the outside.  Host buffers.
+ *   3. exchange                     every rank all-gathers (2*width keys + edges) -- RCCL over xGMI in
+ *                                   richdem_amd/sharded.py; nothing else crosses GPUs.
+ *   4. rdgpu_fill_graph_solve       host: joins the shard graphs along the cuts and floods the label
+ *                                   graph from the outside (= the producer's aggregated Priority-Flood).
+ *                                   keys/levels: [nshards][2][width]; edges: concatenated triples,
+ *                                   edge_offsets[nshards+1] in triples.  Deterministic, so every rank
+ *                                   solves redundantly instead of broadcasting (Job2, main.cpp:549-554).
+ *   5. rdgpu_fill_shard_finish      raises the block (levels = this shard's [2][width] slice), writes
+ *                                   the filled elevations in place and releases the handle.
+ * rdgpu_fill_sharded_<T> runs 1-5 shard after shard on one GPU (tiling-invariance tests; DEMs cut
+ * this way give bit-identical results to rdgpu_fill_<T>). */
+typedef struct rdgpu_fill_shard rdgpu_fill_shard;
+int rdgpu_fill_shard_begin_u8(uint8_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_i16(int16_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_u16(uint16_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_i32(int32_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_u32(uint32_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_f32(float *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_edge_count(rdgpu_fill_shard *shard, uint32_t *n_edges);
+int rdgpu_fill_shard_export(rdgpu_fill_shard *shard, uint32_t *top_keys, uint32_t *bottom_keys, uint32_t *edges);
+int rdgpu_fill_shard_finish(rdgpu_fill_shard *shard, const uint32_t *levels);
+int rdgpu_fill_shard_free(rdgpu_fill_shard *shard);
+int rdgpu_fill_graph_solve(int nshards, int width, int topology, const uint32_t *keys, const uint32_t *edges,
+                           const uint64_t *edge_offsets, uint32_t *levels);
+int rdgpu_fill_sharded_u8(uint8_t *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_i16(int16_t *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_u16(uint16_t *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_i32(int32_t *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_u32(uint32_t *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_f32(float *dem, int width, int height, int topology, int nshards);
+
 /* ---- d8_flow_directions(const Array2D<T>&, Array2D<uint8_t>&) ------------------------------
  * Replaces richdem::d8_flow_directions / d8_FlowDir (include/richdem/flowmet/d8_flowdirs.hpp:96-123,
  * :32-74).  dirs[i] in {0 = NO_FLOW, 1..8 = neighbour in the 234/105/876 numbering, 255 =

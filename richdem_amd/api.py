@@ -41,7 +41,7 @@ def _topo(topology) -> int:
         raise RdgpuError("Unknown topology!") from None  # depressions.hpp:19-20
 
 
-def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = False, topology="D8"):
+def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = False, topology="D8", shards: int = 1):
     """Fill all depressions of ``dem`` (reference: ``rd.FillDepressions``,
     wrappers/pyrichdem/richdem/__init__.py:381-422 -> FillDepressions<topo>, depressions.hpp:13-21).
     Returns the filled array (or None when ``in_place``)."""
@@ -55,8 +55,12 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
             raise RdgpuError("FillDepressions(in_place=True) needs a C-contiguous array")
         out = np.ascontiguousarray(out)
     h, w = out.shape
-    fn = getattr(lib(), f"rdgpu_fill_{_suffix(out.dtype)}")
-    check(fn(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology)), "rdgpu_fill")
+    if shards > 1:   # the multi-GPU row-block protocol, shard after shard on one GPU
+        fn = getattr(lib(), f"rdgpu_fill_sharded_{_suffix(out.dtype)}")
+        check(fn(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology), int(shards)), "rdgpu_fill_sharded")
+    else:
+        fn = getattr(lib(), f"rdgpu_fill_{_suffix(out.dtype)}")
+        check(fn(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology)), "rdgpu_fill")
     return None if in_place else out
 
 

@@ -1,0 +1,183 @@
+// shardgraph.hip -- host side of the row-block shard protocol for the fill.
+//
+// Mirrors the producer of the reference's tiled Priority-Flood (Barnes 2016;
+// programs/parallel_priority_flood/main.cpp: ProducerSpecifics::Calculations :401-547, HandleEdge /
+// HandleCorner :344-398): the per-shard watershed graphs are joined along the cut rows and a
+// Priority-Flood on that small graph, started from the outside, gives every cut-row watershed its
+// final level.  Shards are row blocks, so every cut is a full row and the "corner" cases of the
+// reference's 2-D tiling reduce to the diagonal neighbours x-1 / x+1 across a cut.
+//
+// Plain host C++ (no kernels): runs identically on a box without a GPU, which is how the
+// world_size-2 gloo tests exercise it.
+#include "common.hpp"
+
+#include <algorithm>
+#include <queue>
+#include <utility>
+#include <vector>
+
+struct rdgpu_fill_shard;
+extern "C" {
+int rdgpu_fill_shard_edge_count(rdgpu_fill_shard *sh, uint32_t *n_edges);
+int rdgpu_fill_shard_export(rdgpu_fill_shard *sh, uint32_t *top_keys, uint32_t *bottom_keys, uint32_t *edges);
+int rdgpu_fill_shard_finish(rdgpu_fill_shard *sh, const uint32_t *levels);
+int rdgpu_fill_shard_free(rdgpu_fill_shard *sh);
+}
+
+namespace rdgpu {
+
+constexpr uint32_t OUT_TID = 0xFFFFFFFFu;
+
+// keys:   [nshards][2][w]  order-preserving keys of each shard's top (0) and bottom (1) row
+// edges:  concatenated (a, b, pass) triples per shard, a/b = terminal ids in [0, 2w) (top row: x,
+//         bottom row: w + x) or OUT_TID; edge_offsets[s] .. edge_offsets[s+1] are shard s's triples
+// levels: [nshards][2][w]  out: final level key of every cut-row terminal (0 where not a terminal)
+static void graph_solve(int nshards, int w, int topology, const uint32_t *keys, const uint32_t *edges,
+                        const uint64_t *edge_offsets, uint32_t *levels) {
+  if (nshards < 1 || w < 1 || !keys || !edge_offsets || !levels) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_graph_solve: bad arguments");
+  if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_graph_solve: topology must be 8 or 4");
+  const size_t per = (size_t)2 * w;
+  const uint32_t NOUT = (uint32_t)((size_t)nshards * per);   // node id of the outside
+  std::fill(levels, levels + (size_t)nshards * per, 0u);
+  if (nshards == 1) return;
+
+  struct E { uint32_t a, b, w; };
+  std::vector<E> el;
+  el.reserve((size_t)edge_offsets[nshards] + (size_t)(nshards - 1) * w * 3);
+  auto node = [&](int s, uint32_t tid) -> uint32_t {
+    if (tid == OUT_TID) return NOUT;
+    if (tid >= per) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_graph_solve: terminal id out of range");
+    return (uint32_t)((size_t)s * per + tid);
+  };
+  for (int s = 0; s < nshards; s++)
+    for (uint64_t e = edge_offsets[s]; e < edge_offsets[s + 1]; e++)
+      el.push_back(E{node(s, edges[3 * e]), node(s, edges[3 * e + 1]), edges[3 * e + 2]});
+  // edges across each cut: bottom row of shard s  <->  top row of shard s+1 (HandleEdge, main.cpp:344-378)
+  for (int s = 0; s + 1 < nshards; s++) {
+    const uint32_t *kb = keys + ((size_t)s * 2 + 1) * w, *kt = keys + ((size_t)(s + 1) * 2) * w;
+    for (int x = 0; x < w; x++) {
+      const uint32_t a = (x == 0 || x == w - 1) ? NOUT : node(s, (uint32_t)(w + x));   // side columns are true border
+      for (int dx = -1; dx <= 1; dx++) {
+        if (topology == 4 && dx != 0) continue;
+        const int x2 = x + dx;
+        if (x2 < 0 || x2 >= w) continue;
+        const uint32_t b = (x2 == 0 || x2 == w - 1) ? NOUT : node(s + 1, (uint32_t)x2);
+        if (a == NOUT && b == NOUT) continue;
+        el.push_back(E{a, b, std::max(kb[x], kt[x2])});
+      }
+    }
+  }
+  // CSR adjacency
+  const size_t nn = (size_t)NOUT + 1;
+  std::vector<uint64_t> off(nn + 1, 0);
+  for (const E &e : el) { off[e.a + 1]++; off[e.b + 1]++; }
+  for (size_t i = 0; i < nn; i++) off[i + 1] += off[i];
+  std::vector<std::pair<uint32_t, uint32_t>> adj(off[nn]);
+  {
+    std::vector<uint64_t> pos(off.begin(), off.end() - 1);
+    for (const E &e : el) {
+      adj[pos[e.a]++] = {e.b, e.w};
+      adj[pos[e.b]++] = {e.a, e.w};
+    }
+  }
+  // Priority-Flood on the graph from the outside (main.cpp:498-546): level[v] = min over paths of max pass
+  std::vector<uint32_t> lvl(nn, 0xFFFFFFFFu);
+  std::vector<uint8_t> done(nn, 0);
+  typedef std::pair<uint32_t, uint32_t> QE;   // (level, node)
+  std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+  lvl[NOUT] = 0;
+  pq.push({0u, NOUT});
+  while (!pq.empty()) {
+    const QE t = pq.top();
+    pq.pop();
+    const uint32_t u = t.second;
+    if (done[u]) continue;
+    done[u] = 1;
+    for (uint64_t i = off[u]; i < off[u + 1]; i++) {
+      const uint32_t v = adj[i].first, cand = std::max(t.first, adj[i].second);
+      if (!done[v] && cand < lvl[v]) {
+        lvl[v] = cand;
+        pq.push({cand, v});
+      }
+    }
+  }
+  for (int s = 0; s < nshards; s++)
+    for (int r = 0; r < 2; r++) {
+      const bool cut = (r == 0) ? s > 0 : s + 1 < nshards;
+      if (!cut) continue;
+      for (int x = 1; x < w - 1; x++) {
+        const size_t i = (size_t)s * per + (size_t)r * w + x;
+        if (lvl[i] == 0xFFFFFFFFu) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve: a cut-row terminal is not connected to the outside");
+        levels[i] = lvl[i];
+      }
+    }
+}
+
+// Whole-DEM fill through the shard protocol on ONE GPU, shard after shard: the same code path the
+// multi-GPU ranks run, minus the all-gather.  Used for tiling-invariance tests and as an out-of-core
+// style entry point.
+template <class T, class Begin>
+static void fill_sharded_host(T *dem, int w, int h, int topology, int nshards, Begin begin) {
+  if (!dem || w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_sharded: bad arguments");
+  if (nshards < 1 || (nshards > 1 && h / nshards < 2)) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_sharded: need >= 2 rows per shard");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  std::vector<rdgpu_fill_shard *> sh(nshards, nullptr);
+  std::vector<int> r0(nshards + 1);
+  for (int s = 0; s <= nshards; s++) r0[s] = (int)((int64_t)h * s / nshards);
+  try {
+    const size_t per = (size_t)2 * w;
+    std::vector<uint32_t> keys((size_t)nshards * per, 0), levels((size_t)nshards * per, 0), edges;
+    std::vector<uint64_t> offs(nshards + 1, 0);
+    for (int s = 0; s < nshards; s++) {
+      const int rc = begin(d + (size_t)r0[s] * w, w, r0[s + 1] - r0[s], topology, s > 0, s + 1 < nshards, &sh[s]);
+      if (rc) throw Error(rc, rdgpu_last_error());
+      uint32_t ne = 0;
+      rdgpu_fill_shard_edge_count(sh[s], &ne);
+      offs[s + 1] = offs[s] + ne;
+      edges.resize((size_t)offs[s + 1] * 3);
+      const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
+                                              ne ? &edges[(size_t)offs[s] * 3] : nullptr);
+      if (rc2) throw Error(rc2, rdgpu_last_error());
+    }
+    graph_solve(nshards, w, topology, keys.data(), edges.data(), offs.data(), levels.data());
+    for (int s = 0; s < nshards; s++) {
+      rdgpu_fill_shard *p = sh[s];
+      sh[s] = nullptr;
+      const int rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);
+      if (rc) throw Error(rc, rdgpu_last_error());
+    }
+  } catch (...) {
+    for (auto *p : sh) if (p) rdgpu_fill_shard_free(p);
+    throw;
+  }
+  RD_HIP(hipDeviceSynchronize());
+  RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
+}  // namespace rdgpu
+
+using namespace rdgpu;
+
+extern "C" int rdgpu_fill_graph_solve(int nshards, int width, int topology, const uint32_t *keys, const uint32_t *edges,
+                                      const uint64_t *edge_offsets, uint32_t *levels) {
+  return guarded([&] { graph_solve(nshards, width, topology, keys, edges, edge_offsets, levels); });
+}
+
+#define RD_SHARDED_API(SUF, T)                                                                              \
+  extern "C" int rdgpu_fill_shard_begin_##SUF(T *, int, int, int, int, int, void *, rdgpu_fill_shard **);   \
+  extern "C" int rdgpu_fill_sharded_##SUF(T *dem, int w, int h, int topology, int nshards) {                \
+    return guarded([&] {                                                                                    \
+      fill_sharded_host<T>(dem, w, h, topology, nshards,                                                    \
+                           [](T *d, int w_, int h_, int t, int ot, int ob, rdgpu_fill_shard **o) {          \
+                             return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, nullptr, o);         \
+                           });                                                                              \
+    });                                                                                                     \
+  }
+RD_SHARDED_API(u8, uint8_t)
+RD_SHARDED_API(i16, int16_t)
+RD_SHARDED_API(u16, uint16_t)
+RD_SHARDED_API(i32, int32_t)
+RD_SHARDED_API(u32, uint32_t)
+RD_SHARDED_API(f32, float)

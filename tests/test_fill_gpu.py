@@ -168,3 +168,39 @@ def test_full_size_config_10k_properties(rd, orc):
     zsub = Z[4000:4700, 5000:5900].cpu().numpy().copy()
     zsub[0], zsub[-1], zsub[:, 0], zsub[:, -1] = sub[0], sub[-1], sub[:, 0], sub[:, -1]
     assert np.array_equal(orc.port.fill(zsub), sub)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5, 8])
+@pytest.mark.parametrize("topo", [8, 4])
+def test_row_block_shards_tiling_invariance(rd, orc, shards, topo):
+    """The multi-GPU protocol run shard-after-shard on one GPU: any number of row blocks must give the
+    single-block answer exactly (the reference's own distributed test idea,
+    programs/parallel_priority_flood/test.py:44-118)."""
+    for dem in (fractal_dem(333, 257, seed=90 + shards), fractal_dem_int(200, 161, 91, 0.05),
+                np.random.default_rng(shards).integers(0, 6, (97, 130)).astype(np.int32)):
+        got = rd.FillDepressions(dem, topology=topo, shards=shards)
+        exp = orc.port.fill(dem, topo)
+        if not np.array_equal(got, exp):
+            bad = np.argwhere(got != exp)
+            raise AssertionError(f"shards={shards}: {len(bad)} cells differ, first {bad[:4].tolist()}")
+
+
+def test_row_block_shards_hard_cases(rd, orc):
+    # depressions straddling every cut, a lake spanning all shards, NoData holes on the cuts
+    n = 160
+    yy, xx = np.mgrid[0:n, 0:n]
+    bowl = (np.hypot(yy - n / 2, xx - n / 2)).astype(np.float32)
+    bowl[::7, ::5] -= 20.0
+    for s in (2, 4, 7, 16):
+        assert np.array_equal(rd.FillDepressions(bowl, shards=s), orc.port.fill(bowl))
+    z = fractal_dem(400, 320, seed=77)
+    z[150:170, :] = np.minimum(z[150:170, :], 600.0)
+    z[100:220, 120:180] = -9999.0
+    for s in (2, 4, 8):
+        assert np.array_equal(rd.FillDepressions(z, shards=s), orc.port.fill(z))
+    dem = fractal_dem_int(180, 64, 3, 0.02).astype(np.int16)
+    assert np.array_equal(rd.FillDepressions(dem, shards=32), orc.port.fill(dem))   # 2 rows per shard
+    with pytest.raises(rd.RdgpuError):
+        rd.FillDepressions(dem, shards=33)
+    thin = fractal_dem(2, 50, seed=1)                                                # w <= 2: no terminals at all
+    assert np.array_equal(rd.FillDepressions(thin, shards=5), orc.port.fill(thin))
