@@ -1,5 +1,7 @@
 """GPU parity tests for the fill (rdgpu_fill_* through the C-ABI) against the oracle.
 Bit-exact for integer DEMs; == on every cell for float DEMs (the algorithm only copies input values)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -204,3 +206,37 @@ def test_row_block_shards_hard_cases(rd, orc):
         rd.FillDepressions(dem, shards=33)
     thin = fractal_dem(2, 50, seed=1)                                                # w <= 2: no terminals at all
     assert np.array_equal(rd.FillDepressions(thin, shards=5), orc.port.fill(thin))
+
+
+def test_gpu_shard_engine_python_protocol(rd, orc):
+    """richdem_amd.sharded.GpuShardEngine driven block after block in one process (what each rank does),
+    then the real collective path on a 1-rank RCCL group."""
+    import torch
+    import torch.distributed as dist
+
+    from richdem_amd.sharded import GpuShardEngine, fill_depressions_sharded, graph_solve, row_split
+
+    dem = fractal_dem(500, 410, seed=123)
+    exp = orc.port.fill(dem)
+    for world in (2, 5):
+        blocks = [torch.from_numpy(np.ascontiguousarray(dem[a:b])).cuda() for a, b in row_split(dem.shape[0], world)]
+        engs, keys, edges = [], [], []
+        for s, blk in enumerate(blocks):
+            e = GpuShardEngine()
+            k, ed = e.begin(blk, s > 0, s + 1 < world, 8)
+            engs.append(e); keys.append(k); edges.append(ed)
+        levels = graph_solve(np.stack(keys), edges, 8)
+        for s, e in enumerate(engs):
+            e.finish(levels[s])
+        got = torch.cat(blocks, 0).cpu().numpy()
+        assert np.array_equal(got, exp), world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.from_numpy(dem).cuda()
+        fill_depressions_sharded(t)
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), exp)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,97 @@
+"""The N>1 path on CPU: world_size 2 and 3 gloo process groups run the real exchange
+(richdem_amd.sharded.fill_depressions_sharded: all-gather + rdgpu_fill_graph_solve, product code) around
+a numpy MODEL of the shard-local engine (tests/shard_model.py); the GPU engine itself is covered by the
+tiling-invariance tests in test_fill_gpu.py.  Results must equal the single-process oracle exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_dem(case):
+    from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+    if case == "f32":
+        return fractal_dem(61, 47, seed=5)
+    if case == "i32_flats":
+        return fractal_dem_int(50, 41, 6, 0.05)
+    if case == "bowl":
+        yy, xx = np.mgrid[0:36, 0:40]
+        d = np.hypot(yy - 18, xx - 20).astype(np.float32)
+        d[::5, ::3] -= 9
+        return d
+    raise KeyError(case)
+
+
+def _worker(rank, world, port, case, topo, outdir):
+    import torch.distributed as dist
+
+    from richdem_amd.sharded import fill_depressions_sharded, row_split
+    from shard_model import NumpyShardEngine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dem = _make_dem(case)
+    r0, r1 = row_split(dem.shape[0], world)[rank]
+    block = np.ascontiguousarray(dem[r0:r1]).copy()
+    fill_depressions_sharded(block, topology=topo, engine=NumpyShardEngine(), comm_device="cpu")
+    np.save(os.path.join(outdir, f"block{rank}.npy"), block)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case,topo", [("f32", "D8"), ("i32_flats", "D8"), ("bowl", "D4")])
+def test_gloo_sharded_fill_matches_oracle(orc, tmp_path, world, case, topo):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, topo, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"block{r}.npy") for r in range(world)], axis=0)
+    dem = _make_dem(case)
+    exp = orc.port.fill(dem, 8 if topo == "D8" else 4)
+    assert got.dtype == dem.dtype
+    assert np.array_equal(got, exp)
+
+
+def test_graph_solve_single_shard_and_errors(rd):
+    from richdem_amd.sharded import graph_solve
+
+    lv = graph_solve(np.zeros((1, 2, 7), np.uint32), [np.zeros((0, 3), np.uint32)], 8)
+    assert lv.shape == (1, 2, 7) and not lv.any()
+    with pytest.raises(rd.RdgpuError):
+        graph_solve(np.zeros((2, 2, 7), np.uint32), [np.array([[99, 1, 5]], np.uint32), np.zeros((0, 3), np.uint32)], 8)
+
+
+def test_model_engine_matches_oracle_single_process(orc):
+    """The model engine + product graph solve, shard after shard in one process (no process group)."""
+    from richdem_amd.sharded import graph_solve, row_split
+    from shard_model import NumpyShardEngine
+
+    dem = _make_dem("f32")
+    for world in (2, 4, 5):
+        blocks = [np.ascontiguousarray(dem[a:b]).copy() for a, b in row_split(dem.shape[0], world)]
+        engs, keys, edges = [], [], []
+        for s, blk in enumerate(blocks):
+            e = NumpyShardEngine()
+            k, ed = e.begin(blk, s > 0, s + 1 < world, 8)
+            engs.append(e); keys.append(k); edges.append(ed)
+        levels = graph_solve(np.stack(keys), edges, 8)
+        for s, e in enumerate(engs):
+            e.finish(levels[s])
+        assert np.array_equal(np.concatenate(blocks, axis=0), orc.port.fill(dem, 8)), world
