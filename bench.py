@@ -74,6 +74,8 @@ def main():
     if world > 1 or os.environ.get("RDGPU_BENCH_FORCE_SHARDED") == "1":   # the env switch runs the N>1 code path on 1 rank
         import torch.distributed as dist
 
+        # RCCL logs to stdout by default; route them to a file so stdout carries exactly one JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rdgpu_rccl_%h_%p.log")
         os.environ.setdefault("MASTER_PORT", "29534")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")

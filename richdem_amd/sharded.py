@@ -174,6 +174,7 @@ def bench_sharded(args, rank: int, world: int) -> None:
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     changed = (bufs[0] != Z).sum().to(torch.float64)
     dist.all_reduce(changed)
+    out = None
     if rank == 0:
         sec = float(dt.item())
         cells = n * n
@@ -199,5 +200,6 @@ def bench_sharded(args, rank: int, world: int) -> None:
                 "parallelism": f"row-block x{world}; 1 all-gather of cut rows + spillover graph per fill",
             },
         }
-        print(json.dumps(out))
     dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
