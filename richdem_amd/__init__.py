@@ -29,6 +29,9 @@ from .api import (  # noqa: F401
     barnes_flat_resolution_d8,
     resolve_flats,
     fill_depressions_dev,
+    d8_flow_directions_dev,
+    d8_flow_accum_dev,
+    fa_d8_dev,
     synth_dem_dev,
 )
 
@@ -44,6 +47,9 @@ __all__ = [
     "barnes_flat_resolution_d8",
     "resolve_flats",
     "fill_depressions_dev",
+    "d8_flow_directions_dev",
+    "d8_flow_accum_dev",
+    "fa_d8_dev",
     "synth_dem_dev",
     "fill_stats",
     "profile_enable",

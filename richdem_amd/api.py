@@ -189,3 +189,60 @@ def synth_dem_dev(out, seed: int, x0: int = 0, y0: int = 0, tilt: float = 0.0) -
         ),
         "rdgpu_synth_dem_dev_f32",
     )
+
+
+def _dev2d(t, who, dtype=None):
+    if not (t.is_cuda and t.dim() == 2 and t.is_contiguous()):
+        raise RdgpuError(f"{who}: expected a contiguous 2-D tensor on the GPU")
+    if dtype is not None and t.dtype != dtype:
+        raise RdgpuError(f"{who}: expected dtype {dtype}, got {t.dtype}")
+    return t.shape
+
+
+def _torch_elev_suffix(t) -> str:
+    import torch
+
+    m = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32", torch.float64: "f64"}
+    if t.dtype not in m:
+        raise RdgpuError(f"unsupported tensor dtype {t.dtype}")
+    return m[t.dtype]
+
+
+def d8_flow_directions_dev(dem, nodata, dirs, flats: bool = False) -> None:
+    """dirs (uint8 CUDA tensor) <- D8 directions of dem; flats=True also resolves flats
+    (barnes_flat_resolution_d8, alter=false)."""
+    import torch
+
+    h, w = _dev2d(dem, "d8_flow_directions_dev")
+    if _dev2d(dirs, "d8_flow_directions_dev", torch.uint8) != (h, w):
+        raise RdgpuError("d8_flow_directions_dev: shape mismatch")
+    s = _torch_elev_suffix(dem)
+    name = f"rdgpu_flat_resolution_d8_dev_{s}" if flats else f"rdgpu_d8_flowdirs_dev_{s}"
+    check(getattr(lib(), name)(ctypes.c_void_p(dem.data_ptr()), _CT[s](nodata), w, h, ctypes.c_void_p(dirs.data_ptr()),
+                               _stream_ptr()), name)
+
+
+def d8_flow_accum_dev(dirs, area, nodata: int = 255) -> None:
+    import torch
+
+    h, w = _dev2d(dirs, "d8_flow_accum_dev", torch.uint8)
+    if _dev2d(area, "d8_flow_accum_dev") != (h, w):
+        raise RdgpuError("d8_flow_accum_dev: shape mismatch")
+    s = {torch.int32: "i32", torch.float32: "f32", torch.float64: "f64"}.get(area.dtype)
+    if s is None:
+        raise RdgpuError(f"d8_flow_accum_dev: unsupported accumulation dtype {area.dtype}")
+    check(getattr(lib(), f"rdgpu_d8_flow_accum_dev_{s}")(ctypes.c_void_p(dirs.data_ptr()), ctypes.c_uint8(nodata), w, h,
+                                                         ctypes.c_void_p(area.data_ptr()), _stream_ptr()),
+          "rdgpu_d8_flow_accum_dev")
+
+
+def fa_d8_dev(dem, nodata, accum) -> None:
+    """accum (float64 CUDA tensor, pre-loaded with per-cell weights) <- FA_D8 accumulation."""
+    import torch
+
+    h, w = _dev2d(dem, "fa_d8_dev")
+    if _dev2d(accum, "fa_d8_dev", torch.float64) != (h, w):
+        raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_fa_d8_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _CT[s](nodata), w, h,
+                                                 ctypes.c_void_p(accum.data_ptr()), _stream_ptr()), "rdgpu_fa_d8_dev")
