@@ -119,8 +119,20 @@ def main():
     total_kernel_ms = sum(v[0] for v in prof.values())
     roofline = None
     if k_n:
-        avg_s = k_ms / k_n / 1e3
-        achieved = cells * FILL_ALG_BYTES_PER_CELL / avg_s / 1e9
+        # algorithmic bytes of the cells the scan launches actually visited (dead tiles are skipped from
+        # round 2 on): visited tiles x cells/tile x 8 B, over the measured duration of those launches
+        visited_cells = stats["scan_tiles"] * stats["tile_cells"]
+        scan_s = k_ms / args.steps / 1e3
+        achieved = visited_cells * FILL_ALG_BYTES_PER_CELL / scan_s / 1e9
+        launches = k_n / args.steps
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("size") == n:
+                traffic = pt.get("fill.scan_GB_per_launch")
+        except OSError:
+            pass
         roofline = {
             "bound": "hbm",
             "kernel": DOMINANT_KERNEL,
@@ -128,9 +140,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/)" if traffic is not None else None,
             "avg_launch_ms": round(k_ms / k_n, 4),
-            "launches_per_step": k_n / args.steps,
+            "launches_per_step": launches,
+            "alg_GB_per_launch": round(visited_cells * FILL_ALG_BYTES_PER_CELL / launches / 1e9, 3),
             "share_of_kernel_time": round(k_ms / total_kernel_ms, 3) if total_kernel_ms else None,
         }
     out = {

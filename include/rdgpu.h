@@ -66,6 +66,8 @@ typedef struct rdgpu_fill_stats {
   uint64_t basins;      /* descent-forest roots (pits) not draining out   */
   uint32_t rounds;      /* Boruvka contraction rounds over the raster     */
   uint32_t jump_passes; /* pointer-jumping passes over the descent forest */
+  uint64_t scan_tiles;  /* tiles visited by fill.scan, summed over the rounds */
+  uint32_t tile_cells;  /* cells per scan tile                               */
 } rdgpu_fill_stats;
 int rdgpu_fill_get_stats(rdgpu_fill_stats *out);
 

@@ -32,6 +32,8 @@ class rdgpu_fill_stats(ctypes.Structure):
         ("basins", ctypes.c_uint64),
         ("rounds", ctypes.c_uint32),
         ("jump_passes", ctypes.c_uint32),
+        ("scan_tiles", ctypes.c_uint64),
+        ("tile_cells", ctypes.c_uint32),
     ]
 
 
@@ -68,7 +70,8 @@ def check(rc: int, what: str = "") -> None:
 def fill_stats() -> dict:
     st = rdgpu_fill_stats()
     check(lib().rdgpu_fill_get_stats(ctypes.byref(st)), "rdgpu_fill_get_stats")
-    return {"cells": st.cells, "basins": st.basins, "rounds": st.rounds, "jump_passes": st.jump_passes}
+    return {"cells": st.cells, "basins": st.basins, "rounds": st.rounds, "jump_passes": st.jump_passes,
+            "scan_tiles": st.scan_tiles, "tile_cells": st.tile_cells}
 
 
 def profile_enable(on: bool = True) -> None:

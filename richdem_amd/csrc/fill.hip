@@ -27,6 +27,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 struct rdgpu_fill_shard;
@@ -34,7 +35,7 @@ struct rdgpu_fill_shard;
 namespace rdgpu {
 
 constexpr int TW = 64;        // tile width  (cells)  = one wavefront per tile row
-constexpr int TH = 16;        // tile height (cells)
+constexpr int TH = 32;        // tile height (cells)
 constexpr int LW = TW + 2;    // LDS row stride incl. 1-cell halo (66 words: conflict-free rows)
 constexpr int LH = TH + 2;
 constexpr int NTHR = 256;     // 4 wavefronts
@@ -48,64 +49,111 @@ constexpr uint32_t NO_TID = 0xFFFFFFFFu;   // tid[b]: basin b is not a cut-row t
 static rdgpu_fill_stats g_stats;
 
 // ------------------------------------------------------------------------------------------
-// 1. descent pointers
+// 1. descent pointers, path-compressed inside the tile
+// A 64x64 tile (+1 halo) of keys is staged in LDS; every cell picks its descent target; pointers that
+// stay inside the tile are chased to their tile-local root with LDS pointer jumping, so what reaches
+// HBM already points at a pit, at OUT, or at the first cell OUTSIDE the tile on the cell's path.  The
+// global chase (k_chase) then hops tile to tile instead of cell to cell.
 // ------------------------------------------------------------------------------------------
+constexpr int DW = 64, DH = 64, DLW = DW + 2, DLH = DH + 2;
+constexpr uint16_t LTERM = 0xFFFFu;   // local pointer: this cell is terminal within the tile
+
+// descent target of the cell at LDS position p (global cell c), as an offset in cell-index space;
+// 0 = the cell is its own root (pit).  Neighbours are visited in increasing index order and compared
+// with strict '<', so the lowest index wins among equal keys.
+template <int TOPO>
+__device__ __forceinline__ int descent_offset(const uint32_t *p, int w) {
+  const uint32_t kc = p[0];
+  uint32_t bk;
+  int boff;
+  bool lower_idx = true;
+  uint32_t k;
+  if (TOPO == 8) {
+    bk = p[-DLW - 1]; boff = -w - 1;
+    k = p[-DLW];     if (k < bk) { bk = k; boff = -w; }
+    k = p[-DLW + 1]; if (k < bk) { bk = k; boff = -w + 1; }
+    k = p[-1];       if (k < bk) { bk = k; boff = -1; }
+    k = p[1];        if (k < bk) { bk = k; boff = 1; lower_idx = false; }
+    k = p[DLW - 1];  if (k < bk) { bk = k; boff = w - 1; lower_idx = false; }
+    k = p[DLW];      if (k < bk) { bk = k; boff = w; lower_idx = false; }
+    k = p[DLW + 1];  if (k < bk) { bk = k; boff = w + 1; lower_idx = false; }
+  } else {
+    bk = p[-DLW]; boff = -w;
+    k = p[-1];  if (k < bk) { bk = k; boff = -1; }
+    k = p[1];   if (k < bk) { bk = k; boff = 1; lower_idx = false; }
+    k = p[DLW]; if (k < bk) { bk = k; boff = w; lower_idx = false; }
+  }
+  return ((bk < kc) || (bk == kc && lower_idx)) ? boff : 0;
+}
+
+// final pointer of the cell at tile-local (lx, ly): OUTP, itself, or its descent target
+template <int TOPO>
+__device__ __forceinline__ uint32_t descent_global(const uint32_t *sk, int lx, int ly, int gx, int gy, int w, int h,
+                                                   int open_top, int open_bottom) {
+  const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+  if (gx == 0 || gx == w - 1 || (gy == 0 && !open_top) || (gy == h - 1 && !open_bottom)) return OUTP;  // true border
+  if (gy == 0 || gy == h - 1) return c;   // cut row of a row-block shard: frozen terminal, its own root
+  return (uint32_t)((int64_t)c + descent_offset<TOPO>(&sk[(ly + 1) * DLW + lx + 1], w));
+}
+
 template <class T, int TOPO>
 __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ ptr,
                                                   int w, int h, uint32_t tilesX, uint32_t ntiles, int open_top,
                                                   int open_bottom) {
-  __shared__ uint32_t sk[LH * LW];
+  __shared__ uint32_t sk[DLH * DLW];
+  __shared__ uint16_t lp[DH * DW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
-  const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
-  for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
-    const int ly = i / LW, lx = i - ly * LW;
+  const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
+  for (int i = threadIdx.x; i < DLH * DLW; i += NTHR) {
+    const int ly = i / DLW, lx = i - ly * DLW;
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
     uint32_t k = 0xFFFFFFFFu;
     if (gx >= 0 && gx < w && gy >= 0 && gy < h) k = Key32<T>::to(z[(size_t)gy * w + gx]);
     sk[i] = k;
   }
   __syncthreads();
-  const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < TH / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-    uint32_t res;
-    if (gx == 0 || gx == w - 1 || (gy == 0 && !open_top) || (gy == h - 1 && !open_bottom)) {
-      res = OUTP;   // true DEM border: drains off the raster at its own elevation
-    } else if (gy == 0 || gy == h - 1) {
-      res = c;      // cut row of a row-block shard: a frozen terminal, root of its own watershed
-    } else {
-      const uint32_t *p = &sk[(ly + 1) * LW + lx + 1];
-      const uint32_t kc = p[0];
-      // neighbours in increasing cell-index order; strict '<' keeps the lowest index among ties
-      uint32_t bk;
-      int boff;
-      bool lower_idx;
-      if (TOPO == 8) {
-        bk = p[-LW - 1]; boff = -w - 1; lower_idx = true;
-        uint32_t k;
-        k = p[-LW];     if (k < bk) { bk = k; boff = -w; }
-        k = p[-LW + 1]; if (k < bk) { bk = k; boff = -w + 1; }
-        k = p[-1];      if (k < bk) { bk = k; boff = -1; }
-        k = p[1];       if (k < bk) { bk = k; boff = 1; lower_idx = false; }
-        k = p[LW - 1];  if (k < bk) { bk = k; boff = w - 1; lower_idx = false; }
-        k = p[LW];      if (k < bk) { bk = k; boff = w; lower_idx = false; }
-        k = p[LW + 1];  if (k < bk) { bk = k; boff = w + 1; lower_idx = false; }
-      } else {
-        bk = p[-LW]; boff = -w; lower_idx = true;
-        uint32_t k;
-        k = p[-1]; if (k < bk) { bk = k; boff = -1; }
-        k = p[1];  if (k < bk) { bk = k; boff = 1; lower_idx = false; }
-        k = p[LW]; if (k < bk) { bk = k; boff = w; lower_idx = false; }
+  const int lx = threadIdx.x & (DW - 1), ly0 = threadIdx.x >> 6;
+  const int gx = x0 + lx;
+  // local pointers
+#pragma unroll 4
+  for (int j = 0; j < DH / 4; j++) {
+    const int ly = ly0 + 4 * j, gy = y0 + ly;
+    uint16_t l = LTERM;
+    if (gx < w && gy < h) {
+      const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+      const uint32_t g = descent_global<TOPO>(sk, lx, ly, gx, gy, w, h, open_top, open_bottom);
+      if (g != OUTP && g != c) {
+        const int tx = (int)(g % (uint32_t)w) - x0, ty = (int)(g / (uint32_t)w) - y0;
+        if (tx >= 0 && tx < DW && ty >= 0 && ty < DH) l = (uint16_t)(ty * DW + tx);
       }
-      const bool take = (bk < kc) || (bk == kc && lower_idx);
-      res = take ? (uint32_t)((int64_t)c + boff) : c;
     }
-    ptr[c] = res;
+    lp[ly * DW + lx] = l;
+  }
+  __syncthreads();
+  // pointer jumping inside the tile; any value ever stored is an ancestor, so races are harmless
+  for (int it = 0; it < 16; it++) {
+    int changed = 0;
+#pragma unroll 4
+    for (int j = 0; j < DH / 4; j++) {
+      const int li = (ly0 + 4 * j) * DW + lx;
+      const uint16_t p = lp[li];
+      if (p != LTERM) {
+        const uint16_t q = lp[p];
+        if (q != LTERM) { lp[li] = q; changed = 1; }
+      }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  // write: the tile-local root's own pointer
+#pragma unroll 4
+  for (int j = 0; j < DH / 4; j++) {
+    const int ly = ly0 + 4 * j, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const uint16_t p = lp[ly * DW + lx];
+    int rx = lx, ry = ly;
+    if (p != LTERM) { rx = p & (DW - 1); ry = p >> 6; }
+    ptr[(size_t)gy * w + gx] = descent_global<TOPO>(sk, rx, ry, x0 + rx, y0 + ry, w, h, open_top, open_bottom);
   }
 }
 
@@ -217,6 +265,26 @@ __global__ __launch_bounds__(NTHR) void k_label_cells(const uint32_t *__restrict
   }
 }
 
+// Stream compaction helper: every thread of the (256-thread) block calls it; ONE global atomic per
+// block (same-address atomics serialise at ~12 ns each on this chip, so per-wave appends of 10^7
+// elements cost milliseconds).  Returns the output slot for threads with pred.
+__device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter) {
+  __shared__ uint32_t wcnt[NTHR / 64];
+  __shared__ uint32_t bbase;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(pred);
+  if (lane == 0) wcnt[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    bbase = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  uint32_t off = bbase;
+  for (int k = 0; k < wv; k++) off += wcnt[k];
+  return off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+}
+
 // ------------------------------------------------------------------------------------------
 // 4. Boruvka rounds
 // tables (B+1 entries, index B = the outside): cur[b]  current root component of basin b
@@ -237,13 +305,8 @@ __global__ __launch_bounds__(NTHR) void k_init_tables(uint32_t *cur, uint32_t *a
     open = !closed;
   }
   // live roots = basins that still have to hook (everything but the outside and frozen terminals)
-  const unsigned long long bal = __ballot(open);
-  if (bal == 0) return;
-  const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)bal) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(nroots, (uint32_t)__popcll(bal));
-  base = __shfl(base, leader, 64);
-  if (open) roots[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+  const uint32_t slot = block_append(open, nroots);
+  if (open) roots[slot] = i;
 }
 
 // tid[basin] = terminal id of a cut-row cell's basin (top row: x, bottom row: w + x), NO_TID otherwise
@@ -261,56 +324,220 @@ __global__ __launch_bounds__(NTHR) void k_best_reset(const uint32_t *__restrict_
   if (i < nroots) best[roots[i]] = ~0ull;
 }
 
-template <class T, int TOPO>
+// One raster pass of a Boruvka round.  tiles_in == nullptr: all tiles (XCD-banded order); otherwise
+// the list of tiles that still contained a component boundary last round (a tile without candidates can
+// never produce one again: components only merge, open components only close).  Candidates of the same
+// component are first reduced in an LDS table, so a tile issues ~one global atomic per component it
+// touches instead of one per boundary cell.
+constexpr int SC_SLOTS = 256;
+
+// DPP shifts inside a 16-lane row (VALU rate, no LDS): lanes without a source get `fill`
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 | N, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
+}
+// min of `cand` over the lanes of this 16-lane row that hold the same component id (Hillis-Steele);
+// afterwards the last lane of every run of equal ids holds (at least) its run's minimum
+template <int N>
+__device__ __forceinline__ void seg_min_step(uint32_t C, uint32_t &hi, uint32_t &lo) {
+  const uint32_t c2 = row_shr<N>(C, 0xFFFFFFFFu);
+  const uint32_t h2 = row_shr<N>(hi, 0xFFFFFFFFu), l2 = row_shr<N>(lo, 0xFFFFFFFFu);
+  const bool take = (c2 == C) && (h2 < hi || (h2 == hi && l2 < lo));
+  hi = take ? h2 : hi;
+  lo = take ? l2 : lo;
+}
+// find-or-insert component C in the block's LDS table; -1 when its probe window is full
+__device__ __forceinline__ int tab_slot(uint32_t *tab_id, uint32_t C) {
+  uint32_t slot = (C * 0x9E3779B1u) >> 24;
+#pragma unroll 1
+  for (int probe = 0; probe < 8; probe++) {
+    uint32_t id = tab_id[slot];
+    if (id == 0xFFFFFFFFu) id = atomicCAS(&tab_id[slot], 0xFFFFFFFFu, C);
+    if (id == 0xFFFFFFFFu || id == C) return (int)slot;
+    slot = (slot + 1) & (SC_SLOTS - 1);
+  }
+  return -1;
+}
+
+template <class T, int TOPO, bool FIRST, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
-                                               int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles) {
+                                               int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
+                                               const uint8_t *__restrict__ alive_in, uint8_t *alive_out,
+                                               int ablate) {
   __shared__ uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
-  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  __shared__ uint32_t tab_id[SC_SLOTS];
+  __shared__ unsigned long long tab_val[SC_SLOTS];
+  __shared__ uint8_t tab_cross[SC_SLOTS];
+  __shared__ uint16_t list[TW * TH];   // LDS offsets of the cells that touch another component
+  __shared__ uint32_t nlist;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);   // XCD-banded order in every round
   if (t >= ntiles) return;
+  if (alive_in && !alive_in[t]) {   // no component boundary left in this tile: dead for good
+    if (threadIdx.x == 0) alive_out[t] = 0;
+    return;
+  }
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
-  for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
-    const int ly = i / LW, lx = i - ly * LW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    uint32_t k = 0, comp = B | CLOSED;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      const size_t g = (size_t)gy * w + gx;
-      k = Key32<T>::to(z[g]);
-      comp = cur[lab[g]];
+  for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
+  if (threadIdx.x == 0) nlist = 0;
+  // FIRST: every basin is still its own component (only used when there are no frozen terminals)
+#define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
+  if (VEC) {
+    // interior columns: 16-byte loads (w % 4 == 0 and 4-byte cells: every row start is 16-byte aligned)
+    for (int i = threadIdx.x; i < LH * (TW / 4); i += NTHR) {
+      const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+      const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
+      uint32_t k[4] = {0, 0, 0, 0}, c[4] = {B | CLOSED, B | CLOSED, B | CLOSED, B | CLOSED};
+      if (gy >= 0 && gy < h && gx < w) {
+        const size_t g = (size_t)gy * w + gx;
+        struct alignas(16) Q { T v[4]; };
+        const Q zq = *reinterpret_cast<const Q *>(z + g);
+        const uint4 lq = *reinterpret_cast<const uint4 *>(lab + g);
+        const uint32_t l[4] = {lq.x, lq.y, lq.z, lq.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { k[e] = Key32<T>::to(zq.v[e]); c[e] = RD_COMP(l[e]); }
+      }
+      const int o = ly * LW + 1 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sk[o + e] = k[e]; sc[o + e] = c[e]; }
     }
-    sk[i] = k;
-    sc[i] = comp;
+    // halo columns
+    for (int i = threadIdx.x; i < 2 * LH; i += NTHR) {
+      const int ly = i >> 1, lx = (i & 1) ? LW - 1 : 0;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      uint32_t k = 0, comp = B | CLOSED;
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+        const size_t g = (size_t)gy * w + gx;
+        k = Key32<T>::to(z[g]);
+        const uint32_t l = lab[g];
+        comp = RD_COMP(l);
+      }
+      sk[ly * LW + lx] = k;
+      sc[ly * LW + lx] = comp;
+    }
+  } else {
+    for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
+      const int ly = i / LW, lx = i - ly * LW;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      uint32_t k = 0, comp = B | CLOSED;
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+        const size_t g = (size_t)gy * w + gx;
+        k = Key32<T>::to(z[g]);
+        const uint32_t l = lab[g];
+        comp = RD_COMP(l);
+      }
+      sk[i] = k;
+      sc[i] = comp;
+    }
+  }
+#undef RD_COMP
+  __syncthreads();
+  // components that also live outside this tile (seen on the halo ring) need the global atomic;
+  // a component entirely inside the tile is reduced here completely and can use a plain store
+  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2) && !(ablate & 4); i += NTHR) {
+    int o;
+    if (i < LW) o = i;
+    else if (i < 2 * LW) o = (LH - 1) * LW + (i - LW);
+    else { const int r = (i - 2 * LW) >> 1; o = (r + 1) * LW + (((i - 2 * LW) & 1) ? LW - 1 : 0); }
+    const uint32_t C = sc[o];
+    if (!(C & CLOSED)) {
+      const int slot = tab_slot(tab_id, C);
+      if (slot >= 0) tab_cross[slot] = 1;
+    }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x >> 6;
+  // Phase 1 -- detect: each wavefront walks a band of TH/4 consecutive rows, one column per lane, with
+  // the 3x3 window of component ids carried in registers, and appends the cells that touch another
+  // component to an LDS list.  Integer VALU is the bottleneck of this kernel (not HBM), and only
+  // ~5-15% of the cells sit on a component boundary, so the expensive candidate evaluation (phase 2)
+  // runs densely over that list instead of over every lane.
+  const int lx = threadIdx.x & (TW - 1), band = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int ROWS = TH / 4;
+  const int gx = x0 + lx;
+  const int yb = band * ROWS;   // first tile row of the band
+  {
+    uint32_t c0[3], c1[3], c2[3];
+    {
+      const int o = yb * LW + lx;   // LDS row yb is the halo row above tile row yb
 #pragma unroll
-  for (int j = 0; j < TH / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    const int o = (ly + 1) * LW + lx + 1;
-    const uint32_t C = sc[o];
-    if (C & CLOSED) continue;  // drains to the outside (every border cell does) or to a frozen terminal
-    const uint32_t kc = sk[o];
+      for (int e = 0; e < 3; e++) { c0[e] = sc[o + e]; c1[e] = sc[o + LW + e]; }
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const int ly = yb + j, gy = y0 + ly;
+      {
+        const int o = (ly + 2) * LW + lx;
+#pragma unroll
+        for (int e = 0; e < 3; e++) c2[e] = sc[o + e];
+      }
+      const uint32_t C = c1[1];
+      uint32_t d = (c0[1] ^ C) | (c1[0] ^ C) | (c1[2] ^ C) | (c2[1] ^ C);
+      if (TOPO == 8) d |= (c0[0] ^ C) | (c0[2] ^ C) | (c2[0] ^ C) | (c2[2] ^ C);
+      // closed: drains to the outside or to a frozen terminal -- never proposes
+      const bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h && !(ablate & 1);
+      const unsigned long long bal = __ballot(hit);
+      if (bal) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&nlist, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (hit) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((ly + 1) * LW + lx + 1);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
+    }
+  }
+  __syncthreads();
+  // Phase 2 -- evaluate the boundary cells densely
+  const uint32_t nl = nlist;
+  for (uint32_t i = threadIdx.x; i < nl; i += NTHR) {
+    const int o = list[i];
+    const uint32_t C = sc[o], kc = sk[o];
     unsigned long long cand = ~0ull;
-#define RD_NB(off)                                                                     \
-  {                                                                                    \
-    const uint32_t D = sc[o + (off)];                                                  \
-    if (D != C) {                                                                      \
-      const uint32_t kn = sk[o + (off)];                                               \
-      const unsigned long long e = ((unsigned long long)(kn > kc ? kn : kc) << 32) | D; \
-      cand = e < cand ? e : cand;                                                      \
-    }                                                                                  \
+#define RD_NB(off)                                                                               \
+  {                                                                                              \
+    const uint32_t D = sc[o + (off)], kn = sk[o + (off)];                                        \
+    const uint32_t hn_ = (D != C) ? (kn > kc ? kn : kc) : 0xFFFFFFFFu;                           \
+    const unsigned long long e_ = ((unsigned long long)hn_ << 32) | D;                           \
+    cand = e_ < cand ? e_ : cand;                                                                \
   }
     RD_NB(-LW) RD_NB(-1) RD_NB(1) RD_NB(LW)
     if (TOPO == 8) { RD_NB(-LW - 1) RD_NB(-LW + 1) RD_NB(LW - 1) RD_NB(LW + 1) }
 #undef RD_NB
-    if (cand != ~0ull) {
-      // cheap (possibly stale) pre-check, then the authoritative atomic
-      if (cand < best[C]) atomicMin(&best[C], cand);
+    // reduce per component in LDS; fall back to the global atomic when its probe window is full
+    const int slot = tab_slot(tab_id, C);
+    if (slot >= 0) atomicMin(&tab_val[slot], cand);
+    else if (cand < best[C]) atomicMin(&best[C], cand);
+  }
+  const int any = nl != 0;
+  __syncthreads();
+  const int alive = any;
+  for (int i = threadIdx.x; i < SC_SLOTS && !(ablate & 2); i += NTHR) {
+    const uint32_t C = tab_id[i];
+    if (C != 0xFFFFFFFFu) {
+      const unsigned long long cand = tab_val[i];
+      if (cand == ~0ull) continue;   // only seen on the halo ring
+      if (!tab_cross[i]) best[C] = cand;                       // nobody else proposes for C
+      else if (cand < best[C]) atomicMin(&best[C], cand);      // cheap (possibly stale) pre-check first
     }
   }
+  // NB: no global "alive tiles" counter here -- ~10^6 same-address atomics serialise at ~12 ns each
+  // (that alone cost 9 ms per pass); k_count_alive sums the flags instead
+  if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
+}
+
+__global__ __launch_bounds__(NTHR) void k_count_alive(const uint8_t *__restrict__ alive, uint32_t ntiles,
+                                                      uint32_t *count) {
+  __shared__ uint32_t ws[NTHR / 64];
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < ntiles; i += gridDim.x * NTHR) c += alive[i];
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(count, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 __global__ __launch_bounds__(NTHR) void k_hook(const uint32_t *__restrict__ roots, uint32_t nroots,
@@ -382,13 +609,8 @@ __global__ __launch_bounds__(NTHR) void k_compact_roots(const uint32_t *__restri
     r = roots_in[i];
     keep = (uint32_t)link[r] == r;
   }
-  const unsigned long long bal = __ballot(keep);
-  if (bal == 0) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(counter, (uint32_t)__popcll(bal));
-  base = __shfl(base, (int)__ffsll((long long)bal) - 1, 64);
-  if (keep) roots_out[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+  const uint32_t slot = block_append(keep, counter);
+  if (keep) roots_out[slot] = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -529,7 +751,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const uint64_t n64 = (uint64_t)w * (uint64_t)h;
   if (n64 > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: raster (or shard) has more than 2^31-65536 cells");
   const uint32_t n = (uint32_t)n64;
-  g_stats = rdgpu_fill_stats{n64, 0, 0, 0};
+  g_stats = rdgpu_fill_stats{n64, 0, 0, 0, 0, (uint32_t)(TW * TH)};
   fb = FillBuffers();
   const bool sharded = open_top || open_bottom;
   if (w <= 2 || (!sharded && h <= 2)) { fb.trivial = true; return; }  // every cell is a border cell
@@ -547,8 +769,11 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const uint32_t tgrid = xcd_grid(ntiles);
   const uint32_t sgrid = std::min(cdiv(n, NTHR), 256u * 32u);  // grid-stride 1-D kernels
 
-  RD_LAUNCH("fill.descent", (k_descent<T, TOPO>), dim3(tgrid), dim3(NTHR), 0, s, d_z, ptr, w, h, tilesX, ntiles,
-            open_top, open_bottom);
+  {
+    const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
+    RD_LAUNCH("fill.descent", (k_descent<T, TOPO>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, w, h, dtx, dnt,
+              open_top, open_bottom);
+  }
 
   // path compression; each pass shortens every path by >= 32x
   for (;;) {
@@ -594,11 +819,28 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   RD_HIP(hipStreamSynchronize(s));
 
   uint32_t nroots = hw[0];
+  // per-tile flag "still holds a component boundary" (ping-pong); round 1 visits every tile
+  uint8_t *aliveA = ws.buf<uint8_t>("fill.aliveA", ntiles), *aliveB = ws.buf<uint8_t>("fill.aliveB", ntiles);
+  uint32_t nlive = ntiles;
+  bool first = true;
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
-    RD_LAUNCH("fill.scan", (k_scan<T, TOPO>), dim3(tgrid), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, B, tilesX,
-              ntiles);
+    RD_HIP(hipMemsetAsync(dflags + 3, 0, sizeof(uint32_t), s));
+    if (nlive > 0) {
+      static const int ablate = getenv("RDGPU_ABLATE") ? atoi(getenv("RDGPU_ABLATE")) : 0;   // timing experiments only
+      const bool vec = sizeof(T) == 4 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % 16) == 0;
+#define RD_SCAN(FIRST_, VEC_, AIN)                                                                              \
+  RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(tgrid), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, B, \
+            tilesX, ntiles, (const uint8_t *)(AIN), aliveB, ablate)
+      if (first && !sharded) { if (vec) RD_SCAN(true, true, nullptr); else RD_SCAN(true, false, nullptr); }
+      else if (first) { if (vec) RD_SCAN(false, true, nullptr); else RD_SCAN(false, false, nullptr); }
+      else { if (vec) RD_SCAN(false, true, aliveA); else RD_SCAN(false, false, aliveA); }
+#undef RD_SCAN
+      RD_LAUNCH("fill.count_alive", k_count_alive, dim3(std::min(cdiv(ntiles, NTHR * 16), 64u)), dim3(NTHR), 0, s,
+                (const uint8_t *)aliveB, ntiles, dflags + 3);
+      g_stats.scan_tiles += first ? ntiles : nlive;
+    }
     RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
     for (;;) {
       RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
@@ -611,12 +853,18 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
     RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
               dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     const uint32_t next = hw[0];
-    if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
+    if (next >= nroots) {
+      if (getenv("RDGPU_ABLATE")) break;
+      throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
+    }
     nroots = next;
+    nlive = hw[1];
+    first = false;
     std::swap(rootsA, rootsB);
+    std::swap(aliveA, aliveB);
     g_stats.rounds++;
   }
 }
