@@ -168,8 +168,8 @@ typedef struct rdgpu_flat_stats {
   uint64_t low_edges;      /* find_flat_edges: cells with flow next to an equal NO_FLOW cell */
   uint64_t high_edges;     /* NO_FLOW cells next to higher terrain                           */
   uint64_t noflow_cells;   /* cells without a local gradient                                 */
-  uint32_t away_levels;    /* BFS level launches, away-from-higher gradient (multiple of 8)  */
-  uint32_t towards_levels; /* BFS level launches, towards-lower gradient (multiple of 8)     */
+  uint32_t away_levels;    /* tile-relaxation rounds, away-from-higher gradient              */
+  uint32_t towards_levels; /* tile-relaxation rounds, towards-lower gradient                 */
 } rdgpu_flat_stats;
 int rdgpu_flat_get_stats(rdgpu_flat_stats *out);
 

@@ -282,132 +282,180 @@ __global__ __launch_bounds__(NTHR) void k_flat_mark_low(const uint32_t *__restri
   if (i < nlow) fh[L[low[i]]] = 0;
 }
 
-// AWAY sources: the high edges of labelled flats (:491-500) -> flag cleared for the others, M = -1
-__global__ __launch_bounds__(NTHR) void k_flat_seed_away(uint8_t *flags, const uint32_t *__restrict__ high,
-                                                         uint32_t nhigh, const uint32_t *__restrict__ L,
-                                                         const int32_t *__restrict__ fh, int32_t *M) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  if (i >= nhigh) return;
-  const uint32_t c = high[i];
-  if (fh[L[c]] >= 0) M[c] = -1;            // level 1
-  else flags[c] &= (uint8_t)~F_HIGH;       // its flat has no outlet: not a source
-}
+// ------------------------------------------------------------------------------------------
+// BuildAwayGradient (:152-198) / BuildTowardsCombinedGradient (:241-298): the reference's levels are
+// BFS distances (8-connected, through NO_FLOW cells of the same flat) from the high / low edges.  A
+// level-synchronous BFS needs one global step per level -- 20 000+ steps on a 40k x 40k filled DEM whose
+// lakes are long and thin -- so distances are computed by tile-local relaxation instead: an active
+// 64x32 tile is staged in LDS (elevation, eligibility, distance, 1-cell halo), relaxed to its local fixed
+// point d(c) = min(d(c), min over equal-elevation neighbours d(n) + 1), written back, and the tiles
+// across a changed edge are activated for the next round.  Distances only ever decrease and stay upper
+// bounds, so the fixed point is the exact BFS level; the number of global rounds is the geodesic length in
+// TILES, not in cells.
+// ------------------------------------------------------------------------------------------
+constexpr int32_t DINF = 0x7F7F7F7F;   // memset-able "not reached"
 
-// TOWARDS sources: every low edge, level 1 -> M = 2*1 (:284; low edges never carry an away value)
-__global__ __launch_bounds__(NTHR) void k_flat_seed_towards(const uint32_t *__restrict__ low, uint32_t nlow, int32_t *M) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  if (i < nlow) M[low[i]] = 2;
-}
-
-// claim the unvisited NO_FLOW neighbours of equal elevation of cell c for level lvl+1; returns how many
-template <class T, bool AWAY>
-__device__ __forceinline__ int bfs_expand(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
-                                          const uint32_t *__restrict__ L, const int32_t *__restrict__ fh, int32_t *M,
-                                          uint32_t c, int lvl, int w, int h, uint32_t (&out)[8]) {
-  const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
-  const T e = z[c];
-  int cnt = 0;
-#pragma unroll
-  for (int k = 1; k <= 8; k++) {
-    const int nx = x + fdx(k), ny = y + fdy(k);
-    if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;                 // labels.inGrid, :189 / :289
-    const uint32_t ni = (uint32_t)ny * (uint32_t)w + (uint32_t)nx;
-    if (dirs[ni] != 0 || !(z[ni] == e)) continue;                         // same flat && NO_FLOW, :190-191
-    const int32_t old = __hip_atomic_load(&M[ni], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool claimed = false;
-    if (AWAY) {
-      if (old == 0) claimed = atomicCAS(&M[ni], 0, -(lvl + 1)) == 0;      // :178-180
-    } else if (old <= 0) {                                                // :279
-      const int32_t nv = (old != 0 ? fh[L[ni]] + old : 0) + 2 * (lvl + 1);  // :281-284
-      claimed = atomicCAS(&M[ni], old, nv) == old;
-    }
-    if (claimed) out[cnt++] = ni;
-  }
-  return cnt;
-}
-
-// Wide regime: one launch per level, one thread per frontier cell, ONE queue-tail atomic per block.
-// ctrl: [0] queue tail
-template <class T, bool AWAY>
-__global__ __launch_bounds__(NTHR) void k_flat_bfs_wide(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
-                                                        const uint32_t *__restrict__ L, const int32_t *__restrict__ fh,
-                                                        int32_t *M, uint32_t *queue, uint32_t *ctrl, uint32_t start,
-                                                        uint32_t end, int lvl, int w, int h) {
-  __shared__ uint32_t wsum[NTHR / 64];
+__device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter) {
+  __shared__ uint32_t wcnt[NTHR / 64];
   __shared__ uint32_t bbase;
-  const uint32_t i = start + blockIdx.x * NTHR + threadIdx.x;
-  uint32_t out[8];
-  int cnt = 0;
-  if (i < end) cnt = bfs_expand<T, AWAY>(z, dirs, L, fh, M, queue[i], lvl, w, h, out);
-  // block-wide exclusive scan of cnt
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t inc = (uint32_t)cnt;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  if (lane == 63) wsum[wv] = inc;
+  const unsigned long long bal = __ballot(pred);
+  if (lane == 0) wcnt[wv] = (uint32_t)__popcll(bal);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    bbase = tot ? atomicAdd(&ctrl[0], tot) : 0;
+    const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    bbase = tot ? atomicAdd(counter, tot) : 0;
   }
   __syncthreads();
-  uint32_t off = bbase + inc - (uint32_t)cnt;
-  for (int k = 0; k < wv; k++) off += wsum[k];
-  for (int j = 0; j < cnt; j++) queue[off + j] = out[j];
+  uint32_t off = bbase;
+  for (int k = 0; k < wv; k++) off += wcnt[k];
+  return off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
 }
 
-// Narrow regime: ONE workgroup runs level after level (the long tail of a BFS over thin flats: thousands
-// of levels with a handful of cells each) until the frontier outgrows it, empties, or maxlevels pass.
-// ctrl: [0] tail, [1] start, [2] end, [3] level (all updated on exit)
-constexpr int NARROW_THREADS = 1024;
-template <class T, bool AWAY>
-__global__ __launch_bounds__(NARROW_THREADS) void k_flat_bfs_narrow(const T *__restrict__ z,
-                                                                    const uint8_t *__restrict__ dirs,
-                                                                    const uint32_t *__restrict__ L,
-                                                                    const int32_t *__restrict__ fh, int32_t *M,
-                                                                    uint32_t *queue, uint32_t *ctrl, uint32_t wide_at,
-                                                                    int maxlevels, int w, int h) {
-  __shared__ uint32_t s_cnt;
-  uint32_t start = ctrl[1], end = ctrl[2];
-  int lvl = (int)ctrl[3];
-  for (int it = 0; it < maxlevels; it++) {
-    const uint32_t span = end - start;
-    if (span == 0 || span >= wide_at) break;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < span; i += NARROW_THREADS) {
-      // bypass L1: these queue slots were written by this block a moment ago
-      const uint32_t c = __hip_atomic_load(&queue[start + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t out[8];
-      const int cnt = bfs_expand<T, AWAY>(z, dirs, L, fh, M, c, lvl, w, h, out);
-      if (cnt) {
-        const uint32_t off = end + atomicAdd(&s_cnt, (uint32_t)cnt);
-        for (int j = 0; j < cnt; j++)
-          __hip_atomic_store(&queue[off + j], out[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// sources get distance 1 and activate their tile.  fh != nullptr: only cells of labelled flats (:491-500)
+__global__ __launch_bounds__(NTHR) void k_flat_seed(const uint32_t *__restrict__ src, uint32_t nsrc,
+                                                    const uint32_t *__restrict__ L, const int32_t *__restrict__ fh,
+                                                    int32_t *D, uint8_t *tile_active, int w, uint32_t tilesX,
+                                                    uint32_t tilesY) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= nsrc) return;
+  const uint32_t c = src[i];
+  if (fh && fh[L[c]] < 0) return;   // its flat has no outlet: not a source
+  D[c] = 1;
+  // wake the source's tile and the tiles of its 8 neighbours (a source on a tile edge feeds the next tile)
+  const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
+  const int tx0 = max(x - 1, 0) / CW, tx1 = min(x + 1, w - 1) / CW;
+  const int ty0 = max(y - 1, 0) / CH, ty1 = (y + 1) / CH;
+  for (int ty = ty0; ty <= ty1; ty++)
+    for (int tx = tx0; tx <= tx1; tx++)
+      if ((uint32_t)ty < tilesY) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
+}
+
+// active-tile flags -> list (flags are cleared for the next round)
+__global__ __launch_bounds__(NTHR) void k_tiles_compact(uint8_t *flags, uint32_t ntiles, uint32_t *list,
+                                                        uint32_t *count) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  const bool hit = i < ntiles && flags[i] != 0;
+  if (hit) flags[i] = 0;
+  const uint32_t slot = block_append(hit, count);
+  if (hit) list[slot] = i;
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_flat_relax(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
+                                                     int32_t *D, const uint32_t *__restrict__ tiles,
+                                                     uint8_t *next_active, int w, int h, uint32_t tilesX,
+                                                     uint32_t tilesY) {
+  constexpr int RW = CW + 2, RH = CH + 2, ROWS = CH / 4;
+  __shared__ T sz[RH * RW];
+  __shared__ int32_t sd[RH * RW];
+  __shared__ uint8_t se[RH * RW];
+  const uint32_t t = tiles[blockIdx.x];
+  const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
+  const int x0 = tx * CW, y0 = ty * CH;
+  for (int i = threadIdx.x; i < RH * RW; i += NTHR) {
+    const int ly = i / RW, lx = i - ly * RW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    T v = T();
+    int32_t d = DINF;
+    uint8_t e = 0;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      const size_t g = (size_t)gy * w + gx;
+      v = z[g];
+      d = __hip_atomic_load(&D[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // neighbours' tiles write it
+      e = dirs[g] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold distance 1
+    }
+    sz[i] = v;
+    sd[i] = d;
+    se[i] = e;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
+  const int off[9] = {0, -1, -RW - 1, -RW, -RW + 1, 1, RW + 1, RW, RW - 1};
+  uint32_t msk[ROWS];
+  int any = 0;
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int o = (band * ROWS + j + 1) * RW + lx + 1;
+    uint32_t m = 0;
+    if (se[o]) {
+      const T e = sz[o];
+#pragma unroll
+      for (int k = 1; k <= 8; k++)
+        if (sz[o + off[k]] == e) m |= 1u << (k - 1);   // same flat (halo cells outside the raster hold d = INF)
+    }
+    msk[j] = m;
+    any |= m != 0;
+  }
+  if (!__syncthreads_or(any)) return;
+  uint32_t mine = 0;   // bit j: my cell j changed
+  int still = 0;
+  for (int it = 0; it < 256; it++) {
+    int changed = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const uint32_t m = msk[j];
+      if (m) {
+        const int o = (band * ROWS + j + 1) * RW + lx + 1;
+        int32_t best = sd[o];
+#pragma unroll
+        for (int k = 1; k <= 8; k++)
+          if (m & (1u << (k - 1))) {
+            const int32_t v = sd[o + off[k]] + 1;
+            best = v < best ? v : best;
+          }
+        if (best < sd[o]) { sd[o] = best; changed = 1; mine |= 1u << j; }
       }
     }
-    __syncthreads();
-    start = end;
-    end += s_cnt;
-    lvl++;
-    __syncthreads();
+    still = __syncthreads_or(changed);
+    if (!still) break;
   }
-  if (threadIdx.x == 0) { ctrl[0] = end; ctrl[1] = start; ctrl[2] = end; ctrl[3] = (uint32_t)lvl; }
+  if (still && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
+  // write back and wake the tiles across every edge that changed
+  int top = 0, bot = 0, lef = 0, rig = 0;
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    if (!(mine & (1u << j))) continue;
+    const int ly = band * ROWS + j;
+    const int gx = x0 + lx, gy = y0 + ly;
+    __hip_atomic_store(&D[(size_t)gy * w + gx], sd[(ly + 1) * RW + lx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    top |= ly == 0; bot |= ly == CH - 1; lef |= lx == 0; rig |= lx == CW - 1;
+  }
+  top = __syncthreads_or(top); bot = __syncthreads_or(bot); lef = __syncthreads_or(lef); rig = __syncthreads_or(rig);
+  if (threadIdx.x < 9 && threadIdx.x != 4) {
+    const int dx = (int)threadIdx.x % 3 - 1, dy = (int)threadIdx.x / 3 - 1;
+    const bool need = (dy < 0 ? top : dy > 0 ? bot : 1) && (dx < 0 ? lef : dx > 0 ? rig : 1) && (top | bot | lef | rig);
+    const int ntx = tx + dx, nty = ty + dy;
+    if (need && ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
+  }
 }
 
-// flat_height[label] = deepest away level of the flat (:181).  The queue is in level order, so walking
-// it BACKWARDS meets the deepest cells first and the pre-check turns almost every later cell away.
-__global__ __launch_bounds__(NTHR) void k_flat_height(const uint32_t *__restrict__ queue, uint32_t nq,
-                                                      const uint32_t *__restrict__ L, const int32_t *__restrict__ M,
-                                                      int32_t *fh) {
-  const uint32_t stride = gridDim.x * NTHR;
-  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nq; i += stride) {
-    const uint32_t c = queue[nq - 1 - i];
-    const int32_t lvl = -M[c];
+// flat_height[label] = deepest away level of the flat (:181): atomicMax behind a coherent pre-check
+__global__ __launch_bounds__(NTHR) void k_flat_height(const int32_t *__restrict__ A, const uint32_t *__restrict__ L,
+                                                      int32_t *fh, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int32_t a = A[c];
+    if (a >= DINF) continue;
     const uint32_t r = L[c];
-    if (__hip_atomic_load(&fh[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lvl) atomicMax(&fh[r], lvl);
+    if (__hip_atomic_load(&fh[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a) atomicMax(&fh[r], a);
+  }
+}
+
+// flat_mask from the two distance fields, in place over the towards distances (:279-284):
+//   low edge -> 2;  NO_FLOW cell at towards level t, away level a: (a reached ? flat_height - a : 0) + 2t
+__global__ __launch_bounds__(NTHR) void k_flat_combine(int32_t *M /* in: towards level */, const int32_t *__restrict__ A,
+                                                       const uint32_t *__restrict__ L, const int32_t *__restrict__ fh,
+                                                       uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int32_t t = M[c];
+    int32_t m = 0;
+    if (t < DINF) {
+      const int32_t a = A ? A[c] : DINF;
+      m = (a < DINF ? fh[L[c]] - a : 0) + 2 * t;   // a low edge has t = 1 and no away level: 2
+    }
+    M[c] = m;
   }
 }
 
@@ -475,47 +523,34 @@ static uint32_t compact_flags(const uint8_t *flags, uint8_t mask, uint64_t n, co
   return total;
 }
 
-constexpr uint32_t WIDE_AT = 4096;   // frontier size at which a level gets its own multi-block launch
-
-// queue[0, nseed) holds the level-1 cells.  Returns the number of kernel launches; *total = cells queued.
-template <class T, bool AWAY>
-static uint32_t run_bfs(const T *d_z, const uint8_t *d_dirs, const uint32_t *L, const int32_t *fh, int32_t *M,
-                        uint32_t *queue, uint32_t *ctrl, uint32_t nseed, int w, int h, uint32_t *levels_out,
-                        uint32_t *total, hipStream_t s) {
-  uint32_t *hw = Workspace::get().host_words();
-  uint32_t start = 0, end = nseed;
-  int lvl = 1;
-  uint32_t launches = 0;
-  const char *nm_w = AWAY ? "flats.bfs_away_wide" : "flats.bfs_towards_wide";
-  const char *nm_n = AWAY ? "flats.bfs_away_narrow" : "flats.bfs_towards_narrow";
-  while (end > start) {
-    if (end - start >= WIDE_AT) {
-      hw[0] = end;
-      RD_HIP(hipMemcpyAsync(ctrl, hw, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-      RD_LAUNCH(nm_w, (k_flat_bfs_wide<T, AWAY>), dim3((end - start + NTHR - 1) / NTHR), dim3(NTHR), 0, s, d_z, d_dirs, L,
-                fh, M, queue, ctrl, start, end, lvl, w, h);
-      RD_HIP(hipMemcpyAsync(hw, ctrl, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      start = end;
-      end = hw[0];
-      lvl++;
-    } else {
-      hw[0] = end; hw[1] = start; hw[2] = end; hw[3] = (uint32_t)lvl;
-      RD_HIP(hipMemcpyAsync(ctrl, hw, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-      RD_LAUNCH(nm_n, (k_flat_bfs_narrow<T, AWAY>), dim3(1), dim3(NARROW_THREADS), 0, s, d_z, d_dirs, L, fh, M, queue,
-                ctrl, WIDE_AT, 4096, w, h);
-      RD_HIP(hipMemcpyAsync(hw, ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      start = hw[1];
-      end = hw[2];
-      lvl = (int)hw[3];
-    }
-    launches++;
-    if (lvl > (1 << 30)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: BFS did not terminate");
+// Distances from the cells listed in src (level 1) by tile relaxation.  Returns the number of rounds.
+template <class T>
+static uint32_t run_relax(const T *d_z, const uint8_t *d_dirs, int32_t *D, const uint32_t *src, uint32_t nsrc,
+                          const uint32_t *L, const int32_t *fh_filter, int w, int h, const char *name, hipStream_t s) {
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + CH - 1) / CH, ntiles = tilesX * tilesY;
+  uint8_t *tflags = ws.buf<uint8_t>("flats.tflags", ntiles);
+  uint32_t *tlist = ws.buf<uint32_t>("flats.tlist", ntiles);
+  uint32_t *ctr = ws.buf<uint32_t>("flats.tctr", 4);
+  RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
+  RD_LAUNCH("flats.seed", k_flat_seed, dim3((nsrc + NTHR - 1) / NTHR), dim3(NTHR), 0, s, src, nsrc, L, fh_filter, D,
+            tflags, w, tilesX, tilesY);
+  uint32_t rounds = 0;
+  for (;;) {
+    RD_HIP(hipMemsetAsync(ctr, 0, sizeof(uint32_t), s));
+    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, tflags, ntiles,
+              tlist, ctr);
+    RD_HIP(hipMemcpyAsync(hw, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    const uint32_t nact = hw[0];
+    if (nact == 0) break;
+    RD_LAUNCH(name, (k_flat_relax<T>), dim3(nact), dim3(NTHR), 0, s, d_z, d_dirs, D, (const uint32_t *)tlist, tflags, w, h,
+              tilesX, tilesY);
+    rounds++;
+    if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
   }
-  *levels_out = (uint32_t)(lvl - 1);
-  *total = end;
-  return launches;
+  return rounds;
 }
 
 // Computes flat_mask (M) for the DEM; d_dirs must hold d8_flow_directions output.
@@ -525,7 +560,6 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
                                  int32_t **outFh, hipStream_t s) {
   const uint64_t n = (uint64_t)w * h;
   Workspace &ws = Workspace::get();
-  uint32_t *ctrl = ws.buf<uint32_t>("flats.ctrl", 16);
   int32_t *M = ws.buf<int32_t>("flats.mask", n);
   *outM = M;
   *outL = nullptr;
@@ -563,29 +597,20 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   RD_LAUNCH("flats.mark_low", k_flat_mark_low, dim3((nlow + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)low,
             nlow, (const uint32_t *)L, fh);
 
-  const size_t qcap = (size_t)nnoflow + std::max(nlow, nhigh_all) + 64;
-  uint32_t *queue = ws.buf<uint32_t>("flats.queue", qcap);
-
-  // away gradient: sources = high edges whose flat has a low edge (level 1)
+  // away gradient: sources = high edges whose flat has a low edge
+  int32_t *A = nullptr;
   if (nhigh_all > 0) {
-    RD_LAUNCH("flats.seed_away", k_flat_seed_away, dim3((nhigh_all + NTHR - 1) / NTHR), dim3(NTHR), 0, s, flags,
-              (const uint32_t *)highall, nhigh_all, (const uint32_t *)L, (const int32_t *)fh, M);
-    uint32_t *seeds = nullptr;
-    const uint32_t nseed = compact_flags(flags, F_HIGH, n, "flats.highsrc", &seeds, s);
-    if (nseed) {
-      RD_HIP(hipMemcpyAsync(queue, seeds, (size_t)nseed * 4, hipMemcpyDeviceToDevice, s));
-      uint32_t total = 0;
-      run_bfs<T, true>(d_z, d_dirs, L, fh, M, queue, ctrl, nseed, w, h, &g_fstats.away_levels, &total, s);
-      RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(total)), dim3(NTHR), 0, s, (const uint32_t *)queue, total,
-                (const uint32_t *)L, (const int32_t *)M, fh);
-    }
+    A = ws.buf<int32_t>("flats.away", n);
+    RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
+    g_fstats.away_levels = run_relax<T>(d_z, d_dirs, A, highall, nhigh_all, L, fh, w, h, "flats.relax_away", s);
+    RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
+              n);
   }
-  // towards + combined gradient: sources = all low edges (level 1)
-  RD_LAUNCH("flats.seed_towards", k_flat_seed_towards, dim3((nlow + NTHR - 1) / NTHR), dim3(NTHR), 0, s,
-            (const uint32_t *)low, nlow, M);
-  RD_HIP(hipMemcpyAsync(queue, low, (size_t)nlow * 4, hipMemcpyDeviceToDevice, s));
-  uint32_t total = 0;
-  run_bfs<T, false>(d_z, d_dirs, L, fh, M, queue, ctrl, nlow, w, h, &g_fstats.towards_levels, &total, s);
+  // towards gradient from every low edge, then the combined mask in place
+  RD_HIP(hipMemsetAsync(M, 0x7F, n * sizeof(int32_t), s));
+  g_fstats.towards_levels = run_relax<T>(d_z, d_dirs, M, low, nlow, L, nullptr, w, h, "flats.relax_towards", s);
+  RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, M, (const int32_t *)A, (const uint32_t *)L,
+            (const int32_t *)fh, n);
 }
 
 template <class T>

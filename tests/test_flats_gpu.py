@@ -121,3 +121,16 @@ def test_full_pipeline_fill_dirs_accum(rd, orc):
     assert np.array_equal(dirs, edirs)
     assert (dirs[1:-1, 1:-1] != 0).all()      # a filled DEM has no undrainable flats
     assert np.array_equal(area, orc.port.d8_flow_accum(edirs, 255, np.float64))
+
+
+def test_sources_on_tile_edges(rd, orc):
+    """Flats whose low/high edges sit exactly on 64x32 tile borders (the relaxation must wake the
+    neighbouring tile of a source)."""
+    for (h, w, x0, y0) in [(70, 140, 63, 31), (70, 140, 64, 32), (100, 200, 127, 63), (40, 70, 0, 0)]:
+        dem = np.full((h, w), 10, np.int32)
+        dem[y0:y0 + 3, :] = 5          # a horizontal flat band starting on a tile row boundary
+        dem[:, x0:x0 + 2] = 5          # and a vertical one on a tile column boundary
+        dem[y0 + 1, 0] = 1             # outlets
+        dem[0, x0] = 1
+        check(rd, orc, dem, np.int32(-1))
+        check(rd, orc, dem.T.copy(), np.int32(-1))
