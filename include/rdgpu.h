@@ -108,6 +108,17 @@ int rdgpu_fill_shard_finish(rdgpu_fill_shard *shard, const uint32_t *levels);
 int rdgpu_fill_shard_free(rdgpu_fill_shard *shard);
 int rdgpu_fill_graph_solve(int nshards, int width, int topology, const uint32_t *keys, const uint32_t *edges,
                            const uint64_t *edge_offsets, uint32_t *levels);
+/* Device-resident variants of steps 2, 4 and 5 (nothing but the all-gather leaves HBM):
+ *   export_dev : d_keys[2*width] <- cut-row keys, d_edges[3*cap] <- edge triples (count from edge_count)
+ *   graph_solve_dev : d_keys_all [nshards][2][width], d_edges_all [nshards][cap][3] with d_counts[nshards]
+ *                     valid triples per shard -> d_levels_all [nshards][2][width]; the label graph is
+ *                     contracted on the GPU with the fill's own Boruvka kernels
+ *   finish_dev : levels = this shard's [2][width] slice, on the device */
+int rdgpu_fill_shard_export_dev(rdgpu_fill_shard *shard, uint32_t *d_keys, uint32_t *d_edges, uint32_t cap);
+int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, const uint32_t *d_keys_all,
+                               const uint32_t *d_edges_all, const uint32_t *d_counts, uint32_t cap,
+                               uint32_t *d_levels_all, void *hip_stream);
+int rdgpu_fill_shard_finish_dev(rdgpu_fill_shard *shard, const uint32_t *d_levels);
 int rdgpu_fill_sharded_u8(uint8_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_i16(int16_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_u16(uint16_t *dem, int width, int height, int topology, int nshards);

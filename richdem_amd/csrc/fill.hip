@@ -1036,6 +1036,173 @@ static void shard_finish(rdgpu_fill_shard *sh, const uint32_t *levels2w) {
   RD_HIP(hipStreamSynchronize(s));   // levels2w is caller memory; buffers are freed next
 }
 
+// ------------------------------------------------------------------------------------------
+// 7. GPU solve of the joined shard graph (device-resident variant of shardgraph.hip's host solve)
+// The label graph (cut-row terminals + the outside, watershed edges of every shard, edges across every
+// cut) is contracted with the SAME Boruvka machinery as the raster: only the scan differs -- it
+// enumerates edges instead of cells.  A 105 ms host Priority-Flood at 8 shards becomes ~1 ms.
+//   keys_all  [S][2][w]   cut-row keys of every shard
+//   edges_all [S][cap][3] watershed edges of every shard (a, b, pass), counts[S] valid triples each
+// Nodes: s*2w + tid; NOUT = S*2w is the outside.
+// ------------------------------------------------------------------------------------------
+struct GraphDesc {
+  const uint32_t *keys_all, *edges_all, *counts;
+  uint32_t S, w, cap, topo;
+};
+
+__device__ __forceinline__ bool graph_edge(const GraphDesc &g, uint64_t idx, uint32_t &a, uint32_t &b, uint32_t &pass) {
+  const uint32_t per = 2u * g.w, NOUT = g.S * per;
+  const uint64_t nintra = (uint64_t)g.S * g.cap;
+  if (idx < nintra) {
+    const uint32_t s = (uint32_t)(idx / g.cap), e = (uint32_t)(idx % g.cap);
+    if (e >= g.counts[s]) return false;
+    const uint32_t *t = g.edges_all + ((size_t)s * g.cap + e) * 3;
+    a = t[0] == NO_TID ? NOUT : s * per + t[0];
+    b = t[1] == NO_TID ? NOUT : s * per + t[1];
+    pass = t[2];
+    return true;
+  }
+  // edges across the cut between shard s (bottom row) and s+1 (top row), HandleEdge main.cpp:344-378
+  idx -= nintra;
+  const uint32_t s = (uint32_t)(idx / (3ull * g.w));
+  if (s + 1 >= g.S) return false;
+  const uint32_t r = (uint32_t)(idx % (3ull * g.w));
+  const int x = (int)(r / 3), dx = (int)(r % 3) - 1;
+  if (g.topo == 4 && dx != 0) return false;
+  const int x2 = x + dx;
+  if (x2 < 0 || x2 >= (int)g.w) return false;
+  const bool sa = x == 0 || x == (int)g.w - 1, sb = x2 == 0 || x2 == (int)g.w - 1;   // side columns: true border
+  if (sa && sb) return false;
+  a = sa ? NOUT : s * per + g.w + (uint32_t)x;
+  b = sb ? NOUT : (s + 1) * per + (uint32_t)x2;
+  const uint32_t ka = g.keys_all[((size_t)s * 2 + 1) * g.w + x], kb = g.keys_all[((size_t)(s + 1) * 2) * g.w + x2];
+  pass = ka > kb ? ka : kb;
+  return true;
+}
+
+__global__ __launch_bounds__(NTHR) void k_graph_touch(GraphDesc g, uint64_t nslots, uint32_t *closed) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < nslots; i += stride) {
+    uint32_t a, b, p;
+    if (!graph_edge(g, i, a, b, p)) continue;
+    closed[a] = NO_TID;   // NO_TID = "open" in k_init_tables' convention
+    closed[b] = NO_TID;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_graph_scan(GraphDesc g, uint64_t nslots, const uint32_t *__restrict__ cur,
+                                                     unsigned long long *best) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < nslots; i += stride) {
+    uint32_t a, b, p;
+    if (!graph_edge(g, i, a, b, p)) continue;
+    const uint32_t ca = cur[a], cb = cur[b];
+    if (ca == cb) continue;
+    if (!(ca & CLOSED)) {
+      const unsigned long long e = ((unsigned long long)p << 32) | cb;
+      if (e < best[ca]) atomicMin(&best[ca], e);
+    }
+    if (!(cb & CLOSED)) {
+      const unsigned long long e = ((unsigned long long)p << 32) | ca;
+      if (e < best[cb]) atomicMin(&best[cb], e);
+    }
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_graph_levels(const uint32_t *__restrict__ cur, const uint32_t *__restrict__ acc,
+                                                       const uint32_t *__restrict__ closed, uint32_t *levels, uint32_t NOUT) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= NOUT) return;
+  levels[i] = closed[i] == NO_TID ? acc[i] : 0u;   // untouched ids (non-cut rows, side columns) -> 0
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_rows_to_keys(const T *__restrict__ top, const T *__restrict__ bottom,
+                                                       uint32_t *keys, int w) {
+  const int x = blockIdx.x * NTHR + threadIdx.x;
+  if (x >= w) return;
+  keys[x] = Key32<T>::to(top[x]);
+  keys[w + x] = Key32<T>::to(bottom[x]);
+}
+
+static void graph_solve_device(int S, int w, int topo, const uint32_t *d_keys_all, const uint32_t *d_edges_all,
+                               const uint32_t *d_counts, uint32_t cap, uint32_t *d_levels_all, hipStream_t s) {
+  if (S < 1 || w < 1 || !d_keys_all || !d_levels_all) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_graph_solve_dev: bad arguments");
+  const uint32_t per = 2u * (uint32_t)w, NOUT = (uint32_t)S * per;
+  RD_HIP(hipMemsetAsync(d_levels_all, 0, (size_t)NOUT * 4, s));
+  if (S == 1) return;
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  GraphDesc g{d_keys_all, d_edges_all, d_counts, (uint32_t)S, (uint32_t)w, cap, (uint32_t)topo};
+  const uint64_t nslots = (uint64_t)S * cap + (uint64_t)(S - 1) * 3ull * (uint64_t)w;
+  const uint32_t B = NOUT;   // "basins" = graph nodes, index B = the outside
+  uint32_t *cur = ws.buf<uint32_t>("graph.cur", (size_t)B + 1);
+  uint32_t *acc = ws.buf<uint32_t>("graph.acc", (size_t)B + 1);
+  uint32_t *closed = ws.buf<uint32_t>("graph.closed", (size_t)B + 1);
+  unsigned long long *best = ws.buf<unsigned long long>("graph.best", (size_t)B + 1);
+  unsigned long long *link = ws.buf<unsigned long long>("graph.link", (size_t)B + 1);
+  uint32_t *rootsA = ws.buf<uint32_t>("graph.rootsA", B), *rootsB = ws.buf<uint32_t>("graph.rootsB", B);
+  uint32_t *dflags = ws.buf<uint32_t>("graph.flags", 16);
+  const uint32_t egrid = (uint32_t)std::min<uint64_t>((nslots + NTHR - 1) / NTHR, 256u * 16u);
+  RD_HIP(hipMemsetAsync(closed, 0, ((size_t)B + 1) * 4, s));   // 0 = closed (isolated) until an edge touches it
+  RD_LAUNCH("graph.touch", k_graph_touch, dim3(egrid), dim3(NTHR), 0, s, g, nslots, closed);
+  RD_HIP(hipMemsetAsync(dflags, 0, 16 * 4, s));
+  RD_LAUNCH("graph.init_tables", k_init_tables, dim3(cdiv((uint64_t)B + 1, NTHR)), dim3(NTHR), 0, s, cur, acc, link, rootsA,
+            dflags + 2, (const uint32_t *)closed, B);
+  RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4, hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  uint32_t nroots = hw[0];
+  while (nroots > 0) {
+    const uint32_t rgrid = cdiv(nroots, NTHR);
+    RD_LAUNCH("graph.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
+    RD_LAUNCH("graph.scan", k_graph_scan, dim3(egrid), dim3(NTHR), 0, s, g, nslots, (const uint32_t *)cur, best);
+    RD_LAUNCH("graph.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
+    for (;;) {
+      RD_HIP(hipMemsetAsync(dflags, 0, 4, s));
+      RD_LAUNCH("graph.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 32, dflags);
+      RD_HIP(hipMemcpyAsync(hw, dflags, 4, hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (hw[0] == 0) break;
+    }
+    RD_LAUNCH("graph.update", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
+    RD_HIP(hipMemsetAsync(dflags + 2, 0, 4, s));
+    RD_LAUNCH("graph.compact_roots", k_compact_roots, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB, dflags + 2);
+    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4, hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    if (hw[0] >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve_dev: a cut-row terminal is not connected to the outside");
+    nroots = hw[0];
+    std::swap(rootsA, rootsB);
+  }
+  RD_LAUNCH("graph.levels", k_graph_levels, dim3(cdiv(NOUT, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)cur,
+            (const uint32_t *)acc, (const uint32_t *)closed, d_levels_all, NOUT);
+}
+
+template <class T>
+static void shard_export_dev(rdgpu_fill_shard *sh, uint32_t *d_keys, uint32_t *d_edges, uint32_t cap) {
+  const int w = sh->w, h = sh->h;
+  const T *base = (const T *)sh->d_dem;
+  RD_LAUNCH("shard.rows_to_keys", (k_rows_to_keys<T>), dim3(cdiv(w, NTHR)), dim3(NTHR), 0, sh->stream, base,
+            base + (size_t)(h - 1) * w, d_keys, w);
+  if (sh->nedges) {
+    if (!d_edges || cap < sh->nedges) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_shard_export_dev: edge buffer too small");
+    RD_HIP(hipMemcpyAsync(d_edges, sh->d_edges, (size_t)sh->nedges * 12, hipMemcpyDeviceToDevice, sh->stream));
+  }
+}
+
+template <class T>
+static void shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels2w) {
+  hipStream_t s = sh->stream;
+  if (!sh->fb.trivial) {
+    if (sh->fb.tid) {
+      if (!d_levels2w) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_shard_finish_dev: levels required for a shard with cut rows");
+      RD_LAUNCH("shard.apply", k_shard_apply, dim3(cdiv(sh->fb.B, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)sh->fb.cur,
+                sh->fb.acc, (const uint32_t *)sh->fb.tid, d_levels2w, sh->fb.B);
+    }
+    fill_finalize<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
+  }
+  RD_HIP(hipStreamSynchronize(s));   // the handle's buffers are freed next
+}
+
 }  // namespace rdgpu
 
 using namespace rdgpu;
@@ -1096,6 +1263,30 @@ extern "C" int rdgpu_fill_shard_finish(rdgpu_fill_shard *sh, const uint32_t *lev
   g_stats = sh->stats;
   shard_free(sh);
   return rc;
+}
+
+extern "C" int rdgpu_fill_shard_export_dev(rdgpu_fill_shard *sh, uint32_t *d_keys, uint32_t *d_edges, uint32_t cap) {
+  return guarded([&] {
+    if (!sh || !d_keys) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_shard_export_dev: null pointer");
+    RD_DISPATCH(sh, shard_export_dev<T>(sh, d_keys, d_edges, cap));
+  });
+}
+
+extern "C" int rdgpu_fill_shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels) {
+  if (!sh) { set_last_error("rdgpu_fill_shard_finish_dev: null handle"); return RDGPU_ERR_ARG; }
+  const int rc = guarded([&] { RD_DISPATCH(sh, shard_finish_dev<T>(sh, d_levels)); });
+  g_stats = sh->stats;
+  shard_free(sh);
+  return rc;
+}
+
+extern "C" int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, const uint32_t *d_keys_all,
+                                          const uint32_t *d_edges_all, const uint32_t *d_counts, uint32_t cap,
+                                          uint32_t *d_levels_all, void *stream) {
+  return guarded([&] {
+    if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_graph_solve_dev: topology must be 8 or 4");
+    graph_solve_device(nshards, width, topology, d_keys_all, d_edges_all, d_counts, cap, d_levels_all, (hipStream_t)stream);
+  });
 }
 
 extern "C" int rdgpu_fill_shard_free(rdgpu_fill_shard *sh) {

@@ -63,6 +63,39 @@ class GpuShardEngine:
               "rdgpu_fill_shard_export")
         return keys, edges
 
+    # ---- device-resident variants: nothing but the all-gather leaves HBM -----------------------
+    def begin_dev(self, block, open_top: bool, open_bottom: bool, topology: int):
+        """Local phase; returns (keys int32[2w], edges int32[ne, 3]) as CUDA tensors (bit patterns of uint32)."""
+        import torch
+
+        if not (block.is_cuda and block.dim() == 2 and block.is_contiguous()):
+            raise RdgpuError("GpuShardEngine: expected a contiguous 2-D tensor on the GPU")
+        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32"}.get(block.dtype)
+        if suf is None:
+            raise RdgpuError(f"GpuShardEngine: unsupported dtype {block.dtype}")
+        h, w = block.shape
+        L = lib()
+        handle = ctypes.c_void_p()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(getattr(L, f"rdgpu_fill_shard_begin_{suf}")(ctypes.c_void_p(block.data_ptr()), w, h, topology, int(open_top),
+                                                          int(open_bottom), stream, ctypes.byref(handle)),
+              "rdgpu_fill_shard_begin")
+        self._handle, self._w = handle, w
+        ne = ctypes.c_uint32()
+        check(L.rdgpu_fill_shard_edge_count(handle, ctypes.byref(ne)), "rdgpu_fill_shard_edge_count")
+        keys = torch.empty(2 * w, dtype=torch.int32, device=block.device)
+        edges = torch.empty((ne.value, 3), dtype=torch.int32, device=block.device)
+        check(L.rdgpu_fill_shard_export_dev(handle, ctypes.c_void_p(keys.data_ptr()),
+                                            ctypes.c_void_p(edges.data_ptr()) if ne.value else None, ne.value),
+              "rdgpu_fill_shard_export_dev")
+        return keys, edges
+
+    def finish_dev(self, levels) -> None:
+        """levels: int32 CUDA tensor [2w] (this shard's slice of the solved levels)."""
+        assert levels.is_cuda and levels.is_contiguous() and levels.numel() == 2 * self._w
+        h, self._handle = self._handle, None
+        check(lib().rdgpu_fill_shard_finish_dev(h, ctypes.c_void_p(levels.data_ptr())), "rdgpu_fill_shard_finish_dev")
+
     def finish(self, levels: np.ndarray) -> None:
         levels = np.ascontiguousarray(levels, dtype=np.uint32)
         assert levels.shape == (2, self._w)
@@ -91,6 +124,48 @@ def graph_solve(keys_all: np.ndarray, edges_per_shard, topology: int) -> np.ndar
                                        edges.ctypes.data_as(ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p),
                                        levels.ctypes.data_as(ctypes.c_void_p)), "rdgpu_fill_graph_solve")
     return levels
+
+
+def graph_solve_dev(keys_all, edges_all, counts, topology: int):
+    """GPU solve of the joined label graph (rdgpu_fill_graph_solve_dev).  keys_all int32 [S, 2w],
+    edges_all int32 [S, cap, 3], counts int32 [S] -- CUDA tensors.  Returns levels int32 [S, 2w]."""
+    import torch
+
+    S, per = keys_all.shape
+    cap = edges_all.shape[1]
+    levels = torch.empty((S, per), dtype=torch.int32, device=keys_all.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib().rdgpu_fill_graph_solve_dev(S, per // 2, topology, ctypes.c_void_p(keys_all.data_ptr()),
+                                           ctypes.c_void_p(edges_all.data_ptr()) if cap else None,
+                                           ctypes.c_void_p(counts.data_ptr()), cap, ctypes.c_void_p(levels.data_ptr()),
+                                           stream), "rdgpu_fill_graph_solve_dev")
+    return levels
+
+
+def _fill_sharded_device(block, topo: int, group, eng) -> None:
+    """Device-resident protocol: local phase, ONE all-gather (RCCL), GPU graph solve, finish."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = block.device
+    w = block.shape[1]
+    keys, edges = eng.begin_dev(block, rank > 0, rank + 1 < world, topo)
+    cnt = torch.tensor([edges.shape[0]], dtype=torch.int32, device=dev)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    cap = int(counts.max().item())
+    plen = 2 * w + 3 * cap
+    payload = torch.zeros(plen, dtype=torch.int32, device=dev)
+    payload[: 2 * w] = keys
+    payload[2 * w : 2 * w + 3 * edges.shape[0]] = edges.reshape(-1)
+    gathered = torch.empty(world * plen, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered, payload, group=group)
+    g2 = gathered.view(world, plen)
+    keys_all = g2[:, : 2 * w].contiguous()
+    edges_all = g2[:, 2 * w :].contiguous().view(world, cap, 3)
+    levels = graph_solve_dev(keys_all, edges_all, counts, topo)
+    eng.finish_dev(levels[rank].contiguous())
 
 
 def _all_gather_shards(keys: np.ndarray, edges: np.ndarray, group, device):
@@ -133,6 +208,8 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
     if comm_device is None:
         comm_device = block.device if hasattr(block, "device") else "cpu"
     try:
+        if isinstance(eng, GpuShardEngine) and hasattr(block, "is_cuda") and block.is_cuda:
+            return _fill_sharded_device(block, topo, group, eng)
         keys, edges = eng.begin(block, rank > 0, rank + 1 < world, topo)
         keys_all, edges_all = _all_gather_shards(keys, edges, group, comm_device)
         levels = graph_solve(keys_all, edges_all, topo)

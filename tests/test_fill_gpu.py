@@ -230,6 +230,28 @@ def test_gpu_shard_engine_python_protocol(rd, orc):
             e.finish(levels[s])
         got = torch.cat(blocks, 0).cpu().numpy()
         assert np.array_equal(got, exp), world
+    # device-resident variant + GPU graph solve must agree with the host solve
+    import torch as _t
+    from richdem_amd.sharded import graph_solve_dev
+    for world, topo in ((3, 8), (6, 4)):
+        blocks = [torch.from_numpy(np.ascontiguousarray(dem[a:b])).cuda() for a, b in row_split(dem.shape[0], world)]
+        engs, keys, edges = [], [], []
+        for s, blk in enumerate(blocks):
+            e = GpuShardEngine()
+            k, ed = e.begin_dev(blk, s > 0, s + 1 < world, topo)
+            engs.append(e); keys.append(k); edges.append(ed)
+        cap = max(int(ed.shape[0]) for ed in edges)
+        edges_all = _t.zeros((world, cap, 3), dtype=_t.int32, device="cuda")
+        for s, ed in enumerate(edges):
+            edges_all[s, : ed.shape[0]] = ed
+        counts = _t.tensor([int(ed.shape[0]) for ed in edges], dtype=_t.int32, device="cuda")
+        levels = graph_solve_dev(_t.stack(keys), edges_all, counts, topo)
+        host = graph_solve(np.stack([k.cpu().numpy().view(np.uint32).reshape(2, -1) for k in keys]),
+                           [ed.cpu().numpy().view(np.uint32) for ed in edges], topo)
+        assert np.array_equal(levels.cpu().numpy().view(np.uint32).reshape(world, 2, -1), host), (world, topo)
+        for s, e in enumerate(engs):
+            e.finish_dev(levels[s].contiguous())
+        assert np.array_equal(torch.cat(blocks, 0).cpu().numpy(), orc.port.fill(dem, topo)), (world, topo)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
