@@ -195,6 +195,30 @@ int rdgpu_d8_flow_accum_dev_i32(const uint8_t *d_dirs, uint8_t dir_nodata, int w
 int rdgpu_d8_flow_accum_dev_f32(const uint8_t *d_dirs, uint8_t dir_nodata, int width, int height, float *d_area, void *hip_stream);
 int rdgpu_d8_flow_accum_dev_f64(const uint8_t *d_dirs, uint8_t dir_nodata, int width, int height, double *d_area, void *hip_stream);
 
+/* ---- row-block shards of d8_flow_accum: the protocol of programs/parallel_d8_accum over GPUs -------
+ * (reference programs/parallel_d8_accum/main.cpp: per-tile accumulation :373-464, paths leaving through the
+ * perimeter :270-334, inflow added along the in-tile path :344-370.)  Each rank holds a row block of the
+ * uint8 directions plus the adjacent direction row of each neighbouring block (NULL at the DEM edge).
+ *   begin    pending-inflow counts (including inflow across the cuts) + all walks that start in the block;
+ *            a walk that crosses a cut drops (arrivals << 56 | total) into the outbox slot of the
+ *            receiving column
+ *   outbox   d_out[2][width] <- {sent up, sent down}; clears the outboxes
+ *   inject   the neighbours' outboxes arrive; completed cut-row cells resume walking
+ *   (repeat outbox / exchange / inject until every outbox of every rank is empty)
+ *   finish   area block in the requested type; releases the handle.
+ * Integer arithmetic, exact; the result equals rdgpu_d8_flow_accum_* on the whole raster. */
+typedef struct rdgpu_accum_shard rdgpu_accum_shard;
+int rdgpu_accum_shard_begin(const uint8_t *d_dirs_rows, uint8_t dir_nodata, int width, int rows,
+                            const uint8_t *d_row_above, const uint8_t *d_row_below, void *hip_stream,
+                            rdgpu_accum_shard **out);
+int rdgpu_accum_shard_outbox(rdgpu_accum_shard *shard, unsigned long long *d_out);
+int rdgpu_accum_shard_inject(rdgpu_accum_shard *shard, const unsigned long long *d_from_above,
+                             const unsigned long long *d_from_below);
+int rdgpu_accum_shard_finish_i32(rdgpu_accum_shard *shard, int32_t *d_area);
+int rdgpu_accum_shard_finish_f32(rdgpu_accum_shard *shard, float *d_area);
+int rdgpu_accum_shard_finish_f64(rdgpu_accum_shard *shard, double *d_area);
+int rdgpu_accum_shard_free(rdgpu_accum_shard *shard);
+
 /* ---- FA_D8(const Array2D<T>& elevations, Array2D<double>& accum) ----------------------------
  * Replaces richdem::FA_D8 (include/richdem/methods/flow_accumulation.hpp:27) = FM_D8
  * (flowmet/OCallaghan1984.hpp:13-77) + FlowAccumulation (methods/flow_accumulation_generic.hpp:33-100)

@@ -17,6 +17,9 @@
 #include "common.hpp"
 #include "flowdirs.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace rdgpu {
 
 constexpr int NTHR = 256;
@@ -226,6 +229,212 @@ static void fa_d8_host(const T *dem, T nodata, int w, int h, double *accum) {
   RD_HIP(hipMemcpy(accum, da, n * sizeof(double), hipMemcpyDeviceToHost));
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-block shards of d8_flow_accum (reference programs/parallel_d8_accum/main.cpp: per-tile
+// accumulation :373-464, flow leaving a tile through its perimeter :270-334, inflow added along the
+// in-tile path :344-370).  Same "last arriver continues" engine; a walk that leaves the shard across a
+// cut drops its total into an outbox slot of the receiving cell, (arrivals << 56 | sum), exactly the
+// packed format of a cell's word.  The ranks exchange the two outbox rows, inject them (an arrival of
+// multiplicity k completes a cell iff its pending count was k) and resume walking -- until no outbox is
+// used any more.  Rounds = how often a flow path crosses a cut, not the path length.
+// ------------------------------------------------------------------------------------------
+struct AccShard {
+  const uint8_t *dirs, *above, *below;   // shard rows; last row of the shard above / first row of the one below (or null)
+  unsigned long long *word, *out_top, *out_bottom;
+  int w, h;
+  uint8_t nodata;
+};
+
+__device__ __forceinline__ uint8_t accs_dir(const AccShard &s, int x, int y) {
+  if (x < 0 || x >= s.w) return s.nodata;            // treated as "never flows in"
+  if (y < 0) return s.above ? s.above[x] : s.nodata;
+  if (y >= s.h) return s.below ? s.below[x] : s.nodata;
+  return s.dirs[(size_t)y * s.w + x];
+}
+
+__global__ __launch_bounds__(NTHR) void k_accs_init(AccShard s) {
+  const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)s.w), y = (int)(c / (uint64_t)s.w);
+    unsigned long long v = 0;
+    if (s.dirs[c] != s.nodata) {
+      int k = 0;
+#pragma unroll
+      for (int m = 1; m <= 8; m++) {
+        const uint8_t d = accs_dir(s, x + d8dx(m), y + d8dy(m));
+        if (d == s.nodata) continue;
+        if (d == (m <= 4 ? m + 4 : m - 4)) k++;
+      }
+      v = ((unsigned long long)(k == 0 ? SRC : k) << 56) | 1ull;
+    }
+    s.word[c] = v;
+  }
+}
+
+// continue a walk from cell c (its word is final, total v)
+__device__ __forceinline__ void accs_walk(const AccShard &s, uint32_t c, unsigned long long v) {
+  uint8_t d = s.dirs[c];
+  for (;;) {
+    if (d < 1 || d > 8) return;
+    const int x = (int)(c % (uint32_t)s.w) + d8dx(d), y = (int)(c / (uint32_t)s.w) + d8dy(d);
+    if (x < 0 || x >= s.w) return;                               // off the DEM
+    if (y < 0) {                                                 // across the upper cut (or off the DEM)
+      if (s.above && s.above[x] != s.nodata) atomicAdd(&s.out_top[x], v + CNT1);
+      return;
+    }
+    if (y >= s.h) {
+      if (s.below && s.below[x] != s.nodata) atomicAdd(&s.out_bottom[x], v + CNT1);
+      return;
+    }
+    const uint32_t t = (uint32_t)y * (uint32_t)s.w + (uint32_t)x;
+    const uint8_t dt = s.dirs[t];
+    if (dt == s.nodata) return;
+    const unsigned long long old = atomicAdd(&s.word[t], v - CNT1);
+    if ((old >> 56) != 1) return;
+    v = (old & LOWMASK) + v;
+    c = t;
+    d = dt;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_accs_walk_sources(AccShard s) {
+  const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    if (s.dirs[c] == s.nodata) continue;
+    if ((s.word[c] >> 56) != SRC) continue;
+    accs_walk(s, (uint32_t)c, 1ull);
+  }
+}
+
+// arrivals from the neighbouring shards: in_top[x] is what the shard above sent to my row 0 cell x
+__global__ __launch_bounds__(NTHR) void k_accs_inject(AccShard s, const unsigned long long *__restrict__ in_top,
+                                                      const unsigned long long *__restrict__ in_bottom) {
+  const int i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= 2 * s.w) return;
+  const int x = i % s.w, y = i < s.w ? 0 : s.h - 1;
+  const unsigned long long *in = i < s.w ? in_top : in_bottom;
+  if (!in) return;
+  if (s.h == 1 && i >= s.w && in_top) { /* single-row shard: both boxes hit row 0; handled below */ }
+  const unsigned long long pk = in[x];
+  if (pk == 0) return;
+  const unsigned long long k = pk >> 56, sum = pk & LOWMASK;
+  const uint32_t t = (uint32_t)y * (uint32_t)s.w + (uint32_t)x;
+  const unsigned long long old = atomicAdd(&s.word[t], sum - (k << 56));
+  if ((old >> 56) != k) return;            // other inflows of t are still pending
+  accs_walk(s, t, (old & LOWMASK) + sum);
+}
+
+template <class A>
+__global__ __launch_bounds__(NTHR) void k_accs_out(AccShard s, A *area) {
+  const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    if (s.dirs[c] == s.nodata) { area[c] = (A)-1; continue; }
+    const unsigned long long v = s.word[c], cnt = v >> 56;
+    area[c] = (A)((cnt != 0 && cnt != SRC) ? (v & LOWMASK) - 1 : (v & LOWMASK));
+  }
+}
+
+}  // namespace rdgpu
+
+struct rdgpu_accum_shard {
+  rdgpu::AccShard s;
+  hipStream_t stream = nullptr;
+  std::vector<void *> owned;
+};
+
+namespace rdgpu {
+
+static void accs_free(rdgpu_accum_shard *a) {
+  if (!a) return;
+  for (void *p : a->owned) (void)hipFree(p);
+  delete a;
+}
+
+static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int w, int h, const uint8_t *d_above,
+                                     const uint8_t *d_below, hipStream_t st) {
+  if (!d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_begin: null pointer");
+  check_dims(w, h, "rdgpu_accum_shard_begin");
+  rdgpu_accum_shard *a = new rdgpu_accum_shard();
+  try {
+    a->stream = st;
+    const uint64_t n = (uint64_t)w * h;
+    auto alloc = [&](size_t bytes) {
+      void *p = nullptr;
+      RD_HIP(hipMalloc(&p, bytes));
+      a->owned.push_back(p);
+      return p;
+    };
+    a->s = AccShard{d_dirs, d_above, d_below, (unsigned long long *)alloc(n * 8), (unsigned long long *)alloc((size_t)w * 8),
+                    (unsigned long long *)alloc((size_t)w * 8), w, h, nodata};
+    RD_HIP(hipMemsetAsync(a->s.out_top, 0, (size_t)w * 8, st));
+    RD_HIP(hipMemsetAsync(a->s.out_bottom, 0, (size_t)w * 8, st));
+    RD_LAUNCH("accum.shard_init", k_accs_init, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
+    RD_LAUNCH("accum.shard_walk", k_accs_walk_sources, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
+  } catch (...) {
+    accs_free(a);
+    throw;
+  }
+  return a;
+}
+
+}  // namespace rdgpu
+
+using namespace rdgpu;
+
+extern "C" int rdgpu_accum_shard_begin(const uint8_t *d_dirs, uint8_t dir_nodata, int w, int h, const uint8_t *d_row_above,
+                                       const uint8_t *d_row_below, void *stream, rdgpu_accum_shard **out) {
+  return guarded([&] {
+    if (!out) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_begin: null output handle");
+    *out = accs_begin(d_dirs, dir_nodata, w, h, d_row_above, d_row_below, (hipStream_t)stream);
+  });
+}
+
+// d_out[2][w]: what this shard sends up (row 0) and down (row 1); the outboxes are cleared.
+extern "C" int rdgpu_accum_shard_outbox(rdgpu_accum_shard *a, unsigned long long *d_out) {
+  return guarded([&] {
+    if (!a || !d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_outbox: null pointer");
+    const size_t b = (size_t)a->s.w * 8;
+    RD_HIP(hipMemcpyAsync(d_out, a->s.out_top, b, hipMemcpyDeviceToDevice, a->stream));
+    RD_HIP(hipMemcpyAsync(d_out + a->s.w, a->s.out_bottom, b, hipMemcpyDeviceToDevice, a->stream));
+    RD_HIP(hipMemsetAsync(a->s.out_top, 0, b, a->stream));
+    RD_HIP(hipMemsetAsync(a->s.out_bottom, 0, b, a->stream));
+  });
+}
+
+// d_from_above[w]: the bottom outbox of the shard above; d_from_below[w]: the top outbox of the shard below
+extern "C" int rdgpu_accum_shard_inject(rdgpu_accum_shard *a, const unsigned long long *d_from_above,
+                                        const unsigned long long *d_from_below) {
+  return guarded([&] {
+    if (!a) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_inject: null handle");
+    if (a->s.h == 1 && d_from_above && d_from_below)
+      throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_inject: a shard between two cuts needs at least 2 rows");
+    RD_LAUNCH("accum.shard_inject", k_accs_inject, dim3((2 * a->s.w + NTHR - 1) / NTHR), dim3(NTHR), 0, a->stream, a->s,
+              d_from_above, d_from_below);
+  });
+}
+
+#define RD_ACCS_FINISH(SUF, A)                                                                                \
+  extern "C" int rdgpu_accum_shard_finish_##SUF(rdgpu_accum_shard *a, A *d_area) {                            \
+    if (!a) { set_last_error("rdgpu_accum_shard_finish: null handle"); return RDGPU_ERR_ARG; }                \
+    const int rc = guarded([&] {                                                                              \
+      if (!d_area) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_finish: null pointer");                      \
+      const uint64_t n = (uint64_t)a->s.w * a->s.h;                                                           \
+      RD_LAUNCH("accum.shard_out", (k_accs_out<A>), dim3(sgrid(n)), dim3(NTHR), 0, a->stream, a->s, d_area);  \
+      RD_HIP(hipStreamSynchronize(a->stream));                                                                \
+    });                                                                                                       \
+    accs_free(a);                                                                                             \
+    return rc;                                                                                                \
+  }
+RD_ACCS_FINISH(i32, int32_t)
+RD_ACCS_FINISH(f32, float)
+RD_ACCS_FINISH(f64, double)
+
+extern "C" int rdgpu_accum_shard_free(rdgpu_accum_shard *a) {
+  accs_free(a);
+  return RDGPU_OK;
+}
+
+namespace rdgpu {
 }  // namespace rdgpu
 
 using namespace rdgpu;

@@ -280,3 +280,140 @@ def bench_sharded(args, rank: int, world: int) -> None:
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# D8 directions and D8 accumulation over row blocks (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------------
+def _gather_edge_rows(first_row, last_row, group):
+    """all_gather of every rank's first and last row -> tensor [world, 2, w] (same dtype/device)."""
+    import torch
+    import torch.distributed as dist
+
+    return _all_gather_stack(torch.stack([first_row, last_row]), group)
+
+
+def _all_gather_stack(mine, group):
+    """all_gather of equally shaped tensors -> [world, *shape] (flat buffers: works for nccl and gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    flat = mine.contiguous().view(-1)
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    return out.view((world,) + tuple(mine.shape))
+
+
+def d8_flow_directions_sharded(block, nodata, group=None, flats: bool = False):
+    """uint8 D8 directions of this rank's row block (d8_flow_directions of the whole DEM, restricted to
+    the block): one halo row from each neighbouring block is exchanged, then it is a pure 3x3 stencil.
+    (Flat resolution across cuts is not sharded yet: flats=True is rejected for world_size > 1.)"""
+    import torch
+    import torch.distributed as dist
+
+    from .api import d8_flow_directions_dev
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if flats and world > 1:
+        raise RdgpuError("flat resolution across row blocks is not sharded yet")
+    h, w = block.shape
+    rows = _gather_edge_rows(block[0], block[-1], group)
+    parts = ([rows[rank - 1, 1:2]] if rank > 0 else []) + [block] + ([rows[rank + 1, 0:1]] if rank + 1 < world else [])
+    haloed = torch.cat(parts, 0) if len(parts) > 1 else block
+    dirs = torch.empty(haloed.shape, dtype=torch.uint8, device=block.device)
+    d8_flow_directions_dev(haloed, nodata, dirs, flats=flats)
+    lo = 1 if rank > 0 else 0
+    return dirs[lo : lo + h].contiguous() if len(parts) > 1 else dirs
+
+
+class GpuAccumShard:
+    """rdgpu_accum_shard_* over CUDA tensors."""
+
+    def begin(self, dirs_block, nodata: int, row_above, row_below):
+        import torch
+
+        if not (dirs_block.is_cuda and dirs_block.dtype == torch.uint8 and dirs_block.is_contiguous()):
+            raise RdgpuError("GpuAccumShard: expected a contiguous uint8 CUDA tensor")
+        self._h, self._w = dirs_block.shape
+        self._keep = (dirs_block, row_above.contiguous() if row_above is not None else None,
+                      row_below.contiguous() if row_below is not None else None)
+        handle = ctypes.c_void_p()
+        check(lib().rdgpu_accum_shard_begin(
+            ctypes.c_void_p(dirs_block.data_ptr()), ctypes.c_uint8(nodata), self._w, self._h,
+            ctypes.c_void_p(self._keep[1].data_ptr()) if self._keep[1] is not None else None,
+            ctypes.c_void_p(self._keep[2].data_ptr()) if self._keep[2] is not None else None,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(handle)), "rdgpu_accum_shard_begin")
+        self._handle = handle
+        self._dev = dirs_block.device
+
+    def outbox(self):
+        import torch
+
+        out = torch.empty((2, self._w), dtype=torch.int64, device=self._dev)
+        check(lib().rdgpu_accum_shard_outbox(self._handle, ctypes.c_void_p(out.data_ptr())), "rdgpu_accum_shard_outbox")
+        return out
+
+    def inject(self, from_above, from_below) -> None:
+        fa = from_above.contiguous() if from_above is not None else None
+        fb = from_below.contiguous() if from_below is not None else None
+        check(lib().rdgpu_accum_shard_inject(self._handle, ctypes.c_void_p(fa.data_ptr()) if fa is not None else None,
+                                             ctypes.c_void_p(fb.data_ptr()) if fb is not None else None),
+              "rdgpu_accum_shard_inject")
+
+    def finish(self, area_block) -> None:
+        import torch
+
+        suf = {torch.int32: "i32", torch.float32: "f32", torch.float64: "f64"}.get(area_block.dtype)
+        if suf is None or tuple(area_block.shape) != (self._h, self._w) or not area_block.is_contiguous():
+            self.abort()
+            raise RdgpuError("GpuAccumShard.finish: bad area tensor")
+        h, self._handle = self._handle, None
+        check(getattr(lib(), f"rdgpu_accum_shard_finish_{suf}")(h, ctypes.c_void_p(area_block.data_ptr())),
+              "rdgpu_accum_shard_finish")
+
+    def abort(self) -> None:
+        if getattr(self, "_handle", None) is not None:
+            lib().rdgpu_accum_shard_free(self._handle)
+            self._handle = None
+
+
+def accum_exchange_loop(shard, rank: int, world: int, group, to_tensor, from_tensor) -> int:
+    """Outbox / all-gather / inject until no rank sends anything.  Returns the number of exchanges."""
+    import torch
+    import torch.distributed as dist
+
+    rounds = 0
+    while True:
+        allout = _all_gather_stack(to_tensor(shard.outbox()), group)
+        rounds += 1
+        if not bool((allout != 0).any().item()):   # global convergence: nothing crossed any cut
+            return rounds
+        above = from_tensor(allout[rank - 1, 1]) if rank > 0 else None
+        below = from_tensor(allout[rank + 1, 0]) if rank + 1 < world else None
+        shard.inject(above, below)
+
+
+def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None, shard=None) -> int:
+    """d8_flow_accum of the whole raster, computed on row blocks: area_block <- accumulation of this rank's
+    rows.  Collective.  Returns the number of exchanges."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    eng = shard if shard is not None else GpuAccumShard()
+    is_np = isinstance(dirs_block, np.ndarray)
+    to_t = (lambda a: torch.from_numpy(np.ascontiguousarray(a))) if is_np else (lambda a: a)
+    from_t = (lambda t: t.numpy()) if is_np else (lambda t: t)
+    rows = _gather_edge_rows(to_t(dirs_block[0]), to_t(dirs_block[-1]), group)
+    above = from_t(rows[rank - 1, 1]) if rank > 0 else None
+    below = from_t(rows[rank + 1, 0]) if rank + 1 < world else None
+    try:
+        eng.begin(dirs_block, nodata, above, below)
+        rounds = accum_exchange_loop(eng, rank, world, group, to_t, from_t)
+        eng.finish(area_block)
+        return rounds
+    except BaseException:
+        if hasattr(eng, "abort"):
+            eng.abort()
+        raise

@@ -94,3 +94,92 @@ class NumpyShardEngine:
 
     def abort(self):
         pass
+
+
+class NumpyAccumShard:
+    """Pure-Python model of rdgpu_accum_shard_* (same packed outbox format), for the gloo tests."""
+
+    CNT1 = 1 << 56
+    LOW = (1 << 56) - 1
+    DX = [0, -1, -1, 0, 1, 1, 1, 0, -1]
+    DY = [0, 0, -1, -1, -1, 0, 1, 1, 1]
+
+    def begin(self, dirs, nodata, above, below):
+        self.d, self.nd, self.above, self.below = dirs, int(nodata), above, below
+        h, w = dirs.shape
+        self.h, self.w = h, w
+        self.total = np.ones((h, w), np.int64)
+        self.pending = np.zeros((h, w), np.int64)
+        self.done = np.zeros((h, w), bool)
+        self.out = np.zeros((2, w), np.int64)
+
+        def dir_at(x, y):
+            if x < 0 or x >= w:
+                return self.nd
+            if y < 0:
+                return int(above[x]) if above is not None else self.nd
+            if y >= h:
+                return int(below[x]) if below is not None else self.nd
+            return int(dirs[y, x])
+
+        for y in range(h):
+            for x in range(w):
+                if dirs[y, x] == self.nd:
+                    continue
+                for m in range(1, 9):
+                    d = dir_at(x + self.DX[m], y + self.DY[m])
+                    if d != self.nd and d == (m + 4 if m <= 4 else m - 4):
+                        self.pending[y, x] += 1
+        sources = [(x, y) for y in range(h) for x in range(w) if dirs[y, x] != self.nd and self.pending[y, x] == 0]
+        for x, y in sources:   # fixed before any walk: walks complete other cells (pending -> 0) on the way
+            self._walk(x, y)
+
+    def _walk(self, x, y):
+        while True:
+            self.done[y, x] = True
+            v = int(self.total[y, x])
+            d = int(self.d[y, x])
+            if d < 1 or d > 8:
+                return
+            nx, ny = x + self.DX[d], y + self.DY[d]
+            if nx < 0 or nx >= self.w:
+                return
+            if ny < 0:
+                if self.above is not None and int(self.above[nx]) != self.nd:
+                    self.out[0, nx] += v + self.CNT1
+                return
+            if ny >= self.h:
+                if self.below is not None and int(self.below[nx]) != self.nd:
+                    self.out[1, nx] += v + self.CNT1
+                return
+            if int(self.d[ny, nx]) == self.nd:
+                return
+            self.total[ny, nx] += v
+            self.pending[ny, nx] -= 1
+            if self.pending[ny, nx] != 0:
+                return
+            x, y = nx, ny
+
+    def outbox(self):
+        o = self.out.copy()
+        self.out[:] = 0
+        return o
+
+    def inject(self, from_above, from_below):
+        for row, box in ((0, from_above), (self.h - 1, from_below)):
+            if box is None:
+                continue
+            for x in range(self.w):
+                pk = int(box[x])
+                if pk == 0:
+                    continue
+                k, s = pk >> 56, pk & self.LOW
+                self.total[row, x] += s
+                self.pending[row, x] -= k
+                if self.pending[row, x] == 0:
+                    self._walk(x, row)
+
+    def finish(self, area):
+        a = np.where(self.done, self.total, self.total - 1)
+        a = np.where(self.d == self.nd, -1, a)
+        area[...] = a.astype(area.dtype)

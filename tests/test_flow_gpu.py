@@ -118,3 +118,102 @@ def test_large_accumulation_exact(rd, orc):
     assert exp.max() > 1e5
     assert np.array_equal(rd.FlowAccumulation(zf, "D8", nodata=nd), orc.port.fa_d8(zf, nd))
     assert np.array_equal(rd.FlowAccumulation(z, "D8", nodata=nd), orc.port.fa_d8(z, nd))
+
+
+def _accum_blocks_on_one_gpu(rd, dirs_np, world, dtype):
+    """What the ranks of d8_flow_accum_sharded do, block after block on one GPU (no process group)."""
+    import torch
+
+    from richdem_amd.sharded import GpuAccumShard, row_split
+
+    dirs = torch.from_numpy(dirs_np).cuda()
+    spl = row_split(dirs.shape[0], world)
+    blocks = [dirs[a:b].contiguous() for a, b in spl]
+    shards = []
+    for s, blk in enumerate(blocks):
+        sh = GpuAccumShard()
+        sh.begin(blk, 255, blocks[s - 1][-1] if s > 0 else None, blocks[s + 1][0] if s + 1 < world else None)
+        shards.append(sh)
+    rounds = 0
+    while True:
+        outs = [sh.outbox() for sh in shards]
+        rounds += 1
+        if not any(bool((o != 0).any().item()) for o in outs):
+            break
+        for s, sh in enumerate(shards):
+            sh.inject(outs[s - 1][1] if s > 0 else None, outs[s + 1][0] if s + 1 < world else None)
+        assert rounds < 10000
+    areas = []
+    for sh, blk in zip(shards, blocks):
+        a = torch.empty(blk.shape, dtype=dtype, device="cuda")
+        sh.finish(a)
+        areas.append(a)
+    return torch.cat(areas, 0).cpu().numpy(), rounds
+
+
+def test_sharded_accumulation_tiling_invariance(rd, orc):
+    """Row-block shards of d8_flow_accum give the whole-raster answer exactly (the reference's distributed
+    test idea, programs/parallel_d8_accum/test_small.sh), for 2..9 blocks and all output types."""
+    import torch
+
+    z = orc.port.fill(fractal_dem(400, 333, seed=55))
+    dirs = orc.port.flat_resolution(z, np.float32(-9999))
+    dirs[100:110, 50:70] = 255
+    for world in (2, 3, 9):
+        for dt, ndt in ((torch.float64, np.float64), (torch.int32, np.int32), (torch.float32, np.float32)):
+            got, rounds = _accum_blocks_on_one_gpu(rd, dirs, world, dt)
+            assert np.array_equal(got, orc.port.d8_flow_accum(dirs, 255, ndt)), (world, dt)
+            assert rounds >= 2
+    # 2-row shards, raw (unresolved) directions with NO_FLOW cells, fixtures
+    raw = orc.port.d8_flowdirs(fractal_dem(90, 64, seed=56), np.float32(-9999))
+    got, _ = _accum_blocks_on_one_gpu(rd, raw, 32, torch.float64)
+    assert np.array_equal(got, orc.port.d8_flow_accum(raw, 255, np.float64))
+
+
+def test_sharded_pipeline_one_rank_group(rd, orc):
+    """fill -> d8 directions -> accumulation through the collective entry points on a 1-rank RCCL group."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from richdem_amd.sharded import d8_flow_accum_sharded, d8_flow_directions_sharded, fill_depressions_sharded
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        z = fractal_dem(600, 450, seed=57)
+        t = torch.from_numpy(z).cuda()
+        fill_depressions_sharded(t)
+        dirs = d8_flow_directions_sharded(t, -9999.0, flats=True)
+        area = torch.empty(t.shape, dtype=torch.float64, device="cuda")
+        d8_flow_accum_sharded(dirs, area)
+        ez = orc.port.fill(z)
+        ed = orc.port.flat_resolution(ez, np.float32(-9999))
+        assert np.array_equal(t.cpu().numpy(), ez)
+        assert np.array_equal(dirs.cpu().numpy(), ed)
+        assert np.array_equal(area.cpu().numpy(), orc.port.d8_flow_accum(ed, 255, np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_directions_halo(rd, orc):
+    """d8 directions of row blocks with a 1-row halo equal the whole-raster directions."""
+    import torch
+
+    z = fractal_dem(300, 257, seed=58)
+    z[120:130, 40:60] = -9999.0
+    exp = orc.port.d8_flowdirs(z, np.float32(-9999))
+    from richdem_amd.sharded import row_split
+
+    t = torch.from_numpy(z).cuda()
+    for world in (2, 5):
+        outs = []
+        for s, (a, b) in enumerate(row_split(z.shape[0], world)):
+            lo, hi = max(a - 1, 0), min(b + 1, z.shape[0])
+            halo = t[lo:hi].contiguous()
+            d = torch.empty(halo.shape, dtype=torch.uint8, device="cuda")
+            rd.d8_flow_directions_dev(halo, -9999.0, d)
+            outs.append(d[a - lo : a - lo + (b - a)])
+        assert np.array_equal(torch.cat(outs, 0).cpu().numpy(), exp), world
