@@ -13,8 +13,8 @@
  *   rdgpu_<op>_dev_<dtype>(device pointers...) HBM-resident variant (bench.py,
  *                                              multi-GPU shards, chaining stages)
  *
- * dtype suffixes: u8 i16 u16 i32 u32 f32 (32-bit-key engine).  f64/i64/u64 are
- * rejected with RDGPU_ERR_UNSUPPORTED in this round.
+ * dtype suffixes: u8 i16 u16 i32 u32 f32 (32-bit-key engine) and f64 i64 u64 (fill only, through
+ * value ranks; the row-block shard entry points take the 32-bit types).
  *
  * Threading: one host thread at a time per process (the reference functions
  * are not internally re-entrant on shared arrays either).
@@ -52,6 +52,11 @@ int rdgpu_fill_u16(uint16_t *dem, int width, int height, int topology);
 int rdgpu_fill_i32(int32_t *dem, int width, int height, int topology);
 int rdgpu_fill_u32(uint32_t *dem, int width, int height, int topology);
 int rdgpu_fill_f32(float *dem, int width, int height, int topology);
+/* 64-bit element types: exact as well -- f64 DEMs whose values fit f32 run the f32 engine, everything
+ * else is filled on dense ranks of the values (csrc/fill64.hip). */
+int rdgpu_fill_f64(double *dem, int width, int height, int topology);
+int rdgpu_fill_i64(int64_t *dem, int width, int height, int topology);
+int rdgpu_fill_u64(uint64_t *dem, int width, int height, int topology);
 
 int rdgpu_fill_dev_u8(uint8_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_i16(int16_t *d_dem, int width, int height, int topology, void *hip_stream);
@@ -59,6 +64,9 @@ int rdgpu_fill_dev_u16(uint16_t *d_dem, int width, int height, int topology, voi
 int rdgpu_fill_dev_i32(int32_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u32(uint32_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_f32(float *d_dem, int width, int height, int topology, void *hip_stream);
+int rdgpu_fill_dev_f64(double *d_dem, int width, int height, int topology, void *hip_stream);
+int rdgpu_fill_dev_i64(int64_t *d_dem, int width, int height, int topology, void *hip_stream);
+int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, void *hip_stream);
 
 /* Statistics of the last fill on this process (for DESIGN.md / bench.py reporting). */
 typedef struct rdgpu_fill_stats {

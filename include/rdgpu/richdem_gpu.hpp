@@ -47,6 +47,9 @@ RDGPU_SHIM_ELEV(u16, uint16_t)
 RDGPU_SHIM_ELEV(i32, int32_t)
 RDGPU_SHIM_ELEV(u32, uint32_t)
 RDGPU_SHIM_ELEV(f32, float)
+RDGPU_SHIM_ELEV(f64, double)
+RDGPU_SHIM_ELEV(i64, int64_t)
+RDGPU_SHIM_ELEV(u64, uint64_t)
 #undef RDGPU_SHIM_ELEV
 template <class T>
 int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }

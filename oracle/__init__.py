@@ -29,6 +29,8 @@ _SUFFIX = {
     np.dtype(np.uint32): "u32",
     np.dtype(np.float32): "f32",
     np.dtype(np.float64): "f64",
+    np.dtype(np.int64): "i64",
+    np.dtype(np.uint64): "u64",
 }
 _CT = {
     "u8": ctypes.c_uint8,
@@ -38,6 +40,8 @@ _CT = {
     "u32": ctypes.c_uint32,
     "f32": ctypes.c_float,
     "f64": ctypes.c_double,
+    "i64": ctypes.c_int64,
+    "u64": ctypes.c_uint64,
 }
 #: variants of the reference fill (oracle/ref_wrap.cpp ref_fill)
 ZHOU2016, BARNES2014_D8, BARNES2014_D4, WEI2018, ORIGINAL_D8 = 0, 1, 2, 3, 4

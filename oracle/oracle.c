@@ -67,6 +67,16 @@ static const int D4Y[5] = {0, 0, -1, 0, 1};
 #include "oracle_impl.h"
 #undef T
 #undef SUF
+#define T int64_t
+#define SUF i64
+#include "oracle_impl.h"
+#undef T
+#undef SUF
+#define T uint64_t
+#define SUF u64
+#include "oracle_impl.h"
+#undef T
+#undef SUF
 
 /* d8_masked_FlowDir, flats/flat_resolution.hpp:42-65, applied as in
  * d8_flow_flats :96-116 (interior cells whose direction is NO_FLOW). */

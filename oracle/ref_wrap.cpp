@@ -134,6 +134,8 @@ REF_ELEV_API(i32, int32_t)
 REF_ELEV_API(u32, uint32_t)
 REF_ELEV_API(f32, float)
 REF_ELEV_API(f64, double)
+REF_ELEV_API(i64, int64_t)
+REF_ELEV_API(u64, uint64_t)
 
 extern "C" void ref_d8_flow_accum_i32(const uint8_t *dirs, uint8_t nodata, int w, int h, int32_t *out) {
   ref_d8_flow_accum<int32_t>(dirs, nodata, w, h, out);

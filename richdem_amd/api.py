@@ -18,12 +18,14 @@ _SUFFIX = {
     np.dtype(np.int32): "i32",
     np.dtype(np.uint32): "u32",
     np.dtype(np.float32): "f32",
+    np.dtype(np.float64): "f64",
+    np.dtype(np.int64): "i64",
+    np.dtype(np.uint64): "u64",
 }
 _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
 _CT = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "u16": ctypes.c_uint16, "i32": ctypes.c_int32,
        "u32": ctypes.c_uint32, "f32": ctypes.c_float, "f64": ctypes.c_double}
-_ELEV_SUFFIX = dict(_SUFFIX)
-_ELEV_SUFFIX[np.dtype(np.float64)] = "f64"   # stencil/accumulation entry points also take f64 DEMs
+_ELEV_SUFFIX = {k: v for k, v in _SUFFIX.items() if v not in ("i64", "u64")}   # stencil / accumulation entry points
 _ACC_SUFFIX = {np.dtype(np.int32): "i32", np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 
 
@@ -155,7 +157,8 @@ def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights:
 def _torch_suffix(t) -> str:
     import torch
 
-    m = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32"}
+    m = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32", torch.float64: "f64",
+         torch.int64: "i64"}
     if t.dtype not in m:
         raise RdgpuError(f"unsupported tensor dtype {t.dtype}")
     return m[t.dtype]

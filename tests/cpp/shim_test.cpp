@@ -24,6 +24,7 @@ using Topo = rdgpu::Topology;
 extern "C" {
 void orc_fill_f32(float *, int, int, int);
 void orc_fill_i32(int32_t *, int, int, int);
+void orc_fill_f64(double *, int, int, int);
 void orc_flat_resolution_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
@@ -127,9 +128,25 @@ int main() {
     try { rdgpu::FA_D8(dem, wrong); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
   }
+  // double DEMs (the Python wrapper's default dtype): lossless-f32 path and value-rank path
+  {
+    Arr<double> d(w, h, 0.0), g(w, h, 0.0);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) { d(x, y) = noise(x, y); g(x, y) = noise(x, y) + 1e-9 * ((x * 7 + y * 13) % 11); }
+    std::vector<float> e = ref;
+    orc_fill_f32(e.data(), w, h, 8);
+    rdgpu::FillDepressions<Topo::D8>(d);
+    bool same = true;
+    for (size_t i = 0; i < e.size(); i++) same &= d.data()[i] == (double)e[i];
+    EXPECT(same);
+    std::vector<double> eg(g.data(), g.data() + (size_t)w * h);
+    orc_fill_f64(eg.data(), w, h, 8);
+    rdgpu::FillDepressions<Topo::D8>(g);
+    EXPECT(std::memcmp(g.data(), eg.data(), eg.size() * 8) == 0);
+  }
   // unsupported element type -> std::runtime_error, the reference's error convention
   {
-    Arr<double> d(8, 8, 1.0);
+    Arr<int8_t> d(8, 8, 1);
     bool threw = false;
     try { rdgpu::FillDepressions<Topo::D8>(d); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);

@@ -262,3 +262,28 @@ def test_gpu_shard_engine_python_protocol(rd, orc):
         assert np.array_equal(t.cpu().numpy(), exp)
     finally:
         dist.destroy_process_group()
+
+
+def test_64bit_element_types(rd, orc):
+    """f64 / i64 / u64 DEMs: lossless-f32 fast path and the value-rank path, D8 and D4."""
+    z = fractal_dem(333, 250, seed=201)
+    d_lossless = z.astype(np.float64)                                   # every value fits f32
+    d_general = z.astype(np.float64) + 1e-9 * (np.arange(z.size).reshape(z.shape) % 977)   # needs ranks
+    d_i64 = (np.floor(z * 1000).astype(np.int64) << 24) - (1 << 40)     # beyond 32 bits, mixed signs
+    d_u64 = (np.floor((z - z.min()) * 10).astype(np.uint64) << 40) + np.uint64(1 << 63)
+    flats = np.floor(z * 0.05).astype(np.float64) + 0.1                 # not f32-exact, huge ties
+    for dem in (d_lossless, d_general, d_i64, d_u64, flats):
+        for topo in (8, 4):
+            got = rd.FillDepressions(dem, topology=topo)
+            exp = orc.port.fill(dem, topo)
+            assert got.dtype == dem.dtype
+            assert np.array_equal(got, exp), (dem.dtype, topo)
+            if dem.dtype != np.float64:
+                assert got.tobytes() == exp.tobytes()
+    edge = np.array([[5.0, 5.0, 5.0, 5.0], [5.0, -0.0, 0.0, 5.0], [5.0, 1e-320, -1e308, 5.0], [5.0, 5.0, 5.0, 5.0]])
+    assert np.array_equal(rd.FillDepressions(edge), orc.port.fill(edge))
+    import torch
+
+    t = torch.from_numpy(d_general).cuda()
+    rd.fill_depressions_dev(t)
+    assert np.array_equal(t.cpu().numpy(), orc.port.fill(d_general))

@@ -52,14 +52,20 @@ def test_port_matches_generated_reference_outputs(orc, generated):
 
 
 @pytest.mark.parametrize("seed,scale,dtype", [(21, 1.0, np.float32), (22, 1.0, np.int32), (23, 0.05, np.int32),
-                                              (24, 0.2, np.int16), (25, 0.1, np.uint16), (26, 0.05, np.uint8)])
+                                              (24, 0.2, np.int16), (25, 0.1, np.uint16), (26, 0.05, np.uint8),
+                                              (27, 1.0, np.float64), (28, 3.0, np.int64), (29, 0.5, np.uint64)])
 def test_port_matches_live_reference(orc, seed, scale, dtype):
     if not orc.ref.available:
         pytest.skip("oracle/_ref/libref.so not built here")
     from richdem_amd.synth import fractal_dem
 
     z = fractal_dem(150, 110, seed)
-    dem = z if dtype == np.float32 else np.floor((z - z.min()) * scale).astype(dtype)
+    if dtype == np.float32:
+        dem = z
+    elif dtype == np.float64:
+        dem = z.astype(np.float64) + 1e-7 * np.arange(z.size).reshape(z.shape)   # not representable in f32
+    else:
+        dem = np.floor((z - z.min()) * scale).astype(dtype)
     nd = dtype(0) if np.issubdtype(dtype, np.unsignedinteger) else dtype(-9999)
     P, R = orc.port, orc.ref
     filled = P.fill(dem, 8)
