@@ -249,6 +249,36 @@ int rdgpu_fa_d8_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int h
 int rdgpu_fa_d8_dev_f32(const float *d_dem, float nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_f64(const double *d_dem, double nodata, int width, int height, double *d_accum, void *hip_stream);
 
+/* ---- D-infinity (Tarboton 1997) and the generic FlowAccumulation ---------------------------------
+ * rdgpu_dinf_flowdirs_<T>   replaces richdem::dinf_flow_directions (include/richdem/flowmet/dinf_flowdirs.hpp
+ *                           :128-152): float32 angle in [0, 2*pi), 0 = NO_FLOW, -1 = NoData.
+ * rdgpu_fm_tarboton_<T>     replaces richdem::FM_Tarboton / FM_Dinfinity (flowmet/Tarboton1997.hpp:14-144):
+ *                           9 floats per cell, index 9*i+n (common/Array3D.hpp:203-206).
+ * rdgpu_fa_tarboton_<T>     replaces richdem::FA_Tarboton / FA_Dinfinity (methods/flow_accumulation.hpp:16-17);
+ *                           accum in/out like rdgpu_fa_d8_*.
+ * rdgpu_flow_accumulation_f64  replaces richdem::FlowAccumulation(const Array3D<float>&, Array2D<double>&)
+ *                           (methods/flow_accumulation_generic.hpp:33-100) for ANY proportions array.
+ * Angles/proportions use double atan2/sqrt as the reference does; device libm may differ from glibc in the
+ * last ulp, so these are specified to <= 1 ULP (f32), not bit-exact; accumulation sums in a different
+ * order than the reference's FIFO (exact for integer-valued flows). */
+#define RDGPU_DECL_MFD(SUF, T)                                                                          \
+  int rdgpu_dinf_flowdirs_##SUF(const T *dem, T nodata, int width, int height, float *angles);           \
+  int rdgpu_dinf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int width, int height, float *d_angles, void *hip_stream); \
+  int rdgpu_fm_tarboton_##SUF(const T *dem, T nodata, int width, int height, float *props9);             \
+  int rdgpu_fa_tarboton_##SUF(const T *dem, T nodata, int width, int height, double *accum);             \
+  int rdgpu_fa_tarboton_dev_##SUF(const T *d_dem, T nodata, int width, int height, double *d_accum, void *hip_stream);
+RDGPU_DECL_MFD(u8, uint8_t)
+RDGPU_DECL_MFD(i16, int16_t)
+RDGPU_DECL_MFD(u16, uint16_t)
+RDGPU_DECL_MFD(i32, int32_t)
+RDGPU_DECL_MFD(u32, uint32_t)
+RDGPU_DECL_MFD(f32, float)
+RDGPU_DECL_MFD(f64, double)
+#undef RDGPU_DECL_MFD
+int rdgpu_flow_accumulation_f64(const float *props9, int width, int height, double *accum);
+int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_flow_accumulation_rounds(uint32_t *rounds); /* work-list rounds of the last generic accumulation */
+
 /* ---- synthetic input (test/bench input generator) ----------- */
 int rdgpu_synth_dem_dev_f32(float *d_dem, int width, int height, int seed, int x0, int y0,
                             float tilt, void *hip_stream);

@@ -57,7 +57,9 @@ int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
 #define RDGPU_SHIM_STENCIL(SUF, T)                                                                         \
   inline int c_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_d8_flowdirs_##SUF(p, nd, w, h, o); } \
   inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
-  inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); }
+  inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
+  inline int c_fa_dinf(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_tarboton_##SUF(p, nd, w, h, a); } \
+  inline int c_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_dinf_flowdirs_##SUF(p, nd, w, h, o); }
 RDGPU_SHIM_STENCIL(u8, uint8_t)
 RDGPU_SHIM_STENCIL(i16, int16_t)
 RDGPU_SHIM_STENCIL(u16, uint16_t)
@@ -72,6 +74,10 @@ template <class T>
 int c_flatres(const T *, T, int, int, uint8_t *) { unsupported("barnes_flat_resolution_d8"); }
 template <class T>
 int c_fa_d8(const T *, T, int, int, double *) { unsupported("FA_D8"); }
+template <class T>
+int c_fa_dinf(const T *, T, int, int, double *) { unsupported("FA_Tarboton"); }
+template <class T>
+int c_dinf(const T *, T, int, int, float *) { unsupported("dinf_flow_directions"); }
 
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, int32_t *a) { return rdgpu_d8_flow_accum_i32(d, nd, w, h, a); }
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, float *a) { return rdgpu_d8_flow_accum_f32(d, nd, w, h, a); }
@@ -175,6 +181,35 @@ void FA_D8(const E &elevations, G &accum) {
   detail::check(detail::c_fa_d8((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(),
                                 accum.data()),
                 "FA_D8");
+}
+
+// richdem::FA_Tarboton / FA_Dinfinity(const Array2D<elev_t>&, Array2D<accum_t>&)   methods/flow_accumulation.hpp:16-17
+template <class E, class G>
+void FA_Tarboton(const E &elevations, G &accum) {
+  using T = detail::elem_t<E>;
+  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FA_Tarboton: the accumulation array must be Array2D<double>");
+  accum.setNoData(-1.0);
+  if (accum.width() != elevations.width() || accum.height() != elevations.height())
+    throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_fa_dinf((const T *)elevations.data(), elevations.noData(), elevations.width(),
+                                  elevations.height(), accum.data()),
+                "FA_Tarboton");
+}
+template <class E, class G>
+void FA_Dinfinity(const E &elevations, G &accum) { FA_Tarboton(elevations, accum); }
+
+// richdem::dinf_flow_directions(const Array2D<T>&, Array2D<float>&)   flowmet/dinf_flowdirs.hpp:128-152
+template <class E, class F>
+void dinf_flow_directions(const E &elevations, F &flowdirs) {
+  using T = detail::elem_t<E>;
+  static_assert(std::is_same<detail::elem_t<F>, float>::value, "dinf_flow_directions: flowdirs must be Array2D<float>");
+  flowdirs.resize(elevations);          // :137
+  flowdirs.setNoData(-1.0f);            // dinf_NO_DATA, :138
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_dinf((const T *)elevations.data(), elevations.noData(), elevations.width(),
+                               elevations.height(), flowdirs.data()),
+                "dinf_flow_directions");
 }
 
 }  // namespace rdgpu

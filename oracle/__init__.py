@@ -165,6 +165,30 @@ class _Backend:
         self._fn(f"fm_d8_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
         return out
 
+    def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        out = np.empty((h, w), np.float32)
+        self._fn(f"dinf_flowdirs_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
+        return out
+
+    def fm_tarboton(self, dem: np.ndarray, nodata) -> np.ndarray:
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        out = np.empty((h, w, 9), np.float32)
+        self._fn(f"fm_tarboton_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
+        return out
+
+    def fa_tarboton(self, dem: np.ndarray, nodata, weights: np.ndarray | None = None) -> np.ndarray:
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        acc = np.ones((h, w), np.float64) if weights is None else np.ascontiguousarray(weights, dtype=np.float64).copy()
+        self._fn(f"fa_tarboton_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(acc))
+        return acc
+
     def flow_accumulation(self, props9: np.ndarray, weights: np.ndarray | None = None) -> np.ndarray:
         props9 = np.ascontiguousarray(props9, dtype=np.float32)
         h, w, _ = props9.shape

@@ -21,6 +21,9 @@
  *
  * Build: gcc -O2 -std=c11 -shared -fPIC oracle.c -o liboracle.so  (oracle/Makefile)
  */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

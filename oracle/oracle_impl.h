@@ -288,6 +288,104 @@ void FN(orc_fa_d8)(const T *dem, T nodata, int w, int h, double *accum) {
   free(props);
 }
 
+/* ------------------------------------------------------------------------- */
+/* dinf_FlowDir + dinf_flow_directions, flowmet/dinf_flowdirs.hpp:45-115,    */
+/* :128-152 (facet tables :21-27).                                           */
+/* ------------------------------------------------------------------------- */
+void FN(orc_dinf_flowdirs)(const T *dem, T nodata, int w, int h, float *out) {
+  static const int dy_e1[8] = {0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[8] = {1, 0, 0, -1, -1, 0, 0, 1};
+  static const int dy_e2[8] = {-1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[8] = {1, 1, -1, -1, -1, -1, 1, 1};
+  static const double ac[8] = {0., 1., 1., 2., 2., 3., 3., 4.}, af[8] = {1., -1., 1., -1., 1., -1., 1., -1.};
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) { out[i] = -1.0f; continue; }                  /* :147-148 */
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {                  /* :46-63 */
+        double a;
+        if (x == 0 && y == 0) a = 3 * M_PI / 4;
+        else if (x == 0 && y == h - 1) a = 5 * M_PI / 4;
+        else if (x == w - 1 && y == 0) a = 1 * M_PI / 4;
+        else if (x == w - 1 && y == h - 1) a = 7 * M_PI / 4;
+        else if (x == 0) a = 4 * M_PI / 4;
+        else if (x == w - 1) a = 0 * M_PI / 4;
+        else if (y == 0) a = 2 * M_PI / 4;
+        else a = 6 * M_PI / 4;
+        out[i] = (float)a;
+        continue;
+      }
+      int nmax = -1;
+      double smax = 0, rmax = 0;
+      for (int n = 0; n < 8; n++) {                                        /* :68-96 */
+        const double e0 = (double)dem[i];
+        const double e1 = (double)dem[(size_t)(y + dy_e1[n]) * w + (x + dx_e1[n])];
+        const double e2 = (double)dem[(size_t)(y + dy_e2[n]) * w + (x + dx_e2[n])];
+        const double d1 = 1, d2 = 1;
+        const double s1 = (e0 - e1) / d1, s2 = (e1 - e2) / d2;
+        double r = atan2(s2, s1), s;
+        if (r < 0) { r = 0; s = s1; }
+        else if (r > atan2(d2, d1)) { r = atan2(d2, d1); s = (e0 - e2) / sqrt(d1 * d1 + d2 * d2); }
+        else s = sqrt(s1 * s1 + s2 * s2);
+        if (s > smax) { smax = s; nmax = n; rmax = r; }
+      }
+      double rg = 0;                                                       /* NO_FLOW */
+      if (nmax != -1) rg = af[nmax] * rmax + ac[nmax] * M_PI / 2;
+      out[i] = (float)rg;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* FM_Tarboton = FM_Dinfinity, flowmet/Tarboton1997.hpp:14-144.              */
+/* ------------------------------------------------------------------------- */
+void FN(orc_fm_tarboton)(const T *dem, T nodata, int w, int h, float *props9) {
+  static const int dy_e1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[9] = {0, -1, 0, 0, 1, 1, 0, 0, -1};
+  static const int dy_e2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[9] = {0, -1, -1, 1, 1, 1, 1, -1, -1};
+  static const double af[9] = {0, -1., 1., -1., 1., -1., 1., -1., 1.};
+  const double d1 = 1, d2 = 1;
+  const float dang = (float)atan2(d2, d1);                                 /* :27 */
+  size_t N = (size_t)w * h;
+  for (size_t i = 0; i < N * 9; i++) props9[i] = -1.0f;                    /* :25 */
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) { props9[9 * i] = -2.0f; continue; }           /* :44-47 */
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;          /* :49-50 */
+      int nmax = -1;
+      double smax = 0;
+      float rmax = 0;
+      for (int n = 1; n <= 8; n++) {                                       /* :56-92; neighbours of interior cells are in grid */
+        const T v1 = dem[(size_t)(y + dy_e1[n]) * w + (x + dx_e1[n])], v2 = dem[(size_t)(y + dy_e2[n]) * w + (x + dx_e2[n])];
+        if (v1 == nodata || v2 == nodata) continue;
+        const double e0 = (double)dem[i], e1 = (double)v1, e2 = (double)v2;
+        const double s1 = (e0 - e1) / d1, s2 = (e1 - e2) / d2;
+        double r = atan2(s2, s1), s;
+        if (r < 1e-7) { r = 0; s = s1; }
+        else if (r > dang - 1e-7) { r = dang; s = (e0 - e2) / sqrt(d1 * d1 + d2 * d2); }
+        else s = sqrt(s1 * s1 + s2 * s2);
+        if (s > smax) { smax = s; nmax = n; rmax = (float)r; }
+      }
+      if (nmax == -1) continue;
+      props9[9 * i] = 0.0f;                                                /* :97 */
+      if (af[nmax] == 1 && rmax == 0) rmax = dang;                         /* :99-104 */
+      else if (af[nmax] == 1 && rmax == dang) rmax = 0;
+      else if (af[nmax] == 1) rmax = (float)(M_PI / 4 - rmax);
+      const int nxt = nmax + 1 == 9 ? 1 : nmax + 1;
+      if (rmax == 0) props9[9 * i + nmax] = 1;                             /* :106-113 */
+      else if (rmax == dang) props9[9 * i + nxt] = 1;
+      else {
+        props9[9 * i + nmax] = (float)(rmax / (M_PI / 4.));
+        props9[9 * i + nxt] = (float)(1 - rmax / (M_PI / 4.));
+      }
+    }
+}
+
+/* FA_Tarboton, methods/flow_accumulation.hpp:16 */
+void FN(orc_fa_tarboton)(const T *dem, T nodata, int w, int h, double *accum) {
+  float *props = (float *)malloc((size_t)w * h * 9 * sizeof(float));
+  FN(orc_fm_tarboton)(dem, nodata, w, h, props);
+  orc_flow_accumulation_f64(props, w, h, accum);
+  free(props);
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

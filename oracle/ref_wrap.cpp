@@ -15,6 +15,7 @@
 #include <richdem/common/Array3D.hpp>
 #include <richdem/depressions/depressions.hpp>
 #include <richdem/flowmet/d8_flowdirs.hpp>
+#include <richdem/flowmet/dinf_flowdirs.hpp>
 #include <richdem/flats/flat_resolution.hpp>
 #include <richdem/methods/d8_methods.hpp>
 #include <richdem/methods/flow_accumulation.hpp>
@@ -106,6 +107,32 @@ void ref_fm_d8(const T *dem, T nodata, int w, int h, float *props9) {
   std::memcpy(props9, props.getData(), (size_t)w * h * 9 * sizeof(float));
 }
 
+template <class T>
+void ref_dinf_flowdirs(const T *dem, T nodata, int w, int h, float *out) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<float> fd;
+  dinf_flow_directions(a, fd);   // flowmet/dinf_flowdirs.hpp:128-152
+  std::memcpy(out, fd.data(), (size_t)w * h * sizeof(float));
+}
+
+template <class T>
+void ref_fm_tarboton(const T *dem, T nodata, int w, int h, float *props9) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array3D<float> props(a);
+  FM_Tarboton(a, props);         // flowmet/Tarboton1997.hpp:14-144
+  std::memcpy(props9, props.getData(), (size_t)w * h * 9 * sizeof(float));
+}
+
+template <class T>
+void ref_fa_tarboton(const T *dem, T nodata, int w, int h, double *accum) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<double> acc(accum, w, h);
+  FA_Tarboton(a, acc);           // methods/flow_accumulation.hpp:16
+}
+
 } // namespace
 
 #define REF_ELEV_API(SUF, T)                                                                     \
@@ -125,6 +152,15 @@ void ref_fm_d8(const T *dem, T nodata, int w, int h, float *props9) {
   }                                                                                              \
   extern "C" void ref_fm_d8_##SUF(const T *dem, T nodata, int w, int h, float *props9) {         \
     ref_fm_d8<T>(dem, nodata, w, h, props9);                                                     \
+  }                                                                                              \
+  extern "C" void ref_dinf_flowdirs_##SUF(const T *dem, T nodata, int w, int h, float *out) {    \
+    ref_dinf_flowdirs<T>(dem, nodata, w, h, out);                                                \
+  }                                                                                              \
+  extern "C" void ref_fm_tarboton_##SUF(const T *dem, T nodata, int w, int h, float *props9) {   \
+    ref_fm_tarboton<T>(dem, nodata, w, h, props9);                                               \
+  }                                                                                              \
+  extern "C" void ref_fa_tarboton_##SUF(const T *dem, T nodata, int w, int h, double *accum) {   \
+    ref_fa_tarboton<T>(dem, nodata, w, h, accum);                                                \
   }
 
 REF_ELEV_API(u8, uint8_t)

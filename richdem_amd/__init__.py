@@ -24,6 +24,9 @@ from ._lib import (  # noqa: F401
 from .api import (  # noqa: F401
     FillDepressions,
     FlowAccumulation,
+    FlowProportions,
+    FlowAccumFromProps,
+    dinf_flow_directions,
     d8_flow_directions,
     d8_flow_accum,
     barnes_flat_resolution_d8,
@@ -42,6 +45,9 @@ __all__ = [
     "build",
     "FillDepressions",
     "FlowAccumulation",
+    "FlowProportions",
+    "FlowAccumFromProps",
+    "dinf_flow_directions",
     "d8_flow_directions",
     "d8_flow_accum",
     "barnes_flat_resolution_d8",

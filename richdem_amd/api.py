@@ -133,12 +133,53 @@ def d8_flow_accum(dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.n
     return out
 
 
+def dinf_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
+    """float32 D-infinity angles (reference dinf_flow_directions, flowmet/dinf_flowdirs.hpp:128-152)."""
+    dem, s = _elev(dem, "dinf_flow_directions")
+    h, w = dem.shape
+    out = np.empty((h, w), np.float32)
+    check(getattr(lib(), f"rdgpu_dinf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
+                                                     out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_dinf_flowdirs")
+    return out
+
+
+def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999) -> np.ndarray:
+    """[h, w, 9] float32 flow proportions (reference ``rd.FlowProportions``, FM_Tarboton,
+    flowmet/Tarboton1997.hpp:14-144)."""
+    if method not in ("Dinf", "Tarboton"):
+        raise RdgpuError(f"FlowProportions: method {method!r} is not part of this round's hot path")
+    dem, s = _elev(dem, "FlowProportions")
+    h, w = dem.shape
+    out = np.empty((h, w, 9), np.float32)
+    check(getattr(lib(), f"rdgpu_fm_tarboton_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
+                                                   out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_fm_tarboton")
+    return out
+
+
+def FlowAccumFromProps(props: np.ndarray, weights: np.ndarray | None = None) -> np.ndarray:
+    """Generic accumulation over a 9-float proportions array (reference ``rd.FlowAccumFromProps`` ->
+    FlowAccumulation, methods/flow_accumulation_generic.hpp:33-100)."""
+    if not isinstance(props, np.ndarray) or props.ndim != 3 or props.shape[2] != 9:
+        raise RdgpuError("FlowAccumFromProps: expected an [h, w, 9] array")
+    props = np.ascontiguousarray(props, dtype=np.float32)
+    h, w, _ = props.shape
+    if weights is None:
+        acc = np.ones((h, w), np.float64)
+    else:
+        if weights.shape != (h, w):
+            raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
+        acc = np.ascontiguousarray(weights, dtype=np.float64).copy()
+    check(lib().rdgpu_flow_accumulation_f64(props.ctypes.data_as(ctypes.c_void_p), w, h,
+                                            acc.ctypes.data_as(ctypes.c_void_p)), "rdgpu_flow_accumulation_f64")
+    return acc
+
+
 def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights: np.ndarray | None = None):
     """Flow accumulation (reference ``rd.FlowAccumulation(dem, method='D8', weights=...)``,
     wrappers/pyrichdem/richdem/__init__.py:490-597 -> FA_D8, methods/flow_accumulation.hpp:27).
     Returns float64 accumulation; NoData cells get -1."""
-    if method != "D8":
-        raise RdgpuError(f"FlowAccumulation: method {method!r} is not part of this round's hot path (only 'D8')")
+    if method not in ("D8", "Dinf", "Tarboton"):
+        raise RdgpuError(f"FlowAccumulation: method {method!r} is not part of this round's hot path (D8, Dinf)")
     dem, s = _elev(dem, "FlowAccumulation")
     h, w = dem.shape
     if weights is None:
@@ -147,9 +188,9 @@ def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights:
         if weights.shape != dem.shape:             # flow_accumulation_generic.hpp:42-43
             raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
         acc = np.ascontiguousarray(weights, dtype=np.float64).copy()
-    fn = getattr(lib(), f"rdgpu_fa_d8_{s}")
+    fn = getattr(lib(), f"rdgpu_fa_d8_{s}" if method == "D8" else f"rdgpu_fa_tarboton_{s}")
     check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, acc.ctypes.data_as(ctypes.c_void_p)),
-          "rdgpu_fa_d8")
+          "rdgpu_fa_d8" if method == "D8" else "rdgpu_fa_tarboton")
     return acc
 
 

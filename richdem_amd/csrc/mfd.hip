@@ -1,0 +1,459 @@
+// mfd.hip -- D-infinity flow directions / proportions and the generic (multiple-receiver) flow accumulation.
+//
+//  * rdgpu_dinf_flowdirs_*        replaces dinf_flow_directions / dinf_FlowDir
+//                                 (reference include/richdem/flowmet/dinf_flowdirs.hpp:128-152, :45-115)
+//  * rdgpu_fm_tarboton_*          replaces FM_Tarboton = FM_Dinfinity (flowmet/Tarboton1997.hpp:14-144):
+//                                 the 9-float-per-cell proportions array (common/Array3D.hpp:203-206)
+//  * rdgpu_flow_accumulation_f64  replaces FlowAccumulation(const Array3D<float>&, Array2D<double>&)
+//                                 (methods/flow_accumulation_generic.hpp:33-100) for any proportions array
+//  * rdgpu_fa_tarboton_*          replaces FA_Tarboton / FA_Dinfinity (methods/flow_accumulation.hpp:16-17)
+//                                 without materialising the 36 B/cell array: 5 B/cell (receiver, share)
+//
+// The slope/angle arithmetic is done in double with atan2/sqrt exactly as written in the reference
+// (-ffp-contract=off: no FMA contraction); device libm may differ from glibc in the last ulp of atan2, so
+// these outputs are compared with a tolerance (north_star: <= 1 ULP in f32), not bit for bit.
+//
+// Accumulation: "last arriver continues" generalised to several receivers.  A completed cell pushes
+// share*total to each receiver with a returning device-scope atomic add and decrements the receiver's
+// pending-donor count; it continues inline with the first receiver it completed and flags the others;
+// flagged cells are compacted into the next round's work list.  f64 sums in a different order than the
+// reference's FIFO: exact for integer-valued flows, f64 rounding otherwise.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace rdgpu {
+
+constexpr int NTHR = 256;
+static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + NTHR - 1) / NTHR, 256u * 32u); }
+
+__device__ __forceinline__ int mdx(int n) { return (n == 1 || n == 2 || n == 8) ? -1 : (n >= 4 && n <= 6) ? 1 : 0; }
+__device__ __forceinline__ int mdy(int n) { return (n >= 2 && n <= 4) ? -1 : (n >= 6 && n <= 8) ? 1 : 0; }
+
+// ------------------------------------------------------------------------------------------
+// dinf_FlowDir, flowmet/dinf_flowdirs.hpp:45-115 (facet tables :21-27)
+// ------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_dinf_dirs(const T *__restrict__ z, T nodata, float *__restrict__ out, int w,
+                                                    int h) {
+  const int dy_e1[8] = {0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[8] = {1, 0, 0, -1, -1, 0, 0, 1};
+  const int dy_e2[8] = {-1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[8] = {1, 1, -1, -1, -1, -1, 1, 1};
+  const double ac[8] = {0., 1., 1., 2., 2., 3., 3., 4.}, af[8] = {1., -1., 1., -1., 1., -1., 1., -1.};
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    if (z[c] == nodata) { out[c] = -1.0f; continue; }                 // dinf_NO_DATA, :147-148
+    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {               // :46-63
+      double a;
+      if (x == 0 && y == 0) a = 3 * M_PI / 4;
+      else if (x == 0 && y == h - 1) a = 5 * M_PI / 4;
+      else if (x == w - 1 && y == 0) a = 1 * M_PI / 4;
+      else if (x == w - 1 && y == h - 1) a = 7 * M_PI / 4;
+      else if (x == 0) a = 4 * M_PI / 4;
+      else if (x == w - 1) a = 0 * M_PI / 4;
+      else if (y == 0) a = 2 * M_PI / 4;
+      else a = 6 * M_PI / 4;
+      out[c] = (float)a;
+      continue;
+    }
+    int nmax = -1;
+    double smax = 0, rmax = 0;
+    const double e0 = (double)z[c];
+    const double quarter = atan2(1.0, 1.0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {                                      // :68-96
+      const double e1 = (double)z[(size_t)(y + dy_e1[k]) * w + (x + dx_e1[k])];
+      const double e2 = (double)z[(size_t)(y + dy_e2[k]) * w + (x + dx_e2[k])];
+      const double s1 = (e0 - e1) / 1.0, s2 = (e1 - e2) / 1.0;
+      double r = atan2(s2, s1), s;
+      if (r < 0) { r = 0; s = s1; }
+      else if (r > quarter) { r = quarter; s = (e0 - e2) / sqrt(2.0); }
+      else s = sqrt(s1 * s1 + s2 * s2);
+      if (s > smax) { smax = s; nmax = k; rmax = r; }
+    }
+    double rg = 0;                                                     // NO_FLOW
+    if (nmax != -1) rg = af[nmax] * rmax + ac[nmax] * M_PI / 2;
+    out[c] = (float)rg;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// FM_Tarboton, flowmet/Tarboton1997.hpp:14-144 in compact form: rcv = first receiver n (0 none, 255
+// NoData), share = proportion to neighbour n, share2 = proportion to neighbour nwrap(n + 1).
+// ------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void tarboton_cell(const T *__restrict__ z, T nodata, int x, int y, int w, int h, int &rcv,
+                                              float &share, float &share2) {
+  const int dy_e1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[9] = {0, -1, 0, 0, 1, 1, 0, 0, -1};
+  const int dy_e2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[9] = {0, -1, -1, 1, 1, 1, 1, -1, -1};
+  const double af[9] = {0, -1., 1., -1., 1., -1., 1., -1., 1.};
+  const float dang = (float)atan2(1.0, 1.0);
+  rcv = 0;
+  share = 0.0f;
+  share2 = 0.0f;
+  const size_t c = (size_t)y * w + x;
+  if (z[c] == nodata) { rcv = 255; return; }                           // :44-47
+  if (x == 0 || y == 0 || x == w - 1 || y == h - 1) return;            // :49-50
+  int nmax = -1;
+  double smax = 0;
+  float rmax = 0;
+  const double e0 = (double)z[c];
+#pragma unroll
+  for (int n = 1; n <= 8; n++) {                                       // :56-92
+    const T v1 = z[(size_t)(y + dy_e1[n]) * w + (x + dx_e1[n])], v2 = z[(size_t)(y + dy_e2[n]) * w + (x + dx_e2[n])];
+    if (v1 == nodata || v2 == nodata) continue;
+    const double e1 = (double)v1, e2 = (double)v2;
+    const double s1 = (e0 - e1) / 1.0, s2 = (e1 - e2) / 1.0;
+    double r = atan2(s2, s1), s;
+    if (r < 1e-7) { r = 0; s = s1; }
+    else if (r > dang - 1e-7) { r = dang; s = (e0 - e2) / sqrt(2.0); }
+    else s = sqrt(s1 * s1 + s2 * s2);
+    if (s > smax) { smax = s; nmax = n; rmax = (float)r; }
+  }
+  if (nmax == -1) return;
+  if (af[nmax] == 1 && rmax == 0) rmax = dang;                          // :99-104
+  else if (af[nmax] == 1 && rmax == dang) rmax = 0;
+  else if (af[nmax] == 1) rmax = (float)(M_PI / 4 - rmax);
+  const int nxt = nmax + 1 == 9 ? 1 : nmax + 1;
+  if (rmax == 0) { rcv = nmax; share = 1.0f; }                          // :106-113
+  else if (rmax == dang) { rcv = nxt; share = 1.0f; }
+  else {
+    rcv = nmax | 0x10;                            // 0x10: two receivers
+    share = (float)(rmax / (M_PI / 4.));          // props(x,y,nmax), :111
+    share2 = (float)(1 - rmax / (M_PI / 4.));     // props(x,y,nwrap(nmax+1)), :112
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_tarboton(const T *__restrict__ z, T nodata, uint8_t *__restrict__ rcv,
+                                                   float *__restrict__ sh1, float *__restrict__ sh2, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    int r;
+    float p, q;
+    tarboton_cell<T>(z, nodata, (int)(c % (uint64_t)w), (int)(c / (uint64_t)w), w, h, r, p, q);
+    rcv[c] = (uint8_t)r;
+    sh1[c] = p;
+    sh2[c] = q;
+  }
+}
+
+// expand the compact form into the reference's Array3D layout (9 floats per cell, index 9*i+n)
+__global__ __launch_bounds__(NTHR) void k_tarboton_props(const uint8_t *__restrict__ rcv, const float *__restrict__ sh1,
+                                                         const float *__restrict__ sh2, float *__restrict__ props,
+                                                         uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    float p[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // NO_FLOW_GEN, :25
+    const int rr = rcv[c], r = rr & 0xF;
+    if (rr == 255) p[0] = -2.0f;                         // NO_DATA_GEN, :45
+    else if (r >= 1) {
+      p[0] = 0.0f;                                       // HAS_FLOW_GEN, :97
+      p[r] = sh1[c];
+      if (rr & 0x10) p[r == 8 ? 1 : r + 1] = sh2[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) props[9 * c + k] = p[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// proportions accessors
+// ------------------------------------------------------------------------------------------
+struct PropsAcc {   // the reference's Array3D<float>
+  const float *props;
+  __device__ __forceinline__ bool nodata(uint64_t c) const { return props[9 * c] == -2.0f; }
+  __device__ __forceinline__ float share(uint64_t c, int n) const { return props[9 * c + n]; }
+};
+struct DinfAcc {    // compact D-infinity form
+  const uint8_t *rcv;
+  const float *sh1, *sh2;
+  __device__ __forceinline__ bool nodata(uint64_t c) const { return rcv[c] == 255; }
+  __device__ __forceinline__ float share(uint64_t c, int n) const {
+    const int rr = rcv[c], r = rr & 0xF;
+    if (rr == 255 || r < 1 || r > 8) return -1.0f;
+    if (n == r) return sh1[c];
+    if ((rr & 0x10) && n == (r == 8 ? 1 : r + 1)) return sh2[c];
+    return -1.0f;
+  }
+};
+
+constexpr uint32_t PEND_NODATA = 0xFFFFFFFFu;
+
+// deps, flow_accumulation_generic.hpp:47-58 (donors are interior cells only), + the initial ready flags :61-64
+template <class ACC>
+__global__ __launch_bounds__(NTHR) void k_mfd_init(ACC a, uint32_t *pending, uint8_t *ready, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    uint32_t k = PEND_NODATA;
+    uint8_t rdy = 0;
+    if (!a.nodata(c)) {
+      k = 0;
+#pragma unroll
+      for (int m = 1; m <= 8; m++) {
+        const int dx = x + mdx(m), dy = y + mdy(m);
+        if (dx < 1 || dy < 1 || dx >= w - 1 || dy >= h - 1) continue;   // donors: interior cells
+        const uint64_t d = (uint64_t)dy * w + dx;
+        if (a.nodata(d)) continue;
+        if (a.share(d, m <= 4 ? m + 4 : m - 4) > 0) k++;
+      }
+      rdy = k == 0;
+    }
+    pending[c] = k;
+    ready[c] = rdy;
+  }
+}
+
+template <class ACC>
+__global__ __launch_bounds__(NTHR) void k_mfd_process(ACC a, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                      uint32_t *pending, double *acc, uint8_t *ready, int w, int h) {
+  const uint32_t stride = gridDim.x * NTHR;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nlist; i += stride) {
+    uint64_t c = list[i];
+    double v = acc[c];   // completed in an earlier launch (or a source): final
+    for (;;) {
+      const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) break;   // edge cells never pass flow on (FM_*: :49-50)
+      uint64_t cont = ~0ull;
+#pragma unroll
+      for (int n = 1; n <= 8; n++) {
+        const float p = a.share(c, n);
+        if (!(p > 0)) continue;                                         // :81-82
+        const uint64_t r = (uint64_t)(y + mdy(n)) * w + (x + mdx(n));
+        if (a.nodata(r)) continue;                                      // :85-86
+        const double prev = atomicAdd(&acc[r], (double)p * v);          // :87, returning: done at the memory side
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
+        const uint32_t old = __hip_atomic_fetch_sub(&pending[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 1) {                                                 // r is complete
+          if (cont == ~0ull) cont = r;                                  // continue inline with the first one,
+          else ready[r] = 1;                                            // the others wait for the next round
+        }
+      }
+      if (cont == ~0ull) break;
+      c = cont;
+      v = atomicAdd(&acc[c], 0.0);                                      // final total, read at the memory side
+    }
+  }
+}
+
+template <class ACC>
+__global__ __launch_bounds__(NTHR) void k_mfd_nodata(ACC a, double *acc, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride)
+    if (a.nodata(c)) acc[c] = -1.0;                                     // ACCUM_NO_DATA, :95-97
+}
+
+// ---- ready flags -> work list (count / scan / fill; flags are cleared) ------------------------------
+constexpr int CPB = 4096;
+__global__ __launch_bounds__(NTHR) void k_rdy_count(const uint8_t *__restrict__ f, uint64_t n, uint32_t *counts) {
+  __shared__ uint32_t ws[NTHR / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CPB;
+  uint32_t cnt = 0;
+#pragma unroll 4
+  for (int j = 0; j < CPB / NTHR; j++) {
+    const uint64_t c = base + (uint64_t)j * NTHR + threadIdx.x;
+    if (c < n && f[c]) cnt++;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_rdy_scan(uint32_t *counts, uint32_t m, uint32_t *total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t chunk = (m + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * chunk, hi = min(lo + chunk, m);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    uint32_t v = (threadIdx.x >= (uint32_t)o) ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t v = counts[i];
+    counts[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) *total = part[1023];
+}
+__global__ __launch_bounds__(NTHR) void k_rdy_fill(uint8_t *f, uint64_t n, const uint32_t *__restrict__ offsets,
+                                                   uint32_t *__restrict__ out) {
+  __shared__ uint32_t ws[NTHR / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CPB;
+  uint32_t run = offsets[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = 0; j < CPB / NTHR; j++) {
+    const uint64_t c = base + (uint64_t)j * NTHR + threadIdx.x;
+    const bool hit = c < n && f[c];
+    if (hit) f[c] = 0;
+    const unsigned long long bal = __ballot(hit);
+    const uint32_t rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) ws[wv] = __popcll(bal);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NTHR / 64; k++) {
+      const uint32_t v = ws[k];
+      if (k < wv) woff += v;
+      tot += v;
+    }
+    if (hit) out[run + woff + rank] = (uint32_t)c;
+    run += tot;
+    __syncthreads();
+  }
+}
+
+static uint32_t g_mfd_rounds = 0;
+
+template <class ACC>
+static void mfd_accumulate(ACC a, int w, int h, double *d_acc, hipStream_t s) {
+  const uint64_t n = (uint64_t)w * h;
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  uint32_t *pending = ws.buf<uint32_t>("mfd.pending", n);
+  uint8_t *ready = ws.buf<uint8_t>("mfd.ready", n);
+  uint32_t *list = ws.buf<uint32_t>("mfd.list", n);
+  const uint32_t nblk = (uint32_t)((n + CPB - 1) / CPB);
+  uint32_t *counts = ws.buf<uint32_t>("mfd.counts", (size_t)nblk + 1);
+  RD_LAUNCH("mfd.init", (k_mfd_init<ACC>), dim3(sgrid(n)), dim3(NTHR), 0, s, a, pending, ready, w, h);
+  g_mfd_rounds = 0;
+  for (;;) {
+    RD_LAUNCH("mfd.ready_count", k_rdy_count, dim3(nblk), dim3(NTHR), 0, s, (const uint8_t *)ready, n, counts);
+    RD_LAUNCH("mfd.ready_scan", k_rdy_scan, dim3(1), dim3(1024), 0, s, counts, nblk, counts + nblk);
+    RD_HIP(hipMemcpyAsync(hw, counts + nblk, 4, hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    const uint32_t nl = hw[0];
+    if (nl == 0) break;
+    RD_LAUNCH("mfd.ready_fill", k_rdy_fill, dim3(nblk), dim3(NTHR), 0, s, ready, n, (const uint32_t *)counts, list);
+    RD_LAUNCH("mfd.process", (k_mfd_process<ACC>), dim3(sgrid(nl)), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl, pending,
+              d_acc, ready, w, h);
+    if (++g_mfd_rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flow accumulation did not terminate");
+  }
+  RD_LAUNCH("mfd.nodata", (k_mfd_nodata<ACC>), dim3(sgrid(n)), dim3(NTHR), 0, s, a, d_acc, n);
+}
+
+static void check_dims(int w, int h, const char *who) {
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, std::string(who) + ": width and height must be positive");
+  if ((uint64_t)w * (uint64_t)h > 0xFFFF0000ull) throw Error(RDGPU_ERR_ARG, std::string(who) + ": raster too large");
+}
+
+template <class T>
+static DinfAcc tarboton_device(const T *d_z, T nodata, int w, int h, hipStream_t s) {
+  const uint64_t n = (uint64_t)w * h;
+  Workspace &ws = Workspace::get();
+  uint8_t *rcv = ws.buf<uint8_t>("mfd.rcv", n);
+  float *sh1 = ws.buf<float>("mfd.sh1", n), *sh2 = ws.buf<float>("mfd.sh2", n);
+  RD_LAUNCH("mfd.tarboton", (k_tarboton<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, nodata, rcv, sh1, sh2, w, h);
+  return DinfAcc{rcv, sh1, sh2};
+}
+
+template <class T>
+static void host_dem(const T *dem, int w, int h, T **d) {
+  const size_t n = (size_t)w * h;
+  *d = Workspace::get().buf<T>("host.dem", n);
+  RD_HIP(hipMemcpy(*d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+}
+
+}  // namespace rdgpu
+
+using namespace rdgpu;
+
+#define RD_MFD_API(SUF, T)                                                                                      \
+  extern "C" int rdgpu_dinf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int w, int h, float *d_out, void *st) { \
+    return guarded([&] {                                                                                        \
+      if (!d_dem || !d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_dinf_flowdirs: null pointer");                    \
+      check_dims(w, h, "rdgpu_dinf_flowdirs");                                                                  \
+      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, (hipStream_t)st, \
+                d_dem, nodata, d_out, w, h);                                                                    \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_dinf_flowdirs_##SUF(const T *dem, T nodata, int w, int h, float *out) {                  \
+    return guarded([&] {                                                                                        \
+      if (!dem || !out) throw Error(RDGPU_ERR_ARG, "rdgpu_dinf_flowdirs: null pointer");                        \
+      check_dims(w, h, "rdgpu_dinf_flowdirs");                                                                  \
+      T *d;                                                                                                     \
+      host_dem<T>(dem, w, h, &d);                                                                               \
+      float *o = Workspace::get().buf<float>("host.f32out", (size_t)w * h);                                     \
+      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, (hipStream_t) nullptr, \
+                (const T *)d, nodata, o, w, h);                                                                 \
+      RD_HIP(hipMemcpy(out, o, (size_t)w * h * 4, hipMemcpyDeviceToHost));                                      \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fm_tarboton_##SUF(const T *dem, T nodata, int w, int h, float *props9) {                 \
+    return guarded([&] {                                                                                        \
+      if (!dem || !props9) throw Error(RDGPU_ERR_ARG, "rdgpu_fm_tarboton: null pointer");                       \
+      check_dims(w, h, "rdgpu_fm_tarboton");                                                                    \
+      T *d;                                                                                                     \
+      host_dem<T>(dem, w, h, &d);                                                                               \
+      const DinfAcc a = tarboton_device<T>(d, nodata, w, h, nullptr);                                           \
+      const uint64_t n = (uint64_t)w * h;                                                                       \
+      float *p = Workspace::get().buf<float>("host.props", n * 9);                                              \
+      RD_LAUNCH("mfd.tarboton_props", k_tarboton_props, dim3(sgrid(n)), dim3(NTHR), 0, (hipStream_t) nullptr, a.rcv, a.sh1, \
+                a.sh2, p, n);                                                                                   \
+      RD_HIP(hipMemcpy(props9, p, n * 36, hipMemcpyDeviceToHost));                                              \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fa_tarboton_dev_##SUF(const T *d_dem, T nodata, int w, int h, double *d_accum, void *st) { \
+    return guarded([&] {                                                                                        \
+      if (!d_dem || !d_accum) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_tarboton: null pointer");                    \
+      check_dims(w, h, "rdgpu_fa_tarboton");                                                                    \
+      const DinfAcc a = tarboton_device<T>(d_dem, nodata, w, h, (hipStream_t)st);                               \
+      mfd_accumulate<DinfAcc>(a, w, h, d_accum, (hipStream_t)st);                                               \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fa_tarboton_##SUF(const T *dem, T nodata, int w, int h, double *accum) {                 \
+    return guarded([&] {                                                                                        \
+      if (!dem || !accum) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_tarboton: null pointer");                        \
+      check_dims(w, h, "rdgpu_fa_tarboton");                                                                    \
+      T *d;                                                                                                     \
+      host_dem<T>(dem, w, h, &d);                                                                               \
+      const size_t n = (size_t)w * h;                                                                           \
+      double *da = Workspace::get().buf<double>("host.area", n);                                                \
+      RD_HIP(hipMemcpy(da, accum, n * 8, hipMemcpyHostToDevice));                                               \
+      const DinfAcc a = tarboton_device<T>(d, nodata, w, h, nullptr);                                           \
+      mfd_accumulate<DinfAcc>(a, w, h, da, nullptr);                                                            \
+      RD_HIP(hipStreamSynchronize(nullptr));                                                                    \
+      RD_HIP(hipMemcpy(accum, da, n * 8, hipMemcpyDeviceToHost));                                               \
+    });                                                                                                         \
+  }
+RD_MFD_API(u8, uint8_t)
+RD_MFD_API(i16, int16_t)
+RD_MFD_API(u16, uint16_t)
+RD_MFD_API(i32, int32_t)
+RD_MFD_API(u32, uint32_t)
+RD_MFD_API(f32, float)
+RD_MFD_API(f64, double)
+
+// FlowAccumulation(const Array3D<float>&, Array2D<double>&), methods/flow_accumulation_generic.hpp:33-100
+extern "C" int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int w, int h, double *d_accum, void *st) {
+  return guarded([&] {
+    if (!d_props9 || !d_accum) throw Error(RDGPU_ERR_ARG, "rdgpu_flow_accumulation: null pointer");
+    check_dims(w, h, "rdgpu_flow_accumulation");
+    mfd_accumulate<PropsAcc>(PropsAcc{d_props9}, w, h, d_accum, (hipStream_t)st);
+  });
+}
+extern "C" int rdgpu_flow_accumulation_f64(const float *props9, int w, int h, double *accum) {
+  return guarded([&] {
+    if (!props9 || !accum) throw Error(RDGPU_ERR_ARG, "rdgpu_flow_accumulation: null pointer");
+    check_dims(w, h, "rdgpu_flow_accumulation");
+    const size_t n = (size_t)w * h;
+    float *dp = Workspace::get().buf<float>("host.props", n * 9);
+    double *da = Workspace::get().buf<double>("host.area", n);
+    RD_HIP(hipMemcpy(dp, props9, n * 36, hipMemcpyHostToDevice));
+    RD_HIP(hipMemcpy(da, accum, n * 8, hipMemcpyHostToDevice));
+    mfd_accumulate<PropsAcc>(PropsAcc{dp}, w, h, da, nullptr);
+    RD_HIP(hipStreamSynchronize(nullptr));
+    RD_HIP(hipMemcpy(accum, da, n * 8, hipMemcpyDeviceToHost));
+  });
+}
+extern "C" int rdgpu_flow_accumulation_rounds(uint32_t *rounds) {
+  if (!rounds) return RDGPU_ERR_ARG;
+  *rounds = g_mfd_rounds;
+  return RDGPU_OK;
+}

@@ -11,7 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "rdgpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rdgpu_[a-z0-9_]+)\s*\(", src)))
+    names = set(re.findall(r"\b(rdgpu_[a-z0-9_]+)\s*\(", src))
+    # entry points declared through the RDGPU_DECL_MFD(SUF, T) macro
+    for suf in re.findall(r"RDGPU_DECL_MFD\((\w+),", src):
+        if suf != "SUF":
+            names |= {f"rdgpu_dinf_flowdirs_{suf}", f"rdgpu_dinf_flowdirs_dev_{suf}", f"rdgpu_fm_tarboton_{suf}",
+                      f"rdgpu_fa_tarboton_{suf}", f"rdgpu_fa_tarboton_dev_{suf}"}
+    return sorted(n for n in names if "##" not in n and not n.endswith("_"))
 
 
 def test_library_exports_every_declared_symbol(rd):

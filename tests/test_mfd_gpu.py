@@ -1,0 +1,79 @@
+"""GPU parity tests: D-infinity directions / proportions (FM_Tarboton), FA_Tarboton and the generic
+FlowAccumulation.  Floating point with atan2: compared within north_star's tolerance (<= 1 ULP f32 for
+angles / proportions; accumulation relative 1e-9 in f64 and <= 1 ULP after an f32 cast), not bit for bit."""
+import numpy as np
+import pytest
+
+from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_diff_f32(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+CASES = [("frac_f32", lambda: fractal_dem(300, 220, 301)),
+         ("int_i32", lambda: fractal_dem_int(200, 150, 302, 0.2)),
+         ("filled", lambda: None),
+         ("f64", lambda: fractal_dem(120, 90, 303).astype(np.float64) * 1.000001),
+         ("u8", lambda: np.floor((fractal_dem(100, 80, 304) - 400) * 0.1).clip(0, 255).astype(np.uint8))]
+
+
+def dems(orc):
+    for name, mk in CASES:
+        d = mk()
+        if d is None:
+            d = orc.port.fill(fractal_dem(260, 200, 305))
+        yield name, d
+
+
+def test_dinf_flow_directions(rd, orc):
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        if dem.shape[0] > 50:
+            dem = dem.copy(); dem[30:34, 40:50] = nd
+        got, exp = rd.dinf_flow_directions(dem, nd), orc.port.dinf_flowdirs(dem, nd)
+        assert (ulp_diff_f32(got, exp) <= 1).all(), name
+        assert np.array_equal(got == -1, exp == -1) and np.array_equal(got == 0, exp == 0), name
+
+
+def test_fm_tarboton_proportions(rd, orc):
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        got, exp = rd.FlowProportions(dem, "Dinf", nodata=nd), orc.port.fm_tarboton(dem, nd)
+        # same receivers (sign pattern) everywhere, proportions within 1 ULP
+        assert np.array_equal(np.sign(got), np.sign(exp)), name
+        assert (ulp_diff_f32(got, exp) <= 1).all(), name
+
+
+def test_fa_tarboton_and_generic_accumulation(rd, orc):
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        exp = orc.port.fa_tarboton(dem, nd)
+        got = rd.FlowAccumulation(dem, "Dinf", nodata=nd)
+        assert np.allclose(got, exp, rtol=1e-6, atol=0), name          # proportions may differ by 1 ulp (f32)
+        assert np.array_equal(got == -1, exp == -1), name
+        # the generic engine on EXACTLY the reference's proportions: only the summation order differs
+        props = orc.port.fm_tarboton(dem, nd)
+        g2, e2 = rd.FlowAccumFromProps(props), orc.port.flow_accumulation(props)
+        assert np.allclose(g2, e2, rtol=1e-12, atol=0), name
+        assert (ulp_diff_f32(g2, e2) <= 1).all(), name
+        # D8 proportions through the generic entry: integer flows, exact
+        p8 = orc.port.fm_d8(dem, nd)
+        assert np.array_equal(rd.FlowAccumFromProps(p8), orc.port.flow_accumulation(p8)), name
+        w = np.random.default_rng(7).integers(0, 4, dem.shape).astype(np.float64)
+        assert np.array_equal(rd.FlowAccumFromProps(p8, w), orc.port.flow_accumulation(p8, w)), name
+
+
+def test_generic_accumulation_errors(rd):
+    with pytest.raises(rd.RdgpuError, match="same dimensions"):
+        rd.FlowAccumFromProps(np.zeros((4, 5, 9), np.float32), np.ones((3, 3)))
+    with pytest.raises(rd.RdgpuError):
+        rd.FlowAccumFromProps(np.zeros((4, 5), np.float32))
