@@ -183,6 +183,14 @@ int rdgpu_resolve_flats_u32(const uint32_t *dem, uint32_t nodata, int width, int
 int rdgpu_resolve_flats_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 int rdgpu_resolve_flats_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 
+/* alter == true (flat_resolution.hpp:597-600 + d8_flats_alter_dem :545-582): the DEM is raised in place by
+ * flat_mask increments of nextafterf inside drainable flats, then plain D8 directions are taken on it.
+ * float and double DEMs (the reference applies nextafterf, i.e. float steps, to every element type). */
+int rdgpu_flat_resolution_d8_alter_f32(float *dem, float nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_alter_f64(double *dem, double nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_alter_dev_f32(float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_alter_dev_f64(double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+
 typedef struct rdgpu_flat_stats {
   uint64_t low_edges;      /* find_flat_edges: cells with flow next to an equal NO_FLOW cell */
   uint64_t high_edges;     /* NO_FLOW cells next to higher terrain                           */

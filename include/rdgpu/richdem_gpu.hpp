@@ -79,6 +79,11 @@ int c_fa_dinf(const T *, T, int, int, double *) { unsupported("FA_Tarboton"); }
 template <class T>
 int c_dinf(const T *, T, int, int, float *) { unsupported("dinf_flow_directions"); }
 
+inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
+inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
+template <class T>
+int c_flatres_alter(T *, T, int, int, uint8_t *) { unsupported("barnes_flat_resolution_d8(alter=true)"); }
+
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, int32_t *a) { return rdgpu_d8_flow_accum_i32(d, nd, w, h, a); }
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, float *a) { return rdgpu_d8_flow_accum_f32(d, nd, w, h, a); }
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, double *a) { return rdgpu_d8_flow_accum_f64(d, nd, w, h, a); }
@@ -146,8 +151,21 @@ void d8_flow_directions(const E &elevations, F &flowdirs) {
 // richdem::barnes_flat_resolution_d8(Array2D<T>&, Array2D<U>&, bool alter)   flats/flat_resolution.hpp:587-605
 template <class E, class F>
 void barnes_flat_resolution_d8(E &elevations, F &flowdirs, bool alter) {
-  if (alter) throw std::runtime_error("barnes_flat_resolution_d8: alter=true is not provided by the MI355X engine yet");
   using T = detail::elem_t<E>;
+  if (alter) {   // flat_resolution.hpp:597-600: the DEM itself is raised, then plain D8 directions
+    using U = detail::elem_t<F>;
+    flowdirs.resize(elevations);
+    flowdirs.setNoData((U)255);
+    if (elevations.width() > 0 && elevations.height() > 0) {
+      std::vector<uint8_t> tmp((size_t)elevations.width() * elevations.height());
+      detail::check(detail::c_flatres_alter(elevations.data(), elevations.noData(), elevations.width(),
+                                            elevations.height(), tmp.data()),
+                    "barnes_flat_resolution_d8");
+      for (size_t i = 0; i < tmp.size(); i++) flowdirs.data()[i] = (U)tmp[i];
+    }
+    flowdirs.templateCopy(elevations);
+    return;
+  }
   detail::dirs_into(elevations, flowdirs,
                     [](const T *p, T nd, int w, int h, uint8_t *o) { return detail::c_flatres(p, nd, w, h, o); },
                     "barnes_flat_resolution_d8");

@@ -148,6 +148,18 @@ class _Backend:
             self._fn(f"flat_resolution_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
         return out
 
+    def flat_resolution_alter(self, dem: np.ndarray, nodata):
+        """(altered dem, dirs) of barnes_flat_resolution_d8(dem, dirs, alter=true)."""
+        out_dem = np.ascontiguousarray(dem).copy()
+        h, w = out_dem.shape
+        s = _suf(out_dem)
+        dirs = np.empty((h, w), np.uint8)
+        if self.prefix == "ref":
+            self._fn(f"flat_resolution_{s}")(_ptr(out_dem), _CT[s](nodata), w, h, _ptr(dirs), 1)
+        else:
+            self._fn(f"flat_resolution_alter_{s}")(_ptr(out_dem), _CT[s](nodata), w, h, _ptr(dirs))
+        return out_dem, dirs
+
     # ---- accumulation -----------------------------------------------------------------------
     def d8_flow_accum(self, dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.ndarray:
         dirs = np.ascontiguousarray(dirs, dtype=np.uint8)

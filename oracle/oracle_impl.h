@@ -248,6 +248,24 @@ void FN(orc_flat_resolution)(const T *dem, T nodata, int w, int h, uint8_t *dirs
   free(mask); free(labels);
 }
 
+/* barnes_flat_resolution_d8(alter=true), flats/flat_resolution.hpp:597-600 with
+ * d8_flats_alter_dem :545-582.  The DEM is altered in place.  Meaningful for float / double only
+ * (nextafterf towards numeric_limits<U>::infinity(), which is 0 for integer U). */
+void FN(orc_flat_resolution_alter)(T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  size_t N = (size_t)w * h;
+  int32_t *mask = (int32_t *)malloc(N * 4), *labels = (int32_t *)malloc(N * 4);
+  FN(orc_d8_flowdirs)(dem, nodata, w, h, dirs);
+  FN(orc_resolve_flats)(dem, w, h, dirs, mask, labels);
+  for (int y = 1; y < h - 1; y++)                                            /* :556-558 */
+    for (int x = 1; x < w - 1; x++) {
+      size_t i = (size_t)y * w + x;
+      if (labels[i] == 0) continue;                                          /* :559-560 */
+      for (int k = 0; k < mask[i]; ++k) dem[i] = (T)nextafterf((float)dem[i], INFINITY);   /* :567-568 */
+    }
+  FN(orc_d8_flowdirs)(dem, nodata, w, h, dirs);                             /* :600 */
+  free(mask); free(labels);
+}
+
 /* ------------------------------------------------------------------------- */
 /* FM_OCallaghan<D8> = FM_D8, flowmet/OCallaghan1984.hpp:13-77, :81-84.       */
 /* props9: 9 floats per cell, index 9*i+n (common/Array3D.hpp:203-206).       */

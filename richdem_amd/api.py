@@ -91,7 +91,17 @@ def barnes_flat_resolution_d8(dem: np.ndarray, nodata, alter: bool = False) -> n
     """Flat-resolved uint8 D8 directions (reference barnes_flat_resolution_d8(elev, flowdirs, alter=false),
     flats/flat_resolution.hpp:587-605)."""
     if alter:
-        raise RdgpuError("barnes_flat_resolution_d8(alter=True) is not part of this round's hot path")
+        if not (isinstance(dem, np.ndarray) and dem.ndim == 2 and dem.dtype in (np.float32, np.float64)
+                and dem.flags["C_CONTIGUOUS"]):
+            raise RdgpuError("barnes_flat_resolution_d8(alter=True): needs a C-contiguous float32/float64 DEM "
+                             "(it is altered in place)")
+        h, w = dem.shape
+        s = "f32" if dem.dtype == np.float32 else "f64"
+        out = np.empty((h, w), np.uint8)
+        fn = getattr(lib(), f"rdgpu_flat_resolution_d8_alter_{s}")
+        check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+              "rdgpu_flat_resolution_d8_alter")
+        return out
     dem, s = _elev(dem, "barnes_flat_resolution_d8")
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)

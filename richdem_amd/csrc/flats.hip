@@ -656,6 +656,68 @@ static void flat_resolution_host(const T *dem, T nodata, int w, int h, uint8_t *
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// alter == true: d8_flats_alter_dem (flat_resolution.hpp:545-582) raises every cell of a drainable flat by
+// flat_mask increments of nextafterf (in FLOAT precision, whatever the element type -- the reference calls
+// nextafterf on every U), then plain d8_flow_directions runs on the altered DEM (:598-600).  Provided
+// for float and double DEMs; for integer element types the reference's nextafterf(v, 0) walks values
+// towards zero, which is not a meaningful operation to reproduce.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float next_up_n(float v, uint32_t m) {   // nextafterf(v, +inf) applied m times
+  uint32_t b = __builtin_bit_cast(uint32_t, v);
+  if ((b & 0x7fffffffu) > 0x7f800000u) return v;                  // NaN
+  if (b & 0x80000000u) {                                           // negative (incl. -0.0)
+    const uint32_t mag = b & 0x7fffffffu;
+    if (m <= mag) return __builtin_bit_cast(float, 0x80000000u | (mag - m));   // ... -denorm_min -> -0.0
+    b = m - mag;                                                   // -0.0 -> +denorm_min is one step
+  } else {
+    const uint64_t nb = (uint64_t)b + m;
+    b = nb >= 0x7f800000ull ? 0x7f800000u : (uint32_t)nb;          // saturates at +inf
+  }
+  return __builtin_bit_cast(float, b);
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_flat_alter(T *z, const int32_t *__restrict__ M, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int32_t m = M[c];
+    if (m <= 0) continue;   // cells outside drainable flats (labels == 0) and flat cells with mask 0
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;    // :556-558 interior only
+    z[c] = (T)next_up_n((float)z[c], (uint32_t)m);                 // :567-568
+  }
+}
+
+template <class T>
+void flat_resolution_alter_device(T *d_z, T nodata, int w, int h, uint8_t *d_dirs, hipStream_t s) {
+  if (!d_z || !d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_alter: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_alter: width and height must be positive");
+  if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_alter: raster too large");
+  flowdirs_device<T>(d_z, nodata, w, h, d_dirs, MODE_D8, s);
+  int32_t *M, *fh;
+  uint32_t *L;
+  resolve_flats_device<T>(d_z, d_dirs, w, h, &M, &L, &fh, s);
+  if (L) {
+    RD_LAUNCH("flats.alter", (k_flat_alter<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, w, h);
+    flowdirs_device<T>(d_z, nodata, w, h, d_dirs, MODE_D8, s);
+  }
+}
+
+template <class T>
+static void flat_resolution_alter_host(T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  if (!dem || !dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_alter: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_alter: width and height must be positive");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  uint8_t *dd = Workspace::get().buf<uint8_t>("host.dirs", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  flat_resolution_alter_device<T>(d, nodata, w, h, dd, nullptr);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  RD_HIP(hipMemcpy(dirs, dd, n, hipMemcpyDeviceToHost));
+  RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));   // the DEM is altered in place
+}
+
 #define RD_INST(T) template void flat_resolution_device<T>(const T *, T, int, int, uint8_t *, hipStream_t);
 RD_INST(uint8_t) RD_INST(int16_t) RD_INST(uint16_t) RD_INST(int32_t) RD_INST(uint32_t) RD_INST(float) RD_INST(double)
 #undef RD_INST
@@ -683,6 +745,17 @@ RD_FLATS_API(i32, int32_t)
 RD_FLATS_API(u32, uint32_t)
 RD_FLATS_API(f32, float)
 RD_FLATS_API(f64, double)
+
+#define RD_FLATS_ALTER_API(SUF, T)                                                                             \
+  extern "C" int rdgpu_flat_resolution_d8_alter_##SUF(T *dem, T nodata, int w, int h, uint8_t *dirs) {         \
+    return guarded([&] { flat_resolution_alter_host<T>(dem, nodata, w, h, dirs); });                           \
+  }                                                                                                            \
+  extern "C" int rdgpu_flat_resolution_d8_alter_dev_##SUF(T *d_dem, T nodata, int w, int h, uint8_t *d_dirs,   \
+                                                          void *stream) {                                      \
+    return guarded([&] { flat_resolution_alter_device<T>(d_dem, nodata, w, h, d_dirs, (hipStream_t)stream); }); \
+  }
+RD_FLATS_ALTER_API(f32, float)
+RD_FLATS_ALTER_API(f64, double)
 
 extern "C" int rdgpu_flat_get_stats(rdgpu_flat_stats *out) {
   if (!out) return RDGPU_ERR_ARG;

@@ -26,6 +26,7 @@ void orc_fill_f32(float *, int, int, int);
 void orc_fill_i32(int32_t *, int, int, int);
 void orc_fill_f64(double *, int, int, int);
 void orc_flat_resolution_f32(const float *, float, int, int, uint8_t *);
+void orc_flat_resolution_alter_f32(float *, float, int, int, uint8_t *);
 void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
 void orc_d8_flow_accum_i32(const uint8_t *, uint8_t, int, int, int32_t *);
@@ -111,8 +112,19 @@ int main() {
     orc_d8_flow_accum_i32(ed.data(), 255, w, h, ei.data());
     EXPECT(std::memcmp(areai.data(), ei.data(), ei.size() * 4) == 0);
 
+    // alter = true: the DEM itself is raised (nextafterf steps), then plain D8
+    Arr<float> b = a;
+    Arr<uint8_t> adirs;
+    rdgpu::barnes_flat_resolution_d8(b, adirs, true);
+    std::vector<float> eb(a.data(), a.data() + (size_t)w * h);
+    std::vector<uint8_t> ead((size_t)w * h);
+    orc_flat_resolution_alter_f32(eb.data(), -9999.0f, w, h, ead.data());
+    EXPECT(std::memcmp(b.data(), eb.data(), eb.size() * 4) == 0);
+    EXPECT(std::memcmp(adirs.data(), ead.data(), ead.size()) == 0);
+    Arr<int32_t> ia(8, 8, 1);
+    Arr<uint8_t> idirs;
     bool threw = false;
-    try { rdgpu::barnes_flat_resolution_d8(a, dirs, true); } catch (const std::runtime_error &) { threw = true; }
+    try { rdgpu::barnes_flat_resolution_d8(ia, idirs, true); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
   }
   // rd_flow_accumulation: Array2D<double> accum(dem, 1); FA_D8(dem, accum)

@@ -134,3 +134,20 @@ def test_sources_on_tile_edges(rd, orc):
         dem[0, x0] = 1
         check(rd, orc, dem, np.int32(-1))
         check(rd, orc, dem.T.copy(), np.int32(-1))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_alter_true(rd, orc, dtype):
+    """barnes_flat_resolution_d8(alter=true): the DEM is raised by flat_mask nextafterf steps inside drainable
+    flats (d8_flats_alter_dem, flat_resolution.hpp:545-582) -- bit-exact, including negative values."""
+    base = np.floor(fractal_dem(400, 300, seed=91) * 0.05).astype(np.float32)
+    for shift in (0.0, -40.0, -1e-38):
+        dem = (orc.port.fill(base) + np.float32(shift)).astype(dtype)
+        edem, edirs = orc.port.flat_resolution_alter(dem, dtype(-9999))
+        got = dem.copy()
+        dirs = rd.barnes_flat_resolution_d8(got, dtype(-9999), alter=True)
+        assert got.tobytes() == edem.tobytes(), (dtype, shift)
+        assert np.array_equal(dirs, edirs), (dtype, shift)
+        assert (got != dem).any()
+    with pytest.raises(rd.RdgpuError):
+        rd.barnes_flat_resolution_d8(np.zeros((5, 5), np.int32), -1, alter=True)
