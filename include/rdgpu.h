@@ -249,6 +249,14 @@ int rdgpu_fa_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, d
 int rdgpu_fa_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, double *accum);
 int rdgpu_fa_d8_f32(const float *dem, float nodata, int width, int height, double *accum);
 int rdgpu_fa_d8_f64(const double *dem, double nodata, int width, int height, double *accum);
+/* FM_D8 alone (richdem::FM_D8, flowmet/OCallaghan1984.hpp:81-84) as the 9-float proportions array */
+int rdgpu_fm_d8_u8(const uint8_t *dem, uint8_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_i16(const int16_t *dem, int16_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_u16(const uint16_t *dem, uint16_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_f32(const float *dem, float nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_f64(const double *dem, double nodata, int width, int height, float *props9);
 int rdgpu_fa_d8_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, double *d_accum, void *hip_stream);

@@ -156,12 +156,12 @@ def dinf_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
 def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999) -> np.ndarray:
     """[h, w, 9] float32 flow proportions (reference ``rd.FlowProportions``, FM_Tarboton,
     flowmet/Tarboton1997.hpp:14-144)."""
-    if method not in ("Dinf", "Tarboton"):
+    if method not in ("Dinf", "Tarboton", "D8"):
         raise RdgpuError(f"FlowProportions: method {method!r} is not part of this round's hot path")
     dem, s = _elev(dem, "FlowProportions")
     h, w = dem.shape
     out = np.empty((h, w, 9), np.float32)
-    check(getattr(lib(), f"rdgpu_fm_tarboton_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
+    check(getattr(lib(), f"rdgpu_fm_d8_{s}" if method == "D8" else f"rdgpu_fm_tarboton_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
                                                    out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_fm_tarboton")
     return out
 

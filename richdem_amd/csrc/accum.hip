@@ -451,9 +451,43 @@ RD_ACCUM_API(i32, int32_t)
 RD_ACCUM_API(f32, float)
 RD_ACCUM_API(f64, double)
 
+// FM_D8 as the reference's 9-float proportions array (flowmet/OCallaghan1984.hpp:13-77, Array3D.hpp:203-206)
+__global__ __launch_bounds__(256) void k_fm_props(const uint8_t *__restrict__ dirs, float *__restrict__ props, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += stride) {
+    const int d = dirs[c];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float v = -1.0f;                               // NO_FLOW_GEN, :26
+      if (k == 0 && d == 255) v = -2.0f;             // NO_DATA_GEN, :37-40
+      else if (k == 0 && d >= 1 && d <= 8) v = 0.0f; // HAS_FLOW_GEN, :70
+      else if (k == d && d >= 1 && d <= 8) v = 1.0f; // :74
+      props[9 * c + k] = v;
+    }
+  }
+}
+
+template <class T>
+static void fm_d8_host(const T *dem, T nodata, int w, int h, float *props9) {
+  if (!dem || !props9) throw rdgpu::Error(RDGPU_ERR_ARG, "rdgpu_fm_d8: null pointer");
+  rdgpu::check_dims(w, h, "rdgpu_fm_d8");
+  const size_t n = (size_t)w * h;
+  T *d = rdgpu::Workspace::get().buf<T>("host.dem", n);
+  uint8_t *dirs = rdgpu::Workspace::get().buf<uint8_t>("accum.fmdirs", n);
+  float *p = rdgpu::Workspace::get().buf<float>("host.props", n * 9);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  rdgpu::flowdirs_device<T>(d, nodata, w, h, dirs, rdgpu::MODE_FM, nullptr);
+  RD_LAUNCH("accum.fm_props", k_fm_props, dim3(rdgpu::sgrid(n)), dim3(256), 0, (hipStream_t) nullptr, (const uint8_t *)dirs, p,
+            (uint64_t)n);
+  RD_HIP(hipMemcpy(props9, p, n * 36, hipMemcpyDeviceToHost));
+}
+
 #define RD_FA_API(SUF, T)                                                                                    \
   extern "C" int rdgpu_fa_d8_##SUF(const T *dem, T nodata, int w, int h, double *accum) {                    \
     return guarded([&] { fa_d8_host<T>(dem, nodata, w, h, accum); });                                        \
+  }                                                                                                          \
+  extern "C" int rdgpu_fm_d8_##SUF(const T *dem, T nodata, int w, int h, float *props9) {                     \
+    return guarded([&] { fm_d8_host<T>(dem, nodata, w, h, props9); });                                        \
   }                                                                                                          \
   extern "C" int rdgpu_fa_d8_dev_##SUF(const T *d_dem, T nodata, int w, int h, double *d_accum, void *stream) { \
     return guarded([&] { fa_d8_device<T>(d_dem, nodata, w, h, d_accum, (hipStream_t)stream); });             \

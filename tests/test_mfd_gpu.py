@@ -72,6 +72,12 @@ def test_fa_tarboton_and_generic_accumulation(rd, orc):
         assert np.array_equal(rd.FlowAccumFromProps(p8, w), orc.port.flow_accumulation(p8, w)), name
 
 
+def test_fm_d8_proportions_exact(rd, orc):
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        assert np.array_equal(rd.FlowProportions(dem, "D8", nodata=nd), orc.port.fm_d8(dem, nd)), name
+
+
 def test_generic_accumulation_errors(rd):
     with pytest.raises(rd.RdgpuError, match="same dimensions"):
         rd.FlowAccumFromProps(np.zeros((4, 5, 9), np.float32), np.ones((3, 3)))
