@@ -131,19 +131,24 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
     lp[ly * DW + lx] = l;
   }
   __syncthreads();
-  // pointer jumping inside the tile; any value ever stored is an ancestor, so races are harmless
-  for (int it = 0; it < 16; it++) {
-    int changed = 0;
+  // pointer jumping inside the tile; any value ever stored is an ancestor, so races are harmless.
+  // A cell whose parent is a tile root is finished for good, so only the still-active cells (bit mask
+  // per thread) are revisited: integer VALU + LDS issue, not HBM, bounds this kernel.
+  uint32_t active = 0;
 #pragma unroll 4
-    for (int j = 0; j < DH / 4; j++) {
+  for (int j = 0; j < DH / 4; j++)
+    if (lp[(ly0 + 4 * j) * DW + lx] != LTERM) active |= 1u << j;
+  for (int it = 0; it < 16; it++) {
+    uint32_t still = 0;
+    for (uint32_t m = active; m; m &= m - 1) {
+      const int j = __ffs((int)m) - 1;
       const int li = (ly0 + 4 * j) * DW + lx;
       const uint16_t p = lp[li];
-      if (p != LTERM) {
-        const uint16_t q = lp[p];
-        if (q != LTERM) { lp[li] = q; changed = 1; }
-      }
+      const uint16_t q = lp[p];
+      if (q != LTERM) { lp[li] = q; still |= 1u << j; }
     }
-    if (!__syncthreads_or(changed)) break;
+    active = still;
+    if (!__syncthreads_or(active != 0)) break;
   }
   // write: the tile-local root's own pointer
 #pragma unroll 4
@@ -180,6 +185,29 @@ __global__ __launch_bounds__(NTHR) void k_chase(uint32_t *ptr, uint32_t n, int m
     }
     if (p != p0) ptr[c] = p;
     if (unfinished) *flag = 1;
+  }
+}
+
+// Chase straight to the basin label: after the in-tile compression a path is a few tile-to-tile hops, so
+// nothing is written back; lab[pit] must already hold the pit's dense id.  A cell whose path is longer
+// than maxhops keeps the furthest ancestor found in ptr[] and raises the flag: the host then falls back to
+// the compressing passes (k_chase) + k_label_cells.  lab[c] = B for cells draining off the raster.
+__global__ __launch_bounds__(NTHR) void k_chase_label(uint32_t *ptr, uint32_t *lab, uint32_t n, uint32_t B, int maxhops,
+                                                      uint32_t *flag) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
+    const uint32_t c = (uint32_t)c64;
+    uint32_t p = ptr[c];
+    if (p == c) continue;              // a pit: labelled by k_assign_pits
+    if (p == OUTP) { lab[c] = B; continue; }
+    int hops = 0;
+    for (;;) {
+      const uint32_t q = ptr[p];
+      if (q == OUTP) { lab[c] = B; break; }
+      if (q == p) { lab[c] = lab[p]; break; }
+      p = q;
+      if (++hops >= maxhops) { ptr[c] = p; *flag = 1; break; }
+    }
   }
 }
 
@@ -366,8 +394,7 @@ template <class T, int TOPO, bool FIRST, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
                                                int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
-                                               const uint8_t *__restrict__ alive_in, uint8_t *alive_out,
-                                               int ablate) {
+                                               const uint8_t *__restrict__ alive_in, uint8_t *alive_out) {
   __shared__ uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   __shared__ uint32_t tab_id[SC_SLOTS];
@@ -438,7 +465,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   __syncthreads();
   // components that also live outside this tile (seen on the halo ring) need the global atomic;
   // a component entirely inside the tile is reduced here completely and can use a plain store
-  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2) && !(ablate & 4); i += NTHR) {
+  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2); i += NTHR) {
     int o;
     if (i < LW) o = i;
     else if (i < 2 * LW) o = (LH - 1) * LW + (i - LW);
@@ -478,7 +505,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       uint32_t d = (c0[1] ^ C) | (c1[0] ^ C) | (c1[2] ^ C) | (c2[1] ^ C);
       if (TOPO == 8) d |= (c0[0] ^ C) | (c0[2] ^ C) | (c2[0] ^ C) | (c2[2] ^ C);
       // closed: drains to the outside or to a frozen terminal -- never proposes
-      const bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h && !(ablate & 1);
+      const bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h;
       const unsigned long long bal = __ballot(hit);
       if (bal) {
         uint32_t base = 0;
@@ -515,7 +542,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   const int any = nl != 0;
   __syncthreads();
   const int alive = any;
-  for (int i = threadIdx.x; i < SC_SLOTS && !(ablate & 2); i += NTHR) {
+  for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) {
     const uint32_t C = tab_id[i];
     if (C != 0xFFFFFFFFu) {
       const unsigned long long cand = tab_val[i];
@@ -775,16 +802,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
               open_top, open_bottom);
   }
 
-  // path compression; each pass shortens every path by >= 32x
-  for (;;) {
-    RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("fill.chase", k_chase, dim3(sgrid), dim3(NTHR), 0, s, ptr, n, 32, dflags);
-    RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    g_stats.jump_passes++;
-    if (hw[0] == 0) break;
-  }
-
+  // pits (ptr[c] == c) are final after the descent kernel: number them first
   RD_LAUNCH("fill.count_pits", k_count_pits, dim3(nblk), dim3(NTHR), 0, s, ptr, n, counts);
   RD_LAUNCH("fill.scan_counts", k_scan_counts, dim3(1), dim3(1024), 0, s, counts, nblk, dflags + 1);
   RD_HIP(hipMemcpyAsync(hw, dflags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -794,7 +812,23 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   g_stats.basins = B;
   fb.B = B;
   if (B == 0) { fb.trivial = true; return; }  // no pits and no terminals: nothing to raise
-  RD_LAUNCH("fill.label_cells", k_label_cells, dim3(sgrid), dim3(NTHR), 0, s, ptr, lab, n, B);
+  RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
+  RD_LAUNCH("fill.chase_label", k_chase_label, dim3(sgrid), dim3(NTHR), 0, s, ptr, lab, n, B, 256, dflags);
+  RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  g_stats.jump_passes = 1;
+  if (hw[0] != 0) {
+    // pathologically long tile-to-tile chains: compress them (each pass shortens every path >= 32x), relabel
+    for (;;) {
+      RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
+      RD_LAUNCH("fill.chase", k_chase, dim3(sgrid), dim3(NTHR), 0, s, ptr, n, 32, dflags);
+      RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      g_stats.jump_passes++;
+      if (hw[0] == 0) break;
+    }
+    RD_LAUNCH("fill.label_cells", k_label_cells, dim3(sgrid), dim3(NTHR), 0, s, ptr, lab, n, B);
+  }
 
   uint32_t *cur = alloc.get<uint32_t>("fill.cur", (size_t)B + 1);
   uint32_t *acc = alloc.get<uint32_t>("fill.acc", (size_t)B + 1);
@@ -828,11 +862,10 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
     RD_HIP(hipMemsetAsync(dflags + 3, 0, sizeof(uint32_t), s));
     if (nlive > 0) {
-      static const int ablate = getenv("RDGPU_ABLATE") ? atoi(getenv("RDGPU_ABLATE")) : 0;   // timing experiments only
       const bool vec = sizeof(T) == 4 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % 16) == 0;
 #define RD_SCAN(FIRST_, VEC_, AIN)                                                                              \
   RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(tgrid), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, B, \
-            tilesX, ntiles, (const uint8_t *)(AIN), aliveB, ablate)
+            tilesX, ntiles, (const uint8_t *)(AIN), aliveB)
       if (first && !sharded) { if (vec) RD_SCAN(true, true, nullptr); else RD_SCAN(true, false, nullptr); }
       else if (first) { if (vec) RD_SCAN(false, true, nullptr); else RD_SCAN(false, false, nullptr); }
       else { if (vec) RD_SCAN(false, true, aliveA); else RD_SCAN(false, false, aliveA); }
@@ -856,10 +889,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_HIP(hipMemcpyAsync(hw, dflags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     const uint32_t next = hw[0];
-    if (next >= nroots) {
-      if (getenv("RDGPU_ABLATE")) break;
-      throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
-    }
+    if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
     nroots = next;
     nlive = hw[1];
     first = false;

@@ -287,3 +287,18 @@ def test_64bit_element_types(rd, orc):
     t = torch.from_numpy(d_general).cuda()
     rd.fill_depressions_dev(t)
     assert np.array_equal(t.cpu().numpy(), orc.port.fill(d_general))
+
+
+def test_very_long_tile_chains_fallback(rd, orc):
+    """Descent paths crossing > 256 tiles (a 3 x 70000 corridor) force the compressing fallback passes."""
+    w = 70000
+    dem = np.full((3, w), 50.0, np.float32)
+    dem[1, :] = np.linspace(10.0, 40.0, w, dtype=np.float32)    # interior row descends westward ...
+    dem[1, :200] = 45.0                                         # ... into a pit region at x ~ 200
+    dem[1, 200] = 5.0
+    got = rd.FillDepressions(dem)
+    assert np.array_equal(got, orc.port.fill(dem))
+    assert rd.fill_stats()["jump_passes"] > 1
+    flat = np.zeros((5, 40000), np.int32)                       # one huge flat: chains along whole rows
+    flat[2, 1:-1] = -3
+    assert np.array_equal(rd.FillDepressions(flat), orc.port.fill(flat))
