@@ -59,43 +59,139 @@ __device__ __forceinline__ int inflow_count(const uint8_t *__restrict__ dirs, ui
 }
 
 // ---- unit weights ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_acc_init_unit(const uint8_t *__restrict__ dirs, uint8_t nodata,
+// Raster-wide walk with lane refill.  One thread per source would leave a wavefront waiting for its single
+// longest chain (mean chain ~3 steps, the longest per wave hundreds: 790 ms at 40k x 40k, ~1% lane use).
+// Instead each wavefront owns a chunk of cells; a lane whose chain has ended immediately scans the
+// chunk for the next source, so every loop trip advances up to 64 chains by one step.
+constexpr uint32_t WALK_CHUNK = 8192;   // cells per wavefront
+__global__ __launch_bounds__(NTHR) void k_acc_walk_unit(const uint8_t *__restrict__ dirs, uint8_t nodata,
                                                         unsigned long long *word, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
-    unsigned long long v = 0;
-    if (dirs[c] != nodata) {
-      const int k = inflow_count(dirs, nodata, x, y, w, h);
-      // SRC marks a source: nobody ever adds to it, so the marker is stable while other cells' counts
-      // run down to 0 (testing "count == 0" in the walk kernel would race with last arrivals)
-      v = ((unsigned long long)(k == 0 ? SRC : k) << 56) | 1ull;  // low field: the cell's own area
+  const uint64_t n = (uint64_t)w * h;
+  const uint64_t wave = ((uint64_t)blockIdx.x * NTHR + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t next = wave * WALK_CHUNK;
+  const uint64_t end = next + WALK_CHUNK < n ? next + WALK_CHUNK : n;
+  if (next >= n) return;
+  bool active = false;
+  uint32_t c = 0;
+  unsigned long long v = 0;
+  uint8_t d = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (next < end && idle) {
+      // idle lanes look at the next cells of the chunk (contiguous -> coalesced)
+      const uint64_t my = next + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && my < end) {
+        const uint8_t dd = dirs[my];
+        if (dd != nodata) {
+          const unsigned long long wd = word[my];   // a source's word is never modified: plain read
+          if ((wd >> 56) == SRC) { active = true; c = (uint32_t)my; v = wd & LOWMASK; d = dd; }
+        }
+      }
+      next += (uint64_t)__popcll(idle);
+    } else if (idle == ~0ull) {
+      break;   // chunk exhausted and every chain has ended
     }
-    word[c] = v;
+    if (active) {
+      const int64_t t = flow_target(c, d, w, h);                 // d8_methods.hpp:113-122
+      if (t < 0) active = false;
+      else {
+        const uint8_t dt = dirs[t];
+        if (dt == nodata) active = false;                        // :124-125 flow into NoData is dropped
+        else {
+          const unsigned long long old = atomicAdd(&word[t], v - CNT1);
+          if ((old >> 56) != 1) active = false;                  // not the last inflow of t
+          else { v = (old & LOWMASK) + v; c = (uint32_t)t; d = dt; }   // t's final area: keep walking
+        }
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(NTHR) void k_acc_walk_unit(const uint8_t *__restrict__ dirs, uint8_t nodata,
-                                                        unsigned long long *word, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c0 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c0 < n; c0 += stride) {
-    uint8_t d = dirs[c0];
-    if (d == nodata) continue;
-    // plain read is safe: a source's word is never modified by anyone
-    if ((word[c0] >> 56) != SRC) continue;  // has inflow: some last arriver will come through here
-    uint32_t c = (uint32_t)c0;
-    unsigned long long v = 1;
-    for (;;) {
-      const int64_t t = flow_target(c, d, w, h);                 // d8_methods.hpp:113-122
-      if (t < 0) break;
-      const uint8_t dt = dirs[t];
-      if (dt == nodata) break;                                   // :124-125 flow into NoData is dropped
-      const unsigned long long old = atomicAdd(&word[t], v - CNT1);
-      if ((old >> 56) != 1) break;                               // not the last inflow of t
-      v = (old & LOWMASK) + v;                                   // t's final area
-      c = (uint32_t)t;
-      d = dt;
+// Tile pre-walk: the same last-arriver walk, but confined to one 64x64 tile with the words in LDS
+// ((pending << 24) | area in 32 bits).  Global device atomics are the bottleneck of the raster-wide walk
+// (~2*10^9/s); here only cells whose 8 neighbours all lie in the tile (everything but the tile's outer ring)
+// are ever the TARGET of an add, so their state is private to the block and LDS atomics suffice.  A walk
+// stops when its next target is a ring cell or outside the tile; the cell it stopped on is written back as
+// a "source" carrying its total, and the raster-wide walk (k_acc_walk_unit) continues from there.
+constexpr int AW = 64, AH = 64, ALW = AW + 2, ALH = AH + 2;
+__global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk(const uint8_t *__restrict__ dirs, uint8_t nodata,
+                                                           unsigned long long *__restrict__ word, int w, int h,
+                                                           uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint8_t sd[ALH * ALW];
+  __shared__ uint32_t lw[AH * AW];
+  constexpr uint32_t LCNT1 = 1u << 24, LMASK = LCNT1 - 1u, LSRC = 0xFFu;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
+  for (int i = threadIdx.x; i < ALH * ALW; i += NTHR) {
+    const int ly = i / ALW, lx = i - ly * ALW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : nodata;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
+  // pending inflows (from anywhere) + own area
+  for (int j = 0; j < AH / 4; j++) {
+    const int ly = ly0 + 4 * j, o = (ly + 1) * ALW + lx + 1;
+    uint32_t v = 0;
+    if (x0 + lx < w && y0 + ly < h && sd[o] != nodata) {
+      int k = 0;
+#pragma unroll
+      for (int m = 1; m <= 8; m++) {
+        const uint8_t d = sd[o + d8dy(m) * ALW + d8dx(m)];   // halo cells outside the raster hold nodata
+        if (d != nodata && d == (m <= 4 ? m + 4 : m - 4)) k++;
+      }
+      v = ((uint32_t)k << 24) | 1u;
     }
+    lw[ly * AW + lx] = v;
+  }
+  __syncthreads();
+  // walks from the tile's sources; sources are fixed before any walk (initial pending == 0)
+  uint32_t srcmask = 0;
+  for (int j = 0; j < AH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    if (x0 + lx < w && y0 + ly < h && sd[(ly + 1) * ALW + lx + 1] != nodata && (lw[ly * AW + lx] >> 24) == 0) srcmask |= 1u << j;
+  }
+  __syncthreads();
+  for (uint32_t m = srcmask; m; m &= m - 1) {
+    const int j = __ffs((int)m) - 1;
+    int cx = lx, cy = ly0 + 4 * j;
+    uint32_t v = 1;
+    for (;;) {
+      const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
+      bool stalled = false;
+      if (d >= 1 && d <= 8) {
+        const int tx = cx + d8dx(d), ty = cy + d8dy(d);
+        const uint8_t dt = sd[(ty + 1) * ALW + tx + 1];      // nodata for cells outside the raster
+        if (dt != nodata) {                                    // else: off the DEM / into NoData: dropped
+          if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
+            // target is strictly inside the tile: all its donors are in this tile -> LDS state is complete
+            const uint32_t old = atomicAdd(&lw[ty * AW + tx], v - LCNT1);
+            if ((old >> 24) == 1) { v = (old & LMASK) + v; cx = tx; cy = ty; continue; }
+          } else {
+            stalled = true;                                    // ring cell or another tile: continue raster-wide
+          }
+        }
+      }
+      if (stalled) lw[cy * AW + cx] = (LSRC << 24) | v;        // completed, still has to pass its total on
+      break;
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < AH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const uint32_t v = lw[ly * AW + lx];
+    unsigned long long g = 0;
+    if (sd[(ly + 1) * ALW + lx + 1] != nodata) {
+      uint32_t cnt = v >> 24;
+      // a true source that passed its total on inside the tile is simply complete (count 0); a true source
+      // that could not (first target outside) keeps the SRC marker it would have got from k_acc_init_unit
+      g = ((unsigned long long)(cnt == LSRC ? SRC : cnt) << 56) | (unsigned long long)(v & LMASK);
+    }
+    word[(size_t)gy * w + gx] = g;
   }
 }
 
@@ -132,29 +228,48 @@ __global__ __launch_bounds__(NTHR) void k_acc_init_f64(const uint8_t *__restrict
 
 __global__ __launch_bounds__(NTHR) void k_acc_walk_f64(const uint8_t *__restrict__ dirs, uint32_t *pending,
                                                        double *acc, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c0 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c0 < n; c0 += stride) {
-    uint8_t d = dirs[c0];
-    if (d == 255) continue;
-    if (pending[c0] != SRC32) continue;   // sources only (a source's counter is never written)
-    uint32_t c = (uint32_t)c0;
-    double v = acc[c0];               // a source's total is its own generated flow
-    for (;;) {
+  // lane-refill walk (see k_acc_walk_unit)
+  const uint64_t n = (uint64_t)w * h;
+  const uint64_t wave = ((uint64_t)blockIdx.x * NTHR + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t next = wave * WALK_CHUNK;
+  const uint64_t end = next + WALK_CHUNK < n ? next + WALK_CHUNK : n;
+  if (next >= n) return;
+  bool active = false;
+  uint32_t c = 0;
+  double v = 0;
+  uint8_t d = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (next < end && idle) {
+      const uint64_t my = next + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && my < end) {
+        const uint8_t dd = dirs[my];
+        // sources only; a source's counter and total are never written by anyone else
+        if (dd != 255 && pending[my] == SRC32) { active = true; c = (uint32_t)my; v = acc[my]; d = dd; }
+      }
+      next += (uint64_t)__popcll(idle);
+    } else if (idle == ~0ull) {
+      break;
+    }
+    if (active) {
       const int64_t t = flow_target(c, d, w, h);
-      if (t < 0) break;
-      const uint8_t dt = dirs[t];
-      if (dt == 255) break;                                        // flow_accumulation_generic.hpp:85-86
-      // :87 (proportion is exactly 1 for D8).  All three steps are device-scope atomic RMWs executed
-      // at the memory side: a RETURNING add has completed there before the decrement is issued, and the
-      // last arriver's decrement is ordered after every other arriver's decrement, hence after their
-      // adds -- no cache write-back / invalidate (release/acquire fences cost ~10x here) is needed.
-      const double prev = atomicAdd(&acc[t], v);
-      asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");   // the add has returned
-      const uint32_t old = __hip_atomic_fetch_sub(&pending[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old != 1) break;
-      v = atomicAdd(&acc[t], 0.0);                                 // final total, read at the memory side
-      c = (uint32_t)t;
-      d = dt;
+      if (t < 0) active = false;
+      else {
+        const uint8_t dt = dirs[t];
+        if (dt == 255) active = false;                               // flow_accumulation_generic.hpp:85-86
+        else {
+          // :87 (proportion is exactly 1 for D8).  All three steps are device-scope atomic RMWs executed
+          // at the memory side: a RETURNING add has completed there before the decrement is issued, and
+          // the last arriver's decrement is ordered after every other arriver's decrement, hence after
+          // their adds -- no cache write-back / invalidate (release/acquire fences cost ~10x here).
+          const double prev = atomicAdd(&acc[t], v);
+          asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");   // the add has returned
+          const uint32_t old = __hip_atomic_fetch_sub(&pending[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old != 1) active = false;
+          else { v = atomicAdd(&acc[t], 0.0); c = (uint32_t)t; d = dt; }   // final total, read at the memory side
+        }
+      }
     }
   }
 }
@@ -179,8 +294,13 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
   check_dims(w, h, "rdgpu_d8_flow_accum");
   const uint64_t n = (uint64_t)w * h;
   unsigned long long *word = Workspace::get().buf<unsigned long long>("accum.word", n);
-  RD_LAUNCH("accum.init_unit", k_acc_init_unit, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, nodata, word, w, h);
-  RD_LAUNCH("accum.walk_unit", k_acc_walk_unit, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, nodata, word, w, h);
+  {
+    const uint32_t tilesX = (w + AW - 1) / AW, ntiles = tilesX * ((h + AH - 1) / AH);
+    RD_LAUNCH("accum.tile_prewalk", k_acc_tile_prewalk, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, word, w, h,
+              tilesX, ntiles);
+  }
+  RD_LAUNCH("accum.walk_unit", k_acc_walk_unit, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR), 0,
+            s, d_dirs, nodata, word, w, h);
   RD_LAUNCH("accum.out_unit", (k_acc_out_unit<A>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, nodata, word, d_area, n);
 }
 
@@ -189,7 +309,8 @@ void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, h
   const uint64_t n = (uint64_t)w * h;
   uint32_t *pending = Workspace::get().buf<uint32_t>("accum.pending", n);
   RD_LAUNCH("accum.init_f64", k_acc_init_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, pending, w, h);
-  RD_LAUNCH("accum.walk_f64", k_acc_walk_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, pending, d_acc, w, h);
+  RD_LAUNCH("accum.walk_f64", k_acc_walk_f64, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR), 0, s,
+            d_dirs, pending, d_acc, w, h);
   RD_LAUNCH("accum.nodata_f64", k_acc_nodata_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, d_acc, n);
 }
 
@@ -297,12 +418,55 @@ __device__ __forceinline__ void accs_walk(const AccShard &s, uint32_t c, unsigne
   }
 }
 
+// one walk step from cell c (final total v); returns false when the walk ends
+__device__ __forceinline__ bool accs_step(const AccShard &s, uint32_t &c, unsigned long long &v, uint8_t &d) {
+  if (d < 1 || d > 8) return false;
+  const int x = (int)(c % (uint32_t)s.w) + d8dx(d), y = (int)(c / (uint32_t)s.w) + d8dy(d);
+  if (x < 0 || x >= s.w) return false;                           // off the DEM
+  if (y < 0) {                                                   // across the upper cut (or off the DEM)
+    if (s.above && s.above[x] != s.nodata) atomicAdd(&s.out_top[x], v + CNT1);
+    return false;
+  }
+  if (y >= s.h) {
+    if (s.below && s.below[x] != s.nodata) atomicAdd(&s.out_bottom[x], v + CNT1);
+    return false;
+  }
+  const uint32_t t = (uint32_t)y * (uint32_t)s.w + (uint32_t)x;
+  const uint8_t dt = s.dirs[t];
+  if (dt == s.nodata) return false;
+  const unsigned long long old = atomicAdd(&s.word[t], v - CNT1);
+  if ((old >> 56) != 1) return false;
+  v = (old & LOWMASK) + v;
+  c = t;
+  d = dt;
+  return true;
+}
+
 __global__ __launch_bounds__(NTHR) void k_accs_walk_sources(AccShard s) {
-  const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    if (s.dirs[c] == s.nodata) continue;
-    if ((s.word[c] >> 56) != SRC) continue;
-    accs_walk(s, (uint32_t)c, 1ull);
+  // lane-refill walk (see k_acc_walk_unit)
+  const uint64_t n = (uint64_t)s.w * s.h;
+  const uint64_t wave = ((uint64_t)blockIdx.x * NTHR + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t next = wave * WALK_CHUNK;
+  const uint64_t end = next + WALK_CHUNK < n ? next + WALK_CHUNK : n;
+  if (next >= n) return;
+  bool active = false;
+  uint32_t c = 0;
+  unsigned long long v = 0;
+  uint8_t d = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (next < end && idle) {
+      const uint64_t my = next + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && my < end) {
+        const uint8_t dd = s.dirs[my];
+        if (dd != s.nodata && (s.word[my] >> 56) == SRC) { active = true; c = (uint32_t)my; v = 1ull; d = dd; }
+      }
+      next += (uint64_t)__popcll(idle);
+    } else if (idle == ~0ull) {
+      break;
+    }
+    if (active) active = accs_step(s, c, v, d);
   }
 }
 
@@ -369,7 +533,8 @@ static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int 
     RD_HIP(hipMemsetAsync(a->s.out_top, 0, (size_t)w * 8, st));
     RD_HIP(hipMemsetAsync(a->s.out_bottom, 0, (size_t)w * 8, st));
     RD_LAUNCH("accum.shard_init", k_accs_init, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
-    RD_LAUNCH("accum.shard_walk", k_accs_walk_sources, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
+    RD_LAUNCH("accum.shard_walk", k_accs_walk_sources, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)),
+              dim3(NTHR), 0, st, a->s);
   } catch (...) {
     accs_free(a);
     throw;
