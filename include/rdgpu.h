@@ -200,6 +200,33 @@ typedef struct rdgpu_flat_stats {
 } rdgpu_flat_stats;
 int rdgpu_flat_get_stats(rdgpu_flat_stats *out);
 
+/* ---- flat resolution over row-block shards ---------------------------
+ * barnes_flat_resolution_d8 (flats/flat_resolution.hpp:587-605) when the raster is split into row blocks,
+ * one per GPU.  d_rows = the shard's own rows plus TWO ghost rows per cut (ghost_top / ghost_bottom are 0
+ * at the raster's first / last block, 2 otherwise), device resident and kept alive until _free.
+ * Protocol, for phase 0 (towards low edges) and then phase 1 (away from high edges):
+ *     repeat { _relax(phase); _boundary(phase, out[2w]);  all-gather;  stop when no gathered row changed;
+ *              _inject(phase, last own row of the block above, first own row of the block below) }
+ * then  _heights(out[8w]);  all-gather;  rdgpu_flat_graph_solve_dev(gathered, world, w, solved[world*4w]);
+ *       _finish(solved + rank*4w, dirs of the own rows).
+ * The result equals rdgpu_flat_resolution_d8 of the whole raster restricted to the own rows.           */
+typedef struct rdgpu_flat_shard rdgpu_flat_shard;
+int rdgpu_flat_shard_begin_u8(const uint8_t *d_rows, uint8_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_i16(const int16_t *d_rows, int16_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_u16(const uint16_t *d_rows, uint16_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_i32(const int32_t *d_rows, int32_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_u32(const uint32_t *d_rows, uint32_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_f32(const float *d_rows, float nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_f64(const double *d_rows, double nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_relax(rdgpu_flat_shard *shard, int phase);
+int rdgpu_flat_shard_boundary(rdgpu_flat_shard *shard, int phase, int32_t *d_out_2w);
+int rdgpu_flat_shard_inject(rdgpu_flat_shard *shard, int phase, const int32_t *d_row_above, const int32_t *d_row_below);
+int rdgpu_flat_shard_heights(rdgpu_flat_shard *shard, int32_t *d_out_8w);
+int rdgpu_flat_graph_solve_dev(const int32_t *d_gathered, int world, int width, int32_t *d_out, void *hip_stream);
+int rdgpu_flat_shard_finish(rdgpu_flat_shard *shard, const int32_t *d_heights_4w, uint8_t *d_dirs_out);
+int rdgpu_flat_shard_rounds(const rdgpu_flat_shard *shard, int phase);
+void rdgpu_flat_shard_free(rdgpu_flat_shard *shard);
+
 /* ---- d8_flow_accum(const Array2D<uint8_t>& flowdirs, Array2D<A>& area) ----------------------
  * Replaces richdem::d8_flow_accum (include/richdem/methods/d8_methods.hpp:47-139): area = number of
  * cells draining through each cell (itself included); cells whose direction equals dir_nodata get

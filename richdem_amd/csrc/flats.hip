@@ -316,11 +316,12 @@ __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter) {
 __global__ __launch_bounds__(NTHR) void k_flat_seed(const uint32_t *__restrict__ src, uint32_t nsrc,
                                                     const uint32_t *__restrict__ L, const int32_t *__restrict__ fh,
                                                     int32_t *D, uint8_t *tile_active, int w, uint32_t tilesX,
-                                                    uint32_t tilesY) {
+                                                    uint32_t tilesY, const int32_t *__restrict__ reach) {
   const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
   if (i >= nsrc) return;
   const uint32_t c = src[i];
   if (fh && fh[L[c]] < 0) return;   // its flat has no outlet: not a source
+  if (reach && reach[c] >= DINF) return;   // same test through the towards distances (row-block shards)
   D[c] = 1;
   // wake the source's tile and the tiles of its 8 neighbours (a source on a tile edge feeds the next tile)
   const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
@@ -535,7 +536,7 @@ static uint32_t run_relax(const T *d_z, const uint8_t *d_dirs, int32_t *D, const
   uint32_t *ctr = ws.buf<uint32_t>("flats.tctr", 4);
   RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
   RD_LAUNCH("flats.seed", k_flat_seed, dim3((nsrc + NTHR - 1) / NTHR), dim3(NTHR), 0, s, src, nsrc, L, fh_filter, D,
-            tflags, w, tilesX, tilesY);
+            tflags, w, tilesX, tilesY, (const int32_t *)nullptr);
   uint32_t rounds = 0;
   for (;;) {
     RD_HIP(hipMemsetAsync(ctr, 0, sizeof(uint32_t), s));
@@ -718,6 +719,308 @@ static void flat_resolution_alter_host(T *dem, T nodata, int w, int h, uint8_t *
   RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));   // the DEM is altered in place
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Row-block shards.  A shard works on its rows plus two ghost rows per cut:
+// with them d8_flow_directions and the edge classification of every own cell are exact.  What crosses a
+// cut is (1) the two distance fields -- each shard relaxes to its local fixed point, the cut rows are
+// exchanged, the ghost rows lowered, and that repeats until no cut row changes anywhere -- and (2) the
+// deepest away level per flat: local components are glued through the cells both neighbours hold (one
+// small union-find over the cut rows, solved redundantly by every rank).  "Has an outlet" is read off the
+// towards distances (a NO_FLOW cell is in a drainable flat <=> the towards relaxation reaches it), so the
+// towards field is built first and the away sources are filtered through it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *__restrict__ in, int ghost_row, int own_row,
+                                                    int w, uint8_t *tile_active, uint32_t tilesX) {
+  const int x = blockIdx.x * NTHR + threadIdx.x;
+  if (x >= w) return;
+  const int32_t v = in[x];
+  int32_t *g = &D[(size_t)ghost_row * w + x];
+  if (v < *g) {
+    *g = v;
+    const int ty = own_row / CH;
+    for (int tx = max(x - 1, 0) / CW; tx <= min(x + 1, w - 1) / CW; tx++) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
+  }
+}
+
+struct CutRows { int row[4]; };   // ghost above, first own, last own, ghost below (-1: no such row)
+
+__global__ __launch_bounds__(NTHR) void k_fs_first(const uint32_t *__restrict__ L, uint32_t *first, CutRows cr, int w, int pass) {
+  const int p = blockIdx.x * NTHR + threadIdx.x;
+  if (p >= 4 * w) return;
+  const int r = cr.row[p / w];
+  if (r < 0) return;
+  const uint32_t lab = L[(size_t)r * w + (p % w)];
+  if (pass == 0) first[lab] = 0xFFFFFFFFu;
+  else atomicMin(&first[lab], (uint32_t)p);
+}
+
+// out[0..4w) = lowest cut-row position with the same local label; out[4w..8w) = local flat height of that label
+__global__ __launch_bounds__(NTHR) void k_fs_export(const uint32_t *__restrict__ L, const uint32_t *__restrict__ first,
+                                                    const int32_t *__restrict__ fh, CutRows cr, int w, int32_t *out) {
+  const int p = blockIdx.x * NTHR + threadIdx.x;
+  if (p >= 4 * w) return;
+  const int r = cr.row[p / w];
+  int32_t rep = p, v = 0;
+  if (r >= 0) {
+    const uint32_t lab = L[(size_t)r * w + (p % w)];
+    rep = (int32_t)first[lab];
+    v = fh[lab];
+  }
+  out[p] = rep;
+  out[4 * w + p] = v;
+}
+
+__global__ __launch_bounds__(NTHR) void k_fs_apply(const uint32_t *__restrict__ L, int32_t *fh, const int32_t *__restrict__ in,
+                                                   CutRows cr, int w) {
+  const int p = blockIdx.x * NTHR + threadIdx.x;
+  if (p >= 4 * w) return;
+  const int r = cr.row[p / w];
+  if (r < 0) return;
+  const uint32_t lab = L[(size_t)r * w + (p % w)];
+  const int32_t v = in[p];
+  if (__hip_atomic_load(&fh[lab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(&fh[lab], v);
+}
+
+// ---- the cut-row graph: nodes = (rank, cut-row position); gathered[r] = [4w rep | 4w height] ----
+__global__ __launch_bounds__(NTHR) void k_fg_init(const int32_t *__restrict__ gathered, uint32_t *parent, int32_t *val,
+                                                  int world, int w) {
+  const uint32_t g = blockIdx.x * NTHR + threadIdx.x, per = 4u * (uint32_t)w;
+  if (g >= (uint32_t)world * per) return;
+  const uint32_t r = g / per;
+  parent[g] = r * per + (uint32_t)gathered[(size_t)r * 2 * per + (g - r * per)];
+  val[g] = 0;
+}
+
+__global__ __launch_bounds__(NTHR) void k_fg_glue(uint32_t *parent, int world, int w) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x, per = 4u * (uint32_t)w;
+  if (i >= (uint32_t)(world - 1) * 2u * (uint32_t)w) return;
+  const uint32_t r = i / (2u * (uint32_t)w), j = i % (2u * (uint32_t)w);
+  // the same physical cell seen from both sides: last own row of r == ghost above of r+1;
+  // ghost below of r == first own row of r+1
+  uf_unite(parent, r * per + 2u * (uint32_t)w + j, (r + 1u) * per + j);
+}
+
+__global__ __launch_bounds__(NTHR) void k_fg_max(uint32_t *parent, int32_t *val, const int32_t *__restrict__ gathered,
+                                                 int world, int w) {
+  const uint32_t g = blockIdx.x * NTHR + threadIdx.x, per = 4u * (uint32_t)w;
+  if (g >= (uint32_t)world * per) return;
+  const uint32_t r = g / per, root = uf_find(parent, g);
+  parent[g] = root;   // (only ever lowers a parent: safe next to concurrent finds)
+  const int32_t v = gathered[(size_t)r * 2 * per + per + (g - r * per)];
+  if (v > 0) atomicMax(&val[root], v);
+}
+
+__global__ __launch_bounds__(NTHR) void k_fg_out(const uint32_t *__restrict__ parent, const int32_t *__restrict__ val,
+                                                 int32_t *out, uint32_t total) {
+  const uint32_t g = blockIdx.x * NTHR + threadIdx.x;
+  if (g < total) out[g] = val[parent[g]];
+}
+
+static void flat_graph_solve_device(const int32_t *d_gathered, int world, int w, int32_t *d_out, hipStream_t s) {
+  if (!d_gathered || !d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_graph_solve_dev: null pointer");
+  if (world <= 0 || w <= 0 || (uint64_t)world * 4u * (uint64_t)w > 0x7FFF0000ull)
+    throw Error(RDGPU_ERR_ARG, "rdgpu_flat_graph_solve_dev: bad dimensions");
+  const uint32_t total = (uint32_t)world * 4u * (uint32_t)w;
+  Workspace &ws = Workspace::get();
+  uint32_t *parent = ws.buf<uint32_t>("flatgraph.parent", total);
+  int32_t *val = ws.buf<int32_t>("flatgraph.val", total);
+  const dim3 grid((total + NTHR - 1) / NTHR), blk(NTHR);
+  RD_LAUNCH("flatgraph.init", k_fg_init, grid, blk, 0, s, d_gathered, parent, val, world, w);
+  if (world > 1) {
+    const uint32_t nglue = (uint32_t)(world - 1) * 2u * (uint32_t)w;
+    RD_LAUNCH("flatgraph.glue", k_fg_glue, dim3((nglue + NTHR - 1) / NTHR), blk, 0, s, parent, world, w);
+  }
+  RD_LAUNCH("flatgraph.max", k_fg_max, grid, blk, 0, s, parent, val, d_gathered, world, w);
+  RD_LAUNCH("flatgraph.out", k_fg_out, grid, blk, 0, s, (const uint32_t *)parent, (const int32_t *)val, d_out, total);
+}
+
+}  // namespace rdgpu
+
+struct rdgpu_flat_shard {
+  int w = 0, rows = 0, gtop = 0, gbot = 0;
+  const void *z = nullptr;
+  uint8_t *dirs = nullptr, *flags = nullptr;
+  uint32_t *L = nullptr, *first = nullptr;
+  int32_t *fh = nullptr, *D[2] = {nullptr, nullptr};
+  uint32_t *src[2] = {nullptr, nullptr};
+  uint32_t nsrc[2] = {0, 0};
+  uint8_t *tflags[2] = {nullptr, nullptr};
+  uint32_t *tlist = nullptr, *ctr = nullptr;
+  bool seeded[2] = {false, false};
+  uint32_t rounds[2] = {0, 0};
+  hipStream_t stream = nullptr;
+  std::vector<void *> owned;
+  void (*relax_fn)(rdgpu_flat_shard *, int) = nullptr;
+  void (*finish_fn)(rdgpu_flat_shard *, const int32_t *, uint8_t *) = nullptr;
+};
+
+namespace rdgpu {
+
+static CutRows cut_rows(const rdgpu_flat_shard *f) {
+  CutRows cr;
+  cr.row[0] = f->gtop ? f->gtop - 1 : -1;
+  cr.row[1] = f->gtop;
+  cr.row[2] = f->rows - f->gbot - 1;
+  cr.row[3] = f->gbot ? f->rows - f->gbot : -1;
+  return cr;
+}
+
+static void fs_free(rdgpu_flat_shard *f) {
+  if (!f) return;
+  for (void *p : f->owned) (void)hipFree(p);
+  delete f;
+}
+
+template <class T>
+static void fs_relax(rdgpu_flat_shard *f, int phase) {
+  hipStream_t s = f->stream;
+  const int w = f->w, h = f->rows;
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + CH - 1) / CH, ntiles = tilesX * tilesY;
+  uint32_t *hw = Workspace::get().host_words();
+  const T *z = static_cast<const T *>(f->z);
+  int32_t *D = f->D[phase];
+  if (!f->seeded[phase]) {
+    f->seeded[phase] = true;
+    if (f->nsrc[phase])
+      RD_LAUNCH("flats.seed", k_flat_seed, dim3((f->nsrc[phase] + NTHR - 1) / NTHR), dim3(NTHR), 0, s,
+                (const uint32_t *)f->src[phase], f->nsrc[phase], (const uint32_t *)f->L, (const int32_t *)nullptr, D,
+                f->tflags[phase], w, tilesX, tilesY, phase == 1 ? (const int32_t *)f->D[0] : (const int32_t *)nullptr);
+  }
+  for (;;) {
+    RD_HIP(hipMemsetAsync(f->ctr, 0, sizeof(uint32_t), s));
+    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->tflags[phase],
+              ntiles, f->tlist, f->ctr);
+    RD_HIP(hipMemcpyAsync(hw, f->ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    const uint32_t nact = hw[0];
+    if (nact == 0) break;
+    RD_LAUNCH(phase ? "flats.relax_away" : "flats.relax_towards", (k_flat_relax<T>), dim3(nact), dim3(NTHR), 0, s, z,
+              (const uint8_t *)f->dirs, D, (const uint32_t *)f->tlist, f->tflags[phase], w, h, tilesX, tilesY);
+    if (++f->rounds[phase] > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat shard: relaxation did not terminate");
+  }
+}
+
+template <class T>
+static void fs_finish(rdgpu_flat_shard *f, const int32_t *d_heights, uint8_t *d_dirs_out) {
+  hipStream_t s = f->stream;
+  const int w = f->w, h = f->rows;
+  const uint64_t n = (uint64_t)w * h;
+  if (d_heights)
+    RD_LAUNCH("flatshard.apply", k_fs_apply, dim3((4 * w + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)f->L, f->fh,
+              d_heights, cut_rows(f), w);
+  RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, f->D[0], (const int32_t *)f->D[1],
+            (const uint32_t *)f->L, (const int32_t *)f->fh, n);
+  RD_LAUNCH("flats.masked_dirs", (k_flat_dirs<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, static_cast<const T *>(f->z),
+            (const int32_t *)f->D[0], f->dirs, w, h);
+  RD_HIP(hipMemcpyAsync(d_dirs_out, f->dirs + (size_t)f->gtop * w, (size_t)(h - f->gtop - f->gbot) * w, hipMemcpyDeviceToDevice, s));
+}
+
+template <class T>
+static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int gtop, int gbot, hipStream_t s) {
+  if (!d_z) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_begin: null pointer");
+  if (w <= 0 || rows <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_begin: width and rows must be positive");
+  if ((gtop != 0 && gtop != 2) || (gbot != 0 && gbot != 2) || rows - gtop - gbot < 1)
+    throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_begin: a cut needs exactly two ghost rows, and the shard at least one own row");
+  const uint64_t n = (uint64_t)w * rows;
+  if (n > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_begin: shard too large");
+  rdgpu_flat_shard *f = new rdgpu_flat_shard();
+  try {
+    f->w = w; f->rows = rows; f->gtop = gtop; f->gbot = gbot; f->z = d_z; f->stream = s;
+    f->relax_fn = &fs_relax<T>;
+    f->finish_fn = &fs_finish<T>;
+    auto alloc = [&](size_t bytes) {
+      void *p = nullptr;
+      RD_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+      f->owned.push_back(p);
+      return p;
+    };
+    const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (rows + CH - 1) / CH, ntiles = tilesX * tilesY;
+    f->dirs = (uint8_t *)alloc(n);
+    f->flags = (uint8_t *)alloc(n);
+    f->L = (uint32_t *)alloc(n * 4);
+    f->first = (uint32_t *)alloc(n * 4);
+    f->fh = (int32_t *)alloc(n * 4);
+    f->D[0] = (int32_t *)alloc(n * 4);
+    f->D[1] = (int32_t *)alloc(n * 4);
+    f->tflags[0] = (uint8_t *)alloc(ntiles);
+    f->tflags[1] = (uint8_t *)alloc(ntiles);
+    f->tlist = (uint32_t *)alloc((size_t)ntiles * 4);
+    f->ctr = (uint32_t *)alloc(16);
+    flowdirs_device<T>(d_z, nodata, w, rows, f->dirs, MODE_D8, s);
+    RD_LAUNCH("flats.classify", (k_flat_classify<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint8_t *)f->dirs, w, rows,
+              f->flags);
+    // sources are own cells only; the ghost rows' distances arrive from their owners
+    if (gtop) RD_HIP(hipMemsetAsync(f->flags, 0, (size_t)gtop * w, s));
+    if (gbot) RD_HIP(hipMemsetAsync(f->flags + (size_t)(rows - gbot) * w, 0, (size_t)gbot * w, s));
+    const uint8_t masks[2] = {F_LOW, F_HIGH};
+    for (int ph = 0; ph < 2; ph++) {
+      uint32_t *list = nullptr;
+      const uint32_t cnt = compact_flags(f->flags, masks[ph], n, ph ? "flats.highall" : "flats.low", &list, s);
+      f->nsrc[ph] = cnt;
+      if (cnt) {
+        f->src[ph] = (uint32_t *)alloc((size_t)cnt * 4);
+        RD_HIP(hipMemcpyAsync(f->src[ph], list, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
+      }
+    }
+    // ghost cells are never relaxed or given a direction here: mark them as "has a direction"
+    if (gtop) RD_HIP(hipMemsetAsync(f->dirs, 1, (size_t)gtop * w, s));
+    if (gbot) RD_HIP(hipMemsetAsync(f->dirs + (size_t)(rows - gbot) * w, 1, (size_t)gbot * w, s));
+    RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles);
+    RD_LAUNCH("flats.ccl_border", (k_ccl_border<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, f->L, w, rows);
+    RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, f->L, n);
+    RD_HIP(hipMemsetAsync(f->fh, 0, n * 4, s));
+    RD_HIP(hipMemsetAsync(f->D[0], 0x7F, n * 4, s));
+    RD_HIP(hipMemsetAsync(f->D[1], 0x7F, n * 4, s));
+    RD_HIP(hipMemsetAsync(f->tflags[0], 0, ntiles, s));
+    RD_HIP(hipMemsetAsync(f->tflags[1], 0, ntiles, s));
+    RD_HIP(hipStreamSynchronize(s));
+  } catch (...) {
+    fs_free(f);
+    throw;
+  }
+  return f;
+}
+
+static void fs_check(const rdgpu_flat_shard *f, int phase, const char *who) {
+  if (!f) throw Error(RDGPU_ERR_ARG, std::string(who) + ": null handle");
+  if (phase != 0 && phase != 1) throw Error(RDGPU_ERR_ARG, std::string(who) + ": phase must be 0 (towards) or 1 (away)");
+}
+
+static void fs_boundary(rdgpu_flat_shard *f, int phase, int32_t *d_out) {
+  if (!d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_boundary: null pointer");
+  const CutRows cr = cut_rows(f);
+  const size_t rb = (size_t)f->w * 4;
+  RD_HIP(hipMemcpyAsync(d_out, f->D[phase] + (size_t)cr.row[1] * f->w, rb, hipMemcpyDeviceToDevice, f->stream));
+  RD_HIP(hipMemcpyAsync(d_out + f->w, f->D[phase] + (size_t)cr.row[2] * f->w, rb, hipMemcpyDeviceToDevice, f->stream));
+}
+
+static void fs_inject(rdgpu_flat_shard *f, int phase, const int32_t *d_above, const int32_t *d_below) {
+  const CutRows cr = cut_rows(f);
+  const uint32_t tilesX = (f->w + CW - 1) / CW;
+  const dim3 grid((f->w + NTHR - 1) / NTHR), blk(NTHR);
+  if (d_above && cr.row[0] >= 0)
+    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_above, cr.row[0], cr.row[1], f->w,
+              f->tflags[phase], tilesX);
+  if (d_below && cr.row[3] >= 0)
+    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_below, cr.row[3], cr.row[2], f->w,
+              f->tflags[phase], tilesX);
+}
+
+static void fs_heights(rdgpu_flat_shard *f, int32_t *d_out) {
+  if (!d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_heights: null pointer");
+  hipStream_t s = f->stream;
+  const uint64_t n = (uint64_t)f->w * f->rows;
+  RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)f->D[1], (const uint32_t *)f->L,
+            f->fh, n);
+  const CutRows cr = cut_rows(f);
+  const dim3 grid((4 * f->w + NTHR - 1) / NTHR), blk(NTHR);
+  RD_LAUNCH("flatshard.first", k_fs_first, grid, blk, 0, s, (const uint32_t *)f->L, f->first, cr, f->w, 0);
+  RD_LAUNCH("flatshard.first", k_fs_first, grid, blk, 0, s, (const uint32_t *)f->L, f->first, cr, f->w, 1);
+  RD_LAUNCH("flatshard.export", k_fs_export, grid, blk, 0, s, (const uint32_t *)f->L, (const uint32_t *)f->first,
+            (const int32_t *)f->fh, cr, f->w, d_out);
+}
+
 #define RD_INST(T) template void flat_resolution_device<T>(const T *, T, int, int, uint8_t *, hipStream_t);
 RD_INST(uint8_t) RD_INST(int16_t) RD_INST(uint16_t) RD_INST(int32_t) RD_INST(uint32_t) RD_INST(float) RD_INST(double)
 #undef RD_INST
@@ -756,6 +1059,50 @@ RD_FLATS_API(f64, double)
   }
 RD_FLATS_ALTER_API(f32, float)
 RD_FLATS_ALTER_API(f64, double)
+
+
+#define RD_FLATSHARD_API(SUF, T)                                                                                       \
+  extern "C" int rdgpu_flat_shard_begin_##SUF(const T *d_rows, T nodata, int w, int rows, int ghost_top,               \
+                                              int ghost_bottom, void *stream, rdgpu_flat_shard **out) {                \
+    return guarded([&] {                                                                                               \
+      if (!out) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_begin: null out pointer");                                \
+      *out = fs_begin<T>(d_rows, nodata, w, rows, ghost_top, ghost_bottom, (hipStream_t)stream);                       \
+    });                                                                                                                \
+  }
+RD_FLATSHARD_API(u8, uint8_t)
+RD_FLATSHARD_API(i16, int16_t)
+RD_FLATSHARD_API(u16, uint16_t)
+RD_FLATSHARD_API(i32, int32_t)
+RD_FLATSHARD_API(u32, uint32_t)
+RD_FLATSHARD_API(f32, float)
+RD_FLATSHARD_API(f64, double)
+
+extern "C" int rdgpu_flat_shard_relax(rdgpu_flat_shard *f, int phase) {
+  return guarded([&] { fs_check(f, phase, "rdgpu_flat_shard_relax"); f->relax_fn(f, phase); });
+}
+extern "C" int rdgpu_flat_shard_boundary(rdgpu_flat_shard *f, int phase, int32_t *d_out) {
+  return guarded([&] { fs_check(f, phase, "rdgpu_flat_shard_boundary"); fs_boundary(f, phase, d_out); });
+}
+extern "C" int rdgpu_flat_shard_inject(rdgpu_flat_shard *f, int phase, const int32_t *d_above, const int32_t *d_below) {
+  return guarded([&] { fs_check(f, phase, "rdgpu_flat_shard_inject"); fs_inject(f, phase, d_above, d_below); });
+}
+extern "C" int rdgpu_flat_shard_heights(rdgpu_flat_shard *f, int32_t *d_out) {
+  return guarded([&] { fs_check(f, 0, "rdgpu_flat_shard_heights"); fs_heights(f, d_out); });
+}
+extern "C" int rdgpu_flat_graph_solve_dev(const int32_t *d_gathered, int world, int w, int32_t *d_out, void *stream) {
+  return guarded([&] { flat_graph_solve_device(d_gathered, world, w, d_out, (hipStream_t)stream); });
+}
+extern "C" int rdgpu_flat_shard_finish(rdgpu_flat_shard *f, const int32_t *d_heights, uint8_t *d_dirs_out) {
+  return guarded([&] {
+    fs_check(f, 0, "rdgpu_flat_shard_finish");
+    if (!d_dirs_out) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_shard_finish: null pointer");
+    f->finish_fn(f, d_heights, d_dirs_out);
+  });
+}
+extern "C" int rdgpu_flat_shard_rounds(const rdgpu_flat_shard *f, int phase) {
+  return (f && (phase == 0 || phase == 1)) ? (int)f->rounds[phase] : -1;
+}
+extern "C" void rdgpu_flat_shard_free(rdgpu_flat_shard *f) { fs_free(f); }
 
 extern "C" int rdgpu_flat_get_stats(rdgpu_flat_stats *out) {
   if (!out) return RDGPU_ERR_ARG;

@@ -308,7 +308,7 @@ def _all_gather_stack(mine, group):
 def d8_flow_directions_sharded(block, nodata, group=None, flats: bool = False):
     """uint8 D8 directions of this rank's row block (d8_flow_directions of the whole DEM, restricted to
     the block): one halo row from each neighbouring block is exchanged, then it is a pure 3x3 stencil.
-    (Flat resolution across cuts is not sharded yet: flats=True is rejected for world_size > 1.)"""
+    flats=True: flat-resolved directions through flat_resolution_sharded."""
     import torch
     import torch.distributed as dist
 
@@ -316,7 +316,7 @@ def d8_flow_directions_sharded(block, nodata, group=None, flats: bool = False):
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if flats and world > 1:
-        raise RdgpuError("flat resolution across row blocks is not sharded yet")
+        return flat_resolution_sharded(block, nodata, group)
     h, w = block.shape
     rows = _gather_edge_rows(block[0], block[-1], group)
     parts = ([rows[rank - 1, 1:2]] if rank > 0 else []) + [block] + ([rows[rank + 1, 0:1]] if rank + 1 < world else [])
@@ -325,6 +325,166 @@ def d8_flow_directions_sharded(block, nodata, group=None, flats: bool = False):
     d8_flow_directions_dev(haloed, nodata, dirs, flats=flats)
     lo = 1 if rank > 0 else 0
     return dirs[lo : lo + h].contiguous() if len(parts) > 1 else dirs
+
+
+class GpuFlatShard:
+    """rdgpu_flat_shard_* over CUDA tensors (include/rdgpu.h, "flat resolution over row-block shards")."""
+
+    def begin(self, ext_block, nodata, ghost_top: int, ghost_bottom: int):
+        import torch
+
+        if not (ext_block.is_cuda and ext_block.dim() == 2 and ext_block.is_contiguous()):
+            raise RdgpuError("GpuFlatShard: expected a contiguous 2-D tensor on the GPU")
+        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
+               torch.float64: "f64"}.get(ext_block.dtype)
+        if suf is None:
+            raise RdgpuError(f"GpuFlatShard: unsupported dtype {ext_block.dtype}")
+        ct = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "i32": ctypes.c_int32, "f32": ctypes.c_float,
+              "f64": ctypes.c_double}[suf]
+        self._rows, self._w = ext_block.shape
+        self._own = self._rows - ghost_top - ghost_bottom
+        self._keep = ext_block
+        self._dev = ext_block.device
+        handle = ctypes.c_void_p()
+        check(getattr(lib(), f"rdgpu_flat_shard_begin_{suf}")(
+            ctypes.c_void_p(ext_block.data_ptr()), ct(nodata), self._w, self._rows, int(ghost_top), int(ghost_bottom),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(handle)), "rdgpu_flat_shard_begin")
+        self._handle = handle
+
+    def relax(self, phase: int) -> None:
+        check(lib().rdgpu_flat_shard_relax(self._handle, int(phase)), "rdgpu_flat_shard_relax")
+
+    def boundary(self, phase: int):
+        import torch
+
+        out = torch.empty((2, self._w), dtype=torch.int32, device=self._dev)
+        check(lib().rdgpu_flat_shard_boundary(self._handle, int(phase), ctypes.c_void_p(out.data_ptr())),
+              "rdgpu_flat_shard_boundary")
+        return out
+
+    def inject(self, phase: int, row_above, row_below) -> None:
+        ra = row_above.contiguous() if row_above is not None else None
+        rb = row_below.contiguous() if row_below is not None else None
+        check(lib().rdgpu_flat_shard_inject(self._handle, int(phase),
+                                            ctypes.c_void_p(ra.data_ptr()) if ra is not None else None,
+                                            ctypes.c_void_p(rb.data_ptr()) if rb is not None else None),
+              "rdgpu_flat_shard_inject")
+
+    def heights(self):
+        import torch
+
+        out = torch.empty((8 * self._w,), dtype=torch.int32, device=self._dev)
+        check(lib().rdgpu_flat_shard_heights(self._handle, ctypes.c_void_p(out.data_ptr())), "rdgpu_flat_shard_heights")
+        return out
+
+    def finish(self, heights):
+        import torch
+
+        dirs = torch.empty((self._own, self._w), dtype=torch.uint8, device=self._dev)
+        hts = heights.contiguous() if heights is not None else None
+        check(lib().rdgpu_flat_shard_finish(self._handle, ctypes.c_void_p(hts.data_ptr()) if hts is not None else None,
+                                            ctypes.c_void_p(dirs.data_ptr())), "rdgpu_flat_shard_finish")
+        return dirs
+
+    def rounds(self, phase: int) -> int:
+        return int(lib().rdgpu_flat_shard_rounds(self._handle, int(phase)))
+
+    def abort(self) -> None:
+        if getattr(self, "_handle", None):
+            lib().rdgpu_flat_shard_free(self._handle)
+            self._handle = None
+
+    close = abort
+
+
+def flat_graph_solve_dev(gathered, world: int, w: int):
+    """gathered [world, 8w] int32 (rdgpu_flat_shard_heights of every rank) -> [world, 4w] flat heights."""
+    import torch
+
+    g = gathered.contiguous()
+    out = torch.empty((world, 4 * w), dtype=torch.int32, device=g.device)
+    check(lib().rdgpu_flat_graph_solve_dev(ctypes.c_void_p(g.data_ptr()), int(world), int(w), ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "rdgpu_flat_graph_solve_dev")
+    return out
+
+
+def flat_exchange(shards, ranks, world: int, gather, solve):
+    """The cut-row protocol of the sharded flat resolution for the shard objects this process drives
+    (``shards[i]`` is rank ``ranks[i]``; a torch.distributed rank drives one, the single-GPU drivers all of
+    them).  ``gather(list of per-shard tensors) -> [world, ...]`` is the all-gather, ``solve(gathered)`` the
+    cut-row graph solve.  Returns (directions per shard, exchanges per phase)."""
+    exchanges = []
+    for phase in (0, 1):   # towards the low edges first: it also tells which flats have an outlet
+        prev, n = None, 0
+        while True:
+            for sh in shards:
+                sh.relax(phase)
+            cut = gather([sh.boundary(phase) for sh in shards])          # [world, 2, w]
+            n += 1
+            if prev is not None and bool((cut == prev).all()):
+                break
+            for sh, r in zip(shards, ranks):
+                sh.inject(phase, cut[r - 1, 1] if r > 0 else None, cut[r + 1, 0] if r + 1 < world else None)
+            prev = cut
+        exchanges.append(n)
+    solved = solve(gather([sh.heights() for sh in shards]))             # [world, 4w]
+    return [sh.finish(solved[r]) for sh, r in zip(shards, ranks)], exchanges
+
+
+def _ext_blocks(blocks_or_block, rank, world, rows2):
+    """own rows + two ghost rows per cut; rows2 = [world, 4, w]: first two and last two rows of every block"""
+    import torch
+
+    parts = ([rows2[rank - 1, 2:4]] if rank > 0 else []) + [blocks_or_block] + ([rows2[rank + 1, 0:2]] if rank + 1 < world else [])
+    return torch.cat(parts, 0).contiguous() if len(parts) > 1 else blocks_or_block.contiguous()
+
+
+def flat_resolution_sharded(block, nodata, group=None, shard_factory=None):
+    """barnes_flat_resolution_d8 of the whole DEM restricted to this rank's row block (HBM-resident tensor,
+    at least two rows): returns the uint8 directions of the own rows.  Collectives: one all-gather of two cut
+    rows per block for the ghost rows, one small all-gather per cut-row exchange, one for the flat heights."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if block.shape[0] < 2 and world > 1:
+        raise RdgpuError("flat_resolution_sharded: every row block needs at least two rows")
+    w = block.shape[1]
+    rows2 = _all_gather_stack(torch.cat([block[:2], block[-2:]], 0), group) if world > 1 else None
+    ext = _ext_blocks(block, rank, world, rows2)
+    sh = (shard_factory or GpuFlatShard)()
+    try:
+        sh.begin(ext, nodata, 2 if rank > 0 else 0, 2 if rank + 1 < world else 0)
+        solve = getattr(sh, "solve", None) or (lambda g: flat_graph_solve_dev(g, world, w))
+        dirs, _ = flat_exchange([sh], [rank], world, lambda ts: _all_gather_stack(ts[0], group), solve)
+    finally:
+        sh.abort()
+    return dirs[0]
+
+
+def flat_resolution_blocks(dem, nodata, world: int, shard_factory=None, solve=None):
+    """The same protocol with every row block driven by this one process on one GPU (tests, tools):
+    returns (directions of the whole raster, exchanges per phase)."""
+    import torch
+
+    h, w = dem.shape
+    blocks = [dem[a:b] for a, b in row_split(h, world)]
+    if world > 1 and min(b.shape[0] for b in blocks) < 2:
+        raise RdgpuError("flat_resolution_blocks: every row block needs at least two rows")
+    rows2 = torch.stack([torch.cat([b[:2], b[-2:]], 0) for b in blocks]) if world > 1 else None
+    shards = []
+    try:
+        for r, b in enumerate(blocks):
+            sh = (shard_factory or GpuFlatShard)()
+            shards.append(sh)
+            sh.begin(_ext_blocks(b, r, world, rows2), nodata, 2 if r > 0 else 0, 2 if r + 1 < world else 0)
+        solve = solve or (lambda g: flat_graph_solve_dev(g, world, w))
+        dirs, ex = flat_exchange(shards, list(range(world)), world, lambda ts: torch.stack(ts), solve)
+    finally:
+        for sh in shards:
+            sh.abort()
+    return torch.cat(dirs, 0), ex
 
 
 class GpuAccumShard:

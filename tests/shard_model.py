@@ -183,3 +183,184 @@ class NumpyAccumShard:
         a = np.where(self.done, self.total, self.total - 1)
         a = np.where(self.d == self.nd, -1, a)
         area[...] = a.astype(area.dtype)
+
+
+class NumpyFlatShard:
+    """Model of rdgpu_flat_shard_* (include/rdgpu.h) on torch CPU tensors: same interface as
+    richdem_amd.sharded.GpuFlatShard plus ``solve`` (a Python union-find standing in for
+    rdgpu_flat_graph_solve_dev), so that flat_resolution_sharded's exchange loop runs on gloo ranks."""
+
+    INF = 0x7F7F7F7F
+
+    def begin(self, ext, nodata, gtop, gbot):
+        import oracle
+        from scipy import ndimage
+
+        z = ext.numpy()
+        self.z, (self.rows, self.w) = z, z.shape
+        self.gtop, self.gbot = gtop, gbot
+        rows, w = z.shape
+        dirs = oracle.port.d8_flowdirs(z, nodata)
+        own = np.zeros(rows, bool)
+        own[gtop:rows - gbot] = True
+        low, high = [], []
+        for y in range(rows):
+            if not own[y]:
+                continue
+            for x in range(w):
+                d = dirs[y, x]
+                if d == 255:
+                    continue
+                for dy in (-1, 0, 1):
+                    hit = False
+                    for dx in (-1, 0, 1):
+                        ny, nx = y + dy, x + dx
+                        if (dx == 0 and dy == 0) or not (0 <= ny < rows and 0 <= nx < w) or dirs[ny, nx] == 255:
+                            continue
+                        if d != 0 and dirs[ny, nx] == 0 and z[ny, nx] == z[y, x]:
+                            low.append((y, x)); hit = True; break
+                        if d == 0 and z[y, x] < z[ny, nx]:
+                            high.append((y, x)); hit = True; break
+                    if hit:
+                        break
+        self.src = [low, high]
+        dirs[~own] = 1
+        self.dirs = dirs
+        labels = np.zeros((rows, w), np.int32)
+        nxt = 0
+        for v in np.unique(z):
+            lab, k = ndimage.label(z == v, structure=np.ones((3, 3)))
+            labels[lab > 0] = lab[lab > 0] + nxt
+            nxt += k
+        self.labels = labels
+        self.fh = np.zeros(nxt + 1, np.int64)
+        self.D = [np.full((rows, w), self.INF, np.int64), np.full((rows, w), self.INF, np.int64)]
+        self.seeded = [False, False]
+        self.elig = (dirs == 0) & own[:, None]
+
+    def relax(self, phase):
+        D = self.D[phase]
+        if not self.seeded[phase]:
+            self.seeded[phase] = True
+            for (y, x) in self.src[phase]:
+                if phase == 1 and self.D[0][y, x] >= self.INF:
+                    continue
+                D[y, x] = 1
+        rows, w = self.rows, self.w
+        lp = np.pad(self.labels, 1, constant_values=-1)
+        while True:
+            dp = np.pad(D, 1, constant_values=self.INF)
+            best = D.copy()
+            for dy in (0, 1, 2):
+                for dx in (0, 1, 2):
+                    if dx == 1 and dy == 1:
+                        continue
+                    same = lp[dy:dy + rows, dx:dx + w] == self.labels
+                    cand = np.where(same, dp[dy:dy + rows, dx:dx + w] + 1, self.INF)
+                    best = np.minimum(best, cand)
+            new = np.where(self.elig, best, D)
+            if np.array_equal(new, D):
+                break
+            D[...] = new
+
+    def _cut_rows(self):
+        return [self.gtop - 1 if self.gtop else -1, self.gtop, self.rows - self.gbot - 1,
+                self.rows - self.gbot if self.gbot else -1]
+
+    def boundary(self, phase):
+        import torch
+
+        cr = self._cut_rows()
+        return torch.from_numpy(np.stack([self.D[phase][cr[1]], self.D[phase][cr[2]]]).astype(np.int32))
+
+    def inject(self, phase, above, below):
+        cr = self._cut_rows()
+        if above is not None and cr[0] >= 0:
+            self.D[phase][cr[0]] = np.minimum(self.D[phase][cr[0]], above.numpy().astype(np.int64))
+        if below is not None and cr[3] >= 0:
+            self.D[phase][cr[3]] = np.minimum(self.D[phase][cr[3]], below.numpy().astype(np.int64))
+
+    def heights(self):
+        import torch
+
+        A = self.D[1]
+        reached = A < self.INF
+        np.maximum.at(self.fh, self.labels[reached], A[reached])
+        w = self.w
+        out = np.zeros(8 * w, np.int32)
+        first = {}
+        cr = self._cut_rows()
+        for p in range(4 * w):
+            r = cr[p // w]
+            if r >= 0:
+                first.setdefault(int(self.labels[r, p % w]), p)
+        for p in range(4 * w):
+            r = cr[p // w]
+            if r < 0:
+                out[p] = p
+            else:
+                lab = int(self.labels[r, p % w])
+                out[p], out[4 * w + p] = first[lab], self.fh[lab]
+        return torch.from_numpy(out)
+
+    def solve(self, gathered):
+        import torch
+
+        g = gathered.numpy()
+        world, w = g.shape[0], g.shape[1] // 8
+        per = 4 * w
+        parent = list(range(world * per))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        def unite(a, b):
+            a, b = find(a), find(b)
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+
+        for r in range(world):
+            for p in range(per):
+                unite(r * per + p, r * per + int(g[r, p]))
+        for r in range(world - 1):
+            for j in range(2 * w):
+                unite(r * per + 2 * w + j, (r + 1) * per + j)
+        val = {}
+        for r in range(world):
+            for p in range(per):
+                root = find(r * per + p)
+                val[root] = max(val.get(root, 0), int(g[r, per + p]))
+        out = np.zeros((world, per), np.int32)
+        for r in range(world):
+            for p in range(per):
+                out[r, p] = val[find(r * per + p)]
+        return torch.from_numpy(out)
+
+    def finish(self, heights):
+        import ctypes
+
+        import oracle
+        import torch
+
+        cr = self._cut_rows()
+        hts = heights.numpy()
+        for p in range(4 * self.w):
+            r = cr[p // self.w]
+            if r >= 0:
+                lab = self.labels[r, p % self.w]
+                self.fh[lab] = max(self.fh[lab], int(hts[p]))
+        T, A = self.D[0], self.D[1]
+        M = np.where(T < self.INF, np.where(A < self.INF, self.fh[self.labels] - A, 0) + 2 * T, 0).astype(np.int32)
+        dirs = np.ascontiguousarray(self.dirs)
+        labels = np.ascontiguousarray(self.labels)
+        fn = oracle.port.lib.orc_d8_flow_flats_apply
+        fn.restype = None
+        fn(M.ctypes.data_as(ctypes.c_void_p), labels.ctypes.data_as(ctypes.c_void_p), self.w, self.rows,
+           dirs.ctypes.data_as(ctypes.c_void_p))
+        return torch.from_numpy(dirs[self.gtop:self.rows - self.gbot].copy())
+
+    def abort(self):
+        pass

@@ -133,3 +133,74 @@ def test_gloo_sharded_accumulation_matches_oracle(orc, tmp_path, world):
     dirs[20:24, 30:34] = 255
     assert np.array_equal(got, orc.port.d8_flow_accum(dirs, 255, np.float64))
     assert int(np.load(tmp_path / "rounds0.npy")[0]) >= 2   # flow really crossed the cuts
+
+
+def _flat_dem(case):
+    import oracle
+    from richdem_amd.synth import fractal_dem_int
+
+    if case == "lakes":
+        return oracle.port.fill(fractal_dem_int(57, 46, 8, 0.04)), np.int32(-9999)
+    if case == "snake":
+        comb = np.full((30, 41), 9, np.int32)
+        comb[1:-1, 1:-1] = 5
+        for x in range(4, 38, 4):
+            comb[2:-2, x] = 9
+            if (x // 4) % 2:
+                comb[1:4, x] = 5
+            else:
+                comb[-4:-1, x] = 5
+        comb[14, 0] = 1
+        return comb, np.int32(-1)
+    if case == "raw":
+        rng = np.random.default_rng(3)
+        return rng.integers(0, 3, (40, 37)).astype(np.int32), np.int32(-1)
+    raise KeyError(case)
+
+
+def _flat_worker(rank, world, port, case, outdir):
+    import torch
+    import torch.distributed as dist
+
+    from richdem_amd.sharded import flat_resolution_sharded, row_split
+    from shard_model import NumpyFlatShard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dem, nd = _flat_dem(case)
+    r0, r1 = row_split(dem.shape[0], world)[rank]
+    dirs = flat_resolution_sharded(torch.from_numpy(np.ascontiguousarray(dem[r0:r1])), nd, shard_factory=NumpyFlatShard)
+    np.save(os.path.join(outdir, f"dirs{rank}.npy"), dirs.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["lakes", "snake", "raw"])
+def test_gloo_sharded_flat_resolution_matches_oracle(orc, tmp_path, world, case):
+    """flat_resolution_sharded's ghost-row gather, cut-row exchange loop and flat-height solve (product
+    code) around a numpy model of the shard engine == barnes_flat_resolution_d8 of the whole raster."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_flat_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"dirs{r}.npy") for r in range(world)], axis=0)
+    dem, nd = _flat_dem(case)
+    assert np.array_equal(got, orc.port.flat_resolution(dem, nd))
+
+
+def test_flat_model_blocks_single_process(orc):
+    """Same model, every block driven by one process (flat_resolution_blocks), more shard counts."""
+    import torch
+
+    from richdem_amd.sharded import flat_resolution_blocks
+    from shard_model import NumpyFlatShard
+
+    for case in ("lakes", "snake"):
+        dem, nd = _flat_dem(case)
+        for world in (1, 4, 7):
+            got, ex = flat_resolution_blocks(torch.from_numpy(dem), nd, world, shard_factory=NumpyFlatShard,
+                                             solve=NumpyFlatShard().solve)
+            assert np.array_equal(got.numpy(), orc.port.flat_resolution(dem, nd)), (case, world, ex)
+            if case == "snake" and world == 7:
+                assert ex[0] > 3      # the towards levels crossed the cuts repeatedly
