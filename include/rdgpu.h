@@ -318,6 +318,23 @@ RDGPU_DECL_MFD(u32, uint32_t)
 RDGPU_DECL_MFD(f32, float)
 RDGPU_DECL_MFD(f64, double)
 #undef RDGPU_DECL_MFD
+/* FM_Holmgren(x) / FM_Freeman(x) / FM_Quinn / FM_D4 proportions and the matching FA_* accumulations
+ * (flowmet/Holmgren1994.hpp:14, Freeman1991.hpp:14, Quinn1991.hpp:13, OCallaghan1984.hpp:86;
+ * methods/flow_accumulation.hpp:18-20,28).  method: 0 Holmgren, 1 Freeman, 2 Quinn, 3 D4; xparam is the
+ * exponent of methods 0 and 1.  accum is in/out as for rdgpu_fa_d8 (in: flow generated per cell).      */
+#define RDGPU_DECL_MFD2(SUF, T)                                                                          \
+  int rdgpu_fm_mfd_##SUF(const T *dem, T nodata, int width, int height, int method, double xparam, float *props9); \
+  int rdgpu_fm_mfd_dev_##SUF(const T *d_dem, T nodata, int width, int height, int method, double xparam, float *d_props9, void *hip_stream); \
+  int rdgpu_fa_mfd_##SUF(const T *dem, T nodata, int width, int height, int method, double xparam, double *accum); \
+  int rdgpu_fa_mfd_dev_##SUF(const T *d_dem, T nodata, int width, int height, int method, double xparam, double *d_accum, void *hip_stream);
+RDGPU_DECL_MFD2(u8, uint8_t)
+RDGPU_DECL_MFD2(i16, int16_t)
+RDGPU_DECL_MFD2(u16, uint16_t)
+RDGPU_DECL_MFD2(i32, int32_t)
+RDGPU_DECL_MFD2(u32, uint32_t)
+RDGPU_DECL_MFD2(f32, float)
+RDGPU_DECL_MFD2(f64, double)
+#undef RDGPU_DECL_MFD2
 int rdgpu_flow_accumulation_f64(const float *props9, int width, int height, double *accum);
 int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_flow_accumulation_rounds(uint32_t *rounds); /* work-list rounds of the last generic accumulation */

@@ -177,6 +177,25 @@ class _Backend:
         self._fn(f"fm_d8_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
         return out
 
+    MFD = {"Holmgren": 0, "Freeman": 1, "Quinn": 2, "D4": 3}
+
+    def fm_mfd(self, dem: np.ndarray, nodata, method: str, xparam: float = 1.0) -> np.ndarray:
+        """FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4 proportions [h, w, 9]."""
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        out = np.empty((h, w, 9), np.float32)
+        self._fn(f"fm_mfd_{s}")(_ptr(dem), _CT[s](nodata), w, h, self.MFD[method], ctypes.c_double(xparam), _ptr(out))
+        return out
+
+    def fa_mfd(self, dem: np.ndarray, nodata, method: str, xparam: float = 1.0, weights: np.ndarray | None = None) -> np.ndarray:
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        acc = np.ones((h, w), np.float64) if weights is None else np.ascontiguousarray(weights, dtype=np.float64).copy()
+        self._fn(f"fa_mfd_{s}")(_ptr(dem), _CT[s](nodata), w, h, self.MFD[method], ctypes.c_double(xparam), _ptr(acc))
+        return acc
+
     def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)
         h, w = dem.shape

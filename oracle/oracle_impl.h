@@ -404,6 +404,81 @@ void FN(orc_fa_tarboton)(const T *dem, T nodata, int w, int h, double *accum) {
   free(props);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* FM_Holmgren (flowmet/Holmgren1994.hpp:14-88), FM_Quinn = Holmgren with     */
+/* x = 1 (flowmet/Quinn1991.hpp:13-17), FM_Freeman (flowmet/Freeman1991.hpp:  */
+/* 14-86), FM_OCallaghan<D4> = FM_D4 (flowmet/OCallaghan1984.hpp:13-77, :86). */
+/* method: 0 Holmgren, 1 Freeman, 2 Quinn, 3 D4.                              */
+/* ------------------------------------------------------------------------- */
+void FN(orc_fm_mfd)(const T *dem, T nodata, int w, int h, int method, double xparam, float *props9) {
+  static const double DR[9] = {0, 1, 1.414213562373095048801688724209698078569671875376948, 1,
+                               1.414213562373095048801688724209698078569671875376948, 1,
+                               1.414213562373095048801688724209698078569671875376948, 1,
+                               1.414213562373095048801688724209698078569671875376948};   /* constants.hpp:34,70 */
+  static const double HL[9] = {0, 0.5, 0.354, 0.5, 0.354, 0.5, 0.354, 0.5, 0.354};   /* Holmgren1994.hpp:26-28 */
+  size_t N = (size_t)w * h;
+  if (method == 2) { method = 0; xparam = 1.0; }
+  for (size_t i = 0; i < N * 9; i++) props9[i] = -1.0f;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      float *p = props9 + 9 * i;
+      if (dem[i] == nodata) { p[0] = -2.0f; continue; }
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;
+      const T e = dem[i];
+      if (method == 3) {          /* D4 neighbours (constants.hpp:54-55) stored in slots 1..4, OCallaghan1984.hpp:46-74 */
+        int lowest_n = 0, have = 0;
+        T lowest = 0;
+        for (int n = 1; n <= 4; n++) {
+          size_t ni = (size_t)(y + D4Y[n]) * w + (x + D4X[n]);
+          if (dem[ni] == nodata) continue;
+          T ne = dem[ni];
+          if (ne >= e) continue;
+          if (!have || ne < lowest) { lowest = ne; lowest_n = n; have = 1; }
+        }
+        if (lowest_n == 0) continue;
+        p[0] = 0.0f;
+        p[lowest_n] = 1.0f;
+        continue;
+      }
+      double C = 0;
+      for (int n = 1; n <= 8; n++) {
+        size_t ni = (size_t)(y + D8Y[n]) * w + (x + D8X[n]);
+        if (dem[ni] == nodata) continue;
+        const T ne = dem[ni];
+        if (ne < e) {
+          const double rise = e - ne;
+          const double run = DR[n];
+          const double grad = rise / run;
+          if (method == 0) {
+            p[n] = (float)pow(grad * HL[n], xparam);     /* Holmgren1994.hpp:66-67: C sums the stored floats */
+            C += p[n];
+          } else {
+            const double cval = pow(grad, xparam);       /* Freeman1991.hpp:63-65: C sums the doubles */
+            p[n] = (float)cval;
+            C += cval;
+          }
+        }
+      }
+      if (C > 0) {
+        p[0] = 0.0f;
+        C = 1 / C;
+        for (int n = 1; n <= 8; n++) {
+          if (p[n] > 0) p[n] = (float)(p[n] * C);
+          else p[n] = 0;
+        }
+      }
+    }
+}
+
+void FN(orc_fa_mfd)(const T *dem, T nodata, int w, int h, int method, double xparam, double *accum) {
+  float *props = (float *)malloc((size_t)w * h * 9 * sizeof(float));
+  FN(orc_fm_mfd)(dem, nodata, w, h, method, xparam, props);
+  orc_flow_accumulation_f64(props, w, h, accum);
+  free(props);
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

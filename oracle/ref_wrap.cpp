@@ -108,6 +108,33 @@ void ref_fm_d8(const T *dem, T nodata, int w, int h, float *props9) {
 }
 
 template <class T>
+void ref_fm_mfd(const T *dem, T nodata, int w, int h, int method, double xparam, float *props9) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array3D<float> props(a);
+  switch (method) {
+    case 0: FM_Holmgren(a, props, xparam); break;                 // flowmet/Holmgren1994.hpp:14
+    case 1: FM_Freeman(a, props, xparam); break;                  // flowmet/Freeman1991.hpp:14
+    case 2: FM_Quinn(a, props); break;                            // flowmet/Quinn1991.hpp:13
+    default: FM_D4(a, props); break;                              // flowmet/OCallaghan1984.hpp:86
+  }
+  std::memcpy(props9, props.getData(), (size_t)w * h * 9 * sizeof(float));
+}
+
+template <class T>
+void ref_fa_mfd(const T *dem, T nodata, int w, int h, int method, double xparam, double *accum) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<double> acc(accum, w, h);
+  switch (method) {
+    case 0: FA_Holmgren(a, acc, xparam); break;                   // methods/flow_accumulation.hpp:18
+    case 1: FA_Freeman(a, acc, xparam); break;
+    case 2: FA_Quinn(a, acc); break;
+    default: FA_D4(a, acc); break;
+  }
+}
+
+template <class T>
 void ref_dinf_flowdirs(const T *dem, T nodata, int w, int h, float *out) {
   Array2D<T> a(const_cast<T *>(dem), w, h);
   a.setNoData(nodata);
@@ -161,6 +188,12 @@ void ref_fa_tarboton(const T *dem, T nodata, int w, int h, double *accum) {
   }                                                                                              \
   extern "C" void ref_fa_tarboton_##SUF(const T *dem, T nodata, int w, int h, double *accum) {   \
     ref_fa_tarboton<T>(dem, nodata, w, h, accum);                                                \
+  }                                                                                              \
+  extern "C" void ref_fm_mfd_##SUF(const T *dem, T nodata, int w, int h, int method, double xparam, float *props9) { \
+    ref_fm_mfd<T>(dem, nodata, w, h, method, xparam, props9);                                    \
+  }                                                                                              \
+  extern "C" void ref_fa_mfd_##SUF(const T *dem, T nodata, int w, int h, int method, double xparam, double *accum) { \
+    ref_fa_mfd<T>(dem, nodata, w, h, method, xparam, accum);                                     \
   }
 
 REF_ELEV_API(u8, uint8_t)

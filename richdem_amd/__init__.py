@@ -21,11 +21,20 @@ from ._lib import (  # noqa: F401
     profile_reset,
     profile_totals,
 )
-from .api import (  # noqa: F401
+from .pyrichdem import (  # noqa: F401
+    rdarray,
+    rd3array,
     FillDepressions,
     FlowAccumulation,
     FlowProportions,
     FlowAccumFromProps,
+    ResolveFlats,
+    BreachDepressions,
+    TerrainAttribute,
+    LoadGDAL,
+    SaveGDAL,
+)
+from .api import (  # noqa: F401
     dinf_flow_directions,
     d8_flow_directions,
     d8_flow_accum,
@@ -43,6 +52,8 @@ __all__ = [
     "lib",
     "lib_path",
     "build",
+    "rdarray",
+    "rd3array",
     "FillDepressions",
     "FlowAccumulation",
     "FlowProportions",

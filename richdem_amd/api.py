@@ -153,16 +153,45 @@ def dinf_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
     return out
 
 
-def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999) -> np.ndarray:
-    """[h, w, 9] float32 flow proportions (reference ``rd.FlowProportions``, FM_Tarboton,
-    flowmet/Tarboton1997.hpp:14-144)."""
-    if method not in ("Dinf", "Tarboton", "D8"):
-        raise RdgpuError(f"FlowProportions: method {method!r} is not part of this round's hot path")
+# method name -> (kind, code).  Names and aliases as in the reference's Python wrapper
+# (wrappers/pyrichdem/richdem/__init__.py:532-549, 693-710).
+_METHODS = {
+    "Tarboton": ("tarboton", None), "Dinf": ("tarboton", None),
+    "D8": ("d8", None), "OCallaghanD8": ("d8", None),
+    "Holmgren": ("mfd", 0), "Freeman": ("mfd", 1), "Quinn": ("mfd", 2),
+    "D4": ("mfd", 3), "OCallaghanD4": ("mfd", 3),
+}
+_NEEDS_EXPONENT = ("Holmgren", "Freeman")
+_RANDOM_METHODS = ("Rho8", "Rho4", "FairfieldLeymarieD8", "FairfieldLeymarieD4")
+VALID_METHODS = ["Tarboton", "Dinf", "Quinn", "FairfieldLeymarieD8", "FairfieldLeymarieD4", "Rho8", "Rho4",
+                 "OCallaghanD8", "OCallaghanD4", "D8", "D4", "Freeman", "Holmgren"]
+
+
+def _method(who: str, method, exponent):
+    if method in _RANDOM_METHODS:
+        raise RdgpuError(f"{who}: {method} draws from the reference's process-global random engine in raster order; "
+                         "its output cannot be reproduced by a parallel engine and is not provided")
+    if method not in _METHODS:
+        raise RdgpuError(f"Invalid {who} method. Valid methods are: " + ", ".join(VALID_METHODS))
+    if method in _NEEDS_EXPONENT and exponent is None:
+        raise RdgpuError(f'{who} method "{method}" requires an exponent!')
+    kind, code = _METHODS[method]
+    return kind, code, float(exponent) if (exponent is not None and method in _NEEDS_EXPONENT) else 1.0
+
+
+def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999, exponent=None) -> np.ndarray:
+    """[h, w, 9] float32 flow proportions (reference ``rd.FlowProportions`` -> FM_Tarboton / FM_D8 /
+    FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4, flowmet/*.hpp)."""
+    kind, code, xp = _method("FlowProportions", method, exponent)
     dem, s = _elev(dem, "FlowProportions")
     h, w = dem.shape
     out = np.empty((h, w, 9), np.float32)
-    check(getattr(lib(), f"rdgpu_fm_d8_{s}" if method == "D8" else f"rdgpu_fm_tarboton_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
-                                                   out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_fm_tarboton")
+    pd, po = dem.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
+    if kind == "mfd":
+        check(getattr(lib(), f"rdgpu_fm_mfd_{s}")(pd, _CT[s](nodata), w, h, code, ctypes.c_double(xp), po), "rdgpu_fm_mfd")
+    else:
+        check(getattr(lib(), f"rdgpu_fm_d8_{s}" if kind == "d8" else f"rdgpu_fm_tarboton_{s}")(pd, _CT[s](nodata), w, h, po),
+              "rdgpu_fm_" + kind)
     return out
 
 
@@ -184,23 +213,37 @@ def FlowAccumFromProps(props: np.ndarray, weights: np.ndarray | None = None) -> 
     return acc
 
 
-def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights: np.ndarray | None = None):
-    """Flow accumulation (reference ``rd.FlowAccumulation(dem, method='D8', weights=...)``,
-    wrappers/pyrichdem/richdem/__init__.py:490-597 -> FA_D8, methods/flow_accumulation.hpp:27).
-    Returns float64 accumulation; NoData cells get -1."""
-    if method not in ("D8", "Dinf", "Tarboton"):
-        raise RdgpuError(f"FlowAccumulation: method {method!r} is not part of this round's hot path (D8, Dinf)")
+def flow_accumulation_into(dem: np.ndarray, method, nodata, acc: np.ndarray, exponent=None) -> None:
+    """FA_<method>(dem, acc): acc (float64, C-contiguous, dem's shape) holds the flow generated per cell on
+    entry and the accumulation on return (methods/flow_accumulation.hpp:16-28)."""
+    kind, code, xp = _method("FlowAccumulation", method, exponent)
     dem, s = _elev(dem, "FlowAccumulation")
     h, w = dem.shape
+    if acc.shape != dem.shape:                     # flow_accumulation_generic.hpp:42-43
+        raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
+    if acc.dtype != np.float64 or not acc.flags["C_CONTIGUOUS"]:
+        raise RdgpuError("Accumulation array must be of type 'float64'!")
+    pd, pa = dem.ctypes.data_as(ctypes.c_void_p), acc.ctypes.data_as(ctypes.c_void_p)
+    if kind == "mfd":
+        check(getattr(lib(), f"rdgpu_fa_mfd_{s}")(pd, _CT[s](nodata), w, h, code, ctypes.c_double(xp), pa), "rdgpu_fa_mfd")
+    else:
+        check(getattr(lib(), f"rdgpu_fa_d8_{s}" if kind == "d8" else f"rdgpu_fa_tarboton_{s}")(pd, _CT[s](nodata), w, h, pa),
+              "rdgpu_fa_" + kind)
+
+
+def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights: np.ndarray | None = None, exponent=None):
+    """Flow accumulation (reference ``rd.FlowAccumulation(dem, method, exponent, weights)``,
+    wrappers/pyrichdem/richdem/__init__.py:490-597 -> FA_D8 etc., methods/flow_accumulation.hpp:16-28).
+    Returns float64 accumulation; NoData cells get -1."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("FlowAccumulation: expected a 2-D numpy array")
     if weights is None:
-        acc = np.ones((h, w), np.float64)          # __init__.py:560-563: every cell generates 1
+        acc = np.ones(dem.shape, np.float64)       # __init__.py:560-563: every cell generates 1
     else:
         if weights.shape != dem.shape:             # flow_accumulation_generic.hpp:42-43
             raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
         acc = np.ascontiguousarray(weights, dtype=np.float64).copy()
-    fn = getattr(lib(), f"rdgpu_fa_d8_{s}" if method == "D8" else f"rdgpu_fa_tarboton_{s}")
-    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, acc.ctypes.data_as(ctypes.c_void_p)),
-          "rdgpu_fa_d8" if method == "D8" else "rdgpu_fa_tarboton")
+    flow_accumulation_into(dem, method, nodata, acc, exponent)
     return acc
 
 

@@ -338,6 +338,112 @@ static void mfd_accumulate(ACC a, int w, int h, double *d_acc, hipStream_t s) {
   RD_LAUNCH("mfd.nodata", (k_mfd_nodata<ACC>), dim3(sgrid(n)), dim3(NTHR), 0, s, a, d_acc, n);
 }
 
+// ------------------------------------------------------------------------------------------
+// FM_Holmgren (flowmet/Holmgren1994.hpp:14-88), FM_Quinn (= Holmgren, x = 1; Quinn1991.hpp:13-17),
+// FM_Freeman (Freeman1991.hpp:14-86), FM_D4 = FM_OCallaghan<D4> (OCallaghan1984.hpp:13-77, :86) into the
+// reference's 9-float proportions layout.  The arithmetic is written as in the reference (rise in the
+// element type's promoted type, gradient and pow in double, Holmgren sums the STORED floats, Freeman the
+// doubles, the normalisation multiplies float by double); pow comes from the device libm, so proportions
+// are specified to <= 1 ULP (f32) like D-infinity.  FM_D4 keeps the reference's slot numbering: it
+// stores the chosen D4 neighbour n = 1..4 (left, up, right, down) in slot n, and FlowAccumulation then reads
+// slot n with the D8 offsets -- reproduced as is, because that is what FA_D4 returns.
+// ------------------------------------------------------------------------------------------
+// pow() as the reference's libm returns it, to the extent the f32 proportions can see: glibc's pow is exact
+// whenever x^y is representable, and with short-mantissa gradients (differences of float elevations) and an
+// integer exponent, x^y often IS representable and lands exactly on a float rounding tie -- where the device
+// libm's last-bit error would flip the stored float.  Integer exponents up to 64 are therefore evaluated by
+// binary powering in double-double (one final rounding); everything else goes to the device pow (<= 1 ulp).
+struct dd { double hi, lo; };
+__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+  const double p = a.hi * b.hi;
+  double e = __builtin_fma(a.hi, b.hi, -p);
+  e += a.hi * b.lo + a.lo * b.hi;
+  const double hi = p + e;
+  return dd{hi, e - (hi - p)};
+}
+__device__ __forceinline__ double pow_ref(double x, double y) {
+  if (y == 1.0) return x;
+  if (y >= 2.0 && y <= 64.0 && y == (double)(int)y) {
+    int n = (int)y;
+    dd r{1.0, 0.0}, b{x, 0.0};
+    for (;;) {
+      if (n & 1) r = dd_mul(r, b);
+      n >>= 1;
+      if (!n) break;
+      b = dd_mul(b, b);
+    }
+    return r.hi;
+  }
+  return pow(x, y);
+}
+
+enum { MFD_HOLMGREN = 0, MFD_FREEMAN = 1, MFD_QUINN = 2, MFD_D4 = 3 };
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_fm_mfd(const T *__restrict__ z, T nodata, float *__restrict__ props, int w, int h,
+                                                 int method, double xparam) {
+  constexpr double SQ2 = 1.414213562373095048801688724209698078569671875376948;
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    float p[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k] = -1.0f;
+    const T e = z[c];
+    if (e == nodata) {
+      p[0] = -2.0f;
+    } else if (x > 0 && y > 0 && x < w - 1 && y < h - 1) {
+      if (method == MFD_D4) {
+        int lowest_n = 0;
+        T lowest = T();
+#pragma unroll
+        for (int k = 1; k <= 4; k++) {
+          const int dx = k == 1 ? -1 : k == 3 ? 1 : 0, dy = k == 2 ? -1 : k == 4 ? 1 : 0;   // constants.hpp:54-55
+          const T ne = z[(size_t)(y + dy) * w + (x + dx)];
+          if (ne == nodata || ne >= e) continue;
+          if (lowest_n == 0 || ne < lowest) { lowest = ne; lowest_n = k; }
+        }
+        if (lowest_n) { p[0] = 0.0f; p[lowest_n] = 1.0f; }
+      } else {
+        double C = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+          const T ne = z[(size_t)(y + mdy(k)) * w + (x + mdx(k))];
+          if (ne == nodata) continue;
+          if (ne < e) {
+            const double rise = e - ne;
+            const double run = (k & 1) ? 1.0 : SQ2;
+            const double grad = rise / run;
+            if (method == MFD_HOLMGREN) {
+              p[k] = (float)pow_ref(grad * ((k & 1) ? 0.5 : 0.354), xparam);
+              C += p[k];
+            } else {
+              const double cval = pow_ref(grad, xparam);
+              p[k] = (float)cval;
+              C += cval;
+            }
+          }
+        }
+        if (C > 0) {
+          p[0] = 0.0f;
+          C = 1 / C;
+#pragma unroll
+          for (int k = 1; k <= 8; k++) p[k] = p[k] > 0 ? (float)(p[k] * C) : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) props[c * 9 + k] = p[k];
+  }
+}
+
+template <class T>
+static void fm_mfd_device(const T *d_z, T nodata, int w, int h, int method, double xparam, float *d_props, hipStream_t s) {
+  if (method < 0 || method > 3) throw Error(RDGPU_ERR_ARG, "rdgpu_fm_mfd: method must be 0 (Holmgren), 1 (Freeman), 2 (Quinn) or 3 (D4)");
+  if (method == MFD_QUINN) { method = MFD_HOLMGREN; xparam = 1.0; }
+  RD_LAUNCH("mfd.fm_mfd", (k_fm_mfd<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, nodata, d_props, w, h, method, xparam);
+}
+
 static void check_dims(int w, int h, const char *who) {
   if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, std::string(who) + ": width and height must be positive");
   if ((uint64_t)w * (uint64_t)h > 0xFFFF0000ull) throw Error(RDGPU_ERR_ARG, std::string(who) + ": raster too large");
@@ -429,6 +535,63 @@ RD_MFD_API(i32, int32_t)
 RD_MFD_API(u32, uint32_t)
 RD_MFD_API(f32, float)
 RD_MFD_API(f64, double)
+
+#define RD_MFD2_API(SUF, T)                                                                                     \
+  extern "C" int rdgpu_fm_mfd_dev_##SUF(const T *d_dem, T nodata, int w, int h, int method, double xparam,      \
+                                        float *d_props9, void *st) {                                            \
+    return guarded([&] {                                                                                        \
+      if (!d_dem || !d_props9) throw Error(RDGPU_ERR_ARG, "rdgpu_fm_mfd: null pointer");                        \
+      check_dims(w, h, "rdgpu_fm_mfd");                                                                         \
+      fm_mfd_device<T>(d_dem, nodata, w, h, method, xparam, d_props9, (hipStream_t)st);                         \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fm_mfd_##SUF(const T *dem, T nodata, int w, int h, int method, double xparam,            \
+                                    float *props9) {                                                            \
+    return guarded([&] {                                                                                        \
+      if (!dem || !props9) throw Error(RDGPU_ERR_ARG, "rdgpu_fm_mfd: null pointer");                            \
+      check_dims(w, h, "rdgpu_fm_mfd");                                                                         \
+      T *d;                                                                                                     \
+      host_dem<T>(dem, w, h, &d);                                                                               \
+      const uint64_t n = (uint64_t)w * h;                                                                       \
+      float *p = Workspace::get().buf<float>("host.props", n * 9);                                              \
+      fm_mfd_device<T>(d, nodata, w, h, method, xparam, p, nullptr);                                            \
+      RD_HIP(hipMemcpy(props9, p, n * 36, hipMemcpyDeviceToHost));                                              \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fa_mfd_dev_##SUF(const T *d_dem, T nodata, int w, int h, int method, double xparam,      \
+                                        double *d_accum, void *st) {                                            \
+    return guarded([&] {                                                                                        \
+      if (!d_dem || !d_accum) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_mfd: null pointer");                         \
+      check_dims(w, h, "rdgpu_fa_mfd");                                                                         \
+      float *p = Workspace::get().buf<float>("mfd.props", (uint64_t)w * h * 9);                                 \
+      fm_mfd_device<T>(d_dem, nodata, w, h, method, xparam, p, (hipStream_t)st);                                \
+      mfd_accumulate<PropsAcc>(PropsAcc{p}, w, h, d_accum, (hipStream_t)st);                                    \
+    });                                                                                                         \
+  }                                                                                                             \
+  extern "C" int rdgpu_fa_mfd_##SUF(const T *dem, T nodata, int w, int h, int method, double xparam,            \
+                                    double *accum) {                                                            \
+    return guarded([&] {                                                                                        \
+      if (!dem || !accum) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_mfd: null pointer");                             \
+      check_dims(w, h, "rdgpu_fa_mfd");                                                                         \
+      T *d;                                                                                                     \
+      host_dem<T>(dem, w, h, &d);                                                                               \
+      const size_t n = (size_t)w * h;                                                                           \
+      double *da = Workspace::get().buf<double>("host.area", n);                                                \
+      RD_HIP(hipMemcpy(da, accum, n * 8, hipMemcpyHostToDevice));                                               \
+      float *p = Workspace::get().buf<float>("mfd.props", n * 9);                                               \
+      fm_mfd_device<T>(d, nodata, w, h, method, xparam, p, nullptr);                                            \
+      mfd_accumulate<PropsAcc>(PropsAcc{p}, w, h, da, nullptr);                                                 \
+      RD_HIP(hipStreamSynchronize(nullptr));                                                                    \
+      RD_HIP(hipMemcpy(accum, da, n * 8, hipMemcpyDeviceToHost));                                               \
+    });                                                                                                         \
+  }
+RD_MFD2_API(u8, uint8_t)
+RD_MFD2_API(i16, int16_t)
+RD_MFD2_API(u16, uint16_t)
+RD_MFD2_API(i32, int32_t)
+RD_MFD2_API(u32, uint32_t)
+RD_MFD2_API(f32, float)
+RD_MFD2_API(f64, double)
 
 // FlowAccumulation(const Array3D<float>&, Array2D<double>&), methods/flow_accumulation_generic.hpp:33-100
 extern "C" int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int w, int h, double *d_accum, void *st) {

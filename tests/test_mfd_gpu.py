@@ -83,3 +83,53 @@ def test_generic_accumulation_errors(rd):
         rd.FlowAccumFromProps(np.zeros((4, 5, 9), np.float32), np.ones((3, 3)))
     with pytest.raises(rd.RdgpuError):
         rd.FlowAccumFromProps(np.zeros((4, 5), np.float32))
+
+
+MFD_METHODS = [("Holmgren", 2.0), ("Holmgren", 0.5), ("Holmgren", 8.0), ("Freeman", 1.1), ("Freeman", 4.0), ("Quinn", None),
+               ("D4", None)]
+
+
+def test_fm_holmgren_freeman_quinn_d4_proportions(rd, orc):
+    """FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4 (flowmet/*.hpp): pow() comes from the device libm, so
+    proportions are held to <= 1 ULP (f32); which slots flow (and the -2/-1/0 markers) must be identical.
+    Quinn (pow(x, 1)) and D4 are exact."""
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        if dem.shape[0] > 50:
+            dem = dem.copy(); dem[30:34, 40:50] = nd
+        for method, x in MFD_METHODS:
+            got = rd.FlowProportions(dem, method, nodata=nd, exponent=x)
+            exp = orc.port.fm_mfd(dem, nd, method, 1.0 if x is None else x)
+            assert np.array_equal(got[..., 0], exp[..., 0]), (name, method)
+            assert np.array_equal(got > 0, exp > 0) and np.array_equal(got == -1, exp == -1), (name, method)
+            if method in ("Quinn", "D4"):
+                assert np.array_equal(got, exp), (name, method)
+            else:
+                assert (ulp_diff_f32(got, exp) <= 1).all(), (name, method, x, int(ulp_diff_f32(got, exp).max()))
+
+
+def test_fa_holmgren_freeman_quinn_d4(rd, orc):
+    for name, dem in dems(orc):
+        nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
+        for method, x in MFD_METHODS:
+            got = rd.FlowAccumulation(dem, method, nodata=nd, exponent=x)
+            exp = orc.port.fa_mfd(dem, nd, method, 1.0 if x is None else x)
+            assert np.array_equal(got == -1, exp == -1), (name, method)
+            if method == "D4":
+                assert np.array_equal(got, exp), name
+            else:
+                assert np.allclose(got, exp, rtol=2e-6, atol=0), (name, method, x, float(np.abs(got / exp - 1).max()))
+        w = np.random.default_rng(3).random(dem.shape)
+        got, exp = rd.FlowAccumulation(dem, "Quinn", nodata=nd, weights=w), orc.port.fa_mfd(dem, nd, "Quinn", 1.0, w)
+        assert np.allclose(got, exp, rtol=1e-9, atol=0), name
+
+
+def test_method_errors(rd):
+    z = np.zeros((5, 5), np.float32)
+    for bad in ("Rho8", "FairfieldLeymarieD4", "nope", None):
+        with pytest.raises(Exception):
+            rd.FlowProportions(rd.rdarray(z, no_data=-1), method=bad)
+    with pytest.raises(Exception, match="requires an exponent"):
+        rd.FlowAccumulation(rd.rdarray(z, no_data=-1), method="Freeman")
+    with pytest.raises(rd.RdgpuError):
+        rd.FlowAccumulation(z, "Holmgren")
