@@ -59,6 +59,7 @@ int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
   inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
   inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
   inline int c_fa_dinf(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_tarboton_##SUF(p, nd, w, h, a); } \
+  inline int c_fa_mfd(const T *p, T nd, int w, int h, int m, double x, double *a) { return rdgpu_fa_mfd_##SUF(p, nd, w, h, m, x, a); } \
   inline int c_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_dinf_flowdirs_##SUF(p, nd, w, h, o); }
 RDGPU_SHIM_STENCIL(u8, uint8_t)
 RDGPU_SHIM_STENCIL(i16, int16_t)
@@ -78,6 +79,8 @@ template <class T>
 int c_fa_dinf(const T *, T, int, int, double *) { unsupported("FA_Tarboton"); }
 template <class T>
 int c_dinf(const T *, T, int, int, float *) { unsupported("dinf_flow_directions"); }
+template <class T>
+int c_fa_mfd(const T *, T, int, int, int, double, double *) { unsupported("FA_Holmgren / FA_Freeman / FA_Quinn / FA_D4"); }
 
 inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
 inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
@@ -216,6 +219,34 @@ void FA_Tarboton(const E &elevations, G &accum) {
 }
 template <class E, class G>
 void FA_Dinfinity(const E &elevations, G &accum) { FA_Tarboton(elevations, accum); }
+
+// richdem::FA_Holmgren / FA_Quinn / FA_Freeman / FA_D4   methods/flow_accumulation.hpp:18-20, :28
+namespace detail {
+template <class E, class G>
+void fa_mfd(const E &elevations, G &accum, int method, double xparam, const char *who) {
+  using T = elem_t<E>;
+  static_assert(std::is_same<elem_t<G>, double>::value, "FA_*: the accumulation array must be Array2D<double>");
+  accum.setNoData(-1.0);
+  if (accum.width() != elevations.width() || accum.height() != elevations.height())
+    throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  check(c_fa_mfd((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), method, xparam,
+                 accum.data()),
+        who);
+}
+}  // namespace detail
+template <class E, class G>
+void FA_Holmgren(const E &elevations, G &accum, double xparam) { detail::fa_mfd(elevations, accum, 0, xparam, "FA_Holmgren"); }
+template <class E, class G>
+void FA_Freeman(const E &elevations, G &accum, double xparam) { detail::fa_mfd(elevations, accum, 1, xparam, "FA_Freeman"); }
+template <class E, class G>
+void FA_Quinn(const E &elevations, G &accum) { detail::fa_mfd(elevations, accum, 2, 1.0, "FA_Quinn"); }
+template <class E, class G>
+void FA_D4(const E &elevations, G &accum) { detail::fa_mfd(elevations, accum, 3, 1.0, "FA_D4"); }
+template <class E, class G>
+void FA_OCallaghanD4(const E &elevations, G &accum) { FA_D4(elevations, accum); }
+template <class E, class G>
+void FA_OCallaghanD8(const E &elevations, G &accum) { FA_D8(elevations, accum); }
 
 // richdem::dinf_flow_directions(const Array2D<T>&, Array2D<float>&)   flowmet/dinf_flowdirs.hpp:128-152
 template <class E, class F>

@@ -4,6 +4,7 @@
 // richdem::Array2D<T> (compile check of the drop-in claim; only where /root/reference exists).
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -30,6 +31,7 @@ void orc_flat_resolution_alter_f32(float *, float, int, int, uint8_t *);
 void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
 void orc_d8_flow_accum_i32(const uint8_t *, uint8_t, int, int, int32_t *);
+void orc_fa_mfd_f32(const float *dem, float nodata, int w, int h, int method, double xparam, double *accum);
 void orc_fa_d8_f32(const float *, float, int, int, double *);
 }
 
@@ -139,6 +141,25 @@ int main() {
     bool threw = false;
     try { rdgpu::FA_D8(dem, wrong); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
+  }
+  // rd_flow_accumulation's other deterministic methods: FA_Quinn / FA_Holmgren / FA_Freeman / FA_D4
+  {
+    Arr<double> a1(dem, 1.0), a2(dem, 1.0), a3(dem, 1.0), a4(dem, 1.0);
+    rdgpu::FA_Quinn(dem, a1);
+    rdgpu::FA_Holmgren(dem, a2, 2.0);
+    rdgpu::FA_Freeman(dem, a3, 1.1);
+    rdgpu::FA_D4(dem, a4);
+    const Arr<double> *got[4] = {&a1, &a2, &a3, &a4};
+    const int method[4] = {2, 0, 1, 3};
+    const double xp[4] = {1.0, 2.0, 1.1, 1.0};
+    for (int m = 0; m < 4; m++) {
+      std::vector<double> e((size_t)w * h, 1.0);
+      orc_fa_mfd_f32(dem.data(), -9999.0f, w, h, method[m], xp[m], e.data());
+      bool close = true;
+      for (size_t i = 0; i < e.size(); i++) close &= std::fabs(got[m]->data()[i] - e[i]) <= 2e-6 * std::fabs(e[i]);
+      EXPECT(close);
+      EXPECT(got[m]->noData() == -1.0);
+    }
   }
   // double DEMs (the Python wrapper's default dtype): lossless-f32 path and value-rank path
   {
