@@ -545,6 +545,7 @@ static uint32_t run_relax(const T *d_z, const uint8_t *d_dirs, int32_t *D, const
     RD_HIP(hipMemcpyAsync(hw, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     const uint32_t nact = hw[0];
+    if (getenv("RDGPU_FLAT_TRACE")) fprintf(stderr, "%s round %u nact %u\n", name, rounds, nact);
     if (nact == 0) break;
     RD_LAUNCH(name, (k_flat_relax<T>), dim3(nact), dim3(NTHR), 0, s, d_z, d_dirs, D, (const uint32_t *)tlist, tflags, w, h,
               tilesX, tilesY);

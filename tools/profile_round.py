@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Produces the per-round measurement artifacts for profiles/ on the GPU box:
+
+    python tools/profile_round.py <tag> [--steps K]
+
+runs, back to back and all on the same command (`python bench.py --steps K --warmup 1`):
+  1. the plain bench               -> gpurun_out/<tag>_fill40k_bench.json
+  2. rocprofv3 --kernel-trace --stats  -> gpurun_out/<tag>_fill40k_kernel_stats.csv
+  3. rocprofv3 --pmc FETCH_SIZE  and  4. rocprofv3 --pmc WRITE_SIZE (separate passes, kernel-trace only)
+                                   -> gpurun_out/<tag>_fill40k_pmc_summary.csv, gpurun_out/pmc_traffic.json
+Counters are KiB; WRITE_SIZE x1 and FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md; calibrated in r01a on kernels of
+known byte count: k_synth writes exactly 4 B/cell, k_count_pits reads exactly 4 B/cell).  Copy the four files into
+profiles/ and commit them."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def run(cmd, log):
+    env = dict(os.environ, TMPDIR="/tmp")
+    with open(log, "w") as f:
+        return subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT).returncode
+
+
+def counters(directory, name):
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != name:
+                    continue
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                per[k][0] += 1
+                per[k][1] += float(row["Counter_Value"])
+    return per
+
+
+def main():
+    tag = sys.argv[1]
+    steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1"]
+    os.makedirs(OUT, exist_ok=True)
+    log = os.path.join(OUT, f"{tag}_bench.log")
+    run(bench, log)
+    line = [l for l in open(log) if l.startswith("{")][-1]
+    with open(os.path.join(OUT, f"{tag}_fill40k_bench.json"), "w") as f:
+        f.write(line)
+    for sub, extra in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--kernel-trace", "--pmc", "FETCH_SIZE"]),
+                       ("write", ["--kernel-trace", "--pmc", "WRITE_SIZE"])):
+        d = os.path.join(OUT, f"{tag}_{sub}")
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3"] + extra + ["--output-format", "csv", "-d", d, "-o", "run", "--"] + bench[:2] + ["--steps", "1", "--warmup", "0", "--cpu-sample", "0"]
+        rc = run(cmd, os.path.join(OUT, f"{tag}_{sub}.log"))
+        print(sub, "rc", rc)
+    ks = glob.glob(os.path.join(OUT, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(OUT, f"{tag}_fill40k_kernel_stats.csv"))
+    fetch = counters(os.path.join(OUT, f"{tag}_fetch"), "FETCH_SIZE")
+    write = counters(os.path.join(OUT, f"{tag}_write"), "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        n = max(fetch[k][0], write[k][0])
+        if not k.startswith("rdgpu::") or n == 0:
+            continue
+        fg = fetch[k][1] * 1024 * 2 / 1e9 / n
+        wg = write[k][1] * 1024 / 1e9 / n
+        rows.append((k, n, fg, wg, fg + wg))
+    with open(os.path.join(OUT, f"{tag}_fill40k_pmc_summary.csv"), "w") as f:
+        f.write(f"# {tag} PMC summary: fill, 40000x40000 f32, 1 step (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)\n")
+        f.write("# counters are KiB; WRITE_SIZE x1, FETCH_SIZE x2 (gfx950 half-count; calibration: k_synth writes 6.4e9 B, k_count_pits reads 6.4e9 B)\n")
+        f.write("kernel,launches,fetch_GB_per_launch(x2),write_GB_per_launch,total_GB_per_launch\n")
+        for r in rows:
+            f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f}\n")
+    scan = [r for r in rows if r[0].startswith("rdgpu::k_scan<")]
+    if scan:
+        n = sum(r[1] for r in scan)
+        gb = sum(r[4] * r[1] for r in scan) / n
+        with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
+            json.dump({"size": 40000, "fill.scan_GB_per_launch": round(gb, 3),
+                       "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
+    print(line.strip())
+
+
+if __name__ == "__main__":
+    main()
