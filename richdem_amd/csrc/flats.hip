@@ -42,35 +42,58 @@ constexpr uint8_t F_LOW = 1, F_HIGH = 2, F_NOFLOW = 4;
 // ------------------------------------------------------------------------------------------
 // find_flat_edges (flat_resolution.hpp:381-418) -> one flag byte per cell
 // ------------------------------------------------------------------------------------------
+constexpr int SW = 64, SH = 16, SLW = SW + 2, SLH = SH + 2;   // stencil tiles (classification, masked directions)
+
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
-                                                        int w, int h, uint8_t *__restrict__ flags) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+                                                        int w, int h, uint8_t *__restrict__ flags, uint32_t tilesX,
+                                                        uint32_t ntiles) {
+  __shared__ T sz[SLH * SLW];
+  __shared__ uint8_t sdir[SLH * SLW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
+  for (int i = threadIdx.x; i < SLH * SLW; i += NTHR) {
+    const int ly = i / SLW, lx = i - ly * SLW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    T v = T();
+    uint8_t d = 255;   // outside the raster: skipped like NoData
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      const size_t g = (size_t)gy * w + gx;
+      v = z[g];
+      d = dirs[g];
+    }
+    sz[i] = v;
+    sdir[i] = d;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
+  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+#pragma unroll
+  for (int j = 0; j < SH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const int o = (ly + 1) * SLW + lx + 1;
     uint8_t f = 0;
-    const uint8_t d = dirs[c];
+    const uint8_t d = sdir[o];
     if (d != 255) {
-      const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
       const bool noflow = d == 0;
       if (noflow) f = F_NOFLOW;
       // a cell WITH flow can only be a low edge if some neighbour is NO_FLOW; a NO_FLOW cell is always
       // interior (edge cells always get a direction), so its 8 neighbours exist
-      const T e = z[c];
+      const T e = sz[o];
+      bool hit = false;
 #pragma unroll
       for (int k = 1; k <= 8; k++) {
-        const int nx = x + fdx(k), ny = y + fdy(k);
-        if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
-        const size_t ni = (size_t)ny * w + nx;
-        const uint8_t dn = dirs[ni];
+        const uint8_t dn = sdir[o + off[k]];
         if (dn == 255) continue;
-        if (!noflow) {
-          if (dn == 0 && z[ni] == e) { f |= F_LOW; break; }    // :406-408
-        } else {
-          if (e < z[ni]) { f |= F_HIGH; break; }               // :409-411
-        }
+        const T zn = sz[o + off[k]];
+        hit |= noflow ? (e < zn) : (dn == 0 && zn == e);   // :409-411 / :406-408
       }
+      if (hit) f |= noflow ? F_HIGH : F_LOW;
     }
-    flags[c] = f;
+    flags[(size_t)gy * w + gx] = f;
   }
 }
 
@@ -247,21 +270,29 @@ __device__ __forceinline__ void uf_unite(uint32_t *L, uint32_t a, uint32_t b) {
   }
 }
 
-// unions across tile borders: lower-index neighbours (NW, N, NE, W) that live in another tile
+// unions across tile borders: lower-index neighbours (NW, N, NE, W) that live in another tile.  One thread per
+// cell of a tile's top row, left column and right column (128 per tile) -- the other cells have all four
+// lower-index neighbours inside their own tile.
 template <class T>
-__global__ __launch_bounds__(NTHR) void k_ccl_border(const T *__restrict__ z, uint32_t *L, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
-    const int tx = x & (CW - 1), ty = y & (CH - 1);
-    if (ty != 0 && tx != 0 && tx != CW - 1) continue;   // all four lower-index neighbours are in my tile
+__global__ __launch_bounds__(NTHR) void k_ccl_border(const T *__restrict__ z, uint32_t *L, int w, int h, uint32_t tilesX,
+                                                     uint32_t ntiles) {
+  const uint64_t total = (uint64_t)ntiles * (CW + 2 * CH), stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < total; i += stride) {
+    const uint32_t t = (uint32_t)(i / (CW + 2 * CH));
+    const int k = (int)(i % (CW + 2 * CH));
+    const int tx = k < CW ? k : (k < CW + CH ? 0 : CW - 1);
+    const int ty = k < CW ? 0 : (k < CW + CH ? k - CW : k - CW - CH);
+    if (k >= CW && ty == 0) continue;      // the corners are in the top row already
+    const int x = (int)(t % tilesX) * CW + tx, y = (int)(t / tilesX) * CH + ty;
+    if (x >= w || y >= h) continue;
+    const uint32_t c = (uint32_t)y * (uint32_t)w + (uint32_t)x;
     const T e = z[c];
     if (y > 0) {
-      if (x > 0 && (ty == 0 || tx == 0) && z[c - w - 1] == e) uf_unite(L, (uint32_t)c, (uint32_t)(c - w - 1));
-      if (ty == 0 && z[c - w] == e) uf_unite(L, (uint32_t)c, (uint32_t)(c - w));
-      if (x < w - 1 && (ty == 0 || tx == CW - 1) && z[c - w + 1] == e) uf_unite(L, (uint32_t)c, (uint32_t)(c - w + 1));
+      if (x > 0 && (ty == 0 || tx == 0) && z[c - w - 1] == e) uf_unite(L, c, c - (uint32_t)w - 1u);
+      if (ty == 0 && z[c - w] == e) uf_unite(L, c, c - (uint32_t)w);
+      if (x < w - 1 && (ty == 0 || tx == CW - 1) && z[c - w + 1] == e) uf_unite(L, c, c - (uint32_t)w + 1u);
     }
-    if (x > 0 && tx == 0 && z[c - 1] == e) uf_unite(L, (uint32_t)c, (uint32_t)(c - 1));
+    if (x > 0 && tx == 0 && z[c - 1] == e) uf_unite(L, c, c - 1u);
   }
 }
 
@@ -294,6 +325,9 @@ __global__ __launch_bounds__(NTHR) void k_flat_mark_low(const uint32_t *__restri
 // TILES, not in cells.
 // ------------------------------------------------------------------------------------------
 constexpr int32_t DINF = 0x7F7F7F7F;   // memset-able "not reached"
+constexpr int RCH = 32;                // relaxation tiles are CW x RCH (the labelling tiles CW x CH)
+constexpr int RNT = 256, RBANDS = RNT / 64;   // one wavefront per band of RCH / RBANDS rows
+constexpr int RELAX_BATCH = 8;         // relaxation rounds enqueued per host read-back
 
 __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter) {
   __shared__ uint32_t wcnt[NTHR / 64];
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_seed(const uint32_t *__restrict__
   // wake the source's tile and the tiles of its 8 neighbours (a source on a tile edge feeds the next tile)
   const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
   const int tx0 = max(x - 1, 0) / CW, tx1 = min(x + 1, w - 1) / CW;
-  const int ty0 = max(y - 1, 0) / CH, ty1 = (y + 1) / CH;
+  const int ty0 = max(y - 1, 0) / RCH, ty1 = (y + 1) / RCH;
   for (int ty = ty0; ty <= ty1; ty++)
     for (int tx = tx0; tx <= tx1; tx++)
       if ((uint32_t)ty < tilesY) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
@@ -342,19 +376,35 @@ __global__ __launch_bounds__(NTHR) void k_tiles_compact(uint8_t *flags, uint32_t
   if (hit) list[slot] = i;
 }
 
+// lane l receives lane l-1's value (lane 0: fill) / lane l+1's value (lane 63: fill): full-rate DPP wave shifts
+__device__ __forceinline__ int32_t from_left(int32_t v, int32_t fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
+
+// One active tile to its local fixed point.  Two facts keep the inner loop free of elevation compares and
+// almost free of LDS: (1) two adjacent NO_FLOW cells always have the same elevation (neither has a lower
+// neighbour), so among the cells that are relaxed the flat graph is the plain 8-grid; (2) the cells that are
+// NOT relaxed but hold a distance (low edges, a shard's ghost rows) only feed in, so they are applied once, with
+// the equal-elevation test, before the loop.  A wavefront is one 64-column band of 8 rows: a lane keeps its
+// column strip in registers, sweeps it down and up (Gauss-Seidel), takes the two side columns' vertical
+// 3-minima from the neighbouring lanes with DPP wave shifts, and only the bands' first/last rows go through
+// LDS (double buffered: one barrier per iteration, shared with the "anything changed" vote).
 template <class T>
-__global__ __launch_bounds__(NTHR) void k_flat_relax(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
-                                                     int32_t *D, const uint32_t *__restrict__ tiles,
-                                                     uint8_t *next_active, int w, int h, uint32_t tilesX,
-                                                     uint32_t tilesY) {
-  constexpr int RW = CW + 2, RH = CH + 2, ROWS = CH / 4;
+__device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_t *__restrict__ dirs, int32_t *D,
+                                           const uint32_t t, uint8_t *next_active, int w, int h, uint32_t tilesX,
+                                           uint32_t tilesY) {
+  constexpr int RW = CW + 2, RH = RCH + 2, ROWS = RCH / RBANDS;
   __shared__ T sz[RH * RW];
   __shared__ int32_t sd[RH * RW];
   __shared__ uint8_t se[RH * RW];
-  const uint32_t t = tiles[blockIdx.x];
+  __shared__ int32_t xrow[2][RBANDS][2][CW];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
-  const int x0 = tx * CW, y0 = ty * CH;
-  for (int i = threadIdx.x; i < RH * RW; i += NTHR) {
+  const int x0 = tx * CW, y0 = ty * RCH;
+  for (int i = threadIdx.x; i < RH * RW; i += RNT) {
     const int ly = i / RW, lx = i - ly * RW;
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
     T v = T();
@@ -364,7 +414,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_relax(const T *__restrict__ z, co
       const size_t g = (size_t)gy * w + gx;
       v = z[g];
       d = __hip_atomic_load(&D[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // neighbours' tiles write it
-      e = dirs[g] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold distance 1
+      e = dirs[g] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold a distance
     }
     sz[i] = v;
     sd[i] = d;
@@ -373,54 +423,74 @@ __global__ __launch_bounds__(NTHR) void k_flat_relax(const T *__restrict__ z, co
   __syncthreads();
   const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
   const int off[9] = {0, -1, -RW - 1, -RW, -RW + 1, 1, RW + 1, RW, RW - 1};
-  uint32_t msk[ROWS];
-  int any = 0;
+  int32_t d[ROWS], d0[ROWS];
+  uint32_t elig = 0;
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     const int o = (band * ROWS + j + 1) * RW + lx + 1;
-    uint32_t m = 0;
+    int32_t v = DINF;
     if (se[o]) {
+      elig |= 1u << j;
+      v = sd[o];
       const T e = sz[o];
 #pragma unroll
-      for (int k = 1; k <= 8; k++)
-        if (sz[o + off[k]] == e) m |= 1u << (k - 1);   // same flat (halo cells outside the raster hold d = INF)
-    }
-    msk[j] = m;
-    any |= m != 0;
-  }
-  if (!__syncthreads_or(any)) return;
-  uint32_t mine = 0;   // bit j: my cell j changed
-  int still = 0;
-  for (int it = 0; it < 256; it++) {
-    int changed = 0;
-#pragma unroll
-    for (int j = 0; j < ROWS; j++) {
-      const uint32_t m = msk[j];
-      if (m) {
-        const int o = (band * ROWS + j + 1) * RW + lx + 1;
-        int32_t best = sd[o];
-#pragma unroll
-        for (int k = 1; k <= 8; k++)
-          if (m & (1u << (k - 1))) {
-            const int32_t v = sd[o + off[k]] + 1;
-            best = v < best ? v : best;
-          }
-        if (best < sd[o]) { sd[o] = best; changed = 1; mine |= 1u << j; }
+      for (int k = 1; k <= 8; k++) {   // feeders: not relaxed themselves, same flat <=> same elevation
+        const int q = o + off[k];
+        if (!se[q] && sz[q] == e) v = imin(v, sd[q] + 1);
       }
     }
-    still = __syncthreads_or(changed);
-    if (!still) break;
+    d0[j] = se[o] ? sd[o] : DINF;
+    d[j] = v;
   }
-  if (still && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
+  if (!__syncthreads_or(elig != 0)) return;
+  // fixed surroundings of the tile as seen by the loop: relaxed cells of the neighbouring tiles (INF otherwise)
+  auto ring = [&](int ly /* -1..RCH */, int cx /* -1..CW */) -> int32_t {
+    const int q = (ly + 1) * RW + cx + 1;
+    return se[q] ? sd[q] : DINF;
+  };
+  int32_t sideL[ROWS], sideR[ROWS];   // vertical 3-minima of the halo columns (lanes 0 and 63 use them)
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int ly = band * ROWS + j;
+    sideL[j] = lx == 0 ? imin(ring(ly - 1, -1), imin(ring(ly, -1), ring(ly + 1, -1))) : DINF;
+    sideR[j] = lx == CW - 1 ? imin(ring(ly - 1, CW), imin(ring(ly, CW), ring(ly + 1, CW))) : DINF;
+  }
+  const int32_t halo_up = band == 0 ? ring(-1, lx) : DINF, halo_dn = band == RBANDS - 1 ? ring(RCH, lx) : DINF;
+  int changed = 1, it = 0;
+  for (; it < 256; it++) {
+    // Gauss-Seidel along the strip
+#pragma unroll
+    for (int j = 1; j < ROWS; j++)
+      if (elig & (1u << j)) d[j] = imin(d[j], d[j - 1] + 1);
+#pragma unroll
+    for (int j = ROWS - 2; j >= 0; j--)
+      if (elig & (1u << j)) d[j] = imin(d[j], d[j + 1] + 1);
+    xrow[it & 1][band][0][lx] = d[0];
+    xrow[it & 1][band][1][lx] = d[ROWS - 1];
+    if (!__syncthreads_or(changed)) break;
+    const int32_t up = band == 0 ? halo_up : xrow[it & 1][band - 1][1][lx];
+    const int32_t dn = band == RBANDS - 1 ? halo_dn : xrow[it & 1][band + 1][0][lx];
+    int32_t m[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) m[j] = imin(j ? d[j - 1] : up, imin(d[j], j + 1 < ROWS ? d[j + 1] : dn));
+    changed = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const int32_t side = imin(from_left(m[j], sideL[j]), from_right(m[j], sideR[j]));
+      const int32_t best = imin(m[j], side) + 1;
+      if ((elig & (1u << j)) && best < d[j]) { d[j] = best; changed = 1; }
+    }
+  }
+  if (it == 256 && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
   // write back and wake the tiles across every edge that changed
   int top = 0, bot = 0, lef = 0, rig = 0;
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
-    if (!(mine & (1u << j))) continue;
+    if (!(elig & (1u << j)) || d[j] >= d0[j]) continue;
     const int ly = band * ROWS + j;
     const int gx = x0 + lx, gy = y0 + ly;
-    __hip_atomic_store(&D[(size_t)gy * w + gx], sd[(ly + 1) * RW + lx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    top |= ly == 0; bot |= ly == CH - 1; lef |= lx == 0; rig |= lx == CW - 1;
+    __hip_atomic_store(&D[(size_t)gy * w + gx], d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    top |= ly == 0; bot |= ly == RCH - 1; lef |= lx == 0; rig |= lx == CW - 1;
   }
   top = __syncthreads_or(top); bot = __syncthreads_or(bot); lef = __syncthreads_or(lef); rig = __syncthreads_or(rig);
   if (threadIdx.x < 9 && threadIdx.x != 4) {
@@ -429,6 +499,20 @@ __global__ __launch_bounds__(NTHR) void k_flat_relax(const T *__restrict__ z, co
     const int ntx = tx + dx, nty = ty + dy;
     if (need && ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
   }
+}
+
+// One block per listed tile.  The count lives on the device (rounds are enqueued in batches, the host sizes the
+// grid from the previous batch): blocks past the count leave at once, and tiles past the grid -- the list grew
+// faster than expected -- simply stay active for the next round (relaxation is monotone, order is irrelevant).
+template <class T>
+__global__ __launch_bounds__(RNT) void k_flat_relax(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
+                                                    int32_t *D, const uint32_t *__restrict__ tiles,
+                                                    const uint32_t *__restrict__ count, uint8_t *next_active, int w,
+                                                    int h, uint32_t tilesX, uint32_t tilesY) {
+  const uint32_t n = *count;
+  for (uint32_t i = gridDim.x + blockIdx.x * RNT + threadIdx.x; i < n; i += gridDim.x * RNT) next_active[tiles[i]] = 1;
+  if (blockIdx.x >= n) return;
+  relax_tile<T>(z, dirs, D, tiles[blockIdx.x], next_active, w, h, tilesX, tilesY);
 }
 
 // flat_height[label] = deepest away level of the flat (:181): atomicMax behind a coherent pre-check
@@ -463,29 +547,58 @@ __global__ __launch_bounds__(NTHR) void k_flat_combine(int32_t *M /* in: towards
 // d8_masked_FlowDir (:42-65) for the NO_FLOW cells of drainable flats (M > 0), d8_flow_flats :96-116.
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_flat_dirs(const T *__restrict__ z, const int32_t *__restrict__ M,
-                                                    uint8_t *dirs, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    if (dirs[c] != 0) continue;
-    const int32_t mc = M[c];
-    if (mc <= 0) continue;   // flat without outlet: stays NO_FLOW
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
-    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;   // interior only (:108-109); cannot happen
-    const T e = z[c];
+                                                    uint8_t *dirs, int w, int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ T sz[SLH * SLW];
+  __shared__ int32_t sm[SLH * SLW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
+  for (int i = threadIdx.x; i < SLH * SLW; i += NTHR) {
+    const int ly = i / SLW, lx = i - ly * SLW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    T v = T();
+    int32_t m = 0;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      const size_t g = (size_t)gy * w + gx;
+      v = z[g];
+      m = M[g];
+    }
+    sz[i] = v;
+    sm[i] = m;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
+  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+#pragma unroll
+  for (int j = 0; j < SH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) continue;   // interior only (:108-109)
+    const int o = (ly + 1) * SLW + lx + 1;
+    const int32_t mc = sm[o];
+    if (mc <= 0) continue;                 // not in a drainable flat
+    const size_t g = (size_t)gy * w + gx;
+    if (dirs[g] != 0) continue;            // low edges keep their direction (:112)
+    const T e = sz[o];
     int32_t m = mc;
     int dir = 0;
 #pragma unroll
     for (int k = 1; k <= 8; k++) {
-      const size_t ni = (size_t)(y + fdy(k)) * w + (x + fdx(k));
-      if (!(z[ni] == e)) continue;                                  // labels(n) != labels(c), :56-57
-      const int32_t v = M[ni];
+      if (!(sz[o + off[k]] == e)) continue;                         // labels(n) != labels(c), :56-57
+      const int32_t v = sm[o + off[k]];
       if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1)) {
         m = v;
         dir = k;
       }
     }
-    dirs[c] = (uint8_t)dir;
+    dirs[g] = (uint8_t)dir;
   }
+}
+
+static inline uint32_t stencil_tiles(int w, int h, uint32_t *tilesX) {
+  *tilesX = (uint32_t)((w + SW - 1) / SW);
+  return *tilesX * (uint32_t)((h + SH - 1) / SH);
 }
 
 // label export for tests: lowest cell index of the flat + 1, or 0 for unlabelled cells
@@ -503,6 +616,26 @@ __global__ __launch_bounds__(NTHR) void k_flat_labels_out(const uint32_t *__rest
 // ------------------------------------------------------------------------------------------
 static rdgpu_flat_stats g_fstats;
 static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + NTHR - 1) / NTHR, 256u * 32u); }
+
+template <class T>
+static void launch_classify(const T *d_z, const uint8_t *d_dirs, int w, int h, uint8_t *flags, hipStream_t s) {
+  uint32_t tilesX;
+  const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+  RD_LAUNCH("flats.classify", (k_flat_classify<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, d_dirs, w, h, flags, tilesX,
+            ntiles);
+}
+template <class T>
+static void launch_masked_dirs(const T *d_z, const int32_t *M, uint8_t *d_dirs, int w, int h, hipStream_t s) {
+  uint32_t tilesX;
+  const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+  RD_LAUNCH("flats.masked_dirs", (k_flat_dirs<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, M, d_dirs, w, h, tilesX, ntiles);
+}
+template <class T>
+static void launch_ccl_border(const T *d_z, uint32_t *L, int w, int h, hipStream_t s) {
+  const uint32_t tilesX = (w + CW - 1) / CW, ntiles = tilesX * ((h + CH - 1) / CH);
+  RD_LAUNCH("flats.ccl_border", (k_ccl_border<T>), dim3(sgrid((uint64_t)ntiles * (CW + 2 * CH))), dim3(NTHR), 0, s, d_z, L, w, h,
+            tilesX, ntiles);
+}
 
 // list of the cells with flags & mask, in index order; returns the count
 static uint32_t compact_flags(const uint8_t *flags, uint8_t mask, uint64_t n, const char *name, uint32_t **out,
@@ -524,35 +657,51 @@ static uint32_t compact_flags(const uint8_t *flags, uint8_t mask, uint64_t n, co
   return total;
 }
 
+// Relaxation rounds until no tile is active.  Rounds are enqueued RELAX_BATCH at a time (compact the active
+// tile flags into a list + count on the device, relax that list); the host only reads the counts back once
+// per batch, and the rounds enqueued past the fixed point see an empty list.  Returns the rounds that had work.
+template <class T>
+static uint32_t relax_rounds(const T *d_z, const uint8_t *d_dirs, int32_t *D, uint8_t *tflags, uint32_t *tlist,
+                             uint32_t *ctr /* RELAX_BATCH words */, int w, int h, const char *name, hipStream_t s) {
+  uint32_t *hw = Workspace::get().host_words();
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
+  const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
+  uint32_t rounds = 0, grid = ntiles;   // any tile may be active in the first batch
+  for (;;) {
+    RD_HIP(hipMemsetAsync(ctr, 0, RELAX_BATCH * sizeof(uint32_t), s));
+    for (int b = 0; b < RELAX_BATCH; b++) {
+      RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, tflags, ntiles,
+                tlist, ctr + b);
+      RD_LAUNCH(name, (k_flat_relax<T>), dim3(grid), dim3(RNT), 0, s, d_z, d_dirs, D, (const uint32_t *)tlist,
+                (const uint32_t *)(ctr + b), tflags, w, h, tilesX, tilesY);
+    }
+    RD_HIP(hipMemcpyAsync(hw, ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    uint32_t most = 0;
+    for (int b = 0; b < RELAX_BATCH; b++) {
+      if (trace) fprintf(stderr, "%s round %u nact %u (grid %u)\n", name, rounds, hw[b], grid);
+      if (hw[b] == 0) return rounds;
+      most = std::max(most, hw[b]);
+      rounds++;
+    }
+    grid = std::min<uint32_t>(ntiles, std::max<uint32_t>(1024u, 2u * most));
+    if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
+  }
+}
+
 // Distances from the cells listed in src (level 1) by tile relaxation.  Returns the number of rounds.
 template <class T>
 static uint32_t run_relax(const T *d_z, const uint8_t *d_dirs, int32_t *D, const uint32_t *src, uint32_t nsrc,
                           const uint32_t *L, const int32_t *fh_filter, int w, int h, const char *name, hipStream_t s) {
   Workspace &ws = Workspace::get();
-  uint32_t *hw = ws.host_words();
-  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + CH - 1) / CH, ntiles = tilesX * tilesY;
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
   uint8_t *tflags = ws.buf<uint8_t>("flats.tflags", ntiles);
   uint32_t *tlist = ws.buf<uint32_t>("flats.tlist", ntiles);
-  uint32_t *ctr = ws.buf<uint32_t>("flats.tctr", 4);
+  uint32_t *ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
   RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
   RD_LAUNCH("flats.seed", k_flat_seed, dim3((nsrc + NTHR - 1) / NTHR), dim3(NTHR), 0, s, src, nsrc, L, fh_filter, D,
             tflags, w, tilesX, tilesY, (const int32_t *)nullptr);
-  uint32_t rounds = 0;
-  for (;;) {
-    RD_HIP(hipMemsetAsync(ctr, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, tflags, ntiles,
-              tlist, ctr);
-    RD_HIP(hipMemcpyAsync(hw, ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    const uint32_t nact = hw[0];
-    if (getenv("RDGPU_FLAT_TRACE")) fprintf(stderr, "%s round %u nact %u\n", name, rounds, nact);
-    if (nact == 0) break;
-    RD_LAUNCH(name, (k_flat_relax<T>), dim3(nact), dim3(NTHR), 0, s, d_z, d_dirs, D, (const uint32_t *)tlist, tflags, w, h,
-              tilesX, tilesY);
-    rounds++;
-    if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
-  }
-  return rounds;
+  return relax_rounds<T>(d_z, d_dirs, D, tflags, tlist, ctr, w, h, name, s);
 }
 
 // Computes flat_mask (M) for the DEM; d_dirs must hold d8_flow_directions output.
@@ -570,7 +719,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
 
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
-  RD_LAUNCH("flats.classify", (k_flat_classify<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, d_dirs, w, h, flags);
+  launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   uint32_t *low = nullptr, *dummy = nullptr;
   const uint32_t nlow = compact_flags(flags, F_LOW, n, "flats.low", &low, s);
   g_fstats.low_edges = nlow;
@@ -593,7 +742,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     const uint32_t tilesX = (w + CW - 1) / CW, ntiles = tilesX * ((h + CH - 1) / CH);
     RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, L, w, h, tilesX, ntiles);
   }
-  RD_LAUNCH("flats.ccl_border", (k_ccl_border<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, L, w, h);
+  launch_ccl_border<T>(d_z, L, w, h, s);
   RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, L, n);
   RD_HIP(hipMemsetAsync(fh, 0xFF, n * sizeof(int32_t), s));        // -1 everywhere
   RD_LAUNCH("flats.mark_low", k_flat_mark_low, dim3((nlow + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)low,
@@ -625,7 +774,7 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   uint32_t *L;
   resolve_flats_device<T>(d_z, d_dirs, w, h, &M, &L, &fh, s);
   if (L)   // there is at least one low edge
-    RD_LAUNCH("flats.masked_dirs", (k_flat_dirs<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, M, d_dirs, w, h);
+    launch_masked_dirs<T>(d_z, M, d_dirs, w, h, s);
 }
 
 template <class T>
@@ -642,7 +791,7 @@ static void flat_resolution_host(const T *dem, T nodata, int w, int h, uint8_t *
   int32_t *M, *fh;
   uint32_t *L;
   resolve_flats_device<T>(d, dd, w, h, &M, &L, &fh, s);
-  if (L) RD_LAUNCH("flats.masked_dirs", (k_flat_dirs<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d, M, dd, w, h);
+  if (L) launch_masked_dirs<T>(d, M, dd, w, h, s);
   RD_HIP(hipStreamSynchronize(s));
   RD_HIP(hipMemcpy(dirs, dd, n, hipMemcpyDeviceToHost));
   if (mask) RD_HIP(hipMemcpy(mask, M, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -739,7 +888,7 @@ __global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *_
   int32_t *g = &D[(size_t)ghost_row * w + x];
   if (v < *g) {
     *g = v;
-    const int ty = own_row / CH;
+    const int ty = own_row / RCH;
     for (int tx = max(x - 1, 0) / CW; tx <= min(x + 1, w - 1) / CW; tx++) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
   }
 }
@@ -877,8 +1026,7 @@ template <class T>
 static void fs_relax(rdgpu_flat_shard *f, int phase) {
   hipStream_t s = f->stream;
   const int w = f->w, h = f->rows;
-  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + CH - 1) / CH, ntiles = tilesX * tilesY;
-  uint32_t *hw = Workspace::get().host_words();
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH;
   const T *z = static_cast<const T *>(f->z);
   int32_t *D = f->D[phase];
   if (!f->seeded[phase]) {
@@ -888,18 +1036,8 @@ static void fs_relax(rdgpu_flat_shard *f, int phase) {
                 (const uint32_t *)f->src[phase], f->nsrc[phase], (const uint32_t *)f->L, (const int32_t *)nullptr, D,
                 f->tflags[phase], w, tilesX, tilesY, phase == 1 ? (const int32_t *)f->D[0] : (const int32_t *)nullptr);
   }
-  for (;;) {
-    RD_HIP(hipMemsetAsync(f->ctr, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->tflags[phase],
-              ntiles, f->tlist, f->ctr);
-    RD_HIP(hipMemcpyAsync(hw, f->ctr, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    const uint32_t nact = hw[0];
-    if (nact == 0) break;
-    RD_LAUNCH(phase ? "flats.relax_away" : "flats.relax_towards", (k_flat_relax<T>), dim3(nact), dim3(NTHR), 0, s, z,
-              (const uint8_t *)f->dirs, D, (const uint32_t *)f->tlist, f->tflags[phase], w, h, tilesX, tilesY);
-    if (++f->rounds[phase] > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat shard: relaxation did not terminate");
-  }
+  f->rounds[phase] += relax_rounds<T>(z, (const uint8_t *)f->dirs, D, f->tflags[phase], f->tlist, f->ctr, w, h,
+                                      phase ? "flats.relax_away" : "flats.relax_towards", s);
 }
 
 template <class T>
@@ -912,8 +1050,7 @@ static void fs_finish(rdgpu_flat_shard *f, const int32_t *d_heights, uint8_t *d_
               d_heights, cut_rows(f), w);
   RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, f->D[0], (const int32_t *)f->D[1],
             (const uint32_t *)f->L, (const int32_t *)f->fh, n);
-  RD_LAUNCH("flats.masked_dirs", (k_flat_dirs<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, static_cast<const T *>(f->z),
-            (const int32_t *)f->D[0], f->dirs, w, h);
+  launch_masked_dirs<T>(static_cast<const T *>(f->z), (const int32_t *)f->D[0], f->dirs, w, h, s);
   RD_HIP(hipMemcpyAsync(d_dirs_out, f->dirs + (size_t)f->gtop * w, (size_t)(h - f->gtop - f->gbot) * w, hipMemcpyDeviceToDevice, s));
 }
 
@@ -936,7 +1073,8 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
       f->owned.push_back(p);
       return p;
     };
-    const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (rows + CH - 1) / CH, ntiles = tilesX * tilesY;
+    const uint32_t tilesX = (w + CW - 1) / CW, ntiles = tilesX * ((rows + CH - 1) / CH);   // labelling tiles
+    const uint32_t rtiles = tilesX * ((rows + RCH - 1) / RCH);                               // relaxation tiles
     f->dirs = (uint8_t *)alloc(n);
     f->flags = (uint8_t *)alloc(n);
     f->L = (uint32_t *)alloc(n * 4);
@@ -944,13 +1082,12 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
     f->fh = (int32_t *)alloc(n * 4);
     f->D[0] = (int32_t *)alloc(n * 4);
     f->D[1] = (int32_t *)alloc(n * 4);
-    f->tflags[0] = (uint8_t *)alloc(ntiles);
-    f->tflags[1] = (uint8_t *)alloc(ntiles);
-    f->tlist = (uint32_t *)alloc((size_t)ntiles * 4);
-    f->ctr = (uint32_t *)alloc(16);
+    f->tflags[0] = (uint8_t *)alloc(rtiles);
+    f->tflags[1] = (uint8_t *)alloc(rtiles);
+    f->tlist = (uint32_t *)alloc((size_t)rtiles * 4);
+    f->ctr = (uint32_t *)alloc(RELAX_BATCH * sizeof(uint32_t));
     flowdirs_device<T>(d_z, nodata, w, rows, f->dirs, MODE_D8, s);
-    RD_LAUNCH("flats.classify", (k_flat_classify<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint8_t *)f->dirs, w, rows,
-              f->flags);
+    launch_classify<T>(d_z, (const uint8_t *)f->dirs, w, rows, f->flags, s);
     // sources are own cells only; the ghost rows' distances arrive from their owners
     if (gtop) RD_HIP(hipMemsetAsync(f->flags, 0, (size_t)gtop * w, s));
     if (gbot) RD_HIP(hipMemsetAsync(f->flags + (size_t)(rows - gbot) * w, 0, (size_t)gbot * w, s));
@@ -968,13 +1105,13 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
     if (gtop) RD_HIP(hipMemsetAsync(f->dirs, 1, (size_t)gtop * w, s));
     if (gbot) RD_HIP(hipMemsetAsync(f->dirs + (size_t)(rows - gbot) * w, 1, (size_t)gbot * w, s));
     RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles);
-    RD_LAUNCH("flats.ccl_border", (k_ccl_border<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, f->L, w, rows);
+    launch_ccl_border<T>(d_z, f->L, w, rows, s);
     RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, f->L, n);
     RD_HIP(hipMemsetAsync(f->fh, 0, n * 4, s));
     RD_HIP(hipMemsetAsync(f->D[0], 0x7F, n * 4, s));
     RD_HIP(hipMemsetAsync(f->D[1], 0x7F, n * 4, s));
-    RD_HIP(hipMemsetAsync(f->tflags[0], 0, ntiles, s));
-    RD_HIP(hipMemsetAsync(f->tflags[1], 0, ntiles, s));
+    RD_HIP(hipMemsetAsync(f->tflags[0], 0, rtiles, s));
+    RD_HIP(hipMemsetAsync(f->tflags[1], 0, rtiles, s));
     RD_HIP(hipStreamSynchronize(s));
   } catch (...) {
     fs_free(f);
