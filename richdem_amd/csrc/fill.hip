@@ -9,18 +9,18 @@
 // surface with a GPU-shaped algorithm (see DESIGN.md section 3 for the proof sketch):
 //
 //   1. k_descent      every cell points at its lowest (key, index) neighbour if that is lower than
-//                     itself in the (key, index) total order; border cells drain "OUT".
-//   2. k_chase        pointer chasing with path compression -> every cell knows its pit (root).
-//   3. k_count_pits / k_scan_counts / k_assign_pits / k_label_cells
-//                     pits get dense basin ids 0..B-1; lab[c] = basin of c (B = the outside).
+//                     itself in the (key, index) total order; border cells drain "OUT".  Paths are
+//                     compressed inside a 64x64 tile in LDS, and pits get dense basin ids 0..B-1.
+//   2. k_tile_label   lab[c] = basin of c (B = the outside): the few distinct pointers of a tile are chased
+//                     to their pits once per tile (k_chase / k_label_cells: fallback for very long chains).
 //                     W(c) = max(z(c), L[basin(c)]) with L = minimax pass height basin -> outside.
-//   4. rounds of      k_scan (raster pass: each component's lowest pass to a different component,
+//   3. rounds of      k_scan (raster pass: each component's lowest pass to a different component,
 //                     one 64-bit atomicMin of (pass height << 32 | neighbour component)),
 //                     k_hook (hook every component along its lowest pass; mutual pairs keep the
 //                     smaller id as root), k_chase_links (pointer jumping carrying the path
 //                     maximum), k_update_basins, k_compact_roots.  This is Boruvka's contraction:
 //                     the number of live components at least halves per round.
-//   5. k_finalize     z(c) <- max(z(c), acc[lab[c]]).
+//   4. k_finalize     z(c) <- max(z(c), acc[lab[c]]).
 //
 // All elevation work is on order-preserving 32-bit keys (common.hpp Key32), so it is exact for
 // u8/i16/u16/i32/u32/f32.  HBM-bound integer/compare work: no MFMA anywhere.
@@ -40,7 +40,6 @@ constexpr int LW = TW + 2;    // LDS row stride incl. 1-cell halo (66 words: con
 constexpr int LH = TH + 2;
 constexpr int NTHR = 256;     // 4 wavefronts
 constexpr uint32_t OUTP = 0xFFFFFFFFu;  // descent pointer of a border cell: drains off the raster
-constexpr int CELLS_PER_BLOCK = 4096;   // 1-D kernels: 256 threads x 16 cells
 // Component ids carry CLOSED in the top bit when the component never hooks again: the outside (B) and,
 // in a row-block shard, the frozen terminal basins of the cut rows (Barnes 2016 tile protocol).
 constexpr uint32_t CLOSED = 0x80000000u;
@@ -98,10 +97,13 @@ __device__ __forceinline__ uint32_t descent_global(const uint32_t *sk, int lx, i
 
 template <class T, int TOPO>
 __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ ptr,
+                                                  uint32_t *__restrict__ lab, uint32_t *pit_counter,
                                                   int w, int h, uint32_t tilesX, uint32_t ntiles, int open_top,
                                                   int open_bottom) {
   __shared__ uint32_t sk[DLH * DLW];
   __shared__ uint16_t lp[DH * DW];
+  __shared__ uint32_t wtot[NTHR / 64];
+  __shared__ uint32_t pbase;
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
@@ -150,7 +152,10 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
     active = still;
     if (!__syncthreads_or(active != 0)) break;
   }
-  // write: the tile-local root's own pointer
+  // write: the tile-local root's own pointer.  Pits (and a shard's cut-row terminals), ptr[c] == c, get their
+  // dense basin id here: ONE counter add per tile (ids are dense but not in raster order -- nothing depends on
+  // their order, the filled surface is unique).
+  uint32_t pitmask = 0;
 #pragma unroll 4
   for (int j = 0; j < DH / 4; j++) {
     const int ly = ly0 + 4 * j, gy = y0 + ly;
@@ -158,7 +163,30 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
     const uint16_t p = lp[ly * DW + lx];
     int rx = lx, ry = ly;
     if (p != LTERM) { rx = p & (DW - 1); ry = p >> 6; }
-    ptr[(size_t)gy * w + gx] = descent_global<TOPO>(sk, rx, ry, x0 + rx, y0 + ry, w, h, open_top, open_bottom);
+    const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+    const uint32_t g = descent_global<TOPO>(sk, rx, ry, x0 + rx, y0 + ry, w, h, open_top, open_bottom);
+    ptr[c] = g;
+    if (g == c) pitmask |= 1u << j;
+  }
+  const uint32_t mine = (uint32_t)__popc(pitmask);
+  uint32_t incl = mine;   // inclusive prefix over the wavefront
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if ((threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    pbase = tot ? atomicAdd(pit_counter, tot) : 0;
+  }
+  __syncthreads();
+  uint32_t id = pbase + incl - mine;
+  for (int k = 0; k < (int)(threadIdx.x >> 6); k++) id += wtot[k];
+  for (uint32_t m = pitmask; m; m &= m - 1) {
+    const int j = __ffs((int)m) - 1;
+    lab[(size_t)(y0 + ly0 + 4 * j) * w + gx] = id++;
   }
 }
 
@@ -188,99 +216,81 @@ __global__ __launch_bounds__(NTHR) void k_chase(uint32_t *ptr, uint32_t n, int m
   }
 }
 
-// Chase straight to the basin label: after the in-tile compression a path is a few tile-to-tile hops, so
-// nothing is written back; lab[pit] must already hold the pit's dense id.  A cell whose path is longer
-// than maxhops keeps the furthest ancestor found in ptr[] and raises the flag: the host then falls back to
-// the compressing passes (k_chase) + k_label_cells.  lab[c] = B for cells draining off the raster.
-__global__ __launch_bounds__(NTHR) void k_chase_label(uint32_t *ptr, uint32_t *lab, uint32_t n, uint32_t B, int maxhops,
-                                                      uint32_t *flag) {
-  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
-    const uint32_t c = (uint32_t)c64;
-    uint32_t p = ptr[c];
-    if (p == c) continue;              // a pit: labelled by k_assign_pits
-    if (p == OUTP) { lab[c] = B; continue; }
-    int hops = 0;
-    for (;;) {
-      const uint32_t q = ptr[p];
-      if (q == OUTP) { lab[c] = B; break; }
-      if (q == p) { lab[c] = lab[p]; break; }
-      p = q;
-      if (++hops >= maxhops) { ptr[c] = p; *flag = 1; break; }
-    }
+// Labels per tile: the cells of a 64x64 tile share a handful of distinct pointers (its pits and the ring
+// cells its paths leave through), so the distinct values are collected in an LDS table, each is chased to
+// its pit ONCE (tile-to-tile hops, global gathers), and the 4096 cells read their label from LDS.  lab[pit]
+// must already hold the pit's dense id (k_descent); lab[c] = B for cells draining off the raster.  A chain
+// longer than maxhops raises the flag: the host then falls back to the compressing passes.
+constexpr int LT_SLOTS = 1024;
+constexpr uint32_t LT_EMPTY = 0xFFFFFFFEu;
+
+__device__ __forceinline__ uint32_t chase_to_label(const uint32_t *__restrict__ ptr, const uint32_t *lab, uint32_t p,
+                                                   uint32_t B, int maxhops, uint32_t *flag) {
+  int hops = 0;
+  for (;;) {
+    const uint32_t q = ptr[p];
+    if (q == OUTP) return B;
+    if (q == p) return lab[p];
+    p = q;
+    if (++hops >= maxhops) { *flag = 1; return B; }
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// 3. dense basin ids for pits (ptr[c] == c), then per-cell labels
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_count_pits(const uint32_t *__restrict__ ptr, uint32_t n,
-                                                     uint32_t *__restrict__ counts) {
-  __shared__ uint32_t ws[NTHR / 64];
-  const uint32_t base = blockIdx.x * CELLS_PER_BLOCK;
-  uint32_t cnt = 0;
-#pragma unroll 4
-  for (int j = 0; j < CELLS_PER_BLOCK / NTHR; j++) {
-    const uint32_t c = base + j * NTHR + threadIdx.x;
-    if (c < n && ptr[c] == c) cnt++;
-  }
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+__global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict__ ptr, uint32_t *lab, int w, int h,
+                                                     uint32_t tilesX, uint32_t ntiles, uint32_t B, int maxhops,
+                                                     uint32_t *flag) {
+  __shared__ uint32_t tkey[LT_SLOTS];
+  __shared__ uint32_t tval[LT_SLOTS];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
+  for (int i = threadIdx.x; i < LT_SLOTS; i += NTHR) tkey[i] = LT_EMPTY;
   __syncthreads();
-  if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// single workgroup: exclusive scan of counts[0..m) in place; total -> *total
-__global__ __launch_bounds__(1024) void k_scan_counts(uint32_t *counts, uint32_t m, uint32_t *total) {
-  __shared__ uint32_t part[1024];
-  const uint32_t chunk = (m + 1023u) / 1024u;
-  const uint32_t lo = threadIdx.x * chunk, hi = min(lo + chunk, m);
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += counts[i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan over 1024 partials
-    uint32_t v = (threadIdx.x >= (uint32_t)o) ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t v = counts[i];
-    counts[i] = run;
-    run += v;
-  }
-  if (threadIdx.x == 1023) *total = part[1023];
-}
-
-__global__ __launch_bounds__(NTHR) void k_assign_pits(const uint32_t *__restrict__ ptr, uint32_t n,
-                                                      const uint32_t *__restrict__ offsets,
-                                                      uint32_t *__restrict__ lab) {
-  __shared__ uint32_t ws[NTHR / 64];
-  const uint32_t base = blockIdx.x * CELLS_PER_BLOCK;
-  uint32_t run = offsets[blockIdx.x];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int j = 0; j < CELLS_PER_BLOCK / NTHR; j++) {
-    const uint32_t c = base + j * NTHR + threadIdx.x;
-    const bool pit = c < n && ptr[c] == c;
-    const unsigned long long bal = __ballot(pit);
-    const uint32_t rank = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) ws[wv] = __popcll(bal);
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
+  const int lx = threadIdx.x & (DW - 1), ly0 = threadIdx.x >> 6;
+  const int gx = x0 + lx;
+  constexpr int CELLS = DH / 4;
+  uint32_t pv[CELLS];
+  int16_t sl[CELLS];   // table slot, -1: pit / outside the raster, -2: drains off the raster, -3: table full
 #pragma unroll
-    for (int k = 0; k < NTHR / 64; k++) {
-      const uint32_t v = ws[k];
-      if (k < wv) woff += v;
-      tot += v;
+  for (int j = 0; j < CELLS; j++) {
+    const int gy = y0 + ly0 + 4 * j;
+    sl[j] = -1;
+    pv[j] = 0;
+    if (gx >= w || gy >= h) continue;
+    const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
+    const uint32_t p = ptr[c];
+    pv[j] = p;
+    if (p == c) continue;
+    if (p == OUTP) { sl[j] = -2; continue; }
+    if (j > 0 && sl[j - 1] >= 0 && pv[j - 1] == p) { sl[j] = sl[j - 1]; continue; }
+    uint32_t slot = (p * 0x9E3779B1u) >> 22;
+    int found = -3;
+#pragma unroll 1
+    for (int probe = 0; probe < 16; probe++) {
+      uint32_t k = tkey[slot];
+      if (k == LT_EMPTY) k = atomicCAS(&tkey[slot], LT_EMPTY, p);
+      if (k == LT_EMPTY || k == p) { found = (int)slot; break; }
+      slot = (slot + 1) & (LT_SLOTS - 1);
     }
-    if (pit) lab[c] = run + woff + rank;
-    run += tot;
-    __syncthreads();
+    sl[j] = (int16_t)found;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < LT_SLOTS; i += NTHR) {
+    const uint32_t k = tkey[i];
+    if (k != LT_EMPTY) tval[i] = chase_to_label(ptr, lab, k, B, maxhops, flag);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CELLS; j++) {
+    if (sl[j] == -1) continue;
+    const size_t c = (size_t)(y0 + ly0 + 4 * j) * w + gx;
+    lab[c] = sl[j] >= 0 ? tval[sl[j]] : sl[j] == -2 ? B : chase_to_label(ptr, lab, pv[j], B, maxhops, flag);
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3. per-cell labels after the compressing fallback passes
+// ------------------------------------------------------------------------------------------
 // lab[c] = basin id of c's pit; B for cells draining off the raster.
 __global__ __launch_bounds__(NTHR) void k_label_cells(const uint32_t *__restrict__ ptr, uint32_t *lab,
                                                       uint32_t n, uint32_t B) {
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(NTHR) void k_label_cells(const uint32_t *__restrict
     const uint32_t c = (uint32_t)c64;
     const uint32_t p = ptr[c];
     if (p == OUTP) lab[c] = B;
-    else if (p != c) lab[c] = lab[p];  // lab[p] was written by k_assign_pits (earlier launch)
+    else if (p != c) lab[c] = lab[p];  // lab[p] of a pit was written by k_descent
   }
 }
 
@@ -787,8 +797,6 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   uint32_t *ptr = ws.buf<uint32_t>("fill.ptr", n);
   uint32_t *lab = alloc.get<uint32_t>("fill.lab", n);
   fb.lab = lab;
-  const uint32_t nblk = cdiv(n, CELLS_PER_BLOCK);
-  uint32_t *counts = ws.buf<uint32_t>("fill.counts", nblk);
   uint32_t *dflags = ws.buf<uint32_t>("fill.flags", 16);  // [0] chase flag, [1] pit total, [2] root counter
   uint32_t *hw = ws.host_words();
 
@@ -796,24 +804,19 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const uint32_t tgrid = xcd_grid(ntiles);
   const uint32_t sgrid = std::min(cdiv(n, NTHR), 256u * 32u);  // grid-stride 1-D kernels
 
-  {
-    const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
-    RD_LAUNCH("fill.descent", (k_descent<T, TOPO>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, w, h, dtx, dnt,
-              open_top, open_bottom);
-  }
-
-  // pits (ptr[c] == c) are final after the descent kernel: number them first
-  RD_LAUNCH("fill.count_pits", k_count_pits, dim3(nblk), dim3(NTHR), 0, s, ptr, n, counts);
-  RD_LAUNCH("fill.scan_counts", k_scan_counts, dim3(1), dim3(1024), 0, s, counts, nblk, dflags + 1);
+  // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
+  const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
+  RD_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(uint32_t), s));
+  RD_LAUNCH("fill.descent", (k_descent<T, TOPO>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w, h,
+            dtx, dnt, open_top, open_bottom);
   RD_HIP(hipMemcpyAsync(hw, dflags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  RD_LAUNCH("fill.assign_pits", k_assign_pits, dim3(nblk), dim3(NTHR), 0, s, ptr, n, counts, lab);
   RD_HIP(hipStreamSynchronize(s));
   const uint32_t B = hw[0];
   g_stats.basins = B;
   fb.B = B;
   if (B == 0) { fb.trivial = true; return; }  // no pits and no terminals: nothing to raise
-  RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
-  RD_LAUNCH("fill.chase_label", k_chase_label, dim3(sgrid), dim3(NTHR), 0, s, ptr, lab, n, B, 256, dflags);
+  RD_LAUNCH("fill.tile_label", k_tile_label, dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const uint32_t *)ptr, lab, w, h, dtx,
+            dnt, B, 256, dflags);
   RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   g_stats.jump_passes = 1;
