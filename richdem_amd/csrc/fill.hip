@@ -55,47 +55,9 @@ static rdgpu_fill_stats g_stats;
 // global chase (k_chase) then hops tile to tile instead of cell to cell.
 // ------------------------------------------------------------------------------------------
 constexpr int DW = 64, DH = 64, DLW = DW + 2, DLH = DH + 2;
-constexpr uint16_t LTERM = 0xFFFFu;   // local pointer: this cell is terminal within the tile
+constexpr uint16_t LTERM_BASE = 0xF000u;   // local pointers >= this: the cell is terminal within the tile (low 4 bits: code)
 
-// descent target of the cell at LDS position p (global cell c), as an offset in cell-index space;
-// 0 = the cell is its own root (pit).  Neighbours are visited in increasing index order and compared
-// with strict '<', so the lowest index wins among equal keys.
-template <int TOPO>
-__device__ __forceinline__ int descent_offset(const uint32_t *p, int w) {
-  const uint32_t kc = p[0];
-  uint32_t bk;
-  int boff;
-  bool lower_idx = true;
-  uint32_t k;
-  if (TOPO == 8) {
-    bk = p[-DLW - 1]; boff = -w - 1;
-    k = p[-DLW];     if (k < bk) { bk = k; boff = -w; }
-    k = p[-DLW + 1]; if (k < bk) { bk = k; boff = -w + 1; }
-    k = p[-1];       if (k < bk) { bk = k; boff = -1; }
-    k = p[1];        if (k < bk) { bk = k; boff = 1; lower_idx = false; }
-    k = p[DLW - 1];  if (k < bk) { bk = k; boff = w - 1; lower_idx = false; }
-    k = p[DLW];      if (k < bk) { bk = k; boff = w; lower_idx = false; }
-    k = p[DLW + 1];  if (k < bk) { bk = k; boff = w + 1; lower_idx = false; }
-  } else {
-    bk = p[-DLW]; boff = -w;
-    k = p[-1];  if (k < bk) { bk = k; boff = -1; }
-    k = p[1];   if (k < bk) { bk = k; boff = 1; lower_idx = false; }
-    k = p[DLW]; if (k < bk) { bk = k; boff = w; lower_idx = false; }
-  }
-  return ((bk < kc) || (bk == kc && lower_idx)) ? boff : 0;
-}
-
-// final pointer of the cell at tile-local (lx, ly): OUTP, itself, or its descent target
-template <int TOPO>
-__device__ __forceinline__ uint32_t descent_global(const uint32_t *sk, int lx, int ly, int gx, int gy, int w, int h,
-                                                   int open_top, int open_bottom) {
-  const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-  if (gx == 0 || gx == w - 1 || (gy == 0 && !open_top) || (gy == h - 1 && !open_bottom)) return OUTP;  // true border
-  if (gy == 0 || gy == h - 1) return c;   // cut row of a row-block shard: frozen terminal, its own root
-  return (uint32_t)((int64_t)c + descent_offset<TOPO>(&sk[(ly + 1) * DLW + lx + 1], w));
-}
-
-template <class T, int TOPO>
+template <class T, int TOPO, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ ptr,
                                                   uint32_t *__restrict__ lab, uint32_t *pit_counter,
                                                   int w, int h, uint32_t tilesX, uint32_t ntiles, int open_top,
@@ -107,30 +69,92 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
-  for (int i = threadIdx.x; i < DLH * DLW; i += NTHR) {
-    const int ly = i / DLW, lx = i - ly * DLW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    uint32_t k = 0xFFFFFFFFu;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) k = Key32<T>::to(z[(size_t)gy * w + gx]);
-    sk[i] = k;
+  if (VEC) {
+    // interior columns with 16-byte loads (4-byte cells, w % 4 == 0: every row start is 16-byte aligned)
+    for (int i = threadIdx.x; i < DLH * (DW / 4); i += NTHR) {
+      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+      const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
+      uint32_t kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (gy >= 0 && gy < h && gx < w) {
+        struct alignas(16) Q { T v[4]; };
+        const Q zq = *reinterpret_cast<const Q *>(z + (size_t)gy * w + gx);
+#pragma unroll
+        for (int e = 0; e < 4; e++) kk[e] = Key32<T>::to(zq.v[e]);
+      }
+      const int o = ly * DLW + 1 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; e++) sk[o + e] = kk[e];
+    }
+    for (int i = threadIdx.x; i < 2 * DLH; i += NTHR) {   // halo columns
+      const int ly = i >> 1, lxh = (i & 1) ? DLW - 1 : 0;
+      const int gx = x0 - 1 + lxh, gy = y0 - 1 + ly;
+      uint32_t kk = 0xFFFFFFFFu;
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) kk = Key32<T>::to(z[(size_t)gy * w + gx]);
+      sk[ly * DLW + lxh] = kk;
+    }
+  } else {
+    for (int i = threadIdx.x; i < DLH * DLW; i += NTHR) {
+      const int ly = i / DLW, lx = i - ly * DLW;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      uint32_t kk = 0xFFFFFFFFu;
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) kk = Key32<T>::to(z[(size_t)gy * w + gx]);
+      sk[i] = kk;
+    }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (DW - 1), ly0 = threadIdx.x >> 6;
+  // a wavefront owns a band of DH/4 consecutive rows, one column per lane; the 3x3 window of keys slides
+  // down the column in registers (3 LDS reads per cell instead of 9)
+  const int lx = threadIdx.x & (DW - 1), ly0 = (threadIdx.x >> 6) * (DH / 4);
   const int gx = x0 + lx;
-  // local pointers
+  // local pointers.  A cell whose target stays in the tile stores the target's local index (12 bits); a cell
+  // that is terminal within the tile stores LTERM_BASE | code, code = 0 its own root (pit / cut-row terminal),
+  // 1..8 the descent neighbour (outside the tile) in raster order, 9 = drains off the raster -- so the global
+  // pointer of a terminal never has to be recomputed from the keys.
+  {
+    uint32_t k0[3], k1[3], k2[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) { k0[e] = sk[ly0 * DLW + lx + e]; k1[e] = sk[(ly0 + 1) * DLW + lx + e]; }
 #pragma unroll 4
-  for (int j = 0; j < DH / 4; j++) {
-    const int ly = ly0 + 4 * j, gy = y0 + ly;
-    uint16_t l = LTERM;
-    if (gx < w && gy < h) {
-      const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-      const uint32_t g = descent_global<TOPO>(sk, lx, ly, gx, gy, w, h, open_top, open_bottom);
-      if (g != OUTP && g != c) {
-        const int tx = (int)(g % (uint32_t)w) - x0, ty = (int)(g / (uint32_t)w) - y0;
-        if (tx >= 0 && tx < DW && ty >= 0 && ty < DH) l = (uint16_t)(ty * DW + tx);
+    for (int j = 0; j < DH / 4; j++) {
+      const int ly = ly0 + j, gy = y0 + ly;
+#pragma unroll
+      for (int e = 0; e < 3; e++) k2[e] = sk[(ly + 2) * DLW + lx + e];
+      uint16_t l = LTERM_BASE;
+      if (gx < w && gy < h) {
+        if (gx == 0 || gx == w - 1 || (gy == 0 && !open_top) || (gy == h - 1 && !open_bottom)) l = LTERM_BASE | 9;  // true border
+        else if (gy == 0 || gy == h - 1) l = LTERM_BASE;   // cut row of a row-block shard: frozen terminal
+        else {
+          // lowest (key, index) neighbour: visited in increasing index order and compared with strict '<',
+          // so the lowest index wins among equal keys; a neighbour of EQUAL key is taken only if its index is lower
+          const uint32_t kc = k1[1];
+          uint32_t bk;
+          int n = 0;   // 3x3 raster position of the best neighbour
+          if (TOPO == 8) {
+            bk = k0[0];
+            if (k0[1] < bk) { bk = k0[1]; n = 1; }
+            if (k0[2] < bk) { bk = k0[2]; n = 2; }
+            if (k1[0] < bk) { bk = k1[0]; n = 3; }
+            if (k1[2] < bk) { bk = k1[2]; n = 5; }
+            if (k2[0] < bk) { bk = k2[0]; n = 6; }
+            if (k2[1] < bk) { bk = k2[1]; n = 7; }
+            if (k2[2] < bk) { bk = k2[2]; n = 8; }
+          } else {
+            bk = k0[1]; n = 1;
+            if (k1[0] < bk) { bk = k1[0]; n = 3; }
+            if (k1[2] < bk) { bk = k1[2]; n = 5; }
+            if (k2[1] < bk) { bk = k2[1]; n = 7; }
+          }
+          if ((bk < kc) || (bk == kc && n < 4)) {
+            const int tx = lx + n % 3 - 1, ty = ly + n / 3 - 1;
+            if (tx >= 0 && tx < DW && ty >= 0 && ty < DH) l = (uint16_t)(ty * DW + tx);
+            else l = LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n);
+          }
+        }
       }
+      lp[ly * DW + lx] = l;
+#pragma unroll
+      for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
     }
-    lp[ly * DW + lx] = l;
   }
   __syncthreads();
   // pointer jumping inside the tile; any value ever stored is an ancestor, so races are harmless.
@@ -139,15 +163,15 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   uint32_t active = 0;
 #pragma unroll 4
   for (int j = 0; j < DH / 4; j++)
-    if (lp[(ly0 + 4 * j) * DW + lx] != LTERM) active |= 1u << j;
+    if (lp[(ly0 + j) * DW + lx] < LTERM_BASE) active |= 1u << j;
   for (int it = 0; it < 16; it++) {
     uint32_t still = 0;
     for (uint32_t m = active; m; m &= m - 1) {
       const int j = __ffs((int)m) - 1;
-      const int li = (ly0 + 4 * j) * DW + lx;
+      const int li = (ly0 + j) * DW + lx;
       const uint16_t p = lp[li];
       const uint16_t q = lp[p];
-      if (q != LTERM) { lp[li] = q; still |= 1u << j; }
+      if (q < LTERM_BASE) { lp[li] = q; still |= 1u << j; }
     }
     active = still;
     if (!__syncthreads_or(active != 0)) break;
@@ -158,13 +182,19 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   uint32_t pitmask = 0;
 #pragma unroll 4
   for (int j = 0; j < DH / 4; j++) {
-    const int ly = ly0 + 4 * j, gy = y0 + ly;
+    const int ly = ly0 + j, gy = y0 + ly;
     if (gx >= w || gy >= h) continue;
-    const uint16_t p = lp[ly * DW + lx];
+    uint16_t p = lp[ly * DW + lx];
     int rx = lx, ry = ly;
-    if (p != LTERM) { rx = p & (DW - 1); ry = p >> 6; }
+    if (p < LTERM_BASE) { rx = p & (DW - 1); ry = p >> 6; p = lp[p]; }
     const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-    const uint32_t g = descent_global<TOPO>(sk, rx, ry, x0 + rx, y0 + ry, w, h, open_top, open_bottom);
+    const int code = p & 15;
+    uint32_t g;
+    if (code == 9) g = OUTP;
+    else {
+      const int n = code == 0 ? 4 : (code <= 4 ? code - 1 : code);   // 3x3 position, 4 = centre
+      g = (uint32_t)(y0 + ry + n / 3 - 1) * (uint32_t)w + (uint32_t)(x0 + rx + n % 3 - 1);
+    }
     ptr[c] = g;
     if (g == c) pitmask |= 1u << j;
   }
@@ -186,7 +216,7 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   for (int k = 0; k < (int)(threadIdx.x >> 6); k++) id += wtot[k];
   for (uint32_t m = pitmask; m; m &= m - 1) {
     const int j = __ffs((int)m) - 1;
-    lab[(size_t)(y0 + ly0 + 4 * j) * w + gx] = id++;
+    lab[(size_t)(y0 + ly0 + j) * w + gx] = id++;
   }
 }
 
@@ -807,8 +837,13 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
   const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
   RD_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(uint32_t), s));
-  RD_LAUNCH("fill.descent", (k_descent<T, TOPO>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w, h,
-            dtx, dnt, open_top, open_bottom);
+  const bool vec = sizeof(T) == 4 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % 16) == 0;
+  if (vec)
+    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
+              h, dtx, dnt, open_top, open_bottom);
+  else
+    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
+              h, dtx, dnt, open_top, open_bottom);
   RD_HIP(hipMemcpyAsync(hw, dflags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   const uint32_t B = hw[0];
@@ -865,7 +900,6 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
     RD_HIP(hipMemsetAsync(dflags + 3, 0, sizeof(uint32_t), s));
     if (nlive > 0) {
-      const bool vec = sizeof(T) == 4 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % 16) == 0;
 #define RD_SCAN(FIRST_, VEC_, AIN)                                                                              \
   RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(tgrid), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, B, \
             tilesX, ntiles, (const uint8_t *)(AIN), aliveB)
