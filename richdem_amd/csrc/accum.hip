@@ -26,8 +26,14 @@ constexpr int NTHR = 256;
 constexpr unsigned long long CNT1 = 1ull << 56;
 constexpr unsigned long long LOWMASK = CNT1 - 1ull;
 constexpr unsigned long long SRC = 0xFFull;        // count-field marker of a source cell (unit path)
-constexpr uint32_t SRC32 = 0xFFFFFFFEu;            // pending marker of a source cell (f64 path)
-constexpr uint32_t NODATA32 = 0xFFFFFFFFu;
+// single-block unit path: the cell's own direction rides in bits 52-55 of its word, so the returning add of a
+// step also delivers the direction of the cell just completed -- ONE dependent memory operation per step
+constexpr int DIRSHIFT = 52;
+constexpr unsigned long long AREAMASK = (1ull << DIRSHIFT) - 1ull;
+// f64 path: pending word = (inflows in total << 12) | (own direction << 8) | count of inflows still to arrive; count byte 0xFE marks a
+// source, 0xF0 a NoData cell (at most 8 arrivals ever decrement it: it never reads as 1 or as a source)
+constexpr uint32_t SRC32 = 0xFEu;
+constexpr uint32_t NODATA32 = 0xF0u;
 
 // D8 neighbour offsets, numbering 234/105/876 (reference common/constants.hpp:44-45)
 __device__ __forceinline__ int d8dx(int n) { return (n == 1 || n == 2 || n == 8) ? -1 : (n >= 4 && n <= 6) ? 1 : 0; }
@@ -39,23 +45,6 @@ __device__ __forceinline__ int64_t flow_target(uint32_t c, int n, int w, int h) 
   const int x = (int)(c % (uint32_t)w) + d8dx(n), y = (int)(c / (uint32_t)w) + d8dy(n);
   if (x < 0 || y < 0 || x >= w || y >= h) return -1;
   return (int64_t)y * w + x;
-}
-
-// number of in-grid neighbours whose direction points at (x, y); NoData-direction cells never flow
-__device__ __forceinline__ int inflow_count(const uint8_t *__restrict__ dirs, uint8_t nodata, int x, int y, int w,
-                                            int h) {
-  int cnt = 0;
-#pragma unroll
-  for (int n = 1; n <= 8; n++) {
-    const int nx = x + d8dx(n), ny = y + d8dy(n);
-    if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
-    const uint8_t d = dirs[(size_t)ny * w + nx];
-    if (d == nodata) continue;
-    // neighbour n flows into us iff its direction is the inverse of n (constants.hpp:65 d8_inverse)
-    const int inv = n <= 4 ? n + 4 : n - 4;
-    if (d == inv) cnt++;
-  }
-  return cnt;
 }
 
 // ---- unit weights ---------------------------------------------------------------------------
@@ -85,7 +74,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_walk_unit(const uint8_t *__restric
         const uint8_t dd = dirs[my];
         if (dd != nodata) {
           const unsigned long long wd = word[my];   // a source's word is never modified: plain read
-          if ((wd >> 56) == SRC) { active = true; c = (uint32_t)my; v = wd & LOWMASK; d = dd; }
+          if ((wd >> 56) == SRC) { active = true; c = (uint32_t)my; v = wd & AREAMASK; d = dd; }
         }
       }
       next += (uint64_t)__popcll(idle);
@@ -96,13 +85,11 @@ __global__ __launch_bounds__(NTHR) void k_acc_walk_unit(const uint8_t *__restric
       const int64_t t = flow_target(c, d, w, h);                 // d8_methods.hpp:113-122
       if (t < 0) active = false;
       else {
-        const uint8_t dt = dirs[t];
-        if (dt == nodata) active = false;                        // :124-125 flow into NoData is dropped
-        else {
-          const unsigned long long old = atomicAdd(&word[t], v - CNT1);
-          if ((old >> 56) != 1) active = false;                  // not the last inflow of t
-          else { v = (old & LOWMASK) + v; c = (uint32_t)t; d = dt; }   // t's final area: keep walking
-        }
+        // A NoData target holds word 0 (count field 0, then 0xFF, 0xFE ... after arrivals): never "1", so the
+        // flow into it is dropped (:124-125) without looking its direction up first; k_acc_out ignores its word.
+        const unsigned long long old = atomicAdd(&word[t], v - CNT1);
+        if ((old >> 56) != 1) active = false;                    // not the last inflow of t
+        else { v = (old & AREAMASK) + v; c = (uint32_t)t; d = (uint8_t)((old >> DIRSHIFT) & 15u); }   // t's final area: keep walking
       }
     }
   }
@@ -189,7 +176,9 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk(const uint8_t *__rest
       uint32_t cnt = v >> 24;
       // a true source that passed its total on inside the tile is simply complete (count 0); a true source
       // that could not (first target outside) keeps the SRC marker it would have got from k_acc_init_unit
-      g = ((unsigned long long)(cnt == LSRC ? SRC : cnt) << 56) | (unsigned long long)(v & LMASK);
+      const uint8_t dd = sd[(ly + 1) * ALW + lx + 1];
+      g = ((unsigned long long)(cnt == LSRC ? SRC : cnt) << 56) | ((unsigned long long)(dd <= 8 ? dd : 0) << DIRSHIFT) |
+          (unsigned long long)(v & LMASK);
     }
     word[(size_t)gy * w + gx] = g;
   }
@@ -206,28 +195,47 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
     // cells downstream of a direction loop are never completed by the reference either: they keep the
     // sum of the inflows that did arrive, without their own +1 (d8_methods.hpp:104-131)
     const unsigned long long cnt = v >> 56;
-    const unsigned long long a = (cnt != 0 && cnt != SRC) ? (v & LOWMASK) - 1 : (v & LOWMASK);
+    const unsigned long long a = (cnt != 0 && cnt != SRC) ? (v & AREAMASK) - 1 : (v & AREAMASK);
     area[c] = (A)a;
   }
 }
 
 // ---- f64 weights ----------------------------------------------------------------------------
+constexpr int IW = 64, IH = 16, ILW = IW + 2, ILH = IH + 2;
 __global__ __launch_bounds__(NTHR) void k_acc_init_f64(const uint8_t *__restrict__ dirs, uint32_t *pending, int w,
-                                                       int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+                                                       int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint8_t sd[ILH * ILW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * IW, y0 = (int)(t / tilesX) * IH;
+  for (int i = threadIdx.x; i < ILH * ILW; i += NTHR) {
+    const int ly = i / ILW, lx = i - ly * ILW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : 255;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (IW - 1), ly0 = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < IH / 4; j++) {
+    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const int o = (ly + 1) * ILW + lx + 1;
+    const uint8_t d = sd[o];
     uint32_t p = NODATA32;
-    if (dirs[c] != 255) {
-      const int k = inflow_count(dirs, 255, x, y, w, h);
-      p = k == 0 ? SRC32 : (uint32_t)k;
+    if (d != 255) {
+      int k = 0;
+#pragma unroll
+      for (int m = 1; m <= 8; m++) {
+        const uint8_t dn = sd[o + d8dy(m) * ILW + d8dx(m)];
+        if (dn != 255 && dn == (m <= 4 ? m + 4 : m - 4)) k++;   // neighbour m flows into us (constants.hpp:65)
+      }
+      p = ((uint32_t)k << 12) | ((uint32_t)(d <= 8 ? d : 0) << 8) | (k == 0 ? SRC32 : (uint32_t)k);   // bits 12-15: inflows in total
     }
-    pending[c] = p;
+    pending[(size_t)gy * w + gx] = p;
   }
 }
 
-__global__ __launch_bounds__(NTHR) void k_acc_walk_f64(const uint8_t *__restrict__ dirs, uint32_t *pending,
-                                                       double *acc, int w, int h) {
+__global__ __launch_bounds__(NTHR) void k_acc_walk_f64(uint32_t *pending, double *acc, int w, int h) {
   // lane-refill walk (see k_acc_walk_unit)
   const uint64_t n = (uint64_t)w * h;
   const uint64_t wave = ((uint64_t)blockIdx.x * NTHR + threadIdx.x) >> 6;
@@ -244,9 +252,9 @@ __global__ __launch_bounds__(NTHR) void k_acc_walk_f64(const uint8_t *__restrict
     if (next < end && idle) {
       const uint64_t my = next + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
       if (!active && my < end) {
-        const uint8_t dd = dirs[my];
         // sources only; a source's counter and total are never written by anyone else
-        if (dd != 255 && pending[my] == SRC32) { active = true; c = (uint32_t)my; v = acc[my]; d = dd; }
+        const uint32_t p = pending[my];
+        if ((p & 0xFFu) == SRC32) { active = true; c = (uint32_t)my; v = acc[my]; d = (uint8_t)((p >> 8) & 15u); }
       }
       next += (uint64_t)__popcll(idle);
     } else if (idle == ~0ull) {
@@ -256,18 +264,22 @@ __global__ __launch_bounds__(NTHR) void k_acc_walk_f64(const uint8_t *__restrict
       const int64_t t = flow_target(c, d, w, h);
       if (t < 0) active = false;
       else {
-        const uint8_t dt = dirs[t];
-        if (dt == 255) active = false;                               // flow_accumulation_generic.hpp:85-86
+        // flow_accumulation_generic.hpp:85-87 (proportion is exactly 1 for D8).  A NoData target is not looked
+        // up first: its count byte never reads 1, and its total is overwritten with -1 at the end.
+        // All three steps are device-scope atomic RMWs executed at the memory side: a RETURNING add has
+        // completed there before the decrement is issued, and the last arriver's decrement is ordered after
+        // every other arriver's decrement, hence after their adds -- no cache write-back / invalidate
+        // (release/acquire fences cost ~10x here).
+        const double prev = atomicAdd(&acc[t], v);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");   // the add has returned
+        const uint32_t old = __hip_atomic_fetch_sub(&pending[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & 0xFFu) != 1) active = false;
         else {
-          // :87 (proportion is exactly 1 for D8).  All three steps are device-scope atomic RMWs executed
-          // at the memory side: a RETURNING add has completed there before the decrement is issued, and
-          // the last arriver's decrement is ordered after every other arriver's decrement, hence after
-          // their adds -- no cache write-back / invalidate (release/acquire fences cost ~10x here).
-          const double prev = atomicAdd(&acc[t], v);
-          asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");   // the add has returned
-          const uint32_t old = __hip_atomic_fetch_sub(&pending[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (old != 1) active = false;
-          else { v = atomicAdd(&acc[t], 0.0); c = (uint32_t)t; d = dt; }   // final total, read at the memory side
+          // the only inflow of t (the common case): what the add returned was t's own weight, so the total is known
+          // without a third round trip; at a confluence the final total is read back at the memory side
+          v = ((old >> 12) & 15u) == 1 ? prev + v : atomicAdd(&acc[t], 0.0);
+          c = (uint32_t)t;
+          d = (uint8_t)((old >> 8) & 15u);
         }
       }
     }
@@ -308,9 +320,12 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
 void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, hipStream_t s) {
   const uint64_t n = (uint64_t)w * h;
   uint32_t *pending = Workspace::get().buf<uint32_t>("accum.pending", n);
-  RD_LAUNCH("accum.init_f64", k_acc_init_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, pending, w, h);
+  {
+    const uint32_t tilesX = (w + IW - 1) / IW, ntiles = tilesX * ((h + IH - 1) / IH);
+    RD_LAUNCH("accum.init_f64", k_acc_init_f64, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, pending, w, h, tilesX, ntiles);
+  }
   RD_LAUNCH("accum.walk_f64", k_acc_walk_f64, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR), 0, s,
-            d_dirs, pending, d_acc, w, h);
+            pending, d_acc, w, h);
   RD_LAUNCH("accum.nodata_f64", k_acc_nodata_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, d_acc, n);
 }
 
