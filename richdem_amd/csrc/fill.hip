@@ -454,38 +454,61 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
   if (VEC) {
-    // interior columns: 16-byte loads (w % 4 == 0 and 4-byte cells: every row start is 16-byte aligned)
-    for (int i = threadIdx.x; i < LH * (TW / 4); i += NTHR) {
+    // Interior columns with 16-byte loads (w % 4 == 0 and 4-byte cells: every row start is 16-byte aligned),
+    // the two halo columns with scalar loads.  The kernel is latency bound (SQ counters: waves parked ~75 % of
+    // their cycles), so the loads are issued in two batches -- every z / label quad of this thread, then every
+    // component gather -- instead of item by item: two dependent memory round trips per tile instead of six.
+    constexpr int NQ = LH * (TW / 4);                 // 16-byte items of the tile incl. halo rows
+    constexpr int QPT = (NQ + NTHR - 1) / NTHR;       // per thread
+    struct alignas(16) Q { T v[4]; };
+    Q zq[QPT];
+    uint4 lq[QPT];
+    bool ok[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
       const int ly = i / (TW / 4), q = i - ly * (TW / 4);
       const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
-      uint32_t k[4] = {0, 0, 0, 0}, c[4] = {B | CLOSED, B | CLOSED, B | CLOSED, B | CLOSED};
-      if (gy >= 0 && gy < h && gx < w) {
+      ok[r] = i < NQ && gy >= 0 && gy < h && gx < w;
+      if (ok[r]) {
         const size_t g = (size_t)gy * w + gx;
-        struct alignas(16) Q { T v[4]; };
-        const Q zq = *reinterpret_cast<const Q *>(z + g);
-        const uint4 lq = *reinterpret_cast<const uint4 *>(lab + g);
-        const uint32_t l[4] = {lq.x, lq.y, lq.z, lq.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) { k[e] = Key32<T>::to(zq.v[e]); c[e] = RD_COMP(l[e]); }
+        zq[r] = *reinterpret_cast<const Q *>(z + g);
+        lq[r] = *reinterpret_cast<const uint4 *>(lab + g);
       }
-      const int o = ly * LW + 1 + 4 * q;
+    }
+    // halo columns: one cell per thread for the first 2 * LH threads
+    const bool hcell = threadIdx.x < 2 * LH;
+    const int hly = threadIdx.x >> 1, hlx = (threadIdx.x & 1) ? LW - 1 : 0;
+    bool hok = false;
+    T hz = T();
+    uint32_t hl = 0;
+    if (hcell) {
+      const int gx = x0 - 1 + hlx, gy = y0 - 1 + hly;
+      hok = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      if (hok) { hz = z[(size_t)gy * w + gx]; hl = lab[(size_t)gy * w + gx]; }
+    }
+    uint32_t cq[QPT][4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { sk[o + e] = k[e]; sc[o + e] = c[e]; }
+    for (int r = 0; r < QPT; r++) {
+      // branch-free: an absent quad reads the outside's entry (label B: cur[B] == B | CLOSED), so all gathers of
+      // the thread are in flight together
+      const uint32_t l[4] = {ok[r] ? lq[r].x : B, ok[r] ? lq[r].y : B, ok[r] ? lq[r].z : B, ok[r] ? lq[r].w : B};
+#pragma unroll
+      for (int e = 0; e < 4; e++) cq[r][e] = RD_COMP(l[e]);
     }
-    // halo columns
-    for (int i = threadIdx.x; i < 2 * LH; i += NTHR) {
-      const int ly = i >> 1, lx = (i & 1) ? LW - 1 : 0;
-      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-      uint32_t k = 0, comp = B | CLOSED;
-      if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-        const size_t g = (size_t)gy * w + gx;
-        k = Key32<T>::to(z[g]);
-        const uint32_t l = lab[g];
-        comp = RD_COMP(l);
+    const uint32_t hlsafe = hok ? hl : B;
+    const uint32_t hc = RD_COMP(hlsafe);
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
+      if (i < NQ) {
+        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+        const int o = ly * LW + 1 + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sk[o + e] = ok[r] ? Key32<T>::to(zq[r].v[e]) : 0u; sc[o + e] = cq[r][e]; }
       }
-      sk[ly * LW + lx] = k;
-      sc[ly * LW + lx] = comp;
     }
+    if (hcell) { sk[hly * LW + hlx] = hok ? Key32<T>::to(hz) : 0u; sc[hly * LW + hlx] = hc; }
   } else {
     for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
       const int ly = i / LW, lx = i - ly * LW;
