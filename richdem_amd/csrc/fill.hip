@@ -282,14 +282,17 @@ __global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict_
   uint32_t pv[CELLS];
   int16_t sl[CELLS];   // table slot, -1: pit / outside the raster, -2: drains off the raster, -3: table full
 #pragma unroll
+  for (int j = 0; j < CELLS; j++) {   // all pointer loads of the thread in flight together
+    const int gy = y0 + ly0 + 4 * j;
+    pv[j] = (gx < w && gy < h) ? ptr[(size_t)gy * w + gx] : 0u;
+  }
+#pragma unroll
   for (int j = 0; j < CELLS; j++) {
     const int gy = y0 + ly0 + 4 * j;
     sl[j] = -1;
-    pv[j] = 0;
     if (gx >= w || gy >= h) continue;
     const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-    const uint32_t p = ptr[c];
-    pv[j] = p;
+    const uint32_t p = pv[j];
     if (p == c) continue;
     if (p == OUTP) { sl[j] = -2; continue; }
     if (j > 0 && sl[j - 1] >= 0 && pv[j - 1] == p) { sl[j] = sl[j - 1]; continue; }
@@ -305,9 +308,32 @@ __global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict_
     sl[j] = (int16_t)found;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LT_SLOTS; i += NTHR) {
-    const uint32_t k = tkey[i];
-    if (k != LT_EMPTY) tval[i] = chase_to_label(ptr, lab, k, B, maxhops, flag);
+  {
+    // the thread's table slots are chased together: one gather per live chain and trip, all in flight at once
+    constexpr int SPT = LT_SLOTS / NTHR;
+    uint32_t p[SPT], res[SPT];
+    uint32_t live = 0;
+#pragma unroll
+    for (int r = 0; r < SPT; r++) {
+      p[r] = tkey[threadIdx.x + r * NTHR];
+      res[r] = B;
+      if (p[r] != LT_EMPTY) live |= 1u << r;
+    }
+    for (int hops = 0; live; hops++) {
+      if (hops > maxhops) { *flag = 1; break; }
+      uint32_t q[SPT];
+#pragma unroll
+      for (int r = 0; r < SPT; r++) q[r] = (live >> r & 1u) ? ptr[p[r]] : 0u;
+#pragma unroll
+      for (int r = 0; r < SPT; r++) {
+        if (!(live >> r & 1u)) continue;
+        if (q[r] == OUTP) { res[r] = B; live &= ~(1u << r); }
+        else if (q[r] == p[r]) { res[r] = lab[p[r]]; live &= ~(1u << r); }
+        else p[r] = q[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < SPT; r++) tval[threadIdx.x + r * NTHR] = res[r];
   }
   __syncthreads();
 #pragma unroll
