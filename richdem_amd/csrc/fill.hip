@@ -460,7 +460,8 @@ template <class T, int TOPO, bool FIRST, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
                                                int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
-                                               const uint8_t *__restrict__ alive_in, uint8_t *alive_out) {
+                                               const uint32_t *__restrict__ tiles_in, uint32_t nwork,
+                                               uint8_t *alive_out) {
   __shared__ uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   __shared__ uint32_t tab_id[SC_SLOTS];
@@ -468,12 +469,11 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   __shared__ uint8_t tab_cross[SC_SLOTS];
   __shared__ uint16_t list[TW * TH];   // LDS offsets of the cells that touch another component
   __shared__ uint32_t nlist;
-  const uint32_t t = xcd_tile(blockIdx.x, ntiles);   // XCD-banded order in every round
-  if (t >= ntiles) return;
-  if (alive_in && !alive_in[t]) {   // no component boundary left in this tile: dead for good
-    if (threadIdx.x == 0) alive_out[t] = 0;
-    return;
-  }
+  // XCD-banded order in every round; from round 2 on only the tiles that still held a component boundary last
+  // round are launched (compacted list: a dead tile costs neither a block nor a flag load)
+  const uint32_t wi = xcd_tile(blockIdx.x, nwork);
+  if (wi >= nwork) return;
+  const uint32_t t = tiles_in ? tiles_in[wi] : wi;
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
   for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
   if (threadIdx.x == 0) nlist = 0;
@@ -645,15 +645,13 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
 }
 
-__global__ __launch_bounds__(NTHR) void k_count_alive(const uint8_t *__restrict__ alive, uint32_t ntiles,
-                                                      uint32_t *count) {
-  __shared__ uint32_t ws[NTHR / 64];
-  uint32_t c = 0;
-  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < ntiles; i += gridDim.x * NTHR) c += alive[i];
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(count, ws[0] + ws[1] + ws[2] + ws[3]);
+// alive flags -> list of tiles for the next round (roughly ascending: blocks append in launch order) + count
+__global__ __launch_bounds__(NTHR) void k_compact_alive(const uint8_t *__restrict__ alive, uint32_t ntiles,
+                                                        uint32_t *list, uint32_t *count) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  const bool hit = i < ntiles && alive[i] != 0;
+  const uint32_t slot = block_append(hit, count);
+  if (hit) list[slot] = i;
 }
 
 __global__ __launch_bounds__(NTHR) void k_hook(const uint32_t *__restrict__ roots, uint32_t nroots,
@@ -880,7 +878,6 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   uint32_t *hw = ws.host_words();
 
   const uint32_t tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), ntiles = tilesX * tilesY;
-  const uint32_t tgrid = xcd_grid(ntiles);
   const uint32_t sgrid = std::min(cdiv(n, NTHR), 256u * 32u);  // grid-stride 1-D kernels
 
   // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
@@ -941,7 +938,8 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
 
   uint32_t nroots = hw[0];
   // per-tile flag "still holds a component boundary" (ping-pong); round 1 visits every tile
-  uint8_t *aliveA = ws.buf<uint8_t>("fill.aliveA", ntiles), *aliveB = ws.buf<uint8_t>("fill.aliveB", ntiles);
+  uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
+  uint32_t *tlist = ws.buf<uint32_t>("fill.tlist", ntiles);
   uint32_t nlive = ntiles;
   bool first = true;
   while (nroots > 0) {
@@ -949,15 +947,15 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
     RD_HIP(hipMemsetAsync(dflags + 3, 0, sizeof(uint32_t), s));
     if (nlive > 0) {
-#define RD_SCAN(FIRST_, VEC_, AIN)                                                                              \
-  RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(tgrid), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, B, \
-            tilesX, ntiles, (const uint8_t *)(AIN), aliveB)
-      if (first && !sharded) { if (vec) RD_SCAN(true, true, nullptr); else RD_SCAN(true, false, nullptr); }
-      else if (first) { if (vec) RD_SCAN(false, true, nullptr); else RD_SCAN(false, false, nullptr); }
-      else { if (vec) RD_SCAN(false, true, aliveA); else RD_SCAN(false, false, aliveA); }
+#define RD_SCAN(FIRST_, VEC_, LIST, NWORK)                                                                       \
+  RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(xcd_grid(NWORK)), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, \
+            B, tilesX, ntiles, (const uint32_t *)(LIST), (uint32_t)(NWORK), alive)
+      if (first && !sharded) { if (vec) RD_SCAN(true, true, nullptr, ntiles); else RD_SCAN(true, false, nullptr, ntiles); }
+      else if (first) { if (vec) RD_SCAN(false, true, nullptr, ntiles); else RD_SCAN(false, false, nullptr, ntiles); }
+      else { if (vec) RD_SCAN(false, true, tlist, nlive); else RD_SCAN(false, false, tlist, nlive); }
 #undef RD_SCAN
-      RD_LAUNCH("fill.count_alive", k_count_alive, dim3(std::min(cdiv(ntiles, NTHR * 16), 64u)), dim3(NTHR), 0, s,
-                (const uint8_t *)aliveB, ntiles, dflags + 3);
+      RD_LAUNCH("fill.compact_alive", k_compact_alive, dim3(cdiv(ntiles, NTHR)), dim3(NTHR), 0, s, (const uint8_t *)alive, ntiles,
+                tlist, dflags + 3);
       g_stats.scan_tiles += first ? ntiles : nlive;
     }
     RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
@@ -980,7 +978,6 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     nlive = hw[1];
     first = false;
     std::swap(rootsA, rootsB);
-    std::swap(aliveA, aliveB);
     g_stats.rounds++;
   }
 }
