@@ -552,20 +552,6 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   }
 #undef RD_COMP
   __syncthreads();
-  // components that also live outside this tile (seen on the halo ring) need the global atomic;
-  // a component entirely inside the tile is reduced here completely and can use a plain store
-  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2); i += NTHR) {
-    int o;
-    if (i < LW) o = i;
-    else if (i < 2 * LW) o = (LH - 1) * LW + (i - LW);
-    else { const int r = (i - 2 * LW) >> 1; o = (r + 1) * LW + (((i - 2 * LW) & 1) ? LW - 1 : 0); }
-    const uint32_t C = sc[o];
-    if (!(C & CLOSED)) {
-      const int slot = tab_slot(tab_id, C);
-      if (slot >= 0) tab_cross[slot] = 1;
-    }
-  }
-  __syncthreads();
   // Phase 1 -- detect: each wavefront walks a band of TH/4 consecutive rows, one column per lane, with
   // the 3x3 window of component ids carried in registers, and appends the cells that touch another
   // component to an LDS list.  Integer VALU is the bottleneck of this kernel (not HBM), and only
@@ -604,6 +590,20 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       }
 #pragma unroll
       for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
+    }
+  }
+  // (no barrier needed between the detect phase and this: both only read sc)
+  // components that also live outside this tile (seen on the halo ring) need the global atomic;
+  // a component entirely inside the tile is reduced here completely and can use a plain store
+  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2); i += NTHR) {
+    int o;
+    if (i < LW) o = i;
+    else if (i < 2 * LW) o = (LH - 1) * LW + (i - LW);
+    else { const int r = (i - 2 * LW) >> 1; o = (r + 1) * LW + (((i - 2 * LW) & 1) ? LW - 1 : 0); }
+    const uint32_t C = sc[o];
+    if (!(C & CLOSED)) {
+      const int slot = tab_slot(tab_id, C);
+      if (slot >= 0) tab_cross[slot] = 1;
     }
   }
   __syncthreads();
