@@ -404,21 +404,35 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
   __shared__ int32_t xrow[2][RBANDS][2][CW];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int x0 = tx * CW, y0 = ty * RCH;
-  for (int i = threadIdx.x; i < RH * RW; i += RNT) {
-    const int ly = i / RW, lx = i - ly * RW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    T v = T();
-    int32_t d = DINF;
-    uint8_t e = 0;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+  {
+    // All loads of the thread are issued before the first one is consumed (clamped addresses, branch-free):
+    // item by item the tile paid one memory round trip per loop trip -- nine in a row -- and this kernel is
+    // launched for ~10^6 tiles per gradient.
+    constexpr int IPT = (RH * RW + RNT - 1) / RNT;
+    T zv[IPT];
+    int32_t dv[IPT];
+    uint8_t ev[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = min((int)threadIdx.x + r * RNT, RH * RW - 1);
+      const int ly = i / RW, lxx = i - ly * RW;
+      const int gx = min(max(x0 - 1 + lxx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
       const size_t g = (size_t)gy * w + gx;
-      v = z[g];
-      d = __hip_atomic_load(&D[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // neighbours' tiles write it
-      e = dirs[g] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold a distance
+      zv[r] = z[g];
+      dv[r] = __hip_atomic_load(&D[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // neighbours' tiles write it
+      ev[r] = dirs[g];
     }
-    sz[i] = v;
-    sd[i] = d;
-    se[i] = e;
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = (int)threadIdx.x + r * RNT;
+      if (i >= RH * RW) continue;
+      const int ly = i / RW, lxx = i - ly * RW;
+      const int gx = x0 - 1 + lxx, gy = y0 - 1 + ly;
+      const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      sz[i] = in ? zv[r] : T();
+      sd[i] = in ? dv[r] : DINF;
+      se[i] = in && ev[r] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold a distance
+    }
   }
   __syncthreads();
   const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
