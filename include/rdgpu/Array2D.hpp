@@ -11,12 +11,15 @@
 //   * a raster can WRAP caller memory without owning it (Array2D.hpp:344-352); resizing a wrapping
 //     raster throws (ManagedVector.hpp:158-172);
 //   * NoData value defaults to -1 (Array2D.hpp:114); geotransform / projection / metadata travel
-//     with resize(other) and templateCopy (Array2D.hpp:873-878, 1102-1108).
+//     with resize(other) and templateCopy (Array2D.hpp:873-878, 1102-1108);
+//   * the reference's NATIVE on-disk format (saveToCache / loadNative, Array2D.hpp:209-281, uncompressed
+//     build): files written here load in the reference with Array2D<T>(filename, true) and vice versa.
 #pragma once
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <fstream>
 #include <limits>
 #include <map>
 #include <memory>
@@ -55,6 +58,13 @@ public:
     resize(other, val);
     metadata = other.metadata;
     basename = other.basename;
+  }
+
+  // Load a raster from the reference's native format (reference Array2D(filename, native=true, ...),
+  // Array2D.hpp:421-431).  native == false would mean GDAL, which this container does not link.
+  explicit Array2D(const std::string &filename, bool native = true, bool load_data = true) {
+    if (!native) throw std::runtime_error("RichDEM was not compiled with GDAL!");
+    loadNative(filename, load_data);
   }
 
   Array2D(const Array2D &o) { *this = o; }
@@ -152,6 +162,58 @@ public:
     const size_t n = (size_t)w_ * (size_t)h_;
     for (size_t i = 0; i < n; i++)
       if (ptr_[i] != no_data_) ptr_[i] = (T)(ptr_[i] * x);
+  }
+
+  // Native format (reference saveToCache, Array2D.hpp:209-246): int32 height, width, x offset, y offset; uint32
+  // number of data cells (0xFFFFFFFF = not counted); T NoData; 6 doubles geotransform; size_t projection length +
+  // bytes; width*height cells row-major.  A missing geotransform is written as the reference's fallback
+  // {1000, 1, 0, 1000, 0, -1} (Array2D.hpp:149).
+  void saveToCache(const std::string &filename) const {
+    std::ofstream out(filename, std::ios::binary | std::ios::trunc);
+    if (!out.good()) throw std::logic_error("Failed to open cache file '" + filename + "'.");
+    const xy_t zero = 0;
+    const i_t ndc = NO_I;
+    double gt[6] = {1000., 1., 0., 1000., 0., -1.};
+    if (geotransform.size() >= 6) std::copy(geotransform.begin(), geotransform.begin() + 6, gt);
+    const std::string::size_type plen = projection.size();
+    out.write(reinterpret_cast<const char *>(&h_), sizeof(xy_t));
+    out.write(reinterpret_cast<const char *>(&w_), sizeof(xy_t));
+    out.write(reinterpret_cast<const char *>(&zero), sizeof(xy_t));
+    out.write(reinterpret_cast<const char *>(&zero), sizeof(xy_t));
+    out.write(reinterpret_cast<const char *>(&ndc), sizeof(i_t));
+    out.write(reinterpret_cast<const char *>(&no_data_), sizeof(T));
+    out.write(reinterpret_cast<const char *>(gt), sizeof(gt));
+    out.write(reinterpret_cast<const char *>(&plen), sizeof(plen));
+    out.write(projection.data(), (std::streamsize)plen);
+    out.write(reinterpret_cast<const char *>(ptr_), (std::streamsize)((size_t)w_ * (size_t)h_ * sizeof(T)));
+    if (!out.good()) throw std::runtime_error("Failed to write native file '" + filename + "'!");
+  }
+  void saveNative(const std::string &filename) const { saveToCache(filename); }
+
+  // reference loadNative, Array2D.hpp:251-281
+  void loadNative(const std::string &filename, bool load_data = true) {
+    std::ifstream in(filename, std::ios::in | std::ios::binary);
+    if (!in.good()) throw std::runtime_error("Failed to load native file '" + filename + "!");
+    xy_t hh = 0, ww = 0, xoff = 0, yoff = 0;
+    i_t ndc = 0;
+    std::string::size_type plen = 0;
+    in.read(reinterpret_cast<char *>(&hh), sizeof(xy_t));
+    in.read(reinterpret_cast<char *>(&ww), sizeof(xy_t));
+    in.read(reinterpret_cast<char *>(&xoff), sizeof(xy_t));
+    in.read(reinterpret_cast<char *>(&yoff), sizeof(xy_t));
+    in.read(reinterpret_cast<char *>(&ndc), sizeof(i_t));
+    in.read(reinterpret_cast<char *>(&no_data_), sizeof(T));
+    geotransform.resize(6);
+    in.read(reinterpret_cast<char *>(geotransform.data()), 6 * sizeof(double));
+    in.read(reinterpret_cast<char *>(&plen), sizeof(plen));
+    if (!in.good() || hh < 0 || ww < 0 || plen > (1u << 26)) throw std::runtime_error("Failed to load native file '" + filename + "!");
+    projection.resize(plen, ' ');
+    in.read(&projection[0], (std::streamsize)plen);
+    if (load_data) {
+      resize(ww, hh);
+      in.read(reinterpret_cast<char *>(ptr_), (std::streamsize)((size_t)ww * (size_t)hh * sizeof(T)));
+      if (!in.good()) throw std::runtime_error("Failed to load native file '" + filename + "!");
+    }
   }
 
   // |cell width * cell height| from the geotransform; 1 when there is none

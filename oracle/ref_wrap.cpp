@@ -21,6 +21,7 @@
 #include <richdem/methods/flow_accumulation.hpp>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <omp.h>
 
@@ -226,3 +227,37 @@ extern "C" void ref_flow_accumulation_f64(const float *props9, int w, int h, dou
   props.setNoData(NO_DATA_GEN);
   FlowAccumulation(props, acc);
 }
+
+// native raster format, common/Array2D.hpp:209-281 (saveToCache / Array2D(filename, native=true))
+template <class T>
+int ref_native_save(const char *path, const T *data, int w, int h, T nodata, const double *gt6, const char *proj) {
+  try {
+    Array2D<T> a(const_cast<T *>(data), w, h);
+    a.setNoData(nodata);
+    a.geotransform.assign(gt6, gt6 + 6);
+    a.projection = proj;
+    a.saveToCache(path);
+    return 0;
+  } catch (...) { return 1; }
+}
+template <class T>
+int ref_native_load(const char *path, T *data, int *w, int *h, T *nodata, double *gt6, char *proj, int projcap) {
+  try {
+    Array2D<T> a(std::string(path), true);
+    if (data && (a.width() != *w || a.height() != *h)) return 2;
+    *w = a.width(); *h = a.height(); *nodata = a.noData();
+    for (int i = 0; i < 6; i++) gt6[i] = a.geotransform[i];
+    std::snprintf(proj, projcap, "%s", a.projection.c_str());
+    if (data) std::memcpy(data, a.data(), (size_t)a.width() * a.height() * sizeof(T));
+    return 0;
+  } catch (...) { return 1; }
+}
+#define REF_NATIVE_API(SUF, T)                                                                                        \
+  extern "C" int ref_native_save_##SUF(const char *path, const T *data, int w, int h, T nodata, const double *gt6,    \
+                                       const char *proj) { return ref_native_save<T>(path, data, w, h, nodata, gt6, proj); } \
+  extern "C" int ref_native_load_##SUF(const char *path, T *data, int *w, int *h, T *nodata, double *gt6, char *proj, \
+                                       int projcap) { return ref_native_load<T>(path, data, w, h, nodata, gt6, proj, projcap); }
+REF_NATIVE_API(u8, uint8_t)
+REF_NATIVE_API(i32, int32_t)
+REF_NATIVE_API(f32, float)
+REF_NATIVE_API(f64, double)

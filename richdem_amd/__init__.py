@@ -33,6 +33,8 @@ from .pyrichdem import (  # noqa: F401
     TerrainAttribute,
     LoadGDAL,
     SaveGDAL,
+    LoadNative,
+    SaveNative,
 )
 from .api import (  # noqa: F401
     dinf_flow_directions,
@@ -54,6 +56,8 @@ __all__ = [
     "build",
     "rdarray",
     "rd3array",
+    "LoadNative",
+    "SaveNative",
     "FillDepressions",
     "FlowAccumulation",
     "FlowProportions",

@@ -23,7 +23,7 @@ from . import api as _api
 from ._lib import RdgpuError
 
 __all__ = ["rdarray", "rd3array", "FillDepressions", "FlowAccumulation", "FlowProportions", "FlowAccumFromProps",
-           "ResolveFlats", "BreachDepressions", "TerrainAttribute", "LoadGDAL", "SaveGDAL"]
+           "ResolveFlats", "BreachDepressions", "TerrainAttribute", "LoadGDAL", "SaveGDAL", "LoadNative", "SaveNative"]
 
 _META = ("metadata", "no_data", "projection", "geotransform")
 _META_DEFAULT = {"metadata": dict, "no_data": lambda: None, "projection": str, "geotransform": lambda: None}
@@ -202,6 +202,52 @@ def FlowAccumFromProps(props, weights=None, in_place: bool = False):
     _plain(accum)[...] = res
     accum.no_data = -1.0
     return accum
+
+
+_NATIVE_GT = (1000.0, 1.0, 0.0, 1000.0, 0.0, -1.0)   # the reference's fallback geotransform (Array2D.hpp:149)
+
+
+def SaveNative(filename: str, rda) -> None:
+    """Write a raster in the reference's native format (``Array2D::saveToCache``, common/Array2D.hpp:209-246,
+    uncompressed build): loads in the reference with ``Array2D<T>(filename, true)`` and in
+    ``rdgpu::Array2D<T>(filename)``.  GDAL formats are outside this engine."""
+    if type(rda) is not rdarray:
+        raise Exception("A richdem.rdarray or numpy.ndarray is required!")
+    a = np.ascontiguousarray(_plain(rda))
+    if a.ndim != 2:
+        raise RdgpuError("SaveNative: expected a 2-D raster")
+    gt = tuple(rda.geotransform) if rda.geotransform is not None and len(rda.geotransform) >= 6 else _NATIVE_GT
+    proj = (rda.projection or "").encode()
+    with open(filename, "wb") as f:
+        f.write(np.array([a.shape[0], a.shape[1], 0, 0], np.int32).tobytes())
+        f.write(np.array([0xFFFFFFFF], np.uint32).tobytes())          # data cells: not counted
+        f.write(np.array([_nodata_of(rda)], a.dtype).tobytes())
+        f.write(np.array(gt[:6], np.float64).tobytes())
+        f.write(np.array([len(proj)], np.uint64).tobytes())
+        f.write(proj)
+        f.write(a.tobytes())
+
+
+def LoadNative(filename: str, dtype) -> "rdarray":
+    """Read a raster in the reference's native format (``Array2D::loadNative``, common/Array2D.hpp:251-281).
+    The element type is not stored in the file: ``dtype`` must be the one it was written with."""
+    dt = np.dtype(dtype)
+    with open(filename, "rb") as f:
+        buf = f.read()
+    if len(buf) < 20 + dt.itemsize + 56:
+        raise RdgpuError(f"Failed to load native file '{filename}'!")
+    h, w, _xoff, _yoff = np.frombuffer(buf, np.int32, 4, 0)
+    pos = 20
+    no_data = np.frombuffer(buf, dt, 1, pos)[0]; pos += dt.itemsize
+    gt = np.frombuffer(buf, np.float64, 6, pos); pos += 48
+    plen = int(np.frombuffer(buf, np.uint64, 1, pos)[0]); pos += 8
+    if h < 0 or w < 0 or len(buf) < pos + plen + int(h) * int(w) * dt.itemsize:
+        raise RdgpuError(f"Failed to load native file '{filename}'!")
+    proj = buf[pos:pos + plen].decode(errors="replace"); pos += plen
+    data = np.frombuffer(buf, dt, int(h) * int(w), pos).reshape(int(h), int(w)).copy()
+    out = rdarray(data, no_data=no_data.item(), geotransform=tuple(gt.tolist()))
+    out.projection = proj
+    return out
 
 
 def _outside(name: str):

@@ -177,6 +177,22 @@ int main() {
     rdgpu::FillDepressions<Topo::D8>(g);
     EXPECT(std::memcmp(g.data(), eg.data(), eg.size() * 8) == 0);
   }
+  // native raster format round trip (reference saveToCache / Array2D(filename, native=true), Array2D.hpp:209-281)
+  {
+    Arr<float> a(dem);
+    a.setNoData(-9999.0f);
+    a.geotransform = {10., 2., 0., 20., 0., -2.};
+    a.projection = "PROJCS[test]";
+    const std::string path = "/tmp/rdgpu_shim_test_native.rd";
+    a.saveToCache(path);
+    Arr<float> b(path, true);
+    EXPECT(b == a);
+    EXPECT(b.geotransform == a.geotransform && b.projection == a.projection);
+    bool threw = false;
+    try { Arr<float> c(std::string("/nonexistent/file.rd"), true); } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw);
+    std::remove(path.c_str());
+  }
   // unsupported element type -> std::runtime_error, the reference's error convention
   {
     Arr<int8_t> d(8, 8, 1);

@@ -104,3 +104,52 @@ def test_non_contiguous_and_integer_rdarrays(rd, orc):
         rd.FillDepressions(view, in_place=True)
     acc = rd.FlowAccumulation(rd.rdarray(base.astype(np.int16), no_data=-9999), method="D8")
     assert np.array_equal(np.asarray(acc), orc.port.fa_d8(base.astype(np.int16), np.int16(-9999)))
+
+
+def _ref_native(orc):
+    import ctypes
+
+    if not orc.ref.available:
+        pytest.skip("oracle/_ref/libref.so not built here")
+    return orc.ref.lib, ctypes
+
+
+@pytest.mark.parametrize("dtype,suf", [(np.float32, "f32"), (np.int32, "i32"), (np.uint8, "u8"), (np.float64, "f64")])
+def test_native_format_matches_the_reference(rd, orc, tmp_path, dtype, suf):
+    """SaveNative / LoadNative vs the reference's own saveToCache / Array2D(filename, native=true)
+    (common/Array2D.hpp:209-281): byte-identical files, and each side reads the other's."""
+    L, ctypes = _ref_native(orc)
+    rng = np.random.default_rng(4)
+    a = (rng.random((37, 53)) * 200).astype(dtype)
+    gt = (100.5, 2.0, 0.0, 900.25, 0.0, -2.0)
+    r = rd.rdarray(a, no_data=dtype(7), geotransform=gt)
+    r.projection = "PROJCS[\"made up\"]"
+    mine, theirs = str(tmp_path / "mine.rd"), str(tmp_path / "theirs.rd")
+    rd.SaveNative(mine, r)
+    gtc = (ctypes.c_double * 6)(*gt)
+    ct = {"f32": ctypes.c_float, "i32": ctypes.c_int32, "u8": ctypes.c_uint8, "f64": ctypes.c_double}[suf]
+    save = getattr(L, f"ref_native_save_{suf}")
+    save.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ct, ctypes.c_void_p, ctypes.c_char_p]
+    assert save(theirs.encode(), a.ctypes.data_as(ctypes.c_void_p), 53, 37, ct(7), gtc, r.projection.encode()) == 0
+    assert open(mine, "rb").read() == open(theirs, "rb").read()
+    back = rd.LoadNative(theirs, dtype)
+    assert type(back) is rd.rdarray and np.array_equal(back, a) and back.no_data == 7
+    assert tuple(back.geotransform) == gt and back.projection == r.projection
+    # the reference reads ours
+    load = getattr(L, f"ref_native_load_{suf}")
+    out = np.zeros_like(a)
+    w, h, nd = ctypes.c_int(53), ctypes.c_int(37), ct(0)
+    gto, proj = (ctypes.c_double * 6)(), ctypes.create_string_buffer(256)
+    assert load(mine.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(w), ctypes.byref(h), ctypes.byref(nd), gto,
+                proj, 256) == 0
+    assert np.array_equal(out, a) and nd.value == 7 and tuple(gto) == gt and proj.value.decode() == r.projection
+
+
+def test_native_format_errors(rd, tmp_path):
+    with pytest.raises(Exception):
+        rd.LoadNative(str(tmp_path / "missing.rd"), np.float32)
+    (tmp_path / "short.rd").write_bytes(b"\x01\x02")
+    with pytest.raises(rd.RdgpuError):
+        rd.LoadNative(str(tmp_path / "short.rd"), np.float32)
+    with pytest.raises(Exception, match="rdarray"):
+        rd.SaveNative(str(tmp_path / "x.rd"), np.zeros((2, 2)))
