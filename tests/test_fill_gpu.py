@@ -144,15 +144,16 @@ def _is_filled_surface(W, Z):
     return ok
 
 
-def test_full_size_config_10k_properties(rd, orc):
-    """BASELINE config[1]: 10000x10000 f32.  Too big for the oracle in seconds -> check the fixed-point
+@pytest.mark.parametrize("n,seed", [(10000, 2), (40000, 3)], ids=["config1_10k", "config2_40k"])
+def test_full_size_config_properties(rd, orc, n, seed):
+    """BASELINE configs[1] and [2]: 10000x10000 and 40000x40000 f32 (the bench workload).  Too big for the oracle
+    in seconds -> check the fixed-point
     characterisation, idempotence, and exact equality with the oracle on a row band re-filled with the
     true boundary condition... (band check: cells whose fill level is decided inside a 600-row border band)."""
     import torch
 
-    n = 10000
     Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
-    rd.synth_dem_dev(Z, seed=2)
+    rd.synth_dem_dev(Z, seed=seed)
     W = Z.clone()
     rd.fill_depressions_dev(W)
     torch.cuda.synchronize()
@@ -166,8 +167,9 @@ def test_full_size_config_10k_properties(rd, orc):
     assert bool((W2 == W).all())
     # greatest-fixed-point check on a sub-window against the oracle: fill the window with the GPU's
     # result as boundary condition; an exact fill must reproduce the interior.
-    sub = W[4000:4700, 5000:5900].cpu().numpy()
-    zsub = Z[4000:4700, 5000:5900].cpu().numpy().copy()
+    y0, x0 = (4 * n) // 10, n // 2
+    sub = W[y0:y0 + 700, x0:x0 + 900].cpu().numpy()
+    zsub = Z[y0:y0 + 700, x0:x0 + 900].cpu().numpy().copy()
     zsub[0], zsub[-1], zsub[:, 0], zsub[:, -1] = sub[0], sub[-1], sub[:, 0], sub[:, -1]
     assert np.array_equal(orc.port.fill(zsub), sub)
 

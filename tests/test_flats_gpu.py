@@ -153,17 +153,17 @@ def test_alter_true(rd, orc, dtype):
         rd.barnes_flat_resolution_d8(np.zeros((5, 5), np.int32), -1, alter=True)
 
 
-def test_full_size_chain_invariants_10k(rd):
+@pytest.mark.parametrize("n,seed", [(10000, 2), (40000, 3)], ids=["10k", "config4_40k"])
+def test_full_size_chain_invariants(rd, n, seed):
     """BASELINE config sizes are too big for the oracle in seconds; the whole chain is checked through
-    size-independent invariants at 10000 x 10000 on the device-resident path: after fill + flat resolution no
+    size-independent invariants at 10000 x 10000 and at the bench size 40000 x 40000 on the device-resident path: after fill + flat resolution no
     interior cell is left without a direction, every cell drains off the raster exactly once
     (sum of the border cells' accumulation == number of cells -- this fails for any cycle, dead end or
     double count), accumulation >= 1 everywhere, and the sharded accumulation equals the single-block one."""
     import torch
 
-    n = 10000
     Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
-    rd.synth_dem_dev(Z, seed=2)
+    rd.synth_dem_dev(Z, seed=seed)
     rd.fill_depressions_dev(Z)
     dirs = torch.empty((n, n), dtype=torch.uint8, device="cuda")
     rd.d8_flow_directions_dev(Z, -9999.0, dirs, flats=True)
@@ -181,8 +181,12 @@ def test_full_size_chain_invariants_10k(rd):
     acc = torch.ones((n, n), dtype=torch.float64, device="cuda")
     rd.fa_d8_dev(Z, -9999.0, acc)
     assert bool((acc >= 1).all()) and float(acc.max().item()) <= float(area.max().item()) * 4 + n
-    # row-block shards of the accumulation on one GPU: identical
-    from richdem_amd.sharded import GpuAccumShard, row_split
+    # row-block shards on one GPU: flat resolution over 8 blocks, accumulation over 4 -- identical
+    from richdem_amd.sharded import GpuAccumShard, flat_resolution_blocks, row_split
+
+    sharded_dirs, exchanges = flat_resolution_blocks(Z, -9999.0, 8)
+    assert bool((sharded_dirs == dirs).all()), exchanges
+    del sharded_dirs
 
     world = 4
     blocks = [dirs[a:b] for a, b in row_split(n, world)]
