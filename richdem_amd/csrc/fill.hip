@@ -70,20 +70,28 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
   if (VEC) {
-    // interior columns with 16-byte loads (4-byte cells, w % 4 == 0: every row start is 16-byte aligned)
-    for (int i = threadIdx.x; i < DLH * (DW / 4); i += NTHR) {
+    // interior columns with 16-byte loads (4-byte cells, w % 4 == 0: every row start is 16-byte aligned); all
+    // loads of the thread are issued before the first is consumed (one memory round trip, not one per trip)
+    constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
+    struct alignas(16) Q { T v[4]; };
+    Q zq[QPT];
+    bool okq[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
       const int ly = i / (DW / 4), q = i - ly * (DW / 4);
       const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
-      uint32_t kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-      if (gy >= 0 && gy < h && gx < w) {
-        struct alignas(16) Q { T v[4]; };
-        const Q zq = *reinterpret_cast<const Q *>(z + (size_t)gy * w + gx);
+      okq[r] = i < NQ && gy >= 0 && gy < h && gx < w;
+      if (okq[r]) zq[r] = *reinterpret_cast<const Q *>(z + (size_t)gy * w + gx);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; e++) kk[e] = Key32<T>::to(zq.v[e]);
-      }
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
+      if (i >= NQ) continue;
+      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
       const int o = ly * DLW + 1 + 4 * q;
 #pragma unroll
-      for (int e = 0; e < 4; e++) sk[o + e] = kk[e];
+      for (int e = 0; e < 4; e++) sk[o + e] = okq[r] ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
     }
     for (int i = threadIdx.x; i < 2 * DLH; i += NTHR) {   // halo columns
       const int ly = i >> 1, lxh = (i & 1) ? DLW - 1 : 0;
@@ -160,21 +168,19 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   // pointer jumping inside the tile; any value ever stored is an ancestor, so races are harmless.
   // A cell whose parent is a tile root is finished for good, so only the still-active cells (bit mask
   // per thread) are revisited: integer VALU + LDS issue, not HBM, bounds this kernel.
-  uint32_t active = 0;
-#pragma unroll 4
-  for (int j = 0; j < DH / 4; j++)
-    if (lp[(ly0 + j) * DW + lx] < LTERM_BASE) active |= 1u << j;
+  // Every trip reads all of the thread's pointers, then all of their targets' pointers: two batches of
+  // independent LDS reads (the latency of a dependent read chain per cell was what bounded this loop).
   for (int it = 0; it < 16; it++) {
-    uint32_t still = 0;
-    for (uint32_t m = active; m; m &= m - 1) {
-      const int j = __ffs((int)m) - 1;
-      const int li = (ly0 + j) * DW + lx;
-      const uint16_t p = lp[li];
-      const uint16_t q = lp[p];
-      if (q < LTERM_BASE) { lp[li] = q; still |= 1u << j; }
-    }
-    active = still;
-    if (!__syncthreads_or(active != 0)) break;
+    uint16_t pv[DH / 4], qv[DH / 4];
+#pragma unroll
+    for (int j = 0; j < DH / 4; j++) pv[j] = lp[(ly0 + j) * DW + lx];
+#pragma unroll
+    for (int j = 0; j < DH / 4; j++) qv[j] = lp[pv[j] < LTERM_BASE ? pv[j] : (ly0 + j) * DW + lx];
+    int still = 0;
+#pragma unroll
+    for (int j = 0; j < DH / 4; j++)
+      if (pv[j] < LTERM_BASE && qv[j] < LTERM_BASE) { lp[(ly0 + j) * DW + lx] = qv[j]; still = 1; }
+    if (!__syncthreads_or(still)) break;
   }
   // write: the tile-local root's own pointer.  Pits (and a shard's cut-row terminals), ptr[c] == c, get their
   // dense basin id here: ONE counter add per tile (ids are dense but not in raster order -- nothing depends on
