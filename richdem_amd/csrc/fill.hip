@@ -574,6 +574,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
 #pragma unroll
       for (int e = 0; e < 3; e++) { c0[e] = sc[o + e]; c1[e] = sc[o + LW + e]; }
     }
+    unsigned long long bal[ROWS];   // per row: the lanes whose cell touches another component
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
       const int ly = yb + j, gy = y0 + ly;
@@ -587,15 +588,24 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       if (TOPO == 8) d |= (c0[0] ^ C) | (c0[2] ^ C) | (c2[0] ^ C) | (c2[2] ^ C);
       // closed: drains to the outside or to a frozen terminal -- never proposes
       const bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h;
-      const unsigned long long bal = __ballot(hit);
-      if (bal) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&nlist, (uint32_t)__popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (hit) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((ly + 1) * LW + lx + 1);
-      }
+      bal[j] = __ballot(hit);
 #pragma unroll
       for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
+    }
+    // one list reservation per wavefront (a returning LDS atomic per row was a dependent chain of eight)
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) total += (uint32_t)__popcll(bal[j]);
+    if (total) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&nlist, total);
+      base = __shfl(base, 0, 64);
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) {
+        if (bal[j] >> lane & 1ull)
+          list[base + __popcll(bal[j] & ((1ull << lane) - 1ull))] = (uint16_t)((yb + j + 1) * LW + lx + 1);
+        base += (uint32_t)__popcll(bal[j]);
+      }
     }
   }
   // (no barrier needed between the detect phase and this: both only read sc)
