@@ -431,24 +431,6 @@ __global__ __launch_bounds__(NTHR) void k_best_reset(const uint32_t *__restrict_
 // touches instead of one per boundary cell.
 constexpr int SC_SLOTS = 256;
 
-// DPP shifts inside a 16-lane row (VALU rate, no LDS): lanes without a source get `fill`
-template <int N>
-__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 | N, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t fill) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
-}
-// min of `cand` over the lanes of this 16-lane row that hold the same component id (Hillis-Steele);
-// afterwards the last lane of every run of equal ids holds (at least) its run's minimum
-template <int N>
-__device__ __forceinline__ void seg_min_step(uint32_t C, uint32_t &hi, uint32_t &lo) {
-  const uint32_t c2 = row_shr<N>(C, 0xFFFFFFFFu);
-  const uint32_t h2 = row_shr<N>(hi, 0xFFFFFFFFu), l2 = row_shr<N>(lo, 0xFFFFFFFFu);
-  const bool take = (c2 == C) && (h2 < hi || (h2 == hi && l2 < lo));
-  hi = take ? h2 : hi;
-  lo = take ? l2 : lo;
-}
 // find-or-insert component C in the block's LDS table; -1 when its probe window is full
 __device__ __forceinline__ int tab_slot(uint32_t *tab_id, uint32_t C) {
   uint32_t slot = (C * 0x9E3779B1u) >> 24;
