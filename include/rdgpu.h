@@ -200,6 +200,22 @@ typedef struct rdgpu_flat_stats {
 } rdgpu_flat_stats;
 int rdgpu_flat_get_stats(rdgpu_flat_stats *out);
 
+/* ResolveFlatsEpsilon(Array2D<T>&) (flats/flats.hpp:21-28; rd.ResolveFlats): the DEM is altered in place so
+ * that every flat with an outlet drains -- each interior cell of such a flat is raised by flat_mask increments
+ * of std::nextafter(e, numeric_limits<T>::infinity()) in its own type (float / double: towards +inf; integer
+ * types: numeric_limits<int>::infinity() is 0, so the reference moves the value towards zero -- kept). */
+#define RDGPU_DECL_RFE(SUF, T)                                                    \
+  int rdgpu_resolve_flats_epsilon_##SUF(T *dem, T nodata, int width, int height); \
+  int rdgpu_resolve_flats_epsilon_dev_##SUF(T *d_dem, T nodata, int width, int height, void *hip_stream);
+RDGPU_DECL_RFE(u8, uint8_t)
+RDGPU_DECL_RFE(i16, int16_t)
+RDGPU_DECL_RFE(u16, uint16_t)
+RDGPU_DECL_RFE(i32, int32_t)
+RDGPU_DECL_RFE(u32, uint32_t)
+RDGPU_DECL_RFE(f32, float)
+RDGPU_DECL_RFE(f64, double)
+#undef RDGPU_DECL_RFE
+
 /* ---- flat resolution over row-block shards ---------------------------
  * barnes_flat_resolution_d8 (flats/flat_resolution.hpp:587-605) when the raster is split into row blocks,
  * one per GPU.  d_rows = the shard's own rows plus TWO ghost rows per cut (ghost_top / ghost_bottom are 0

@@ -60,6 +60,7 @@ int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
   inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
   inline int c_fa_dinf(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_tarboton_##SUF(p, nd, w, h, a); } \
   inline int c_fa_mfd(const T *p, T nd, int w, int h, int m, double x, double *a) { return rdgpu_fa_mfd_##SUF(p, nd, w, h, m, x, a); } \
+  inline int c_rfe(T *p, T nd, int w, int h) { return rdgpu_resolve_flats_epsilon_##SUF(p, nd, w, h); } \
   inline int c_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_dinf_flowdirs_##SUF(p, nd, w, h, o); }
 RDGPU_SHIM_STENCIL(u8, uint8_t)
 RDGPU_SHIM_STENCIL(i16, int16_t)
@@ -81,6 +82,8 @@ template <class T>
 int c_dinf(const T *, T, int, int, float *) { unsupported("dinf_flow_directions"); }
 template <class T>
 int c_fa_mfd(const T *, T, int, int, int, double, double *) { unsupported("FA_Holmgren / FA_Freeman / FA_Quinn / FA_D4"); }
+template <class T>
+int c_rfe(T *, T, int, int) { unsupported("ResolveFlatsEpsilon"); }
 
 inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
 inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
@@ -247,6 +250,15 @@ template <class E, class G>
 void FA_OCallaghanD4(const E &elevations, G &accum) { FA_D4(elevations, accum); }
 template <class E, class G>
 void FA_OCallaghanD8(const E &elevations, G &accum) { FA_D8(elevations, accum); }
+
+// richdem::ResolveFlatsEpsilon(Array2D<T>&)   flats/flats.hpp:21-28 (pywrapper.hpp:37 rdResolveFlatsEpsilon)
+template <class E>
+void ResolveFlatsEpsilon(E &elevations) {
+  using T = detail::elem_t<E>;
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_rfe((T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height()),
+                "ResolveFlatsEpsilon");
+}
 
 // richdem::dinf_flow_directions(const Array2D<T>&, Array2D<float>&)   flowmet/dinf_flowdirs.hpp:128-152
 template <class E, class F>

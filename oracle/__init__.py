@@ -196,6 +196,14 @@ class _Backend:
         self._fn(f"fa_mfd_{s}")(_ptr(dem), _CT[s](nodata), w, h, self.MFD[method], ctypes.c_double(xparam), _ptr(acc))
         return acc
 
+    def resolve_flats_epsilon(self, dem: np.ndarray, nodata) -> np.ndarray:
+        """ResolveFlatsEpsilon (flats/flats.hpp:21-28): returns the altered DEM."""
+        dem = np.ascontiguousarray(dem).copy()
+        h, w = dem.shape
+        s = _suf(dem)
+        self._fn(f"resolve_flats_epsilon_{s}")(_ptr(dem), _CT[s](nodata), w, h)
+        return dem
+
     def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)
         h, w = dem.shape

@@ -479,6 +479,49 @@ void FN(orc_fa_mfd)(const T *dem, T nodata, int w, int h, int method, double xpa
   free(props);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* ResolveFlatsEpsilon, flats/flats.hpp:21-28 = FindFlats (flats/find_flats.hpp:29-69) + GetFlatMask          */
+/* (flats/Barnes2014.hpp:398-467) + ResolveFlatsEpsilon_Barnes2014 (:496-550).  The flat mask of GetFlatMask   */
+/* is the BFS construction restated in orc_resolve_flats, applied to FindFlats' notion of "flat" (no lower    */
+/* neighbour AND no NoData neighbour; edge cells never flat); equivalence with the compiled reference is      */
+/* checked in tests/test_oracle_pinning.py.  Every labelled interior cell is raised by flat_mask increments   */
+/* of std::nextafter(e, numeric_limits<T>::infinity()) IN TYPE T; for integer T that infinity() is 0 and the  */
+/* arguments promote to double, so a step moves the value by one TOWARDS ZERO -- reproduced as is.            */
+/* ------------------------------------------------------------------------- */
+#define ORC_NEXT_UP(x) _Generic((x), float: nextafterf((float)(x), INFINITY), double: nextafter((double)(x), (double)INFINITY), \
+                                default: nextafter((double)(x), 0.0))
+void FN(orc_find_flats)(const T *dem, T nodata, int w, int h, uint8_t *flats /* 0 flat, 1 not, 255 NoData */) {
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) { flats[i] = 255; continue; }                    /* find_flats.hpp:43-46 */
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) { flats[i] = 1; continue; }   /* :48-51 */
+      uint8_t f = 0;
+      for (int n = 1; n <= 8; n++) {                                          /* :56-63 */
+        size_t ni = (size_t)(y + D8Y[n]) * w + (x + D8X[n]);
+        if (dem[ni] < dem[i] || dem[ni] == nodata) { f = 1; break; }
+      }
+      flats[i] = f;
+    }
+}
+
+void FN(orc_resolve_flats_epsilon)(T *dem, T nodata, int w, int h) {
+  size_t N = (size_t)w * h;
+  uint8_t *flats = (uint8_t *)malloc(N);
+  int32_t *mask = (int32_t *)malloc(N * 4), *labels = (int32_t *)malloc(N * 4);
+  FN(orc_find_flats)(dem, nodata, w, h, flats);
+  FN(orc_resolve_flats)(dem, w, h, flats, mask, labels);
+  for (int y = 1; y < h - 1; y++)                                            /* Barnes2014.hpp:511-512 */
+    for (int x = 1; x < w - 1; x++) {
+      size_t i = (size_t)y * w + x;
+      if (labels[i] == 0) continue;                                          /* :516-517 */
+      for (int k = 0; k < mask[i]; ++k) dem[i] = (T)ORC_NEXT_UP(dem[i]);     /* :527-528 */
+    }
+  free(flats); free(mask); free(labels);
+}
+#undef ORC_NEXT_UP
+
 #undef CAT_
 #undef CAT
 #undef FN

@@ -17,6 +17,7 @@
 #include <richdem/flowmet/d8_flowdirs.hpp>
 #include <richdem/flowmet/dinf_flowdirs.hpp>
 #include <richdem/flats/flat_resolution.hpp>
+#include <richdem/flats/flats.hpp>
 #include <richdem/methods/d8_methods.hpp>
 #include <richdem/methods/flow_accumulation.hpp>
 
@@ -261,3 +262,20 @@ REF_NATIVE_API(u8, uint8_t)
 REF_NATIVE_API(i32, int32_t)
 REF_NATIVE_API(f32, float)
 REF_NATIVE_API(f64, double)
+
+// ResolveFlatsEpsilon, flats/flats.hpp:21-28 (what rd.ResolveFlats calls, pywrapper.hpp:37)
+template <class T>
+void ref_resolve_flats_epsilon(T *dem, T nodata, int w, int h) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  ResolveFlatsEpsilon(a);
+}
+#define REF_RFE_API(SUF, T) \
+  extern "C" void ref_resolve_flats_epsilon_##SUF(T *dem, T nodata, int w, int h) { ref_resolve_flats_epsilon<T>(dem, nodata, w, h); }
+REF_RFE_API(u8, uint8_t)
+REF_RFE_API(i16, int16_t)
+REF_RFE_API(u16, uint16_t)
+REF_RFE_API(i32, int32_t)
+REF_RFE_API(u32, uint32_t)
+REF_RFE_API(f32, float)
+REF_RFE_API(f64, double)

@@ -42,6 +42,7 @@ from .api import (  # noqa: F401
     d8_flow_accum,
     barnes_flat_resolution_d8,
     resolve_flats,
+    resolve_flats_epsilon,
     fill_depressions_dev,
     d8_flow_directions_dev,
     d8_flow_accum_dev,

@@ -125,6 +125,26 @@ def resolve_flats(dem: np.ndarray, nodata):
     return dirs, mask, labels
 
 
+def resolve_flats_epsilon(dem: np.ndarray, nodata, in_place: bool = False):
+    """ResolveFlatsEpsilon (reference flats/flats.hpp:21-28, what ``rd.ResolveFlats`` calls): the DEM altered so
+    that every flat with an outlet drains.  Returns the altered array (None when ``in_place``)."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("ResolveFlats: expected a 2-D numpy array")
+    out = dem if in_place else dem.copy()
+    if not out.flags["C_CONTIGUOUS"]:
+        if in_place:
+            raise RdgpuError("ResolveFlats(in_place=True) needs a C-contiguous array")
+        out = np.ascontiguousarray(out)
+    try:
+        s = _ELEV_SUFFIX[out.dtype]
+    except KeyError:
+        raise RdgpuError(f"ResolveFlats: unsupported elevation dtype {out.dtype}") from None
+    h, w = out.shape
+    check(getattr(lib(), f"rdgpu_resolve_flats_epsilon_{s}")(out.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h),
+          "rdgpu_resolve_flats_epsilon")
+    return None if in_place else out
+
+
 def d8_flow_accum(dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.ndarray:
     """Cells draining through each cell from uint8 D8 directions (reference d8_flow_accum,
     methods/d8_methods.hpp:47-139)."""

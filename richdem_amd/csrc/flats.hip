@@ -1173,6 +1173,119 @@ static void fs_heights(rdgpu_flat_shard *f, int32_t *d_out) {
             (const int32_t *)f->fh, cr, f->w, d_out);
 }
 
+// ------------------------------------------------------------------------------------------
+// ResolveFlatsEpsilon (flats/flats.hpp:21-28) = FindFlats (flats/find_flats.hpp:29-69) + GetFlatMask
+// (flats/Barnes2014.hpp:398-467) + ResolveFlatsEpsilon_Barnes2014 (:496-550): what rd.ResolveFlats calls.
+// GetFlatMask is the same BFS construction as resolve_flats_barnes, applied to FindFlats' notion of a flat
+// cell (interior, no lower neighbour AND no NoData neighbour).  So FindFlats is written as a pseudo direction
+// raster (0 = flat, 1 = not, 255 = NoData) and the engine above runs unchanged -- the two facts it leans on
+// (adjacent flat cells have equal elevation; drainable <=> reached by the towards gradient) hold for this
+// definition too.  Then every interior cell with flat_mask > 0 is raised by flat_mask increments of
+// std::nextafter(e, numeric_limits<T>::infinity()) in ITS OWN type: float and double in closed form on the bit
+// pattern; for integer T that "infinity" is 0 and the arguments promote to double, so one step moves the value
+// by one towards zero -- reproduced as is (it is what the reference returns).
+// ------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_find_flats(const T *__restrict__ z, T nodata, uint8_t *__restrict__ flats, int w,
+                                                     int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ T sz[SLH * SLW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
+  for (int i = threadIdx.x; i < SLH * SLW; i += NTHR) {
+    const int ly = i / SLW, lx = i - ly * SLW;
+    const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);   // clamped: edge cells are decided by position
+    sz[i] = z[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
+  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+#pragma unroll
+  for (int j = 0; j < SH / 4; j++) {
+    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const int o = (ly + 1) * SLW + lx + 1;
+    const T e = sz[o];
+    uint8_t f;
+    if (e == nodata) f = 255;                                                  // find_flats.hpp:43-46
+    else if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) f = 1;          // :48-51
+    else {
+      f = 0;
+#pragma unroll
+      for (int k = 1; k <= 8; k++) {
+        const T zn = sz[o + off[k]];
+        if (zn < e || zn == nodata) f = 1;                                     // :56-63
+      }
+    }
+    flats[(size_t)gy * w + gx] = f;
+  }
+}
+
+__device__ __forceinline__ double next_up_n64(double v, uint32_t m) {   // nextafter(v, +inf) applied m times
+  uint64_t b = __builtin_bit_cast(uint64_t, v);
+  if ((b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) return v;    // NaN
+  if (b >> 63) {
+    const uint64_t mag = b & 0x7fffffffffffffffull;
+    if (m <= mag) return __builtin_bit_cast(double, 0x8000000000000000ull | (mag - m));
+    b = m - mag;
+  } else {
+    b += m;
+    if (b >= 0x7ff0000000000000ull) b = 0x7ff0000000000000ull;
+  }
+  return __builtin_bit_cast(double, b);
+}
+template <class T>
+__device__ __forceinline__ T epsilon_steps(T v, uint32_t m) {   // m steps towards zero, stopping there
+  const long long x = (long long)v, mm = (long long)m;
+  return (T)(x > 0 ? (x > mm ? x - mm : 0) : (x < -mm ? x + mm : 0));
+}
+template <>
+__device__ __forceinline__ float epsilon_steps<float>(float v, uint32_t m) { return next_up_n(v, m); }
+template <>
+__device__ __forceinline__ double epsilon_steps<double>(double v, uint32_t m) { return next_up_n64(v, m); }
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_flat_epsilon(T *z, const int32_t *__restrict__ M, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const int32_t m = M[c];
+    if (m <= 0) continue;   // unlabelled cells, and labelled cells outside the flat proper (mask 0)
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;    // Barnes2014.hpp:511-512 interior only
+    z[c] = epsilon_steps<T>(z[c], (uint32_t)m);                    // :527-528
+  }
+}
+
+template <class T>
+void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s) {
+  if (!d_z) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: width and height must be positive");
+  if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: raster too large");
+  uint8_t *flats = Workspace::get().buf<uint8_t>("flats.findflats", (size_t)w * h);
+  {
+    uint32_t tilesX;
+    const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+    RD_LAUNCH("flats.find_flats", (k_find_flats<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z, nodata, flats, w, h,
+              tilesX, ntiles);
+  }
+  int32_t *M, *fh;
+  uint32_t *L;
+  resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s);
+  if (L) RD_LAUNCH("flats.epsilon", (k_flat_epsilon<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, w, h);
+}
+
+template <class T>
+static void resolve_flats_epsilon_host(T *dem, T nodata, int w, int h) {
+  if (!dem) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: width and height must be positive");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  resolve_flats_epsilon_device<T>(d, nodata, w, h, nullptr);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
 #define RD_INST(T) template void flat_resolution_device<T>(const T *, T, int, int, uint8_t *, hipStream_t);
 RD_INST(uint8_t) RD_INST(int16_t) RD_INST(uint16_t) RD_INST(int32_t) RD_INST(uint32_t) RD_INST(float) RD_INST(double)
 #undef RD_INST
@@ -1212,6 +1325,21 @@ RD_FLATS_API(f64, double)
 RD_FLATS_ALTER_API(f32, float)
 RD_FLATS_ALTER_API(f64, double)
 
+
+#define RD_RFE_API(SUF, T)                                                                                     \
+  extern "C" int rdgpu_resolve_flats_epsilon_##SUF(T *dem, T nodata, int w, int h) {                           \
+    return guarded([&] { resolve_flats_epsilon_host<T>(dem, nodata, w, h); });                                 \
+  }                                                                                                            \
+  extern "C" int rdgpu_resolve_flats_epsilon_dev_##SUF(T *d_dem, T nodata, int w, int h, void *stream) {       \
+    return guarded([&] { resolve_flats_epsilon_device<T>(d_dem, nodata, w, h, (hipStream_t)stream); });        \
+  }
+RD_RFE_API(u8, uint8_t)
+RD_RFE_API(i16, int16_t)
+RD_RFE_API(u16, uint16_t)
+RD_RFE_API(i32, int32_t)
+RD_RFE_API(u32, uint32_t)
+RD_RFE_API(f32, float)
+RD_RFE_API(f64, double)
 
 #define RD_FLATSHARD_API(SUF, T)                                                                                       \
   extern "C" int rdgpu_flat_shard_begin_##SUF(const T *d_rows, T nodata, int w, int rows, int ghost_top,               \

@@ -10,7 +10,8 @@ reference's argument names, defaults, return conventions and error messages, so 
 
 reads like the reference's own examples (docs/flow_accumulation.rst).  Every function also accepts a plain
 ``numpy.ndarray`` (then ``nodata=`` names the NoData value and plain arrays come back).  GDAL I/O
-(LoadGDAL / SaveGDAL), breaching, terrain attributes and the depression hierarchy are outside this engine.
+(LoadGDAL / SaveGDAL), breaching, terrain attributes and the depression hierarchy are outside this engine;
+``ResolveFlats`` and the native raster format (``LoadNative`` / ``SaveNative``) are provided.
 """
 from __future__ import annotations
 
@@ -259,7 +260,29 @@ def _outside(name: str):
     return fn
 
 
-ResolveFlats = _outside("ResolveFlats")
+def ResolveFlats(dem, in_place: bool = False, nodata=None):
+    """Attempts to resolve flats by imposing a local gradient (reference __init__.py:461-487 ->
+    rdResolveFlatsEpsilon = ResolveFlatsEpsilon, flats/flats.hpp:21-28).  rdarray in: returns a new rdarray, or
+    None when ``in_place``."""
+    if type(dem) is not rdarray:
+        if isinstance(dem, np.ndarray) and type(dem) is np.ndarray:
+            return _api.resolve_flats_epsilon(dem, -9999 if nodata is None else nodata, in_place=in_place)
+        raise Exception("A richdem.rdarray or numpy.ndarray is required!")
+    if not in_place:
+        dem = dem.copy()
+    elif not dem.flags["C_CONTIGUOUS"]:
+        raise RdgpuError("ResolveFlats(in_place=True) needs a C-contiguous array")
+    _add_analysis(dem, f"ResolveFlats(dem, in_place={in_place})")
+    work = _plain(dem)
+    if work.flags["C_CONTIGUOUS"]:
+        _api.resolve_flats_epsilon(work, _nodata_of(dem), in_place=True)
+    else:
+        work[...] = _api.resolve_flats_epsilon(np.ascontiguousarray(work), _nodata_of(dem))
+    if not in_place:
+        return dem
+    return None
+
+
 BreachDepressions = _outside("BreachDepressions")
 TerrainAttribute = _outside("TerrainAttribute")
 LoadGDAL = _outside("LoadGDAL")

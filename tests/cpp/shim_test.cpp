@@ -32,6 +32,7 @@ void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
 void orc_d8_flow_accum_i32(const uint8_t *, uint8_t, int, int, int32_t *);
 void orc_fa_mfd_f32(const float *dem, float nodata, int w, int h, int method, double xparam, double *accum);
+void orc_resolve_flats_epsilon_f32(float *dem, float nodata, int w, int h);
 void orc_fa_d8_f32(const float *, float, int, int, double *);
 }
 
@@ -176,6 +177,17 @@ int main() {
     orc_fill_f64(eg.data(), w, h, 8);
     rdgpu::FillDepressions<Topo::D8>(g);
     EXPECT(std::memcmp(g.data(), eg.data(), eg.size() * 8) == 0);
+  }
+  // rd.ResolveFlats: ResolveFlatsEpsilon(Array2D<T>&) on the filled DEM
+  {
+    Arr<float> a(dem);
+    a.setNoData(-9999.0f);
+    for (size_t i = 0; i < ref.size(); i++) a.data()[i] = ref[i];
+    rdgpu::FillDepressions<Topo::D8>(a);
+    std::vector<float> e(a.data(), a.data() + (size_t)w * h);
+    orc_resolve_flats_epsilon_f32(e.data(), -9999.0f, w, h);
+    rdgpu::ResolveFlatsEpsilon(a);
+    EXPECT(std::memcmp(a.data(), e.data(), e.size() * 4) == 0);
   }
   // native raster format round trip (reference saveToCache / Array2D(filename, native=true), Array2D.hpp:209-281)
   {

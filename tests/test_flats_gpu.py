@@ -210,3 +210,44 @@ def test_full_size_chain_invariants(rd, n, seed):
         sh.finish(a)
         parts.append(a)
     assert bool((torch.cat(parts, 0) == area).all())
+
+
+def _epsilon_cases(orc):
+    rng = np.random.default_rng(12)
+    for seed in range(3):
+        z = fractal_dem(230, 170, 400 + seed)
+        yield "filled_f32", orc.port.fill(z), np.float32(-9999)
+        yield "steps_f32", np.floor((z - z.min()) * 0.05).astype(np.float32), np.float32(-9999)
+        yield "filled_f64", orc.port.fill(np.floor((z - z.min()) * 0.1).astype(np.float64)), np.float64(-9999)
+        zi = np.floor((z - z.min()) * 0.05).astype(np.int32) - 40          # negative and positive levels
+        yield "filled_i32", orc.port.fill(zi), np.int32(-9999)
+        yield "raw_i16", zi.astype(np.int16), np.int16(-9999)
+        yield "u8_nodata_high", np.clip(zi + 40, 0, 254).astype(np.uint8), np.uint8(255)
+        yield "u16", np.clip(zi + 40, 0, 60000).astype(np.uint16), np.uint16(0)
+        d = orc.port.fill(z).copy(); d[30:35, 40:50] = -9999; d[60, 70] = -9999
+        yield "holes", d, np.float32(-9999)
+        d2 = orc.port.fill(np.floor((z - z.min()) * 0.05).astype(np.float32)); d2[rng.random(d2.shape) < 0.03] = 1e9
+        yield "nodata_above_the_data", d2, np.float32(1e9)
+    yield "noise", rng.integers(0, 3, (90, 110)).astype(np.float32), np.float32(-1)
+    yield "tiny", np.zeros((3, 3), np.float32), np.float32(-1)
+    yield "row", np.zeros((1, 9), np.float64), np.float64(-1)
+    tiny = np.full((40, 40), -1e-44, np.float32); tiny[0, 0] = -1                # negative denormals: through -0.0 to +denormals
+    yield "denormals", tiny, np.float32(-9999)
+
+
+def test_resolve_flats_epsilon(rd, orc):
+    """rd.ResolveFlats = ResolveFlatsEpsilon (flats/flats.hpp:21-28): bit-exact for every element type, including
+    the reference's towards-zero behaviour on integer DEMs and NoData values above the data."""
+    for name, dem, nd in _epsilon_cases(orc):
+        exp = orc.port.resolve_flats_epsilon(dem, nd)
+        got = rd.ResolveFlats(dem, nodata=nd)
+        assert got.dtype == dem.dtype and got.tobytes() == exp.tobytes(), (name, int((got != exp).sum()))
+    dem = orc.port.fill(fractal_dem(120, 100, 9))
+    r = rd.rdarray(dem.copy(), no_data=-9999)
+    out = rd.ResolveFlats(r)
+    assert type(out) is rd.rdarray and np.array_equal(r, dem) and "ResolveFlats" in out.metadata["PROCESSING_HISTORY"]
+    assert np.asarray(out).tobytes() == orc.port.resolve_flats_epsilon(dem, np.float32(-9999)).tobytes()
+    assert rd.ResolveFlats(r, in_place=True) is None and np.array_equal(r, out)
+    # every flat cell of a filled DEM drains afterwards
+    dirs = rd.d8_flow_directions(np.asarray(out), np.float32(-9999))
+    assert (dirs[1:-1, 1:-1] != 0).all()

@@ -40,7 +40,7 @@ def test_argument_errors_without_gpu(rd):
         rd.FlowAccumulation(z, method="D8", weights=rd.rdarray(np.ones((4, 4), np.float32), no_data=-1))
     with pytest.raises(Exception, match="rd3array or numpy.ndarray is required"):
         rd.FlowAccumFromProps(z)
-    for name in ("ResolveFlats", "BreachDepressions", "TerrainAttribute", "LoadGDAL", "SaveGDAL"):
+    for name in ("BreachDepressions", "TerrainAttribute", "LoadGDAL", "SaveGDAL"):
         with pytest.raises(rd.RdgpuError, match="outside"):
             getattr(rd, name)(z)
 
