@@ -201,37 +201,89 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
 }
 
 // ---- f64 weights ----------------------------------------------------------------------------
-constexpr int IW = 64, IH = 16, ILW = IW + 2, ILH = IH + 2;
-__global__ __launch_bounds__(NTHR) void k_acc_init_f64(const uint8_t *__restrict__ dirs, uint32_t *pending, int w,
-                                                       int h, uint32_t tilesX, uint32_t ntiles) {
-  __shared__ uint8_t sd[ILH * ILW];
+// Tile pre-walk for f64 weights: k_acc_tile_prewalk's scheme with the totals as doubles in LDS.  It also
+// replaces a separate inflow-counting pass: the pending words written here are what the raster-wide walk
+// expects ((inflows in total << 12) | (direction << 8) | inflows still to arrive / SRC32 / NODATA32).
+// LDS executes a wavefront's operations in order, so "add, then decrement, then (if last) read" needs no fences
+// here: the last decrementer's read comes after every other arriver's decrement, hence after their adds.
+__global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk_f64(const uint8_t *__restrict__ dirs, uint32_t *__restrict__ pending,
+                                                               double *__restrict__ acc, int w, int h, uint32_t tilesX,
+                                                               uint32_t ntiles) {
+  __shared__ uint8_t sd[ALH * ALW];
+  __shared__ uint32_t lc[AH * AW];
+  __shared__ double lt[AH * AW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
-  const int x0 = (int)(t % tilesX) * IW, y0 = (int)(t / tilesX) * IH;
-  for (int i = threadIdx.x; i < ILH * ILW; i += NTHR) {
-    const int ly = i / ILW, lx = i - ly * ILW;
+  const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
+  for (int i = threadIdx.x; i < ALH * ALW; i += NTHR) {
+    const int ly = i / ALW, lx = i - ly * ALW;
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
     sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : 255;
   }
-  __syncthreads();
-  const int lx = threadIdx.x & (IW - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
+  {
+    double wv[AH / 4];
 #pragma unroll
-  for (int j = 0; j < IH / 4; j++) {
-    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    const int o = (ly + 1) * ILW + lx + 1;
-    const uint8_t d = sd[o];
-    uint32_t p = NODATA32;
-    if (d != 255) {
-      int k = 0;
+    for (int j = 0; j < AH / 4; j++) {   // the weights: all loads in flight together
+      const int gx = x0 + lx, gy = y0 + ly0 + 4 * j;
+      wv[j] = (gx < w && gy < h) ? acc[(size_t)gy * w + gx] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < AH / 4; j++) lt[(ly0 + 4 * j) * AW + lx] = wv[j];
+  }
+  __syncthreads();
+  uint32_t srcmask = 0;
+  for (int j = 0; j < AH / 4; j++) {
+    const int ly = ly0 + 4 * j, o = (ly + 1) * ALW + lx + 1;
+    uint32_t v = NODATA32;
+    if (x0 + lx < w && y0 + ly < h && sd[o] != 255) {
+      uint32_t k = 0;
 #pragma unroll
       for (int m = 1; m <= 8; m++) {
-        const uint8_t dn = sd[o + d8dy(m) * ILW + d8dx(m)];
-        if (dn != 255 && dn == (m <= 4 ? m + 4 : m - 4)) k++;   // neighbour m flows into us (constants.hpp:65)
+        const uint8_t d = sd[o + d8dy(m) * ALW + d8dx(m)];   // halo cells outside the raster hold 255
+        if (d != 255 && d == (m <= 4 ? m + 4 : m - 4)) k++;   // neighbour m flows into us (constants.hpp:65)
       }
-      p = ((uint32_t)k << 12) | ((uint32_t)(d <= 8 ? d : 0) << 8) | (k == 0 ? SRC32 : (uint32_t)k);   // bits 12-15: inflows in total
+      v = (k << 12) | ((uint32_t)(sd[o] <= 8 ? sd[o] : 0) << 8) | k;
+      if (k == 0) srcmask |= 1u << j;
     }
-    pending[(size_t)gy * w + gx] = p;
+    lc[ly * AW + lx] = v;
+  }
+  __syncthreads();
+  for (uint32_t m = srcmask; m; m &= m - 1) {
+    const int j = __ffs((int)m) - 1;
+    int cx = lx, cy = ly0 + 4 * j;
+    double v = lt[cy * AW + cx];
+    for (;;) {
+      const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
+      bool stalled = false;
+      if (d >= 1 && d <= 8) {
+        const int tx = cx + d8dx(d), ty = cy + d8dy(d);
+        if (sd[(ty + 1) * ALW + tx + 1] != 255) {                // else: off the DEM / into NoData: dropped
+          if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
+            atomicAdd(&lt[ty * AW + tx], v);
+            const uint32_t old = atomicSub(&lc[ty * AW + tx], 1u);
+            if ((old & 0xFFu) == 1) {
+              v = __hip_atomic_load(&lt[ty * AW + tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              cx = tx; cy = ty;
+              continue;
+            }
+          } else {
+            stalled = true;                                      // ring cell or another tile: continue raster-wide
+          }
+        }
+      }
+      if (stalled) lc[cy * AW + cx] = (lc[cy * AW + cx] & ~0xFFu) | SRC32;   // complete, still has to pass its total on
+      break;
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < AH / 4; j++) {
+    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const size_t g = (size_t)gy * w + gx;
+    const uint32_t v = lc[ly * AW + lx];
+    pending[g] = v;
+    if (v != NODATA32) acc[g] = lt[ly * AW + lx];
   }
 }
 
@@ -321,8 +373,9 @@ void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, h
   const uint64_t n = (uint64_t)w * h;
   uint32_t *pending = Workspace::get().buf<uint32_t>("accum.pending", n);
   {
-    const uint32_t tilesX = (w + IW - 1) / IW, ntiles = tilesX * ((h + IH - 1) / IH);
-    RD_LAUNCH("accum.init_f64", k_acc_init_f64, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, pending, w, h, tilesX, ntiles);
+    const uint32_t tilesX = (w + AW - 1) / AW, ntiles = tilesX * ((h + AH - 1) / AH);
+    RD_LAUNCH("accum.tile_prewalk_f64", k_acc_tile_prewalk_f64, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, pending, d_acc,
+              w, h, tilesX, ntiles);
   }
   RD_LAUNCH("accum.walk_f64", k_acc_walk_f64, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR), 0, s,
             pending, d_acc, w, h);
