@@ -205,36 +205,80 @@ __global__ __launch_bounds__(NTHR) void k_mfd_init(ACC a, uint32_t *pending, uin
   }
 }
 
+// One round: every thread takes one COMPLETED cell of the round's list and pushes its total to the receivers --
+// all returning adds in flight together, one wait, then all counter decrements together: two memory round trips
+// per cell however many receivers it has.  It continues inline with the first receiver it completed; the others go
+// into the thread's LDS buffer, and at the end the block appends all buffered cells to the next round's list with
+// ONE counter add (same-address atomics serialise at ~12 ns on this chip, and full-raster flag compaction cost
+// 4 ms per round x hundreds of rounds: r01b FA_Tarboton 1.2 s at 40k x 40k).  A thread whose buffer could not
+// take a worst case (8 completions) hands its current cell over to the next round unprocessed.
+constexpr int MBUF = 20;
 template <class ACC>
-__global__ __launch_bounds__(NTHR) void k_mfd_process(ACC a, const uint32_t *__restrict__ list, uint32_t nlist,
-                                                      uint32_t *pending, double *acc, uint8_t *ready, int w, int h) {
-  const uint32_t stride = gridDim.x * NTHR;
-  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nlist; i += stride) {
-    uint64_t c = list[i];
+__global__ __launch_bounds__(NTHR) void k_mfd_round(ACC a, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    uint32_t *pending, double *acc, uint32_t *next_list,
+                                                    uint32_t *next_count, int w, int h) {
+  __shared__ uint32_t buf[MBUF][NTHR];
+  __shared__ uint32_t wtot[NTHR / 64];
+  __shared__ uint32_t bbase;
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  uint32_t nb = 0;
+  if (i < nlist) {
+    uint32_t c = list[i];
     double v = acc[c];   // completed in an earlier launch (or a source): final
     for (;;) {
-      const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+      const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
       if (x == 0 || y == 0 || x == w - 1 || y == h - 1) break;   // edge cells never pass flow on (FM_*: :49-50)
-      uint64_t cont = ~0ull;
+      if (nb + 8 > MBUF) { buf[nb++][threadIdx.x] = c; break; }
+      float p[8];
+      bool nd[8];
+#pragma unroll
+      for (int n = 1; n <= 8; n++) p[n - 1] = a.share(c, n);
+#pragma unroll
+      for (int n = 1; n <= 8; n++)   // flow_accumulation_generic.hpp:81-86
+        nd[n - 1] = (p[n - 1] > 0) ? a.nodata((uint64_t)(y + mdy(n)) * w + (x + mdx(n))) : true;
+      double prev = 0;
+#pragma unroll
+      for (int n = 1; n <= 8; n++)
+        if (!nd[n - 1]) prev += atomicAdd(&acc[(uint64_t)(y + mdy(n)) * w + (x + mdx(n))], (double)p[n - 1] * v);   // :87
+      // every add has returned (= was performed at the memory side) before any counter is decremented
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
+      uint32_t old[8];
+#pragma unroll
+      for (int n = 1; n <= 8; n++)
+        if (!nd[n - 1])
+          old[n - 1] = __hip_atomic_fetch_sub(&pending[(uint64_t)(y + mdy(n)) * w + (x + mdx(n))], 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t cont = 0xFFFFFFFFu;
 #pragma unroll
       for (int n = 1; n <= 8; n++) {
-        const float p = a.share(c, n);
-        if (!(p > 0)) continue;                                         // :81-82
-        const uint64_t r = (uint64_t)(y + mdy(n)) * w + (x + mdx(n));
-        if (a.nodata(r)) continue;                                      // :85-86
-        const double prev = atomicAdd(&acc[r], (double)p * v);          // :87, returning: done at the memory side
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
-        const uint32_t old = __hip_atomic_fetch_sub(&pending[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 1) {                                                 // r is complete
-          if (cont == ~0ull) cont = r;                                  // continue inline with the first one,
-          else ready[r] = 1;                                            // the others wait for the next round
-        }
+        if (nd[n - 1] || old[n - 1] != 1) continue;
+        const uint32_t r = (uint32_t)(y + mdy(n)) * (uint32_t)w + (uint32_t)(x + mdx(n));   // r is complete
+        if (cont == 0xFFFFFFFFu) cont = r;          // continue inline with the first one,
+        else buf[nb++][threadIdx.x] = r;            // the others are for the next round
       }
-      if (cont == ~0ull) break;
+      if (cont == 0xFFFFFFFFu) break;
       c = cont;
-      v = atomicAdd(&acc[c], 0.0);                                      // final total, read at the memory side
+      v = atomicAdd(&acc[c], 0.0);                  // final total, read at the memory side
     }
   }
+  // block-wide exclusive prefix of nb, one counter add per block
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = nb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    bbase = tot ? atomicAdd(next_count, tot) : 0;
+  }
+  __syncthreads();
+  uint32_t off = bbase + incl - nb;
+  for (int k = 0; k < wv; k++) off += wtot[k];
+  for (uint32_t k = 0; k < nb; k++) next_list[off + k] = buf[k][threadIdx.x];
 }
 
 template <class ACC>
@@ -323,16 +367,23 @@ static void mfd_accumulate(ACC a, int w, int h, double *d_acc, hipStream_t s) {
   uint32_t *counts = ws.buf<uint32_t>("mfd.counts", (size_t)nblk + 1);
   RD_LAUNCH("mfd.init", (k_mfd_init<ACC>), dim3(sgrid(n)), dim3(NTHR), 0, s, a, pending, ready, w, h);
   g_mfd_rounds = 0;
-  for (;;) {
-    RD_LAUNCH("mfd.ready_count", k_rdy_count, dim3(nblk), dim3(NTHR), 0, s, (const uint8_t *)ready, n, counts);
-    RD_LAUNCH("mfd.ready_scan", k_rdy_scan, dim3(1), dim3(1024), 0, s, counts, nblk, counts + nblk);
-    RD_HIP(hipMemcpyAsync(hw, counts + nblk, 4, hipMemcpyDeviceToHost, s));
+  // the sources, once, by flag compaction; afterwards every round appends its successor list itself
+  RD_LAUNCH("mfd.ready_count", k_rdy_count, dim3(nblk), dim3(NTHR), 0, s, (const uint8_t *)ready, n, counts);
+  RD_LAUNCH("mfd.ready_scan", k_rdy_scan, dim3(1), dim3(1024), 0, s, counts, nblk, counts + nblk);
+  RD_HIP(hipMemcpyAsync(hw, counts + nblk, 4, hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  uint32_t nl = hw[0];
+  if (nl) RD_LAUNCH("mfd.ready_fill", k_rdy_fill, dim3(nblk), dim3(NTHR), 0, s, ready, n, (const uint32_t *)counts, list);
+  uint32_t *list2 = ws.buf<uint32_t>("mfd.list2", n);
+  uint32_t *ctr = counts + nblk;
+  while (nl) {
+    RD_HIP(hipMemsetAsync(ctr, 0, sizeof(uint32_t), s));
+    RD_LAUNCH("mfd.round", (k_mfd_round<ACC>), dim3((nl + NTHR - 1) / NTHR), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl,
+              pending, d_acc, list2, ctr, w, h);
+    RD_HIP(hipMemcpyAsync(hw, ctr, 4, hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
-    const uint32_t nl = hw[0];
-    if (nl == 0) break;
-    RD_LAUNCH("mfd.ready_fill", k_rdy_fill, dim3(nblk), dim3(NTHR), 0, s, ready, n, (const uint32_t *)counts, list);
-    RD_LAUNCH("mfd.process", (k_mfd_process<ACC>), dim3(sgrid(nl)), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl, pending,
-              d_acc, ready, w, h);
+    nl = hw[0];
+    std::swap(list, list2);
     if (++g_mfd_rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flow accumulation did not terminate");
   }
   RD_LAUNCH("mfd.nodata", (k_mfd_nodata<ACC>), dim3(sgrid(n)), dim3(NTHR), 0, s, a, d_acc, n);
