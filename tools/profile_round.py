@@ -86,6 +86,12 @@ def main():
         with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
             json.dump({"size": 40000, "fill.scan_GB_per_launch": round(gb, 3),
                        "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
+        # the bench line above was printed before these passes ran: give it this round's traffic figure
+        d = json.loads(line)
+        d["roofline"]["traffic"] = round(gb, 3)
+        line = json.dumps(d)
+        with open(os.path.join(OUT, f"{tag}_fill40k_bench.json"), "w") as f:
+            f.write(line + "\n")
     print(line.strip())
 
 
