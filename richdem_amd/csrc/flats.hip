@@ -326,6 +326,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_mark_low(const uint32_t *__restri
 // ------------------------------------------------------------------------------------------
 constexpr int32_t DINF = 0x7F7F7F7F;   // memset-able "not reached"
 constexpr int RCH = 32;                // relaxation tiles are CW x RCH (the labelling tiles CW x CH)
+constexpr int HSTEPS = 4;              // stencil steps per barrier inside a relaxation tile
 constexpr int RNT = 256, RBANDS = RNT / 64;   // one wavefront per band of RCH / RBANDS rows
 constexpr int RELAX_BATCH = 8;         // relaxation rounds enqueued per host read-back
 
@@ -484,15 +485,21 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
     if (!__syncthreads_or(changed)) break;
     const int32_t up = band == 0 ? halo_up : xrow[it & 1][band - 1][1][lx];
     const int32_t dn = band == RBANDS - 1 ? halo_dn : xrow[it & 1][band + 1][0][lx];
-    int32_t m[ROWS];
-#pragma unroll
-    for (int j = 0; j < ROWS; j++) m[j] = imin(j ? d[j - 1] : up, imin(d[j], j + 1 < ROWS ? d[j + 1] : dn));
+    // HSTEPS stencil steps per barrier: the sideways exchange is all DPP (registers), so a front crosses HSTEPS
+    // columns per trip; the rows above / below the band are one trip stale, which only delays, never breaks,
+    // convergence (distances are upper bounds and only decrease)
     changed = 0;
 #pragma unroll
-    for (int j = 0; j < ROWS; j++) {
-      const int32_t side = imin(from_left(m[j], sideL[j]), from_right(m[j], sideR[j]));
-      const int32_t best = imin(m[j], side) + 1;
-      if ((elig & (1u << j)) && best < d[j]) { d[j] = best; changed = 1; }
+    for (int sub = 0; sub < HSTEPS; sub++) {
+      int32_t m[ROWS];
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) m[j] = imin(j ? d[j - 1] : up, imin(d[j], j + 1 < ROWS ? d[j + 1] : dn));
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) {
+        const int32_t side = imin(from_left(m[j], sideL[j]), from_right(m[j], sideR[j]));
+        const int32_t best = imin(m[j], side) + 1;
+        if ((elig & (1u << j)) && best < d[j]) { d[j] = best; changed = 1; }
+      }
     }
   }
   if (it == 256 && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
