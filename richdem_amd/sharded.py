@@ -204,6 +204,22 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
     if topo is None:
         raise RdgpuError("Unknown topology!")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if hasattr(block, "is_cuda") and block.is_cuda:
+        import torch
+
+        if block.dtype == torch.float64:
+            # DEMs stored as float64 (numpy's default) whose values all fit float32 -- on EVERY rank -- are filled
+            # through the float32 engine, exactly (comparisons and copies only).  Anything else would need globally
+            # consistent value ranks across the shards, which the shard engine does not build.
+            f32 = block.to(torch.float32)
+            lossless = (f32.to(torch.float64) == block).all().to(torch.int32).reshape(1)
+            dist.all_reduce(lossless, op=dist.ReduceOp.MIN, group=group)
+            if int(lossless.item()) == 0:
+                raise RdgpuError("fill_depressions_sharded: float64 DEM with values that do not fit float32 "
+                                 "(the row-block shard engine takes 32-bit element types)")
+            fill_depressions_sharded(f32, topology, group, engine, comm_device)
+            block.copy_(f32.to(torch.float64))
+            return None
     eng = engine if engine is not None else GpuShardEngine()
     if comm_device is None:
         comm_device = block.device if hasattr(block, "device") else "cpu"
