@@ -58,6 +58,8 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
         out = np.ascontiguousarray(out)
     h, w = out.shape
     if shards > 1:   # the multi-GPU row-block protocol, shard after shard on one GPU
+        if _suffix(out.dtype) in ("f64", "i64", "u64"):
+            raise RdgpuError("FillDepressions(shards=...): the row-block shard engine takes the 32-bit element types")
         fn = getattr(lib(), f"rdgpu_fill_sharded_{_suffix(out.dtype)}")
         check(fn(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology), int(shards)), "rdgpu_fill_sharded")
     else:

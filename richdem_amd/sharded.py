@@ -42,7 +42,8 @@ class GpuShardEngine:
 
         if not (block.is_cuda and block.dim() == 2 and block.is_contiguous()):
             raise RdgpuError("GpuShardEngine: expected a contiguous 2-D tensor on the GPU")
-        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32"}.get(block.dtype)
+        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
+               getattr(torch, "uint16", None): "u16", getattr(torch, "uint32", None): "u32"}.get(block.dtype)
         if suf is None:
             raise RdgpuError(f"GpuShardEngine: unsupported dtype {block.dtype}")
         h, w = block.shape
@@ -70,7 +71,8 @@ class GpuShardEngine:
 
         if not (block.is_cuda and block.dim() == 2 and block.is_contiguous()):
             raise RdgpuError("GpuShardEngine: expected a contiguous 2-D tensor on the GPU")
-        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32"}.get(block.dtype)
+        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
+               getattr(torch, "uint16", None): "u16", getattr(torch, "uint32", None): "u32"}.get(block.dtype)
         if suf is None:
             raise RdgpuError(f"GpuShardEngine: unsupported dtype {block.dtype}")
         h, w = block.shape
@@ -351,12 +353,12 @@ class GpuFlatShard:
 
         if not (ext_block.is_cuda and ext_block.dim() == 2 and ext_block.is_contiguous()):
             raise RdgpuError("GpuFlatShard: expected a contiguous 2-D tensor on the GPU")
-        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
-               torch.float64: "f64"}.get(ext_block.dtype)
+        suf = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32", torch.float64: "f64",
+               getattr(torch, "uint16", None): "u16", getattr(torch, "uint32", None): "u32"}.get(ext_block.dtype)
         if suf is None:
             raise RdgpuError(f"GpuFlatShard: unsupported dtype {ext_block.dtype}")
         ct = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "i32": ctypes.c_int32, "f32": ctypes.c_float,
-              "f64": ctypes.c_double}[suf]
+              "f64": ctypes.c_double, "u16": ctypes.c_uint16, "u32": ctypes.c_uint32}[suf]
         self._rows, self._w = ext_block.shape
         self._own = self._rows - ghost_top - ghost_bottom
         self._keep = ext_block
