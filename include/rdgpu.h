@@ -68,6 +68,20 @@ int rdgpu_fill_dev_f64(double *d_dem, int width, int height, int topology, void 
 int rdgpu_fill_dev_i64(int64_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, void *hip_stream);
 
+/* pit_mask<topology>(const Array2D<T>&, Array2D<uint8_t>&) (depressions/Barnes2014.hpp:593-676,
+ * apps/rd_depressions_mask.cpp:16): 1 = the cell lies in a depression (the fill would raise it), 0 = not,
+ * 3 = NoData.  The DEM is not modified. */
+#define RDGPU_DECL_PITMASK(SUF, T)                                                                        \
+  int rdgpu_pit_mask_##SUF(const T *dem, T nodata, int width, int height, int topology, uint8_t *mask);   \
+  int rdgpu_pit_mask_dev_##SUF(const T *d_dem, T nodata, int width, int height, int topology, uint8_t *d_mask, void *hip_stream);
+RDGPU_DECL_PITMASK(u8, uint8_t)
+RDGPU_DECL_PITMASK(i16, int16_t)
+RDGPU_DECL_PITMASK(u16, uint16_t)
+RDGPU_DECL_PITMASK(i32, int32_t)
+RDGPU_DECL_PITMASK(u32, uint32_t)
+RDGPU_DECL_PITMASK(f32, float)
+#undef RDGPU_DECL_PITMASK
+
 /* Statistics of the last fill on this process (for DESIGN.md / bench.py reporting). */
 typedef struct rdgpu_fill_stats {
   uint64_t cells;       /* width*height                                   */

@@ -85,6 +85,18 @@ int c_fa_mfd(const T *, T, int, int, int, double, double *) { unsupported("FA_Ho
 template <class T>
 int c_rfe(T *, T, int, int) { unsupported("ResolveFlatsEpsilon"); }
 
+#define RDGPU_SHIM_PITMASK(SUF, T) \
+  inline int c_pitmask(const T *p, T nd, int w, int h, int topo, uint8_t *m) { return rdgpu_pit_mask_##SUF(p, nd, w, h, topo, m); }
+RDGPU_SHIM_PITMASK(u8, uint8_t)
+RDGPU_SHIM_PITMASK(i16, int16_t)
+RDGPU_SHIM_PITMASK(u16, uint16_t)
+RDGPU_SHIM_PITMASK(i32, int32_t)
+RDGPU_SHIM_PITMASK(u32, uint32_t)
+RDGPU_SHIM_PITMASK(f32, float)
+#undef RDGPU_SHIM_PITMASK
+template <class T>
+int c_pitmask(const T *, T, int, int, int, uint8_t *) { unsupported("pit_mask"); }
+
 inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
 inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
 template <class T>
@@ -250,6 +262,19 @@ template <class E, class G>
 void FA_OCallaghanD4(const E &elevations, G &accum) { FA_D4(elevations, accum); }
 template <class E, class G>
 void FA_OCallaghanD8(const E &elevations, G &accum) { FA_D8(elevations, accum); }
+
+// richdem::pit_mask<topo>(const Array2D<T>&, Array2D<uint8_t>&)   depressions/Barnes2014.hpp:593-676
+template <auto topo, class E, class M>
+void pit_mask(const E &elevations, M &mask) {
+  using T = detail::elem_t<E>;
+  static_assert(std::is_same<detail::elem_t<M>, uint8_t>::value, "pit_mask: the mask must be Array2D<uint8_t>");
+  mask.resize(elevations.width(), elevations.height());   // :619
+  mask.setNoData(3);                                       // :620
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_pitmask((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(),
+                                  detail::topology_code<topo>(), mask.data()),
+                "pit_mask");
+}
 
 // richdem::ResolveFlatsEpsilon(Array2D<T>&)   flats/flats.hpp:21-28 (pywrapper.hpp:37 rdResolveFlatsEpsilon)
 template <class E>

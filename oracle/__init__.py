@@ -204,6 +204,15 @@ class _Backend:
         self._fn(f"resolve_flats_epsilon_{s}")(_ptr(dem), _CT[s](nodata), w, h)
         return dem
 
+    def pit_mask(self, dem: np.ndarray, nodata, topo: int = 8) -> np.ndarray:
+        """pit_mask<topo> (depressions/Barnes2014.hpp:593-676): 1 in a depression, 0 not, 3 NoData."""
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        out = np.empty((h, w), np.uint8)
+        self._fn(f"pit_mask_{s}")(_ptr(dem), _CT[s](nodata), w, h, int(topo), _ptr(out))
+        return out
+
     def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)
         h, w = dem.shape

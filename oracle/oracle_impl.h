@@ -522,6 +522,19 @@ void FN(orc_resolve_flats_epsilon)(T *dem, T nodata, int w, int h) {
 }
 #undef ORC_NEXT_UP
 
+
+/* pit_mask<topo>, depressions/Barnes2014.hpp:593-676: the Priority-Flood of orc_fill with a mask instead of a raised
+ * DEM: a cell is 1 iff it is strictly below the level it is reached at (:653-656), i.e. iff the fill raises it;
+ * cells reached at their own level or above stay / become 0 (:651, :659); every NoData cell ends as 3 (:668-669). */
+void FN(orc_pit_mask)(const T *dem, T nodata, int w, int h, int topo, uint8_t *mask) {
+  size_t N = (size_t)w * h;
+  T *filled = (T *)malloc(N * sizeof(T));
+  memcpy(filled, dem, N * sizeof(T));
+  FN(orc_fill)(filled, w, h, topo);
+  for (size_t i = 0; i < N; i++) mask[i] = dem[i] == nodata ? 3 : (filled[i] > dem[i] ? 1 : 0);
+  free(filled);
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

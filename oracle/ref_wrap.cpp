@@ -279,3 +279,23 @@ REF_RFE_API(i32, int32_t)
 REF_RFE_API(u32, uint32_t)
 REF_RFE_API(f32, float)
 REF_RFE_API(f64, double)
+
+// pit_mask<topo>, depressions/Barnes2014.hpp:593-676 (apps/rd_depressions_mask.cpp)
+template <class T>
+void ref_pit_mask(const T *dem, T nodata, int w, int h, int topo, uint8_t *out) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  a.setNoData(nodata);
+  Array2D<uint8_t> m;
+  if (topo == 8) pit_mask<Topology::D8>(a, m);
+  else pit_mask<Topology::D4>(a, m);
+  std::memcpy(out, m.data(), (size_t)w * h);
+}
+#define REF_PM_API(SUF, T) \
+  extern "C" void ref_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topo, uint8_t *out) { ref_pit_mask<T>(dem, nodata, w, h, topo, out); }
+REF_PM_API(u8, uint8_t)
+REF_PM_API(i16, int16_t)
+REF_PM_API(u16, uint16_t)
+REF_PM_API(i32, int32_t)
+REF_PM_API(u32, uint32_t)
+REF_PM_API(f32, float)
+REF_PM_API(f64, double)

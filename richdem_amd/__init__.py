@@ -37,6 +37,7 @@ from .pyrichdem import (  # noqa: F401
     SaveNative,
 )
 from .api import (  # noqa: F401
+    pit_mask,
     dinf_flow_directions,
     d8_flow_directions,
     d8_flow_accum,

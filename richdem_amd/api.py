@@ -68,6 +68,22 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     return None if in_place else out
 
 
+def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
+    """uint8 mask of the cells lying in depressions: 1 = the fill would raise the cell, 0 = not, 3 = NoData
+    (reference pit_mask<topo>, depressions/Barnes2014.hpp:593-676; apps/rd_depressions_mask.cpp)."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("pit_mask: expected a 2-D numpy array")
+    dem = np.ascontiguousarray(dem)
+    s = _suffix(dem.dtype)
+    if s in ("f64", "i64", "u64"):
+        raise RdgpuError("pit_mask: 64-bit element types are not provided")
+    h, w = dem.shape
+    out = np.empty((h, w), np.uint8)
+    check(getattr(lib(), f"rdgpu_pit_mask_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, _topo(topology),
+                                                out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_pit_mask")
+    return out
+
+
 def _elev(dem, who):
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError(f"{who}: expected a 2-D numpy array")

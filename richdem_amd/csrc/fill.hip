@@ -994,6 +994,53 @@ static void check_fill_args(const void *p, int w, int h, int topology) {
   if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: topology must be 8 or 4");  // depressions.hpp:19-20
 }
 
+// pit_mask<topo>(elevations, pit_mask) (reference depressions/Barnes2014.hpp:593-676; apps/rd_depressions_mask.cpp):
+// the same flood, recording which cells it would raise instead of raising them.  1 = the cell lies strictly below the
+// level it is reached at (W > z), 0 = not in a pit, 3 = NoData (every NoData cell, :668-669).
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_pit_mask(const T *__restrict__ z, T nodata, const uint32_t *__restrict__ lab,
+                                                   const uint32_t *__restrict__ acc, uint8_t *__restrict__ mask, uint32_t n,
+                                                   uint32_t B, int trivial) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
+    const uint32_t c = (uint32_t)c64;
+    const T e = z[c];
+    uint8_t m = 0;
+    if (e == nodata) m = 3;
+    else if (!trivial) {
+      const uint32_t b = lab[c];
+      if (b != B && acc[b] > Key32<T>::to(e)) m = 1;
+    }
+    mask[c] = m;
+  }
+}
+
+template <class T>
+static void pit_mask_device(const T *d_z, T nodata, int w, int h, int topology, uint8_t *d_mask, hipStream_t s) {
+  check_fill_args(d_z, w, h, topology);
+  if (!d_mask) throw Error(RDGPU_ERR_ARG, "rdgpu_pit_mask: null mask pointer");
+  FillBuffers fb;
+  BufAlloc ws_alloc{false, nullptr};
+  if (topology == 8) fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s);
+  else fill_local_phase<T, 4>(d_z, w, h, 0, 0, ws_alloc, fb, s);
+  const uint32_t n = (uint32_t)((uint64_t)w * h);
+  RD_LAUNCH("fill.pit_mask", (k_pit_mask<T>), dim3(std::min(cdiv(n, NTHR), 256u * 32u)), dim3(NTHR), 0, s, d_z, nodata,
+            (const uint32_t *)fb.lab, (const uint32_t *)fb.acc, d_mask, n, fb.B, fb.trivial ? 1 : 0);
+}
+
+template <class T>
+static void pit_mask_host(const T *dem, T nodata, int w, int h, int topology, uint8_t *mask) {
+  check_fill_args(dem, w, h, topology);
+  if (!mask) throw Error(RDGPU_ERR_ARG, "rdgpu_pit_mask: null mask pointer");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  uint8_t *dm = Workspace::get().buf<uint8_t>("host.dirs", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  pit_mask_device<T>(d, nodata, w, h, topology, dm, nullptr);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  RD_HIP(hipMemcpy(mask, dm, n, hipMemcpyDeviceToHost));
+}
+
 template <class T>
 static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
   check_fill_args(d_z, w, h, topology);
@@ -1324,6 +1371,13 @@ using namespace rdgpu;
   }                                                                                               \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
     return guarded([&] { fill_device<T>(d_dem, w, h, topology, (hipStream_t)stream); });          \
+  }                                                                                               \
+  extern "C" int rdgpu_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topology, uint8_t *mask) { \
+    return guarded([&] { pit_mask_host<T>(dem, nodata, w, h, topology, mask); });                 \
+  }                                                                                               \
+  extern "C" int rdgpu_pit_mask_dev_##SUF(const T *d_dem, T nodata, int w, int h, int topology, uint8_t *d_mask, \
+                                          void *stream) {                                         \
+    return guarded([&] { pit_mask_device<T>(d_dem, nodata, w, h, topology, d_mask, (hipStream_t)stream); }); \
   }                                                                                               \
   extern "C" int rdgpu_fill_shard_begin_##SUF(T *d_dem, int w, int h, int topology, int open_top, \
                                               int open_bottom, void *stream, rdgpu_fill_shard **out) { \

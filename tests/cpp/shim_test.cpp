@@ -33,6 +33,7 @@ void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
 void orc_d8_flow_accum_i32(const uint8_t *, uint8_t, int, int, int32_t *);
 void orc_fa_mfd_f32(const float *dem, float nodata, int w, int h, int method, double xparam, double *accum);
 void orc_resolve_flats_epsilon_f32(float *dem, float nodata, int w, int h);
+void orc_pit_mask_f32(const float *dem, float nodata, int w, int h, int topo, uint8_t *mask);
 void orc_fa_d8_f32(const float *, float, int, int, double *);
 }
 
@@ -177,6 +178,15 @@ int main() {
     orc_fill_f64(eg.data(), w, h, 8);
     rdgpu::FillDepressions<Topo::D8>(g);
     EXPECT(std::memcmp(g.data(), eg.data(), eg.size() * 8) == 0);
+  }
+  // rd_depressions_mask: pit_mask<Topology::D8>(elevation, mask)
+  {
+    Arr<uint8_t> mask;
+    rdgpu::pit_mask<Topo::D8>(dem, mask);
+    std::vector<uint8_t> e((size_t)w * h);
+    orc_pit_mask_f32(dem.data(), -9999.0f, w, h, 8, e.data());
+    EXPECT(mask.width() == w && mask.height() == h && mask.noData() == 3);
+    EXPECT(std::memcmp(mask.data(), e.data(), e.size()) == 0);
   }
   // rd.ResolveFlats: ResolveFlatsEpsilon(Array2D<T>&) on the filled DEM
   {

@@ -304,3 +304,27 @@ def test_very_long_tile_chains_fallback(rd, orc):
     flat = np.zeros((5, 40000), np.int32)                       # one huge flat: chains along whole rows
     flat[2, 1:-1] = -3
     assert np.array_equal(rd.FillDepressions(flat), orc.port.fill(flat))
+
+
+def test_pit_mask(rd, orc):
+    """pit_mask<topo> (depressions/Barnes2014.hpp:593-676, apps/rd_depressions_mask.cpp): 1 where the fill raises
+    the cell, 3 on NoData, 0 elsewhere -- for both topologies and every 32-bit-key element type."""
+    rng = np.random.default_rng(8)
+    z = fractal_dem(260, 190, seed=33)
+    cases = [(z, np.float32(-9999)), (fractal_dem_int(211, 157, 34, 0.1), np.int32(-9999)),
+             (np.clip(np.floor((z - z.min()) * 0.2), 0, 255).astype(np.uint8), np.uint8(3)),
+             (rng.integers(0, 4, (50, 60)).astype(np.int16), np.int16(2)),
+             (rng.integers(0, 9, (33, 70)).astype(np.uint16), np.uint16(0)),
+             (np.zeros((1, 7), np.float32), np.float32(-1)), (np.zeros((5, 2), np.uint32), np.uint32(9))]
+    for dem, nd in cases:
+        d = dem.copy()
+        if d.dtype == np.float32 and d.shape[0] > 40:
+            d[20:24, 30:40] = nd
+            d[0, 5] = nd
+        for topo, name in ((8, "D8"), (4, "D4")):
+            got = rd.pit_mask(d, nd, name)
+            assert np.array_equal(got, orc.port.pit_mask(d, nd, topo)), (d.dtype, d.shape, name)
+            if d.shape[0] > 2 and d.shape[1] > 2:
+                assert np.array_equal(got == 1, (rd.FillDepressions(d, topology=name) != d) & (d != nd))
+    with pytest.raises(rd.RdgpuError):
+        rd.pit_mask(np.zeros((4, 4), np.float64), -1.0)

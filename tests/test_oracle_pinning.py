@@ -84,6 +84,8 @@ def test_port_matches_live_reference(orc, seed, scale, dtype):
         assert np.array_equal(P.fa_d8(src, nd, wts), R.fa_d8(src, nd, wts))
         if dtype not in (np.int64, np.uint64):
             assert np.array_equal(P.resolve_flats_epsilon(src, nd), R.resolve_flats_epsilon(src, nd))
+            assert np.array_equal(P.pit_mask(src, nd, 8), R.pit_mask(src, nd, 8))
+            assert np.array_equal(P.pit_mask(src, nd, 4), R.pit_mask(src, nd, 4))
             for method, x in (("Holmgren", 2.0), ("Holmgren", 0.7), ("Freeman", 1.1), ("Quinn", 1.0), ("D4", 1.0)):
                 assert np.array_equal(P.fm_mfd(src, nd, method, x), R.fm_mfd(src, nd, method, x)), (method, x)
                 assert np.array_equal(P.fa_mfd(src, nd, method, x), R.fa_mfd(src, nd, method, x)), (method, x)
