@@ -658,6 +658,80 @@ static void launch_ccl_border(const T *d_z, uint32_t *L, int w, int h, hipStream
             tilesX, ntiles);
 }
 
+// ---- the two edge lists (and the NO_FLOW count) in ONE count pass and ONE fill pass over the flag raster ----
+__global__ __launch_bounds__(NTHR) void k_flag_count3(const uint8_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ cl,
+                                                      uint32_t *__restrict__ cn, uint32_t *__restrict__ ch) {
+  __shared__ uint32_t ws[3][NTHR / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CPB;
+  uint32_t a = 0, b = 0, c = 0;
+#pragma unroll 4
+  for (int j = 0; j < CPB / NTHR; j++) {
+    const uint64_t i = base + (uint64_t)j * NTHR + threadIdx.x;
+    const uint8_t f = i < n ? flags[i] : 0;
+    a += (f & F_LOW) != 0; b += (f & F_NOFLOW) != 0; c += (f & F_HIGH) != 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = a; ws[1][threadIdx.x >> 6] = b; ws[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cl[blockIdx.x] = ws[0][0] + ws[0][1] + ws[0][2] + ws[0][3];
+    cn[blockIdx.x] = ws[1][0] + ws[1][1] + ws[1][2] + ws[1][3];
+    ch[blockIdx.x] = ws[2][0] + ws[2][1] + ws[2][2] + ws[2][3];
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_flag_fill2(const uint8_t *__restrict__ flags, uint64_t n,
+                                                     const uint32_t *__restrict__ offl, const uint32_t *__restrict__ offh,
+                                                     uint32_t *__restrict__ outl, uint32_t *__restrict__ outh) {
+  __shared__ uint32_t ws[2][NTHR / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * CPB;
+  uint32_t runl = offl[blockIdx.x], runh = offh[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = 0; j < CPB / NTHR; j++) {
+    const uint64_t c = base + (uint64_t)j * NTHR + threadIdx.x;
+    const uint8_t f = c < n ? flags[c] : 0;
+    const bool hl = (f & F_LOW) != 0, hh = (f & F_HIGH) != 0;
+    const unsigned long long bl = __ballot(hl), bh = __ballot(hh);
+    if (lane == 0) { ws[0][wv] = __popcll(bl); ws[1][wv] = __popcll(bh); }
+    __syncthreads();
+    uint32_t wl = 0, tl = 0, wh = 0, th = 0;
+#pragma unroll
+    for (int k = 0; k < NTHR / 64; k++) {
+      if (k < wv) { wl += ws[0][k]; wh += ws[1][k]; }
+      tl += ws[0][k]; th += ws[1][k];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (hl) outl[runl + wl + __popcll(bl & below)] = (uint32_t)c;
+    if (hh) outh[runh + wh + __popcll(bh & below)] = (uint32_t)c;
+    runl += tl; runh += th;
+    __syncthreads();
+  }
+}
+
+static void compact_edges(const uint8_t *flags, uint64_t n, uint32_t **low, uint32_t *nlow, uint32_t **high, uint32_t *nhigh,
+                          uint32_t *nnoflow, hipStream_t s) {
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  const uint32_t nblk = (uint32_t)((n + CPB - 1) / CPB);
+  uint32_t *counts = ws.buf<uint32_t>("flats.counts3", 3 * ((size_t)nblk + 1));
+  uint32_t *cl = counts, *cn = counts + (nblk + 1), *ch = counts + 2 * ((size_t)nblk + 1);
+  RD_LAUNCH("flats.flag_count", k_flag_count3, dim3(nblk), dim3(NTHR), 0, s, flags, n, cl, cn, ch);
+  RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, cl, nblk, cl + nblk);
+  RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, cn, nblk, cn + nblk);
+  RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, ch, nblk, ch + nblk);
+  RD_HIP(hipMemcpyAsync(hw, cl + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipMemcpyAsync(hw + 1, cn + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipMemcpyAsync(hw + 2, ch + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  *nlow = hw[0]; *nnoflow = hw[1]; *nhigh = hw[2];
+  *low = *high = nullptr;
+  if (*nlow == 0) return;   // nothing will be resolved: the lists are not needed
+  *low = ws.buf<uint32_t>("flats.low", *nlow);
+  *high = ws.buf<uint32_t>("flats.highall", std::max<uint32_t>(*nhigh, 1u));
+  RD_LAUNCH("flats.flag_fill", k_flag_fill2, dim3(nblk), dim3(NTHR), 0, s, flags, n, (const uint32_t *)cl, (const uint32_t *)ch,
+            *low, *high);
+}
+
 // list of the cells with flags & mask, in index order; returns the count
 static uint32_t compact_flags(const uint8_t *flags, uint8_t mask, uint64_t n, const char *name, uint32_t **out,
                               hipStream_t s) {
@@ -741,19 +815,13 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
 
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   launch_classify<T>(d_z, d_dirs, w, h, flags, s);
-  uint32_t *low = nullptr, *dummy = nullptr;
-  const uint32_t nlow = compact_flags(flags, F_LOW, n, "flats.low", &low, s);
+  uint32_t *low = nullptr, *highall = nullptr;
+  uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
+  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s);
   g_fstats.low_edges = nlow;
-  if (nlow == 0) {   // no flats, or none with an outlet (:475-481)
-    g_fstats.noflow_cells = compact_flags(flags, F_NOFLOW, n, nullptr, &dummy, s);
-    g_fstats.high_edges = compact_flags(flags, F_HIGH, n, nullptr, &dummy, s);
-    return;
-  }
-  const uint32_t nnoflow = compact_flags(flags, F_NOFLOW, n, nullptr, &dummy, s);
   g_fstats.noflow_cells = nnoflow;
-  uint32_t *highall = nullptr;
-  const uint32_t nhigh_all = compact_flags(flags, F_HIGH, n, "flats.highall", &highall, s);
   g_fstats.high_edges = nhigh_all;
+  if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
 
   uint32_t *L = ws.buf<uint32_t>("flats.L", n);
   int32_t *fh = ws.buf<int32_t>("flats.fh", n);
