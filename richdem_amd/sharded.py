@@ -256,6 +256,8 @@ def bench_sharded(args, rank: int, world: int) -> None:
     for _ in range(args.warmup):
         scratch.copy_(Z)
         fill_depressions_sharded(scratch)
+    rd.profile_reset()
+    rd.profile_enable(True)    # HIP events around every kernel of this rank (as in the 1-GPU bench)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -266,6 +268,8 @@ def bench_sharded(args, rank: int, world: int) -> None:
     dist.barrier()
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    rd.profile_enable(False)
+    prof, stats = rd.profile_totals(), rd.fill_stats()
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     changed = (bufs[0] != Z).sum().to(torch.float64)
     dist.all_reduce(changed)
@@ -295,6 +299,16 @@ def bench_sharded(args, rank: int, world: int) -> None:
                 "parallelism": f"row-block x{world}; 1 all-gather of cut rows + spillover graph per fill",
             },
         }
+        k_ms, k_n = prof.get("fill.scan", (0.0, 0))
+        if k_n:   # the dominant kernel on rank 0's row block: algorithmic bytes of the cells its launches visited
+            visited = stats["scan_tiles"] * stats["tile_cells"]
+            achieved = visited * 8 / (k_ms / args.steps / 1e3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "fill.scan", "achieved": round(achieved, 1), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                               "avg_launch_ms": round(k_ms / k_n, 4), "launches_per_step": k_n / args.steps,
+                               "alg_GB_per_launch": round(visited * 8 / (k_n / args.steps) / 1e9, 3), "scope": "rank 0, per GPU"}
+            out["kernels_ms_per_step_rank0"] = {k: round(v[0] / args.steps, 3)
+                                                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:10]}
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
