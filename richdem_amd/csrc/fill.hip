@@ -754,31 +754,70 @@ __device__ __forceinline__ uint32_t shard_label(uint32_t c, const uint32_t *__re
   return l == B ? NO_TID : tid[l];   // NO_TID doubles as "the outside" in exported edges
 }
 
-// open-addressing table of (min(la,lb) << 32 | max(la,lb)) + 1 -> lowest pass key
+// open-addressing table of (min(la,lb) << 32 | max(la,lb)) + 1 -> lowest pass key.
+// One 64x32 tile per block: the watershed label (three dependent gathers: basin -> component -> terminal id) and
+// the locally filled level of every cell of the tile and of its forward halo are fetched ONCE, in three batches,
+// into LDS; the pair tests then run on LDS and only cells on a watershed boundary touch the global table.
+constexpr int EW = 64, EH = 32, ELW = EW + 2, ELH = EH + 1;
+constexpr uint32_t E_INVALID = 0xFFFFFFFEu;   // outside the raster: pairs with it are skipped
 template <class T, int TOPO>
 __global__ __launch_bounds__(NTHR) void k_shard_edges(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                       const uint32_t *__restrict__ cur, const uint32_t *__restrict__ acc,
                                                       const uint32_t *__restrict__ tid, uint32_t B, int w, int h,
                                                       unsigned long long *hkeys, uint32_t *hvals, uint32_t hmask,
-                                                      uint32_t *overflow) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
-    const uint32_t c = (uint32_t)c64;
-    const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
-    const uint32_t la = shard_label(c, lab, cur, tid, B);
-    uint32_t wa = Key32<T>::to(z[c]);
-    { const uint32_t b = lab[c]; if (b != B && acc[b] > wa) wa = acc[b]; }
+                                                      uint32_t *overflow, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint32_t sl[ELH * ELW];
+  __shared__ uint32_t sw[ELH * ELW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * EW, y0 = (int)(t / tilesX) * EH;
+  constexpr int IPT = (ELH * ELW + NTHR - 1) / NTHR;
+  uint32_t lv[IPT], kv[IPT];
+  bool ok[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {   // batch 1: basin label and elevation key
+    const int i = threadIdx.x + r * NTHR;
+    const int ly = i / ELW, lx = i - ly * ELW;
+    const int gx = x0 - 1 + lx, gy = y0 + ly;
+    ok[r] = i < ELH * ELW && gx >= 0 && gx < w && gy < h;
+    lv[r] = B;
+    kv[r] = 0;
+    if (ok[r]) { lv[r] = lab[(size_t)gy * w + gx]; kv[r] = Key32<T>::to(z[(size_t)gy * w + gx]); }
+  }
+  uint32_t cv[IPT], av[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {   // batch 2: component and filled level (label B = the outside: cur[B], acc[B] exist)
+    cv[r] = cur[lv[r]] & ~CLOSED;
+    av[r] = acc[lv[r]];
+  }
+  uint32_t tv[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) tv[r] = cv[r] == B ? NO_TID : tid[cv[r]];   // batch 3: NO_TID doubles as "the outside"
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {
+    const int i = threadIdx.x + r * NTHR;
+    if (i < ELH * ELW) {
+      sl[i] = ok[r] ? tv[r] : E_INVALID;
+      sw[i] = (lv[r] != B && av[r] > kv[r]) ? av[r] : kv[r];
+    }
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (EW - 1), ly0 = threadIdx.x >> 6;
+#pragma unroll 2
+  for (int j = 0; j < EH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int o = ly * ELW + lx + 1;
+    const uint32_t la = sl[o];
+    if (la == E_INVALID) continue;
+    const uint32_t wa = sw[o];
     // forward neighbours only (E, SW, S, SE): every adjacent pair is seen once
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (TOPO == 4 && (k == 1 || k == 3)) continue;
-      const int nx = x + (k == 0 ? 1 : k == 1 ? -1 : k == 2 ? 0 : 1), ny = y + (k == 0 ? 0 : 1);
-      if (nx < 0 || nx >= w || ny >= h) continue;
-      const uint32_t d = (uint32_t)ny * (uint32_t)w + (uint32_t)nx;
-      const uint32_t lb = shard_label(d, lab, cur, tid, B);
-      if (lb == la) continue;
-      uint32_t wb = Key32<T>::to(z[d]);
-      { const uint32_t b = lab[d]; if (b != B && acc[b] > wb) wb = acc[b]; }
+      const int q = o + (k == 0 ? 1 : k == 1 ? ELW - 1 : k == 2 ? ELW : ELW + 1);
+      const uint32_t lb = sl[q];
+      if (lb == la || lb == E_INVALID) continue;
+      const uint32_t wb = sw[q];
       const uint32_t pass = wa > wb ? wa : wb;
       const uint32_t lo = la < lb ? la : lb, hi = la < lb ? lb : la;
       const unsigned long long key = (((unsigned long long)lo << 32) | hi) + 1ull;   // never 0 (lo != hi)
@@ -788,7 +827,7 @@ __global__ __launch_bounds__(NTHR) void k_shard_edges(const T *__restrict__ z, c
         unsigned long long cur_k = __hip_atomic_load(&hkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur_k == 0) cur_k = atomicCAS(&hkeys[slot], 0ull, key);
         if (cur_k == 0 || cur_k == key) {
-          atomicMin(&hvals[slot], pass);
+          if (__hip_atomic_load(&hvals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pass) atomicMin(&hvals[slot], pass);
           break;
         }
         slot = (slot + 1) & hmask;
@@ -796,6 +835,7 @@ __global__ __launch_bounds__(NTHR) void k_shard_edges(const T *__restrict__ z, c
     }
   }
 }
+
 
 __global__ __launch_bounds__(NTHR) void k_shard_edges_compact(const unsigned long long *__restrict__ hkeys,
                                                               const uint32_t *__restrict__ hvals, uint32_t hsize,
@@ -1112,10 +1152,11 @@ static void shard_edges(rdgpu_fill_shard *sh) {
     RD_HIP(hipMemsetAsync(hkeys, 0, (size_t)hsize * 8, s));
     RD_HIP(hipMemsetAsync(hvals, 0xFF, (size_t)hsize * 4, s));
     RD_HIP(hipMemsetAsync(ctr, 0, 16, s));
-    const uint64_t n = (uint64_t)w * h;
-    RD_LAUNCH("shard.edges", (k_shard_edges<T, TOPO>), dim3(std::min(cdiv(n, NTHR), 256u * 32u)), dim3(NTHR), 0, s,
+    const uint32_t etx = cdiv(w, EW), ent = etx * cdiv(h, EH);
+    RD_LAUNCH("shard.edges", (k_shard_edges<T, TOPO>), dim3(xcd_grid(ent)), dim3(NTHR), 0, s,
               (const T *)sh->d_dem, (const uint32_t *)sh->fb.lab, (const uint32_t *)sh->fb.cur,
-              (const uint32_t *)sh->fb.acc, (const uint32_t *)sh->fb.tid, sh->fb.B, w, h, hkeys, hvals, hsize - 1, ctr);
+              (const uint32_t *)sh->fb.acc, (const uint32_t *)sh->fb.tid, sh->fb.B, w, h, hkeys, hvals, hsize - 1, ctr, etx,
+              ent);
     uint32_t *edges = (uint32_t *)nullptr;
     {
       void *p = nullptr;
