@@ -885,8 +885,10 @@ struct FillBuffers {
 struct BufAlloc {   // where persistent buffers come from: the shared workspace, or owned hipMalloc
   bool owned;
   std::vector<void *> *owned_list;
+  bool shard_ws = false;   // workspace buffers under their own names ("shard." + name): the one cached shard
   template <class U>
   U *get(const char *name, size_t count) {
+    if (!owned && shard_ws) return Workspace::get().buf<U>((std::string("shard.") + name).c_str(), count);
     if (!owned) return Workspace::get().buf<U>(name, count);
     void *p = nullptr;
     RD_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(U)));
@@ -1114,6 +1116,7 @@ struct rdgpu_fill_shard {
   hipStream_t stream = nullptr;
   rdgpu::FillBuffers fb;
   std::vector<void *> owned;
+  bool cached = false;   // its buffers are the process-wide cached shard workspace (see shard_begin)
   uint32_t *d_edges = nullptr;
   uint32_t nedges = 0;
   rdgpu_fill_stats stats{};
@@ -1130,9 +1133,16 @@ template <> struct DtypeCode<int32_t> { static constexpr int v = 3; };
 template <> struct DtypeCode<uint32_t> { static constexpr int v = 4; };
 template <> struct DtypeCode<float> { static constexpr int v = 5; };
 
+// One shard per process is the multi-GPU case (one rank, one GPU, one row block), and there a fill must not pay
+// hipMalloc / hipFree of its ~5 B/cell of tables on every call: the first live shard keeps its buffers in the
+// grow-only workspace (under names of their own); shards begun while it is alive own theirs (tests and tools
+// drive many shards from one process).
+static bool g_cached_shard_live = false;
+
 static void shard_free(rdgpu_fill_shard *sh) {
   if (!sh) return;
   for (void *p : sh->owned) (void)hipFree(p);
+  if (sh->cached) g_cached_shard_live = false;
   delete sh;
 }
 
@@ -1158,7 +1168,9 @@ static void shard_edges(rdgpu_fill_shard *sh) {
               (const uint32_t *)sh->fb.acc, (const uint32_t *)sh->fb.tid, sh->fb.B, w, h, hkeys, hvals, hsize - 1, ctr, etx,
               ent);
     uint32_t *edges = (uint32_t *)nullptr;
-    {
+    if (sh->cached) {
+      edges = ws.buf<uint32_t>("shard.edges", (size_t)hsize * 3);
+    } else {
       void *p = nullptr;
       RD_HIP(hipMalloc(&p, (size_t)hsize * 12));
       sh->owned.push_back(p);
@@ -1190,7 +1202,9 @@ static rdgpu_fill_shard *shard_begin(T *d_dem, int w, int h, int topology, int o
     sh->w = w; sh->h = h; sh->topology = topology;
     sh->open_top = open_top ? 1 : 0; sh->open_bottom = open_bottom ? 1 : 0;
     sh->stream = s;
-    BufAlloc alloc{true, &sh->owned};
+    sh->cached = !g_cached_shard_live;
+    if (sh->cached) g_cached_shard_live = true;
+    BufAlloc alloc{!sh->cached, &sh->owned, sh->cached};
     if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
     else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
     sh->stats = g_stats;
