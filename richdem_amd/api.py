@@ -48,7 +48,7 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     wrappers/pyrichdem/richdem/__init__.py:381-422 -> FillDepressions<topo>, depressions.hpp:13-21).
     Returns the filled array (or None when ``in_place``)."""
     if epsilon:
-        raise RdgpuError("FillDepressions(epsilon=True) is not part of this round's hot path")
+        raise RdgpuError("FillDepressions(epsilon=True) is not provided: PriorityFloodEpsilon's result depends on the order in which the reference's heap pops equal elevations")
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("FillDepressions: expected a 2-D numpy array")
     out = dem if in_place else dem.copy()
