@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: random shapes / element types / terrain styles / NoData, every entry
 point through the C-ABI against the oracle.  Prints one JSON line {"cases": n, "mismatches": [...]}.
-    python tools/fuzz_parity.py --seconds 120 --seed 1"""
+    python tests/tools/fuzz_parity.py --seconds 120 --seed 1"""
 import argparse
 import json
 import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 
 
 def ulp32(a, b):

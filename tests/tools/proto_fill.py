@@ -1,6 +1,6 @@
 """numpy model of the GPU fill algorithm (descent forest -> basins -> raster Boruvka rounds).
 Algorithm validation only; not product, not oracle."""
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from richdem_amd.synth import fractal_dem, fractal_dem_int
