@@ -328,3 +328,11 @@ def test_pit_mask(rd, orc):
                 assert np.array_equal(got == 1, (rd.FillDepressions(d, topology=name) != d) & (d != nd))
     with pytest.raises(rd.RdgpuError):
         rd.pit_mask(np.zeros((4, 4), np.float64), -1.0)
+
+
+def test_config0_beauford_shaped_dem(rd, orc):
+    """BASELINE configs[0]: the 2418 x 1636 float32 stand-in for data/beauford (G(seed=1)) -- small enough for the
+    oracle, so the GPU fill is compared cell for cell at the full size, through the host-pointer C-ABI."""
+    z = fractal_dem(2418, 1636, 1)
+    assert np.array_equal(rd.FillDepressions(z), orc.port.fill(z))
+    assert np.array_equal(rd.FillDepressions(z, topology="D4"), orc.port.fill(z, 4))

@@ -102,3 +102,20 @@ def test_zhou_barnes_wei_agree_on_random_terrain(orc):
     assert np.array_equal(a, orc.ref.fill(z, 8, orc.BARNES2014_D8))
     assert np.array_equal(a, orc.ref.fill(z, 8, orc.WEI2018))
     assert np.array_equal(a, orc.port.fill(z, 8))
+
+
+def test_config0_beauford_shaped_dem(orc):
+    """BASELINE configs[0]: the reference's own CPU-runnable case.  data/beauford.tif is not in the
+    checkout, so the stand-in is the 2418 x 1636 float32 generator DEM G(seed=1): the restatement must equal the
+    compiled reference's FillDepressions<D8> on it, cell for cell."""
+    if not orc.ref.available:
+        pytest.skip("oracle/_ref/libref.so not built here")
+    from richdem_amd.synth import fractal_dem
+
+    z = fractal_dem(2418, 1636, 1)
+    exp = orc.ref.fill(z, 8)
+    got = orc.port.fill(z, 8)
+    assert np.array_equal(got, exp)
+    frac = float((exp != z).mean())
+    assert 0.05 < frac < 0.9 and (exp >= z).all()
+    assert np.array_equal(exp[0], z[0]) and np.array_equal(exp[:, -1], z[:, -1])
