@@ -336,3 +336,17 @@ def test_config0_beauford_shaped_dem(rd, orc):
     z = fractal_dem(2418, 1636, 1)
     assert np.array_equal(rd.FillDepressions(z), orc.port.fill(z))
     assert np.array_equal(rd.FillDepressions(z, topology="D4"), orc.port.fill(z, 4))
+
+
+def test_config1_10k_equals_reference_on_every_cell(rd, orc):
+    """BASELINE configs[1]: 10000 x 10000 float32 G(seed=2), `==` on every cell against
+    PriorityFlood_Zhou2016 -- the compiled reference where it is present, its restatement otherwise (~5-25 s of CPU)."""
+    import torch
+
+    n = 10000
+    Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    rd.synth_dem_dev(Z, seed=2)
+    z = Z.cpu().numpy()
+    rd.fill_depressions_dev(Z)
+    exp = (orc.ref if orc.ref.available else orc.port).fill(z, 8)
+    assert np.array_equal(Z.cpu().numpy(), exp)

@@ -251,3 +251,27 @@ def test_resolve_flats_epsilon(rd, orc):
     # every flat cell of a filled DEM drains afterwards
     dirs = rd.d8_flow_directions(np.asarray(out), np.float32(-9999))
     assert (dirs[1:-1, 1:-1] != 0).all()
+
+
+def test_10k_chain_equals_reference_on_every_cell(rd, orc):
+    """The whole path at 10000 x 10000 (G(seed=2), filled): flat-resolved directions, D8 accumulation and FA_D8 must
+    equal the reference on every cell -- big lakes, long flow paths, ~25 s of CPU for the reference side."""
+    import torch
+
+    n = 10000
+    Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    rd.synth_dem_dev(Z, seed=2)
+    rd.fill_depressions_dev(Z)
+    filled = Z.cpu().numpy()
+    R = orc.ref if orc.ref.available else orc.port
+    nd = np.float32(-9999)
+    dirs = torch.empty((n, n), dtype=torch.uint8, device="cuda")
+    rd.d8_flow_directions_dev(Z, -9999.0, dirs, flats=True)
+    exp_dirs = R.flat_resolution(filled, nd)
+    assert np.array_equal(dirs.cpu().numpy(), exp_dirs)
+    area = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    rd.d8_flow_accum_dev(dirs, area)
+    assert np.array_equal(area.cpu().numpy(), R.d8_flow_accum(exp_dirs, 255, np.float64))
+    acc = torch.ones((n, n), dtype=torch.float64, device="cuda")
+    rd.fa_d8_dev(Z, -9999.0, acc)
+    assert np.array_equal(acc.cpu().numpy(), R.fa_d8(filled, nd))
