@@ -1,5 +1,6 @@
 /* rdgpu.h -- C-ABI of librdgpu.so, the MI355X (gfx950) engine behind RichDEM's
- * FillDepressions / d8_flow_directions / barnes_flat_resolution_d8 / d8_flow_accum / FA_D8.
+ * FillDepressions / pit_mask / d8_flow_directions / barnes_flat_resolution_d8 / ResolveFlatsEpsilon /
+ * d8_flow_accum / FA_D8 / FA_Tarboton / FA_Quinn / FA_Holmgren / FA_Freeman / FlowAccumulation(props).
  *
  * Plain pointers and sizes only.  Rasters are dense row-major, i = y*width + x,
  * no padding (reference: include/richdem/common/Array2D.hpp:592-595).  All
@@ -13,8 +14,9 @@
  *   rdgpu_<op>_dev_<dtype>(device pointers...) HBM-resident variant (bench.py,
  *                                              multi-GPU shards, chaining stages)
  *
- * dtype suffixes: u8 i16 u16 i32 u32 f32 (32-bit-key engine) and f64 i64 u64 (fill only, through
- * value ranks; the row-block shard entry points take the 32-bit types).
+ * dtype suffixes: u8 i16 u16 i32 u32 f32 everywhere; f64 additionally for the fill (exact: through the f32 engine
+ * when the values fit, through dense value ranks otherwise), the stencil stages, flat resolution and the
+ * accumulations; i64 u64 for the fill only.  The row-block shard entry points of the fill take the 32-bit types.
  *
  * Threading: one host thread at a time per process (the reference functions
  * are not internally re-entrant on shared arrays either).
