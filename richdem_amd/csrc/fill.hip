@@ -70,10 +70,10 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
   if (VEC) {
-    // interior columns with 16-byte loads (4-byte cells, w % 4 == 0: every row start is 16-byte aligned); all
+    // interior columns with quad loads (w % 4 == 0: every row starts on a quad boundary); all
     // loads of the thread are issued before the first is consumed (one memory round trip, not one per trip)
     constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
-    struct alignas(16) Q { T v[4]; };
+    struct alignas(4 * sizeof(T)) Q { T v[4]; };   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
     Q zq[QPT];
     bool okq[QPT];
 #pragma unroll
@@ -468,13 +468,13 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
   if (VEC) {
-    // Interior columns with 16-byte loads (w % 4 == 0 and 4-byte cells: every row start is 16-byte aligned),
+    // Interior columns with quad loads (w % 4 == 0: every row starts on a quad boundary; 16 bytes for 4-byte cells),
     // the two halo columns with scalar loads.  The kernel is latency bound (SQ counters: waves parked ~75 % of
     // their cycles), so the loads are issued in two batches -- every z / label quad of this thread, then every
     // component gather -- instead of item by item: two dependent memory round trips per tile instead of six.
     constexpr int NQ = LH * (TW / 4);                 // 16-byte items of the tile incl. halo rows
     constexpr int QPT = (NQ + NTHR - 1) / NTHR;       // per thread
-    struct alignas(16) Q { T v[4]; };
+    struct alignas(4 * sizeof(T)) Q { T v[4]; };   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
     Q zq[QPT];
     uint4 lq[QPT];
     bool ok[QPT];
@@ -923,7 +923,8 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
   const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
   RD_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(uint32_t), s));
-  const bool vec = sizeof(T) == 4 && (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % 16) == 0;
+  // quad loads: rows must start on a quad boundary (w % 4 == 0; labels are 4-byte cells, the raster base is aligned)
+  const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
   if (vec)
     RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
               h, dtx, dnt, open_top, open_bottom);
