@@ -57,6 +57,30 @@ static rdgpu_fill_stats g_stats;
 constexpr int DW = 64, DH = 64, DLW = DW + 2, DLH = DH + 2;
 constexpr uint16_t LTERM_BASE = 0xF000u;   // local pointers >= this: the cell is terminal within the tile (low 4 bits: code)
 
+// Four consecutive cells of a row starting at column gx in one load.  ALIGNED: the raster width is a multiple of 4
+// and its base is aligned, so every quad of every row is naturally aligned (the case the compiler may assume and
+// the fastest one: the 40000-wide bench DEM).  Otherwise the hardware still takes any element-aligned address for a
+// 16 / 8 / 4-byte load (3 % slower when the data happens to be aligned), and the last quad of a row may hang over
+// its end: those cells read as `fill`.
+template <class U>
+struct Quad { U v[4]; };
+template <class U, bool ALIGNED>
+__device__ __forceinline__ Quad<U> load_quad(const U *__restrict__ row, int gx, int w, U fill) {
+  Quad<U> q;
+  if (ALIGNED) {
+    struct alignas(4 * sizeof(U)) AQ { U v[4]; };
+    const AQ a = *reinterpret_cast<const AQ *>(row + gx);
+#pragma unroll
+    for (int e = 0; e < 4; e++) q.v[e] = a.v[e];
+  } else if (gx + 3 < w) {
+    __builtin_memcpy(&q, row + gx, sizeof(q));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++) q.v[e] = gx + e < w ? row[gx + e] : fill;
+  }
+  return q;
+}
+
 template <class T, int TOPO, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ ptr,
                                                   uint32_t *__restrict__ lab, uint32_t *pit_counter,
@@ -69,12 +93,11 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
-  if (VEC) {
-    // interior columns with quad loads (w % 4 == 0: every row starts on a quad boundary); all
+  {
+    // interior columns with quad loads (VEC: naturally aligned quads, else any width -- see load_quad); all
     // loads of the thread are issued before the first is consumed (one memory round trip, not one per trip)
     constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
-    struct alignas(4 * sizeof(T)) Q { T v[4]; };   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
-    Q zq[QPT];
+    Quad<T> zq[QPT];   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
     bool okq[QPT];
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
@@ -82,7 +105,7 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       const int ly = i / (DW / 4), q = i - ly * (DW / 4);
       const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
       okq[r] = i < NQ && gy >= 0 && gy < h && gx < w;
-      if (okq[r]) zq[r] = *reinterpret_cast<const Q *>(z + (size_t)gy * w + gx);
+      if (okq[r]) zq[r] = load_quad<T, VEC>(z + (size_t)gy * w, gx, w, T());
     }
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
@@ -91,7 +114,7 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       const int ly = i / (DW / 4), q = i - ly * (DW / 4);
       const int o = ly * DLW + 1 + 4 * q;
 #pragma unroll
-      for (int e = 0; e < 4; e++) sk[o + e] = okq[r] ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
+      for (int e = 0; e < 4; e++) sk[o + e] = (okq[r] && x0 + 4 * q + e < w) ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
     }
     for (int i = threadIdx.x; i < 2 * DLH; i += NTHR) {   // halo columns
       const int ly = i >> 1, lxh = (i & 1) ? DLW - 1 : 0;
@@ -99,14 +122,6 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       uint32_t kk = 0xFFFFFFFFu;
       if (gx >= 0 && gx < w && gy >= 0 && gy < h) kk = Key32<T>::to(z[(size_t)gy * w + gx]);
       sk[ly * DLW + lxh] = kk;
-    }
-  } else {
-    for (int i = threadIdx.x; i < DLH * DLW; i += NTHR) {
-      const int ly = i / DLW, lx = i - ly * DLW;
-      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-      uint32_t kk = 0xFFFFFFFFu;
-      if (gx >= 0 && gx < w && gy >= 0 && gy < h) kk = Key32<T>::to(z[(size_t)gy * w + gx]);
-      sk[i] = kk;
     }
   }
   __syncthreads();
@@ -467,16 +482,15 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   if (threadIdx.x == 0) nlist = 0;
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
-  if (VEC) {
-    // Interior columns with quad loads (w % 4 == 0: every row starts on a quad boundary; 16 bytes for 4-byte cells),
+  {
+    // Interior columns with quad loads (VEC: naturally aligned quads, else any width -- see load_quad),
     // the two halo columns with scalar loads.  The kernel is latency bound (SQ counters: waves parked ~75 % of
     // their cycles), so the loads are issued in two batches -- every z / label quad of this thread, then every
     // component gather -- instead of item by item: two dependent memory round trips per tile instead of six.
     constexpr int NQ = LH * (TW / 4);                 // 16-byte items of the tile incl. halo rows
     constexpr int QPT = (NQ + NTHR - 1) / NTHR;       // per thread
-    struct alignas(4 * sizeof(T)) Q { T v[4]; };   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
-    Q zq[QPT];
-    uint4 lq[QPT];
+    Quad<T> zq[QPT];   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
+    Quad<uint32_t> lq[QPT];
     bool ok[QPT];
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
@@ -486,8 +500,8 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       ok[r] = i < NQ && gy >= 0 && gy < h && gx < w;
       if (ok[r]) {
         const size_t g = (size_t)gy * w + gx;
-        zq[r] = *reinterpret_cast<const Q *>(z + g);
-        lq[r] = *reinterpret_cast<const uint4 *>(lab + g);
+        zq[r] = load_quad<T, VEC>(z + (g - gx), gx, w, T());
+        lq[r] = load_quad<uint32_t, VEC>(lab + (g - gx), gx, w, B);   // past the row end: the outside's label
       }
     }
     // halo columns: one cell per thread for the first 2 * LH threads
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     for (int r = 0; r < QPT; r++) {
       // branch-free: an absent quad reads the outside's entry (label B: cur[B] == B | CLOSED), so all gathers of
       // the thread are in flight together
-      const uint32_t l[4] = {ok[r] ? lq[r].x : B, ok[r] ? lq[r].y : B, ok[r] ? lq[r].z : B, ok[r] ? lq[r].w : B};
+      const uint32_t l[4] = {ok[r] ? lq[r].v[0] : B, ok[r] ? lq[r].v[1] : B, ok[r] ? lq[r].v[2] : B, ok[r] ? lq[r].v[3] : B};
 #pragma unroll
       for (int e = 0; e < 4; e++) cq[r][e] = RD_COMP(l[e]);
     }
@@ -519,24 +533,10 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
         const int ly = i / (TW / 4), q = i - ly * (TW / 4);
         const int o = ly * LW + 1 + 4 * q;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { sk[o + e] = ok[r] ? Key32<T>::to(zq[r].v[e]) : 0u; sc[o + e] = cq[r][e]; }
+        for (int e = 0; e < 4; e++) { sk[o + e] = (ok[r] && x0 + 4 * q + e < w) ? Key32<T>::to(zq[r].v[e]) : 0u; sc[o + e] = cq[r][e]; }
       }
     }
     if (hcell) { sk[hly * LW + hlx] = hok ? Key32<T>::to(hz) : 0u; sc[hly * LW + hlx] = hc; }
-  } else {
-    for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
-      const int ly = i / LW, lx = i - ly * LW;
-      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-      uint32_t k = 0, comp = B | CLOSED;
-      if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-        const size_t g = (size_t)gy * w + gx;
-        k = Key32<T>::to(z[g]);
-        const uint32_t l = lab[g];
-        comp = RD_COMP(l);
-      }
-      sk[i] = k;
-      sc[i] = comp;
-    }
   }
 #undef RD_COMP
   __syncthreads();
@@ -923,7 +923,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
   const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
   RD_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(uint32_t), s));
-  // quad loads: rows must start on a quad boundary (w % 4 == 0; labels are 4-byte cells, the raster base is aligned)
+  // naturally aligned quads when every row starts on a quad boundary; the any-width quad loads otherwise
   const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
   if (vec)
     RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
