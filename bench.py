@@ -165,6 +165,7 @@ def main():
             "cells": cells,
             "basins": stats["basins"],
             "boruvka_rounds": stats["rounds"],
+            "pair_records": stats["edge_records"],
             "jump_passes": stats["jump_passes"],
             "cells_raised_frac": round(changed, 4),
             "parallelism": "1 GPU",

@@ -88,10 +88,11 @@ RDGPU_DECL_PITMASK(f32, float)
 typedef struct rdgpu_fill_stats {
   uint64_t cells;       /* width*height                                   */
   uint64_t basins;      /* descent-forest roots (pits) not draining out   */
-  uint32_t rounds;      /* Boruvka contraction rounds over the raster     */
+  uint32_t rounds;      /* Boruvka contraction rounds                     */
   uint32_t jump_passes; /* pointer-jumping passes over the descent forest */
   uint64_t scan_tiles;  /* tiles visited by fill.scan, summed over the rounds */
   uint32_t tile_cells;  /* cells per scan tile                               */
+  uint32_t edge_records; /* component-pair records the first raster pass handed to rounds 2.. (0: raster rounds) */
 } rdgpu_fill_stats;
 int rdgpu_fill_get_stats(rdgpu_fill_stats *out);
 

@@ -459,12 +459,53 @@ __device__ __forceinline__ int tab_slot(uint32_t *tab_id, uint32_t C) {
   return -1;
 }
 
-template <class T, int TOPO, bool FIRST, bool VEC>
+// The component-pair list of the first round (EMIT).  A raster pass is only needed ONCE: while it looks for every
+// component's lowest pass it also sees every pair of adjacent components, and the lowest pass of each PAIR is all the
+// later rounds need.  The pairs of a tile are reduced in an LDS table and appended to a global list of
+// (component, component, pass key) records; rounds 2.. contract that list (k_edge_round) instead of re-reading the
+// raster.  The list is split into ESEG segments with their own fill counters: a single counter bumped once per
+// tile would serialise (~12 ns per same-address atomic, 7.8e5 tiles).  Anything that does not fit -- the tile's pair
+// table, a segment -- raises `overflow`, and the host falls back to raster passes for the remaining rounds.
+constexpr int PT_SLOTS = 512, PT_PROBES = 16;
+constexpr uint32_t ESEG = 8192;
+struct EdgeOut {
+  uint32_t *a, *b, *k;     // nseg segments of `segcap` records each
+  uint32_t *segcount;      // fill count per segment
+  uint32_t segcap;
+  uint32_t segmask;        // nseg - 1 (nseg: a power of two <= ESEG)
+  uint32_t *overflow;
+  uint32_t dbg;
+};
+
+__device__ __forceinline__ uint32_t pair_home(uint32_t C, uint32_t D) {
+  return (((C * 0x9E3779B1u) ^ (D * 0x85EBCA6Bu)) >> 16) & (PT_SLOTS - 1);
+}
+// find-or-insert the pair (C, D) in the tile's LDS pair table and lower its pass key; false when the probe window is full
+__device__ __forceinline__ bool pair_insert(unsigned long long *pt_pair, uint32_t *pt_key, uint32_t C, uint32_t D, uint32_t key) {
+  const unsigned long long pr = ((unsigned long long)C << 32) | D;
+  uint32_t slot = pair_home(C, D);
+#pragma unroll 1
+  for (int probe = 0; probe < PT_PROBES; probe++) {
+    unsigned long long v = pt_pair[slot];
+    if (v == ~0ull) {
+      v = atomicCAS(&pt_pair[slot], ~0ull, pr);
+      if (v == ~0ull) v = pr;
+    }
+    if (v == pr) {
+      if (key < pt_key[slot]) atomicMin(&pt_key[slot], key);
+      return true;
+    }
+    slot = (slot + 1) & (PT_SLOTS - 1);
+  }
+  return false;
+}
+
+template <class T, int TOPO, bool FIRST, bool VEC, bool EMIT>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
                                                int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
                                                const uint32_t *__restrict__ tiles_in, uint32_t nwork,
-                                               uint8_t *alive_out) {
+                                               uint8_t *alive_out, EdgeOut eo) {
   __shared__ uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   __shared__ uint32_t tab_id[SC_SLOTS];
@@ -472,6 +513,9 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   __shared__ uint8_t tab_cross[SC_SLOTS];
   __shared__ uint16_t list[TW * TH];   // LDS offsets of the cells that touch another component
   __shared__ uint32_t nlist;
+  __shared__ unsigned long long pt_pair[EMIT ? PT_SLOTS : 1];   // (smaller id << 32 | larger id), ~0 = empty
+  __shared__ uint32_t pt_key[EMIT ? PT_SLOTS : 1];              // lowest pass key of the pair
+  __shared__ uint32_t pt_over, pt_n, pt_base;
   // XCD-banded order in every round; from round 2 on only the tiles that still held a component boundary last
   // round are launched (compacted list: a dead tile costs neither a block nor a flag load)
   const uint32_t wi = xcd_tile(blockIdx.x, nwork);
@@ -479,7 +523,9 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   const uint32_t t = tiles_in ? tiles_in[wi] : wi;
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
   for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
-  if (threadIdx.x == 0) nlist = 0;
+  if (EMIT)
+    for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) { pt_pair[i] = ~0ull; pt_key[i] = 0xFFFFFFFFu; }
+  if (threadIdx.x == 0) { nlist = 0; pt_over = 0; pt_n = 0; }
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
   {
@@ -568,8 +614,8 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       const uint32_t C = c1[1];
       uint32_t d = (c0[1] ^ C) | (c1[0] ^ C) | (c1[2] ^ C) | (c2[1] ^ C);
       if (TOPO == 8) d |= (c0[0] ^ C) | (c0[2] ^ C) | (c2[0] ^ C) | (c2[2] ^ C);
-      // closed: drains to the outside or to a frozen terminal -- never proposes
-      const bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h;
+      // closed: drains to the outside or to a frozen terminal -- never proposes (listed only for the pair records)
+      const bool hit = d != 0 && (EMIT || !(C & CLOSED)) && gx < w && gy < h;
       bal[j] = __ballot(hit);
 #pragma unroll
       for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
@@ -611,20 +657,65 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     const int o = list[i];
     const uint32_t C = sc[o], kc = sk[o];
     unsigned long long cand = ~0ull;
-#define RD_NB(off)                                                                               \
-  {                                                                                              \
-    const uint32_t D = sc[o + (off)], kn = sk[o + (off)];                                        \
-    const uint32_t hn_ = (D != C) ? (kn > kc ? kn : kc) : 0xFFFFFFFFu;                           \
-    const unsigned long long e_ = ((unsigned long long)hn_ << 32) | D;                           \
-    cand = e_ < cand ? e_ : cand;                                                                \
-  }
-    RD_NB(-LW) RD_NB(-1) RD_NB(1) RD_NB(LW)
-    if (TOPO == 8) { RD_NB(-LW - 1) RD_NB(-LW + 1) RD_NB(LW - 1) RD_NB(LW + 1) }
-#undef RD_NB
+    // the ring of neighbours, read once: N, NE, E, SE, S, SW, W, NW (D4: N, E, S, W)
+    constexpr int NNB = TOPO == 8 ? 8 : 4;
+    const int noff[8] = {-LW, TOPO == 8 ? -LW + 1 : 1, TOPO == 8 ? 1 : LW, TOPO == 8 ? LW + 1 : -1, LW, LW - 1, -1, -LW - 1};
+    uint32_t nD[NNB], nH[NNB];
+#pragma unroll
+    for (int e = 0; e < NNB; e++) { nD[e] = sc[o + noff[e]]; nH[e] = sk[o + noff[e]]; }
+#pragma unroll
+    for (int e = 0; e < NNB; e++) {
+      nH[e] = nH[e] > kc ? nH[e] : kc;   // pass height of the cell pair
+      const unsigned long long e_ = ((unsigned long long)(nD[e] != C ? nH[e] : 0xFFFFFFFFu) << 32) | nD[e];
+      cand = e_ < cand ? e_ : cand;
+    }
     // reduce per component in LDS; fall back to the global atomic when its probe window is full
-    const int slot = tab_slot(tab_id, C);
-    if (slot >= 0) atomicMin(&tab_val[slot], cand);
-    else if (cand < best[C]) atomicMin(&best[C], cand);
+    if (!EMIT || !(C & CLOSED)) {   // (the EMIT pass also lists closed cells: they record pairs but never propose)
+      const int slot = tab_slot(tab_id, C);
+      if (slot >= 0) atomicMin(&tab_val[slot], cand);
+      else if (cand < best[C]) atomicMin(&best[C], cand);
+    }
+    if (EMIT && !(eo.dbg & 1)) {
+      // Every adjacent cell pair is recorded exactly once, by its earlier cell in raster order: a cell only looks at
+      // its E, SE, S, SW neighbours (D4: E, S), and the pair is stored as (smaller id, larger id).  That is half the
+      // neighbours per cell, evenly spread over the lanes.  Up to two distinct neighbouring components are kept in
+      // registers and looked up together: the common case -- the pair is already in its home slot with a pass at
+      // least as low -- costs one LDS round trip for the whole cell.
+      constexpr int F0 = TOPO == 8 ? 2 : 1, F1 = TOPO == 8 ? 6 : 3;
+      uint32_t pd[2] = {C, C}, pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // pd == C: unused
+#pragma unroll
+      for (int e = F0; e < F1; e++) {
+        const uint32_t D = nD[e];
+        if (D != C && !(C & D & CLOSED)) {   // two closed components never merge
+          if (pd[0] == C) pd[0] = D;
+          if (D == pd[0]) pk[0] = nH[e] < pk[0] ? nH[e] : pk[0];
+          else {
+            if (pd[1] == C) pd[1] = D;
+            if (D == pd[1]) pk[1] = nH[e] < pk[1] ? nH[e] : pk[1];
+            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, nH[e])) pt_over = 1;
+          }
+        }
+      }
+      if (eo.dbg & 4) { if (pd[0] == 77) pt_over = 1; continue; }
+      uint32_t ps[2], pq[2], lo[2], hi[2];
+      unsigned long long pv[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        lo[j] = C < pd[j] ? C : pd[j];
+        hi[j] = C < pd[j] ? pd[j] : C;
+        ps[j] = pair_home(lo[j], hi[j]);
+        pv[j] = pt_pair[ps[j]];
+        pq[j] = pt_key[ps[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (pd[j] != C) {
+          const unsigned long long pr = ((unsigned long long)lo[j] << 32) | hi[j];
+          if (pv[j] == pr) { if (pk[j] < pq[j]) atomicMin(&pt_key[ps[j]], pk[j]); }
+          else if (!(eo.dbg & 8) && !pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pt_over = 1;
+        }
+      }
+    }
   }
   const int any = nl != 0;
   __syncthreads();
@@ -641,6 +732,129 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // NB: no global "alive tiles" counter here -- ~10^6 same-address atomics serialise at ~12 ns each
   // (that alone cost 9 ms per pass); k_count_alive sums the flags instead
   if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
+  if (EMIT && !(eo.dbg & 2)) {
+    // the tile's pairs -> its segment of the global list: compact the occupied slots (`list` is free again),
+    // reserve the space with ONE atomic on the segment's counter, write the records coalesced
+    const int lane64 = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) {
+      const bool occ = pt_pair[i] != ~0ull;
+      const unsigned long long bal = __ballot(occ);
+      uint32_t base = 0;
+      if (lane64 == 0 && bal) base = atomicAdd(&pt_n, (uint32_t)__popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (occ) list[base + __popcll(bal & ((1ull << lane64) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint32_t seg = t & eo.segmask, tot = pt_n;
+    if (threadIdx.x == 0) {
+      uint32_t ob = 0xFFFFFFFFu;
+      if (pt_over) *eo.overflow = 1;
+      else if (tot) {
+        ob = atomicAdd(&eo.segcount[seg], tot);
+        if (ob + tot > eo.segcap) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
+      }
+      pt_base = ob;
+    }
+    __syncthreads();
+    const uint32_t ob = pt_base;
+    if (ob != 0xFFFFFFFFu) {
+      const size_t g0 = (size_t)seg * eo.segcap + ob;
+      for (uint32_t i = threadIdx.x; i < tot; i += NTHR) {
+        const int sl = list[i];
+        const unsigned long long pr = pt_pair[sl];
+        eo.a[g0 + i] = (uint32_t)(pr >> 32);
+        eo.b[g0 + i] = (uint32_t)pr;
+        eo.k[g0 + i] = pt_key[sl];
+      }
+    }
+  }
+}
+
+// One contraction round on the pair list: every record (a, b, key) is mapped to the current components of its two
+// sides; a record inside one component (or between two closed ones) is dropped for good, the others propose
+// (key << 32 | other side) to best[] exactly as the raster pass does, and are written to the next round's list as
+// (current a, current b, key).  SEG: the input is the segmented list of the raster pass (one segment per block
+// range: segcap is a multiple of the 2048 records a block covers); otherwise a dense list of n records.
+constexpr int EPT = 8;
+template <bool SEG>
+__global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict__ ea, const uint32_t *__restrict__ eb,
+                                                     const uint32_t *__restrict__ ek, uint32_t n,
+                                                     const uint32_t *__restrict__ segcount, uint32_t segcap,
+                                                     const uint32_t *__restrict__ cur, unsigned long long *best, uint32_t B,
+                                                     uint32_t *oa, uint32_t *ob, uint32_t *ok, uint32_t *ocount) {
+  __shared__ uint32_t wtot[NTHR / 64];
+  __shared__ uint32_t bbase;
+  const size_t i0 = (size_t)blockIdx.x * (NTHR * EPT);
+  size_t lim = n;   // records of this block's range that exist
+  if (SEG) {
+    const uint32_t seg = (uint32_t)(i0 / segcap);
+    lim = (size_t)seg * segcap + segcount[seg];
+    if (i0 >= lim) return;
+  }
+  uint32_t a[EPT], b[EPT], k[EPT];
+  bool ok_[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; r++) {
+    const size_t i = i0 + (size_t)r * NTHR + threadIdx.x;
+    ok_[r] = i < lim;
+    a[r] = ok_[r] ? ea[i] : B;   // an absent record reads as (outside, outside): dead
+    b[r] = ok_[r] ? eb[i] : B;
+    k[r] = ok_[r] ? ek[i] : 0u;
+  }
+  uint32_t ca[EPT], cb[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; r++) { ca[r] = cur[a[r] & ~CLOSED]; cb[r] = cur[b[r] & ~CLOSED]; }
+  bool live[EPT];
+  unsigned long long pa[EPT], pb[EPT];   // current best of either side (possibly stale: only a pre-check)
+#pragma unroll
+  for (int r = 0; r < EPT; r++) {
+    live[r] = ca[r] != cb[r] && !(ca[r] & cb[r] & CLOSED);
+    pa[r] = (live[r] && !(ca[r] & CLOSED)) ? best[ca[r]] : 0ull;
+    pb[r] = (live[r] && !(cb[r] & CLOSED)) ? best[cb[r]] : 0ull;
+  }
+#pragma unroll
+  for (int r = 0; r < EPT; r++) {
+    const unsigned long long candA = ((unsigned long long)k[r] << 32) | cb[r];
+    const unsigned long long candB = ((unsigned long long)k[r] << 32) | ca[r];
+    if (candA < pa[r]) atomicMin(&best[ca[r]], candA);
+    if (candB < pb[r]) atomicMin(&best[cb[r]], candB);
+  }
+  // survivors -> next list, in order, one global atomic per block
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long bal[EPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int r = 0; r < EPT; r++) { bal[r] = __ballot(live[r]); mine += (uint32_t)__popcll(bal[r]); }
+  if (lane == 0) wtot[wv] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    bbase = tot ? atomicAdd(ocount, tot) : 0;
+  }
+  __syncthreads();
+  uint32_t off = bbase;
+  for (int q = 0; q < wv; q++) off += wtot[q];
+#pragma unroll
+  for (int r = 0; r < EPT; r++) {
+    if (live[r]) {
+      const uint32_t g = off + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
+      oa[g] = ca[r]; ob[g] = cb[r]; ok[g] = k[r];
+    }
+    off += (uint32_t)__popcll(bal[r]);
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_sum_segments(const uint32_t *__restrict__ segcount, uint32_t nseg, uint32_t *total) {
+  __shared__ uint32_t part[NTHR];
+  uint32_t v = 0;
+  for (uint32_t i = threadIdx.x; i < nseg; i += NTHR) v += segcount[i];
+  part[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = NTHR / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = part[0];
 }
 
 // alive flags -> list of tiles for the next round (roughly ascending: blocks append in launch order) + count
@@ -905,7 +1119,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const uint64_t n64 = (uint64_t)w * (uint64_t)h;
   if (n64 > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: raster (or shard) has more than 2^31-65536 cells");
   const uint32_t n = (uint32_t)n64;
-  g_stats = rdgpu_fill_stats{n64, 0, 0, 0, 0, (uint32_t)(TW * TH)};
+  g_stats = rdgpu_fill_stats{n64, 0, 0, 0, 0, (uint32_t)(TW * TH), 0};
   fb = FillBuffers();
   const bool sharded = open_top || open_bottom;
   if (w <= 2 || (!sharded && h <= 2)) { fb.trivial = true; return; }  // every cell is a border cell
@@ -983,20 +1197,63 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   uint32_t *tlist = ws.buf<uint32_t>("fill.tlist", ntiles);
   uint32_t nlive = ntiles;
   bool first = true;
+  // The pair list (see k_scan EMIT): round 1 is the only raster pass unless something overflows.  Capacity: 12
+  // records per basin (measured at S3: 4.6), at most one per two cells; per segment a multiple of a k_edge_round block.
+  static const bool edges_enabled = [] { const char *e = getenv("RDGPU_FILL_EDGES"); return !(e && e[0] == '0'); }();
+  bool edge_mode = false;           // rounds 2.. run on the pair list
+  EdgeOut eo{};
+  uint32_t nseg = 1, nedges = 0;
+  uint32_t *elist[2] = {nullptr, nullptr};   // ping-pong record buffers: a | b | k planes of ecap[] records
+  size_t ecap[2] = {0, 0};
+  int ein = 0;
+  bool eseg = true;                 // the input list is still the segmented one of the raster pass
+  if (edges_enabled && nroots > 0) {
+    while (nseg < ESEG && (uint64_t)nseg * 128 <= ntiles) nseg *= 2;
+    const uint64_t cap = std::min<uint64_t>(12ull * B, n / 2) + 2048;
+    const uint32_t segcap = cdiv(cdiv(cap, nseg), NTHR * EPT) * (NTHR * EPT);
+    ecap[0] = (size_t)nseg * segcap;
+    elist[0] = ws.buf<uint32_t>("fill.edges0", 3 * ecap[0]);
+    uint32_t *segcount = ws.buf<uint32_t>("fill.segcount", nseg);
+    RD_HIP(hipMemsetAsync(segcount, 0, nseg * sizeof(uint32_t), s));
+    RD_HIP(hipMemsetAsync(dflags + 4, 0, 2 * sizeof(uint32_t), s));
+    eo = EdgeOut{elist[0], elist[0] + ecap[0], elist[0] + 2 * ecap[0], segcount, segcap, nseg - 1, dflags + 5, 0};
+    if (const char *e = getenv("RDGPU_DBG")) eo.dbg = (uint32_t)atoi(e);
+  }
+  const bool emit = eo.a != nullptr;
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
     RD_HIP(hipMemsetAsync(dflags + 3, 0, sizeof(uint32_t), s));
-    if (nlive > 0) {
-#define RD_SCAN(FIRST_, VEC_, LIST, NWORK)                                                                       \
-  RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_>), dim3(xcd_grid(NWORK)), dim3(NTHR), 0, s, d_z, lab, cur, best, w, h, \
-            B, tilesX, ntiles, (const uint32_t *)(LIST), (uint32_t)(NWORK), alive)
-      if (first && !sharded) { if (vec) RD_SCAN(true, true, nullptr, ntiles); else RD_SCAN(true, false, nullptr, ntiles); }
-      else if (first) { if (vec) RD_SCAN(false, true, nullptr, ntiles); else RD_SCAN(false, false, nullptr, ntiles); }
-      else { if (vec) RD_SCAN(false, true, tlist, nlive); else RD_SCAN(false, false, tlist, nlive); }
+    if (edge_mode) {
+      // contract the pair list: in -> out (dense), proposals to best[]
+      const int eout = ein ^ 1;
+      RD_HIP(hipMemsetAsync(dflags + 4, 0, sizeof(uint32_t), s));
+      const uint32_t *ia = elist[ein], *ib = elist[ein] + ecap[ein], *ik = elist[ein] + 2 * ecap[ein];
+      uint32_t *oa = elist[eout], *ob = elist[eout] + ecap[eout], *ok = elist[eout] + 2 * ecap[eout];
+      if (eseg)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<true>), dim3(cdiv(ecap[ein], NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+                  (uint32_t)ecap[ein], (const uint32_t *)eo.segcount, eo.segcap, (const uint32_t *)cur, best, B, oa, ob, ok,
+                  dflags + 4);
+      else if (nedges > 0)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+                  nedges, (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
+      eseg = false;
+      ein = eout;
+    } else if (nlive > 0) {
+#define RD_SCAN(FIRST_, VEC_, EMIT_, LIST, NWORK)                                                                \
+  RD_LAUNCH("fill.scan", (k_scan<T, TOPO, FIRST_, VEC_, EMIT_>), dim3(xcd_grid(NWORK)), dim3(NTHR), 0, s, d_z, lab, cur, best, w, \
+            h, B, tilesX, ntiles, (const uint32_t *)(LIST), (uint32_t)(NWORK), alive, eo)
+#define RD_SCAN_V(FIRST_, EMIT_, LIST, NWORK)                                                                    \
+  { if (vec) RD_SCAN(FIRST_, true, EMIT_, LIST, NWORK); else RD_SCAN(FIRST_, false, EMIT_, LIST, NWORK); }
+      if (first && !sharded) { if (emit) RD_SCAN_V(true, true, nullptr, ntiles) else RD_SCAN_V(true, false, nullptr, ntiles) }
+      else if (first) { if (emit) RD_SCAN_V(false, true, nullptr, ntiles) else RD_SCAN_V(false, false, nullptr, ntiles) }
+      else RD_SCAN_V(false, false, tlist, nlive)
+#undef RD_SCAN_V
 #undef RD_SCAN
       RD_LAUNCH("fill.compact_alive", k_compact_alive, dim3(cdiv(ntiles, NTHR)), dim3(NTHR), 0, s, (const uint8_t *)alive, ntiles,
                 tlist, dflags + 3);
+      if (first && emit)
+        RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, dflags + 4);
       g_stats.scan_tiles += first ? ntiles : nlive;
     }
     RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
@@ -1011,12 +1268,22 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
     RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
               dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     const uint32_t next = hw[0];
     if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
     nroots = next;
     nlive = hw[1];
+    if (first && emit && hw[3] == 0 && nroots > 0 && !eo.dbg) {
+      // the raster pass recorded every adjacent component pair: the remaining rounds run on that list
+      edge_mode = true;
+      nedges = hw[2];
+      g_stats.edge_records = nedges;
+      ecap[1] = std::max<size_t>(nedges, 1);
+      elist[1] = ws.buf<uint32_t>("fill.edges1", 3 * ecap[1]);
+    } else if (edge_mode) {
+      nedges = hw[2];
+    }
     first = false;
     std::swap(rootsA, rootsB);
     g_stats.rounds++;
