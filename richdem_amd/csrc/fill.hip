@@ -464,8 +464,9 @@ __device__ __forceinline__ int tab_slot(uint32_t *tab_id, uint32_t C) {
 // later rounds need.  The pairs of a tile are reduced in an LDS table and appended to a global list of
 // (component, component, pass key) records; rounds 2.. contract that list (k_edge_round) instead of re-reading the
 // raster.  The list is split into ESEG segments with their own fill counters: a single counter bumped once per
-// tile would serialise (~12 ns per same-address atomic, 7.8e5 tiles).  Anything that does not fit -- the tile's pair
-// table, a segment -- raises `overflow`, and the host falls back to raster passes for the remaining rounds.
+// tile would serialise (~12 ns per same-address atomic, 7.8e5 tiles).  A pair that finds no slot in the tile's table is
+// appended on its own (pair_spill); a segment that runs full raises `overflow`, and the host falls back to raster
+// passes for the remaining rounds.
 constexpr int PT_SLOTS = 512, PT_PROBES = 16;
 constexpr uint32_t ESEG = 8192;
 struct EdgeOut {
@@ -474,7 +475,6 @@ struct EdgeOut {
   uint32_t segcap;
   uint32_t segmask;        // nseg - 1 (nseg: a power of two <= ESEG)
   uint32_t *overflow;
-  uint32_t dbg;
 };
 
 __device__ __forceinline__ uint32_t pair_home(uint32_t C, uint32_t D) {
@@ -500,6 +500,18 @@ __device__ __forceinline__ bool pair_insert(unsigned long long *pt_pair, uint32_
   return false;
 }
 
+// A pair that found no slot in the tile's table goes straight to the tile's segment, one record per atomic: slow, but
+// it keeps rasters with hundreds of basins per tile on the pair list (the records are only not merged per tile).
+__device__ __forceinline__ void pair_spill(const EdgeOut &eo, uint32_t seg, uint32_t lo, uint32_t hi, uint32_t key) {
+  const uint32_t g = atomicAdd(&eo.segcount[seg], 1u);
+  if (g < eo.segcap) {
+    const size_t i = (size_t)seg * eo.segcap + g;
+    eo.a[i] = lo; eo.b[i] = hi; eo.k[i] = key;
+  } else {
+    *eo.overflow = 1;
+  }
+}
+
 template <class T, int TOPO, bool FIRST, bool VEC, bool EMIT>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   __shared__ uint32_t nlist;
   __shared__ unsigned long long pt_pair[EMIT ? PT_SLOTS : 1];   // (smaller id << 32 | larger id), ~0 = empty
   __shared__ uint32_t pt_key[EMIT ? PT_SLOTS : 1];              // lowest pass key of the pair
-  __shared__ uint32_t pt_over, pt_n, pt_base;
+  __shared__ uint32_t pt_n, pt_base;
   // XCD-banded order in every round; from round 2 on only the tiles that still held a component boundary last
   // round are launched (compacted list: a dead tile costs neither a block nor a flag load)
   const uint32_t wi = xcd_tile(blockIdx.x, nwork);
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
   if (EMIT)
     for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) { pt_pair[i] = ~0ull; pt_key[i] = 0xFFFFFFFFu; }
-  if (threadIdx.x == 0) { nlist = 0; pt_over = 0; pt_n = 0; }
+  if (threadIdx.x == 0) { nlist = 0; pt_n = 0; }
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
   {
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       if (slot >= 0) atomicMin(&tab_val[slot], cand);
       else if (cand < best[C]) atomicMin(&best[C], cand);
     }
-    if (EMIT && !(eo.dbg & 1)) {
+    if (EMIT) {
       // Every adjacent cell pair is recorded exactly once, by its earlier cell in raster order: a cell only looks at
       // its E, SE, S, SW neighbours (D4: E, S), and the pair is stored as (smaller id, larger id).  That is half the
       // neighbours per cell, evenly spread over the lanes.  Up to two distinct neighbouring components are kept in
@@ -692,11 +704,10 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
           else {
             if (pd[1] == C) pd[1] = D;
             if (D == pd[1]) pk[1] = nH[e] < pk[1] ? nH[e] : pk[1];
-            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, nH[e])) pt_over = 1;
+            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, nH[e])) pair_spill(eo, t & eo.segmask, C < D ? C : D, C < D ? D : C, nH[e]);
           }
         }
       }
-      if (eo.dbg & 4) { if (pd[0] == 77) pt_over = 1; continue; }
       uint32_t ps[2], pq[2], lo[2], hi[2];
       unsigned long long pv[2];
 #pragma unroll
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
         if (pd[j] != C) {
           const unsigned long long pr = ((unsigned long long)lo[j] << 32) | hi[j];
           if (pv[j] == pr) { if (pk[j] < pq[j]) atomicMin(&pt_key[ps[j]], pk[j]); }
-          else if (!(eo.dbg & 8) && !pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pt_over = 1;
+          else if (!pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pair_spill(eo, t & eo.segmask, lo[j], hi[j], pk[j]);
         }
       }
     }
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // NB: no global "alive tiles" counter here -- ~10^6 same-address atomics serialise at ~12 ns each
   // (that alone cost 9 ms per pass); k_count_alive sums the flags instead
   if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
-  if (EMIT && !(eo.dbg & 2)) {
+  if (EMIT) {
     // the tile's pairs -> its segment of the global list: compact the occupied slots (`list` is free again),
     // reserve the space with ONE atomic on the segment's counter, write the records coalesced
     const int lane64 = threadIdx.x & 63;
@@ -748,8 +759,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     const uint32_t seg = t & eo.segmask, tot = pt_n;
     if (threadIdx.x == 0) {
       uint32_t ob = 0xFFFFFFFFu;
-      if (pt_over) *eo.overflow = 1;
-      else if (tot) {
+      if (tot) {
         ob = atomicAdd(&eo.segcount[seg], tot);
         if (ob + tot > eo.segcap) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
       }
@@ -1199,7 +1209,10 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   bool first = true;
   // The pair list (see k_scan EMIT): round 1 is the only raster pass unless something overflows.  Capacity: 12
   // records per basin (measured at S3: 4.6), at most one per two cells; per segment a multiple of a k_edge_round block.
-  static const bool edges_enabled = [] { const char *e = getenv("RDGPU_FILL_EDGES"); return !(e && e[0] == '0'); }();
+  // RDGPU_FILL_EDGES=0 keeps every round on the raster; RDGPU_FILL_EDGE_CAP=<records> overrides the list capacity
+  // (both exist for the tests of the overflow fallback and for A/B timing).
+  const char *env_edges = getenv("RDGPU_FILL_EDGES"), *env_cap = getenv("RDGPU_FILL_EDGE_CAP");
+  const bool edges_enabled = !(env_edges && env_edges[0] == '0');
   bool edge_mode = false;           // rounds 2.. run on the pair list
   EdgeOut eo{};
   uint32_t nseg = 1, nedges = 0;
@@ -1209,15 +1222,14 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   bool eseg = true;                 // the input list is still the segmented one of the raster pass
   if (edges_enabled && nroots > 0) {
     while (nseg < ESEG && (uint64_t)nseg * 128 <= ntiles) nseg *= 2;
-    const uint64_t cap = std::min<uint64_t>(12ull * B, n / 2) + 2048;
+    const uint64_t cap = env_cap ? strtoull(env_cap, nullptr, 10) : std::min<uint64_t>(12ull * B, n / 2) + 2048;
     const uint32_t segcap = cdiv(cdiv(cap, nseg), NTHR * EPT) * (NTHR * EPT);
     ecap[0] = (size_t)nseg * segcap;
     elist[0] = ws.buf<uint32_t>("fill.edges0", 3 * ecap[0]);
     uint32_t *segcount = ws.buf<uint32_t>("fill.segcount", nseg);
     RD_HIP(hipMemsetAsync(segcount, 0, nseg * sizeof(uint32_t), s));
     RD_HIP(hipMemsetAsync(dflags + 4, 0, 2 * sizeof(uint32_t), s));
-    eo = EdgeOut{elist[0], elist[0] + ecap[0], elist[0] + 2 * ecap[0], segcount, segcap, nseg - 1, dflags + 5, 0};
-    if (const char *e = getenv("RDGPU_DBG")) eo.dbg = (uint32_t)atoi(e);
+    eo = EdgeOut{elist[0], elist[0] + ecap[0], elist[0] + 2 * ecap[0], segcount, segcap, nseg - 1, dflags + 5};
   }
   const bool emit = eo.a != nullptr;
   while (nroots > 0) {
@@ -1274,7 +1286,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
     nroots = next;
     nlive = hw[1];
-    if (first && emit && hw[3] == 0 && nroots > 0 && !eo.dbg) {
+    if (first && emit && hw[3] == 0 && nroots > 0) {
       // the raster pass recorded every adjacent component pair: the remaining rounds run on that list
       edge_mode = true;
       nedges = hw[2];

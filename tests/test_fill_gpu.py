@@ -350,3 +350,39 @@ def test_config1_10k_equals_reference_on_every_cell(rd, orc):
     rd.fill_depressions_dev(Z)
     exp = (orc.ref if orc.ref.available else orc.port).fill(z, 8)
     assert np.array_equal(Z.cpu().numpy(), exp)
+
+
+def _with_env(rd, env, dem, topo=8):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        out = rd.FillDepressions(dem, topology=topo)
+        return out, rd.fill_stats()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("topo", [8, 4])
+def test_pair_list_rounds_equal_raster_rounds(rd, orc, topo):
+    """Rounds 2.. run on the component-pair list the first raster pass records; RDGPU_FILL_EDGES=0 keeps them on
+    the raster, and a list that does not fit (RDGPU_FILL_EDGE_CAP) falls back to the raster: same surface always."""
+    rng = np.random.default_rng(11)
+    rough = fractal_dem(900, 700, seed=22) + (rng.random((700, 900)) * 3).astype(np.float32)
+    dems = [(fractal_dem(900, 700, seed=21), True),                       # a dozen basins per tile
+            (rough, None),                                                # many small pits on top of the terrain: pairs spill
+            (rng.random((300, 500)).astype(np.float32), None),            # ~230 basins per tile: the list may not fit at all
+            (np.floor(fractal_dem(640, 480, seed=5) * 0.05).astype(np.int16), True)]
+    for dem, must_use_list in dems:
+        exp = orc.port.fill(dem, topo)
+        got, st = _with_env(rd, {}, dem, topo)
+        assert np.array_equal(got, exp)
+        if must_use_list:
+            assert st["edge_records"] > 0 and st["rounds"] > 1, st        # the pair list was used
+        got, st = _with_env(rd, {"RDGPU_FILL_EDGES": "0"}, dem, topo)
+        assert np.array_equal(got, exp) and st["edge_records"] == 0, st
+        got, st = _with_env(rd, {"RDGPU_FILL_EDGE_CAP": "64"}, dem, topo)  # far too small: overflow -> raster rounds
+        assert np.array_equal(got, exp) and st["edge_records"] == 0, st
