@@ -502,7 +502,13 @@ __device__ __forceinline__ bool pair_insert(unsigned long long *pt_pair, uint32_
 
 // A pair that found no slot in the tile's table goes straight to the tile's segment, one record per atomic: slow, but
 // it keeps rasters with hundreds of basins per tile on the pair list (the records are only not merged per tile).
-__device__ __forceinline__ void pair_spill(const EdgeOut &eo, uint32_t seg, uint32_t lo, uint32_t hi, uint32_t key) {
+__device__ __forceinline__ void pair_spill(const EdgeOut &eo, unsigned long long *best, uint32_t seg,
+                                           uint32_t lo, uint32_t hi, uint32_t key) {
+  // (it bypasses the table the components' proposals are derived from, so it proposes on its own)
+
+  const unsigned long long cl = ((unsigned long long)key << 32) | hi, ch = ((unsigned long long)key << 32) | lo;
+  if (!(lo & CLOSED) && cl < best[lo]) atomicMin(&best[lo], cl);
+  if (!(hi & CLOSED) && ch < best[hi]) atomicMin(&best[hi], ch);
   const uint32_t g = atomicAdd(&eo.segcount[seg], 1u);
   if (g < eo.segcap) {
     const size_t i = (size_t)seg * eo.segcap + g;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   __shared__ uint32_t nlist;
   __shared__ unsigned long long pt_pair[EMIT ? PT_SLOTS : 1];   // (smaller id << 32 | larger id), ~0 = empty
   __shared__ uint32_t pt_key[EMIT ? PT_SLOTS : 1];              // lowest pass key of the pair
-  __shared__ uint32_t pt_n, pt_base;
+  __shared__ uint32_t pt_n, pt_base, any_open;
   // XCD-banded order in every round; from round 2 on only the tiles that still held a component boundary last
   // round are launched (compacted list: a dead tile costs neither a block nor a flag load)
   const uint32_t wi = xcd_tile(blockIdx.x, nwork);
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
   if (EMIT)
     for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) { pt_pair[i] = ~0ull; pt_key[i] = 0xFFFFFFFFu; }
-  if (threadIdx.x == 0) { nlist = 0; pt_n = 0; }
+  if (threadIdx.x == 0) { nlist = 0; pt_n = 0; any_open = 0; }
   // FIRST: every basin is still its own component (only used when there are no frozen terminals)
 #define RD_COMP(l) (FIRST ? ((l) == B ? (B | CLOSED) : (l)) : cur[(l)])
   {
@@ -615,6 +621,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       for (int e = 0; e < 3; e++) { c0[e] = sc[o + e]; c1[e] = sc[o + LW + e]; }
     }
     unsigned long long bal[ROWS];   // per row: the lanes whose cell touches another component
+    unsigned long long balive = 0;
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
       const int ly = yb + j, gy = y0 + ly;
@@ -626,12 +633,21 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       const uint32_t C = c1[1];
       uint32_t d = (c0[1] ^ C) | (c1[0] ^ C) | (c1[2] ^ C) | (c2[1] ^ C);
       if (TOPO == 8) d |= (c0[0] ^ C) | (c0[2] ^ C) | (c2[0] ^ C) | (c2[2] ^ C);
-      // closed: drains to the outside or to a frozen terminal -- never proposes (listed only for the pair records)
-      const bool hit = d != 0 && (EMIT || !(C & CLOSED)) && gx < w && gy < h;
+      // closed: drains to the outside or to a frozen terminal -- never proposes
+      bool hit = d != 0 && !(C & CLOSED) && gx < w && gy < h;
+      if (EMIT) {
+        // the pair pass lists the cells with a foreign E / SE / S / SW neighbour (open or closed: see phase 2);
+        // "this tile holds a component boundary" keeps its meaning for the raster fallback
+        balive |= __ballot(hit);
+        uint32_t df = (c1[2] ^ C) | (c2[1] ^ C);
+        if (TOPO == 8) df |= (c2[0] ^ C) | (c2[2] ^ C);
+        hit = df != 0 && gx < w && gy < h;
+      }
       bal[j] = __ballot(hit);
 #pragma unroll
       for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
     }
+    if (EMIT && balive && lane == 0) any_open = 1;
     // one list reservation per wavefront (a returning LDS atomic per row was a dependent chain of eight)
     uint32_t total = 0;
 #pragma unroll
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // (no barrier needed between the detect phase and this: both only read sc)
   // components that also live outside this tile (seen on the halo ring) need the global atomic;
   // a component entirely inside the tile is reduced here completely and can use a plain store
-  for (int i = threadIdx.x; i < 2 * LW + 2 * (LH - 2); i += NTHR) {
+  for (int i = threadIdx.x; !EMIT && i < 2 * LW + 2 * (LH - 2); i += NTHR) {   // (the pair pass always uses the atomic)
     int o;
     if (i < LW) o = i;
     else if (i < 2 * LW) o = (LH - 1) * LW + (i - LW);
@@ -663,48 +679,33 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     }
   }
   __syncthreads();
-  // Phase 2 -- evaluate the boundary cells densely
   const uint32_t nl = nlist;
-  for (uint32_t i = threadIdx.x; i < nl; i += NTHR) {
-    const int o = list[i];
-    const uint32_t C = sc[o], kc = sk[o];
-    unsigned long long cand = ~0ull;
-    // the ring of neighbours, read once: N, NE, E, SE, S, SW, W, NW (D4: N, E, S, W)
-    constexpr int NNB = TOPO == 8 ? 8 : 4;
-    const int noff[8] = {-LW, TOPO == 8 ? -LW + 1 : 1, TOPO == 8 ? 1 : LW, TOPO == 8 ? LW + 1 : -1, LW, LW - 1, -1, -LW - 1};
-    uint32_t nD[NNB], nH[NNB];
+  if (EMIT) {
+    // Phase 2 (pair pass) -- every adjacent cell pair is recorded exactly once, by its earlier cell in raster order:
+    // a listed cell looks at its E, SE, S, SW neighbours (D4: E, S) and the pair is stored as (smaller id, larger
+    // id) with its pass height.  Up to two distinct neighbouring components are kept in registers and looked up
+    // together: the common case -- the pair is already in its home slot with a pass at least as low -- costs one
+    // LDS round trip for the whole cell.  The components' own lowest passes are derived from the pairs afterwards.
+    constexpr int NF = TOPO == 8 ? 4 : 2;
+    const int foff[4] = {1, TOPO == 8 ? LW + 1 : LW, LW, LW - 1};
+    const uint32_t seg = t & eo.segmask;
+    for (uint32_t i = threadIdx.x; i < nl; i += NTHR) {
+      const int o = list[i];
+      const uint32_t C = sc[o], kc = sk[o];
+      uint32_t nD[NF], nH[NF];
 #pragma unroll
-    for (int e = 0; e < NNB; e++) { nD[e] = sc[o + noff[e]]; nH[e] = sk[o + noff[e]]; }
-#pragma unroll
-    for (int e = 0; e < NNB; e++) {
-      nH[e] = nH[e] > kc ? nH[e] : kc;   // pass height of the cell pair
-      const unsigned long long e_ = ((unsigned long long)(nD[e] != C ? nH[e] : 0xFFFFFFFFu) << 32) | nD[e];
-      cand = e_ < cand ? e_ : cand;
-    }
-    // reduce per component in LDS; fall back to the global atomic when its probe window is full
-    if (!EMIT || !(C & CLOSED)) {   // (the EMIT pass also lists closed cells: they record pairs but never propose)
-      const int slot = tab_slot(tab_id, C);
-      if (slot >= 0) atomicMin(&tab_val[slot], cand);
-      else if (cand < best[C]) atomicMin(&best[C], cand);
-    }
-    if (EMIT) {
-      // Every adjacent cell pair is recorded exactly once, by its earlier cell in raster order: a cell only looks at
-      // its E, SE, S, SW neighbours (D4: E, S), and the pair is stored as (smaller id, larger id).  That is half the
-      // neighbours per cell, evenly spread over the lanes.  Up to two distinct neighbouring components are kept in
-      // registers and looked up together: the common case -- the pair is already in its home slot with a pass at
-      // least as low -- costs one LDS round trip for the whole cell.
-      constexpr int F0 = TOPO == 8 ? 2 : 1, F1 = TOPO == 8 ? 6 : 3;
+      for (int e = 0; e < NF; e++) { nD[e] = sc[o + foff[e]]; nH[e] = sk[o + foff[e]]; }
       uint32_t pd[2] = {C, C}, pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // pd == C: unused
 #pragma unroll
-      for (int e = F0; e < F1; e++) {
-        const uint32_t D = nD[e];
+      for (int e = 0; e < NF; e++) {
+        const uint32_t D = nD[e], hn = nH[e] > kc ? nH[e] : kc;   // pass height of the cell pair
         if (D != C && !(C & D & CLOSED)) {   // two closed components never merge
           if (pd[0] == C) pd[0] = D;
-          if (D == pd[0]) pk[0] = nH[e] < pk[0] ? nH[e] : pk[0];
+          if (D == pd[0]) pk[0] = hn < pk[0] ? hn : pk[0];
           else {
             if (pd[1] == C) pd[1] = D;
-            if (D == pd[1]) pk[1] = nH[e] < pk[1] ? nH[e] : pk[1];
-            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, nH[e])) pair_spill(eo, t & eo.segmask, C < D ? C : D, C < D ? D : C, nH[e]);
+            if (D == pd[1]) pk[1] = hn < pk[1] ? hn : pk[1];
+            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, hn)) pair_spill(eo, best, seg, C < D ? C : D, C < D ? D : C, hn);
           }
         }
       }
@@ -723,10 +724,95 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
         if (pd[j] != C) {
           const unsigned long long pr = ((unsigned long long)lo[j] << 32) | hi[j];
           if (pv[j] == pr) { if (pk[j] < pq[j]) atomicMin(&pt_key[ps[j]], pk[j]); }
-          else if (!pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pair_spill(eo, t & eo.segmask, lo[j], hi[j], pk[j]);
+          else if (!pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pair_spill(eo, best, seg, lo[j], hi[j], pk[j]);
         }
       }
     }
+    __syncthreads();
+    // compact the occupied slots (`list` is free again)
+    const int lane64 = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) {
+      const bool occ = pt_pair[i] != ~0ull;
+      const unsigned long long bal = __ballot(occ);
+      uint32_t base = 0;
+      if (lane64 == 0 && bal) base = atomicAdd(&pt_n, (uint32_t)__popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (occ) list[base + __popcll(bal & ((1ull << lane64) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // reserve the tile's space in its segment with ONE atomic (its latency hides behind the loop below)
+    const uint32_t tot = pt_n;
+    if (threadIdx.x == 0) {
+      uint32_t ob = 0xFFFFFFFFu;
+      if (tot) {
+        ob = atomicAdd(&eo.segcount[seg], tot);
+        if (ob + tot > eo.segcap) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
+      }
+      pt_base = ob;
+      alive_out[t] = any_open ? 1 : 0;
+    }
+    // every pair proposes its pass to its open sides, reduced per component in the LDS table
+    for (uint32_t i = threadIdx.x; i < tot; i += NTHR) {
+      const int sl = list[i];
+      const unsigned long long pr = pt_pair[sl];
+      const uint32_t lo = (uint32_t)(pr >> 32), hi = (uint32_t)pr, key = pt_key[sl];
+      if (!(lo & CLOSED)) {
+        const unsigned long long cand = ((unsigned long long)key << 32) | hi;
+        const int slot = tab_slot(tab_id, lo);
+        if (slot >= 0) atomicMin(&tab_val[slot], cand);
+        else if (cand < best[lo]) atomicMin(&best[lo], cand);
+      }
+      if (!(hi & CLOSED)) {
+        const unsigned long long cand = ((unsigned long long)key << 32) | lo;
+        const int slot = tab_slot(tab_id, hi);
+        if (slot >= 0) atomicMin(&tab_val[slot], cand);
+        else if (cand < best[hi]) atomicMin(&best[hi], cand);
+      }
+    }
+    __syncthreads();
+    // (always the atomic: a pair of C with a cell above / left of it is recorded -- and proposed -- by the tile that
+    // owns that earlier cell, so even a component entirely inside this tile can have another proposer)
+    for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) {
+      const uint32_t C = tab_id[i];
+      if (C != 0xFFFFFFFFu) {
+        const unsigned long long cand = tab_val[i];
+        if (cand < best[C]) atomicMin(&best[C], cand);      // cheap (possibly stale) pre-check first
+      }
+    }
+    const uint32_t ob = pt_base;
+    if (ob != 0xFFFFFFFFu) {
+      const size_t g0 = (size_t)seg * eo.segcap + ob;
+      for (uint32_t i = threadIdx.x; i < tot; i += NTHR) {
+        const int sl = list[i];
+        const unsigned long long pr = pt_pair[sl];
+        eo.a[g0 + i] = (uint32_t)(pr >> 32);
+        eo.b[g0 + i] = (uint32_t)pr;
+        eo.k[g0 + i] = pt_key[sl];
+      }
+    }
+    return;
+  }
+  // Phase 2 -- evaluate the boundary cells densely
+  for (uint32_t i = threadIdx.x; i < nl; i += NTHR) {
+    const int o = list[i];
+    const uint32_t C = sc[o], kc = sk[o];
+    unsigned long long cand = ~0ull;
+    // the ring of neighbours, read once: N, NE, E, SE, S, SW, W, NW (D4: N, E, S, W)
+    constexpr int NNB = TOPO == 8 ? 8 : 4;
+    const int noff[8] = {-LW, TOPO == 8 ? -LW + 1 : 1, TOPO == 8 ? 1 : LW, TOPO == 8 ? LW + 1 : -1, LW, LW - 1, -1, -LW - 1};
+    uint32_t nD[NNB], nH[NNB];
+#pragma unroll
+    for (int e = 0; e < NNB; e++) { nD[e] = sc[o + noff[e]]; nH[e] = sk[o + noff[e]]; }
+#pragma unroll
+    for (int e = 0; e < NNB; e++) {
+      nH[e] = nH[e] > kc ? nH[e] : kc;   // pass height of the cell pair
+      const unsigned long long e_ = ((unsigned long long)(nD[e] != C ? nH[e] : 0xFFFFFFFFu) << 32) | nD[e];
+      cand = e_ < cand ? e_ : cand;
+    }
+    // reduce per component in LDS; fall back to the global atomic when its probe window is full
+    const int slot = tab_slot(tab_id, C);
+    if (slot >= 0) atomicMin(&tab_val[slot], cand);
+    else if (cand < best[C]) atomicMin(&best[C], cand);
   }
   const int any = nl != 0;
   __syncthreads();
@@ -743,41 +829,6 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   // NB: no global "alive tiles" counter here -- ~10^6 same-address atomics serialise at ~12 ns each
   // (that alone cost 9 ms per pass); k_count_alive sums the flags instead
   if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
-  if (EMIT) {
-    // the tile's pairs -> its segment of the global list: compact the occupied slots (`list` is free again),
-    // reserve the space with ONE atomic on the segment's counter, write the records coalesced
-    const int lane64 = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < PT_SLOTS; i += NTHR) {
-      const bool occ = pt_pair[i] != ~0ull;
-      const unsigned long long bal = __ballot(occ);
-      uint32_t base = 0;
-      if (lane64 == 0 && bal) base = atomicAdd(&pt_n, (uint32_t)__popcll(bal));
-      base = __shfl(base, 0, 64);
-      if (occ) list[base + __popcll(bal & ((1ull << lane64) - 1ull))] = (uint16_t)i;
-    }
-    __syncthreads();
-    const uint32_t seg = t & eo.segmask, tot = pt_n;
-    if (threadIdx.x == 0) {
-      uint32_t ob = 0xFFFFFFFFu;
-      if (tot) {
-        ob = atomicAdd(&eo.segcount[seg], tot);
-        if (ob + tot > eo.segcap) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
-      }
-      pt_base = ob;
-    }
-    __syncthreads();
-    const uint32_t ob = pt_base;
-    if (ob != 0xFFFFFFFFu) {
-      const size_t g0 = (size_t)seg * eo.segcap + ob;
-      for (uint32_t i = threadIdx.x; i < tot; i += NTHR) {
-        const int sl = list[i];
-        const unsigned long long pr = pt_pair[sl];
-        eo.a[g0 + i] = (uint32_t)(pr >> 32);
-        eo.b[g0 + i] = (uint32_t)pr;
-        eo.k[g0 + i] = pt_key[sl];
-      }
-    }
-  }
 }
 
 // One contraction round on the pair list: every record (a, b, key) is mapped to the current components of its two
