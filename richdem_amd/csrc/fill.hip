@@ -419,7 +419,13 @@ __global__ __launch_bounds__(NTHR) void k_init_tables(uint32_t *cur, uint32_t *a
     link[i] = (unsigned long long)i;
     open = !closed;
   }
-  // live roots = basins that still have to hook (everything but the outside and frozen terminals)
+  // live roots = basins that still have to hook (everything but the outside and frozen terminals).  Without
+  // terminals that is simply 0..B-1: no compaction (one same-address atomic per block is 0.5 ms for 4e4 blocks)
+  if (!tid) {
+    if (i < B) roots[i] = i;
+    if (i == 0) *nroots = B;
+    return;
+  }
   const uint32_t slot = block_append(open, nroots);
   if (open) roots[slot] = i;
 }
@@ -477,13 +483,15 @@ struct EdgeOut {
   uint32_t *overflow;
 };
 
+template <int SLOTS = PT_SLOTS>
 __device__ __forceinline__ uint32_t pair_home(uint32_t C, uint32_t D) {
-  return (((C * 0x9E3779B1u) ^ (D * 0x85EBCA6Bu)) >> 16) & (PT_SLOTS - 1);
+  return (((C * 0x9E3779B1u) ^ (D * 0x85EBCA6Bu)) >> 16) & (SLOTS - 1);
 }
 // find-or-insert the pair (C, D) in the tile's LDS pair table and lower its pass key; false when the probe window is full
+template <int SLOTS = PT_SLOTS>
 __device__ __forceinline__ bool pair_insert(unsigned long long *pt_pair, uint32_t *pt_key, uint32_t C, uint32_t D, uint32_t key) {
   const unsigned long long pr = ((unsigned long long)C << 32) | D;
-  uint32_t slot = pair_home(C, D);
+  uint32_t slot = pair_home<SLOTS>(C, D);
 #pragma unroll 1
   for (int probe = 0; probe < PT_PROBES; probe++) {
     unsigned long long v = pt_pair[slot];
@@ -495,7 +503,7 @@ __device__ __forceinline__ bool pair_insert(unsigned long long *pt_pair, uint32_
       if (key < pt_key[slot]) atomicMin(&pt_key[slot], key);
       return true;
     }
-    slot = (slot + 1) & (PT_SLOTS - 1);
+    slot = (slot + 1) & (SLOTS - 1);
   }
   return false;
 }
@@ -837,20 +845,31 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
 // (current a, current b, key).  SEG: the input is the segmented list of the raster pass (one segment per block
 // range: segcap is a multiple of the 2048 records a block covers); otherwise a dense list of n records.
 constexpr int EPT = 8;
-template <bool SEG>
+constexpr int DT_SLOTS = 4096;   // DEDUP: pair table of a block (2048 records)
+// DEDUP (the dense rounds): the records of a block are first merged per component pair in an LDS table -- after a few
+// rounds most records of a block connect the same few large components, and without this the lists stop shrinking
+// and thousands of lanes hit the same best[] entries with atomics.
+template <bool SEG, bool DEDUP>
 __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict__ ea, const uint32_t *__restrict__ eb,
                                                      const uint32_t *__restrict__ ek, uint32_t n,
                                                      const uint32_t *__restrict__ segcount, uint32_t segcap,
                                                      const uint32_t *__restrict__ cur, unsigned long long *best, uint32_t B,
                                                      uint32_t *oa, uint32_t *ob, uint32_t *ok, uint32_t *ocount) {
   __shared__ uint32_t wtot[NTHR / 64];
-  __shared__ uint32_t bbase;
+  __shared__ uint32_t bbase, dn;
+  __shared__ unsigned long long dt_pair[DEDUP ? DT_SLOTS : 1];
+  __shared__ uint32_t dt_key[DEDUP ? DT_SLOTS : 1];
+  __shared__ uint16_t dt_list[DEDUP ? DT_SLOTS : 1];
   const size_t i0 = (size_t)blockIdx.x * (NTHR * EPT);
   size_t lim = n;   // records of this block's range that exist
   if (SEG) {
     const uint32_t seg = (uint32_t)(i0 / segcap);
     lim = (size_t)seg * segcap + segcount[seg];
     if (i0 >= lim) return;
+  }
+  if (DEDUP) {
+    for (int i = threadIdx.x; i < DT_SLOTS; i += NTHR) { dt_pair[i] = ~0ull; dt_key[i] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) dn = 0;
   }
   uint32_t a[EPT], b[EPT], k[EPT];
   bool ok_[EPT];
@@ -866,10 +885,42 @@ __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict_
 #pragma unroll
   for (int r = 0; r < EPT; r++) { ca[r] = cur[a[r] & ~CLOSED]; cb[r] = cur[b[r] & ~CLOSED]; }
   bool live[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; r++) live[r] = ca[r] != cb[r] && !(ca[r] & cb[r] & CLOSED);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t nd = 0;
+  if (DEDUP) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+      if (live[r]) {
+        const uint32_t lo = ca[r] < cb[r] ? ca[r] : cb[r], hi = ca[r] < cb[r] ? cb[r] : ca[r];
+        if (pair_insert<DT_SLOTS>(dt_pair, dt_key, lo, hi, k[r])) live[r] = false;   // merged; else it stays a record of its own
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DT_SLOTS; i += NTHR) {
+      const bool occ = dt_pair[i] != ~0ull;
+      const unsigned long long bal = __ballot(occ);
+      uint32_t base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&dn, (uint32_t)__popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (occ) dt_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    nd = dn;
+    for (uint32_t i = threadIdx.x; i < nd; i += NTHR) {
+      const int sl = dt_list[i];
+      const unsigned long long pr = dt_pair[sl];
+      const uint32_t lo = (uint32_t)(pr >> 32), hi = (uint32_t)pr, key = dt_key[sl];
+      const unsigned long long cl = ((unsigned long long)key << 32) | hi, ch = ((unsigned long long)key << 32) | lo;
+      if (!(lo & CLOSED) && cl < best[lo]) atomicMin(&best[lo], cl);
+      if (!(hi & CLOSED) && ch < best[hi]) atomicMin(&best[hi], ch);
+    }
+  }
   unsigned long long pa[EPT], pb[EPT];   // current best of either side (possibly stale: only a pre-check)
 #pragma unroll
   for (int r = 0; r < EPT; r++) {
-    live[r] = ca[r] != cb[r] && !(ca[r] & cb[r] & CLOSED);
     pa[r] = (live[r] && !(ca[r] & CLOSED)) ? best[ca[r]] : 0ull;
     pb[r] = (live[r] && !(cb[r] & CLOSED)) ? best[cb[r]] : 0ull;
   }
@@ -881,7 +932,6 @@ __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict_
     if (candB < pb[r]) atomicMin(&best[cb[r]], candB);
   }
   // survivors -> next list, in order, one global atomic per block
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned long long bal[EPT];
   uint32_t mine = 0;
 #pragma unroll
@@ -889,11 +939,19 @@ __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict_
   if (lane == 0) wtot[wv] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3] + nd;
     bbase = tot ? atomicAdd(ocount, tot) : 0;
   }
   __syncthreads();
   uint32_t off = bbase;
+  if (DEDUP) {
+    for (uint32_t i = threadIdx.x; i < nd; i += NTHR) {
+      const int sl = dt_list[i];
+      const unsigned long long pr = dt_pair[sl];
+      oa[off + i] = (uint32_t)(pr >> 32); ob[off + i] = (uint32_t)pr; ok[off + i] = dt_key[sl];
+    }
+    off += nd;
+  }
   for (int q = 0; q < wv; q++) off += wtot[q];
 #pragma unroll
   for (int r = 0; r < EPT; r++) {
@@ -986,18 +1044,43 @@ __global__ __launch_bounds__(NTHR) void k_update_basins(uint32_t *cur, uint32_t 
   }
 }
 
+constexpr int RPT = 8;   // roots per thread: 2048 per block, so a round over 1e7 roots is 5e3 same-address atomics
 __global__ __launch_bounds__(NTHR) void k_compact_roots(const uint32_t *__restrict__ roots_in, uint32_t nroots,
                                                         const unsigned long long *__restrict__ link,
                                                         uint32_t *roots_out, uint32_t *counter) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  bool keep = false;
-  uint32_t r = 0;
-  if (i < nroots) {
-    r = roots_in[i];
-    keep = (uint32_t)link[r] == r;
+  __shared__ uint32_t wtot[NTHR / 64];
+  __shared__ uint32_t bbase;
+  const uint32_t i0 = blockIdx.x * (NTHR * RPT);
+  uint32_t r[RPT];
+  bool ok[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) {
+    const uint32_t i = i0 + q * NTHR + threadIdx.x;
+    ok[q] = i < nroots;
+    r[q] = ok[q] ? roots_in[i] : 0u;
   }
-  const uint32_t slot = block_append(keep, counter);
-  if (keep) roots_out[slot] = r;
+  bool keep[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) keep[q] = ok[q] && (uint32_t)link[r[q]] == r[q];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long bal[RPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < RPT; q++) { bal[q] = __ballot(keep[q]); mine += (uint32_t)__popcll(bal[q]); }
+  if (lane == 0) wtot[wv] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    bbase = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  uint32_t off = bbase;
+  for (int k = 0; k < wv; k++) off += wtot[k];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) {
+    if (keep[q]) roots_out[off + (uint32_t)__popcll(bal[q] & ((1ull << lane) - 1ull))] = r[q];
+    off += (uint32_t)__popcll(bal[q]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1264,6 +1347,8 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   // (both exist for the tests of the overflow fallback and for A/B timing).
   const char *env_edges = getenv("RDGPU_FILL_EDGES"), *env_cap = getenv("RDGPU_FILL_EDGE_CAP");
   const bool edges_enabled = !(env_edges && env_edges[0] == '0');
+  const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
+  const bool dedup = !(env_dedup && env_dedup[0] == '0');
   bool edge_mode = false;           // rounds 2.. run on the pair list
   EdgeOut eo{};
   uint32_t nseg = 1, nedges = 0;
@@ -1294,11 +1379,14 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
       const uint32_t *ia = elist[ein], *ib = elist[ein] + ecap[ein], *ik = elist[ein] + 2 * ecap[ein];
       uint32_t *oa = elist[eout], *ob = elist[eout] + ecap[eout], *ok = elist[eout] + 2 * ecap[eout];
       if (eseg)
-        RD_LAUNCH("fill.edge_round", (k_edge_round<true>), dim3(cdiv(ecap[ein], NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+        RD_LAUNCH("fill.edge_round", (k_edge_round<true, false>), dim3(cdiv(ecap[ein], NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
                   (uint32_t)ecap[ein], (const uint32_t *)eo.segcount, eo.segcap, (const uint32_t *)cur, best, B, oa, ob, ok,
                   dflags + 4);
+      else if (nedges > 0 && dedup)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, true>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+                  nedges, (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
       else if (nedges > 0)
-        RD_LAUNCH("fill.edge_round", (k_edge_round<false>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, false>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
                   nedges, (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
       eseg = false;
       ein = eout;
@@ -1329,8 +1417,8 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     }
     RD_LAUNCH("fill.update_basins", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
     RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
-              dflags + 2);
+    RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link,
+              rootsB, dflags + 2);
     RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     const uint32_t next = hw[0];
@@ -1710,7 +1798,8 @@ static void graph_solve_device(int S, int w, int topo, const uint32_t *d_keys_al
     }
     RD_LAUNCH("graph.update", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
     RD_HIP(hipMemsetAsync(dflags + 2, 0, 4, s));
-    RD_LAUNCH("graph.compact_roots", k_compact_roots, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB, dflags + 2);
+    RD_LAUNCH("graph.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
+              dflags + 2);
     RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4, hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     if (hw[0] >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve_dev: a cut-row terminal is not connected to the outside");
