@@ -20,7 +20,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FILL_ALG_BYTES_PER_CELL = 8.0  # read z (4 B) + write W (4 B)
-DOMINANT_KERNEL = "fill.scan"
+# The fill's raster kernels, each one pass over the DEM: a launch's algorithmic bytes are 8 B x the cells it visits
+# (fill.scan: the tiles it is launched on -- all of them in the single pair pass; the others: every cell).
+RASTER_KERNELS = ("fill.scan", "fill.descent", "fill.tile_label", "fill.finalize")
 
 
 def cpu_baseline(Z, sample: int):
@@ -115,27 +117,30 @@ def main():
     ms_step = dt * 1e3 / args.steps
     value = cells / 1e6 / (dt / args.steps)
 
-    k_ms, k_n = prof.get(DOMINANT_KERNEL, (0.0, 0))
     total_kernel_ms = sum(v[0] for v in prof.values())
+    # the dominant kernel = the raster kernel with the largest share of the step
+    dominant = max(RASTER_KERNELS, key=lambda k: prof.get(k, (0.0, 0))[0])
+    k_ms, k_n = prof.get(dominant, (0.0, 0))
     roofline = None
     if k_n:
-        # algorithmic bytes of the cells the scan launches actually visited (dead tiles are skipped from
-        # round 2 on): visited tiles x cells/tile x 8 B, over the measured duration of those launches
-        visited_cells = stats["scan_tiles"] * stats["tile_cells"]
-        scan_s = k_ms / args.steps / 1e3
-        achieved = visited_cells * FILL_ALG_BYTES_PER_CELL / scan_s / 1e9
         launches = k_n / args.steps
+        if dominant == "fill.scan":   # tiles visited x cells per tile (dead tiles are skipped by raster rounds 2..)
+            visited_cells = stats["scan_tiles"] * stats["tile_cells"]
+        else:
+            visited_cells = cells * launches
+        k_s = k_ms / args.steps / 1e3
+        achieved = visited_cells * FILL_ALG_BYTES_PER_CELL / k_s / 1e9
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
             if pt.get("size") == n:
-                traffic = pt.get("fill.scan_GB_per_launch")
+                traffic = pt.get("GB_per_launch", {}).get(dominant)
         except OSError:
             pass
         roofline = {
             "bound": "hbm",
-            "kernel": DOMINANT_KERNEL,
+            "kernel": dominant,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -146,6 +151,7 @@ def main():
             "launches_per_step": launches,
             "alg_GB_per_launch": round(visited_cells * FILL_ALG_BYTES_PER_CELL / launches / 1e9, 3),
             "share_of_kernel_time": round(k_ms / total_kernel_ms, 3) if total_kernel_ms else None,
+            "whole_fill_alg_GBps": round(cells * FILL_ALG_BYTES_PER_CELL / (dt / args.steps) / 1e9, 1),
         }
     out = {
         "metric": "Mcells/s Priority-Flood fill, 40k x 40k f32 DEM",

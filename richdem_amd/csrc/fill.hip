@@ -1,4 +1,4 @@
-// fill.hip -- depression filling on MI355X: descent forest -> basins -> raster Boruvka rounds.
+// fill.hip -- depression filling on MI355X: descent forest -> basins -> one raster pass -> Boruvka rounds on a pair list.
 //
 // Replaces FillDepressions<D8/D4> (reference include/richdem/depressions/depressions.hpp:13-21,
 // i.e. PriorityFlood_Zhou2016, depressions/Zhou2016.hpp:126-191, and PriorityFlood_Barnes2014<D4>,
@@ -14,8 +14,10 @@
 //   2. k_tile_label   lab[c] = basin of c (B = the outside): the few distinct pointers of a tile are chased
 //                     to their pits once per tile (k_chase / k_label_cells: fallback for very long chains).
 //                     W(c) = max(z(c), L[basin(c)]) with L = minimax pass height basin -> outside.
-//   3. rounds of      k_scan (raster pass: each component's lowest pass to a different component,
-//                     one 64-bit atomicMin of (pass height << 32 | neighbour component)),
+//   3. rounds of      round 1: k_scan<EMIT> (the one raster pass: the lowest pass of every PAIR of adjacent
+//                     components, reduced per tile and appended to a list; each component's lowest pass to a
+//                     different component = one 64-bit atomicMin of (pass height << 32 | neighbour component));
+//                     rounds 2..: k_edge_round on the pair list (raster k_scan passes as overflow fallback);
 //                     k_hook (hook every component along its lowest pass; mutual pairs keep the
 //                     smaller id as root), k_chase_links (pointer jumping carrying the path
 //                     maximum), k_update_basins, k_compact_roots.  This is Boruvka's contraction:

@@ -79,16 +79,24 @@ def main():
         f.write("kernel,launches,fetch_GB_per_launch(x2),write_GB_per_launch,total_GB_per_launch\n")
         for r in rows:
             f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f}\n")
-    scan = [r for r in rows if r[0].startswith("rdgpu::k_scan<")]
-    if scan:
-        n = sum(r[1] for r in scan)
-        gb = sum(r[4] * r[1] for r in scan) / n
+    # per-launch HBM traffic of the fill's kernels, under the names the library's profiler (and bench.py) uses
+    names = {"k_scan": "fill.scan", "k_descent": "fill.descent", "k_tile_label": "fill.tile_label",
+             "k_finalize": "fill.finalize", "k_edge_round": "fill.edge_round"}
+    per = {}
+    for kern, prof_name in names.items():
+        sel = [r for r in rows if r[0].split("<")[0] == "rdgpu::" + kern]
+        if sel:
+            cnt = sum(r[1] for r in sel)
+            per[prof_name] = round(sum(r[4] * r[1] for r in sel) / cnt, 3)
+    if per:
         with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
-            json.dump({"size": 40000, "fill.scan_GB_per_launch": round(gb, 3),
+            json.dump({"size": 40000, "GB_per_launch": per,
                        "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
         # the bench line above was printed before these passes ran: give it this round's traffic figure
         d = json.loads(line)
-        d["roofline"]["traffic"] = round(gb, 3)
+        if d.get("roofline") and d["roofline"].get("kernel") in per:
+            d["roofline"]["traffic"] = per[d["roofline"]["kernel"]]
+            d["roofline"]["traffic_unit"] = "GB per launch (rocprofv3 PMC, profiles/)"
         line = json.dumps(d)
         with open(os.path.join(OUT, f"{tag}_fill40k_bench.json"), "w") as f:
             f.write(line + "\n")
