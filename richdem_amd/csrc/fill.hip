@@ -57,6 +57,7 @@ static rdgpu_fill_stats g_stats;
 // global chase (k_chase) then hops tile to tile instead of cell to cell.
 // ------------------------------------------------------------------------------------------
 constexpr int DW = 64, DH = 64, DLW = DW + 2, DLH = DH + 2;
+constexpr uint32_t LAB_PEND = 0x80000000u;   // lab word not resolved yet: LAB_PEND | next cell on the path (OUTP: off the raster)
 constexpr uint16_t LTERM_BASE = 0xF000u;   // local pointers >= this: the cell is terminal within the tile (low 4 bits: code)
 
 // Four consecutive cells of a row starting at column gx in one load.  ALIGNED: the raster width is a multiple of 4
@@ -84,8 +85,8 @@ __device__ __forceinline__ Quad<U> load_quad(const U *__restrict__ row, int gx, 
 }
 
 template <class T, int TOPO, bool VEC>
-__global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ ptr,
-                                                  uint32_t *__restrict__ lab, uint32_t *pit_counter,
+__global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ lab,
+                                                  uint32_t *pit_counter,
                                                   int w, int h, uint32_t tilesX, uint32_t ntiles, int open_top,
                                                   int open_bottom) {
   __shared__ uint32_t sk[DLH * DLW];
@@ -199,27 +200,14 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       if (pv[j] < LTERM_BASE && qv[j] < LTERM_BASE) { lp[(ly0 + j) * DW + lx] = qv[j]; still = 1; }
     if (!__syncthreads_or(still)) break;
   }
-  // write: the tile-local root's own pointer.  Pits (and a shard's cut-row terminals), ptr[c] == c, get their
-  // dense basin id here: ONE counter add per tile (ids are dense but not in raster order -- nothing depends on
-  // their order, the filled surface is unique).
+  // Pits (and a shard's cut-row terminals) -- the cells that are their own root -- get their dense basin id here:
+  // ONE counter add per tile (ids are dense but not in raster order -- nothing depends on their order, the filled
+  // surface is unique).
   uint32_t pitmask = 0;
 #pragma unroll 4
   for (int j = 0; j < DH / 4; j++) {
     const int ly = ly0 + j, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    uint16_t p = lp[ly * DW + lx];
-    int rx = lx, ry = ly;
-    if (p < LTERM_BASE) { rx = p & (DW - 1); ry = p >> 6; p = lp[p]; }
-    const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
-    const int code = p & 15;
-    uint32_t g;
-    if (code == 9) g = OUTP;
-    else {
-      const int n = code == 0 ? 4 : (code <= 4 ? code - 1 : code);   // 3x3 position, 4 = centre
-      g = (uint32_t)(y0 + ry + n / 3 - 1) * (uint32_t)w + (uint32_t)(x0 + rx + n % 3 - 1);
-    }
-    ptr[c] = g;
-    if (g == c) pitmask |= 1u << j;
+    if (gx < w && gy < h && lp[ly * DW + lx] == LTERM_BASE) pitmask |= 1u << j;
   }
   const uint32_t mine = (uint32_t)__popc(pitmask);
   uint32_t incl = mine;   // inclusive prefix over the wavefront
@@ -237,61 +225,83 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   __syncthreads();
   uint32_t id = pbase + incl - mine;
   for (int k = 0; k < (int)(threadIdx.x >> 6); k++) id += wtot[k];
+  uint32_t *pid = sk;   // the keys are no longer needed: basin id of the pit at local index i
   for (uint32_t m = pitmask; m; m &= m - 1) {
     const int j = __ffs((int)m) - 1;
-    lab[(size_t)(y0 + ly0 + j) * w + gx] = id++;
+    pid[(ly0 + j) * DW + lx] = id++;
+  }
+  __syncthreads();
+  // One word per cell: its basin id when its path ends at a pit of this tile (final), LAB_PEND | the first cell
+  // outside the tile on its path otherwise, OUTP when it drains off the raster.  k_tile_label resolves the rest.
+#pragma unroll 4
+  for (int j = 0; j < DH / 4; j++) {
+    const int ly = ly0 + j, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    uint16_t p = lp[ly * DW + lx];
+    int r = ly * DW + lx;
+    if (p < LTERM_BASE) { r = p; p = lp[p]; }
+    const int code = p & 15;
+    uint32_t word;
+    if (code == 9) word = OUTP;
+    else if (code == 0) word = pid[r];
+    else {
+      const int rx = r & (DW - 1), ry = r >> 6;
+      const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour
+      word = LAB_PEND | ((uint32_t)(y0 + ry + n / 3 - 1) * (uint32_t)w + (uint32_t)(x0 + rx + n % 3 - 1));
+    }
+    lab[(size_t)gy * w + gx] = word;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// 2. pointer chasing with path compression (bounded hops per pass; host repeats while flagged).
-// Any value ever stored in ptr[c] is an ancestor of c (or OUTP), so concurrent in-place updates
-// and stale cached reads are harmless.
+// 2. labels.  After k_descent a word of lab[] is a basin id (final), LAB_PEND | next cell, or OUTP.  Every value ever
+// stored in a word is the cell's basin, or a cell further down its path, or OUTP when the path leaves the raster --
+// so concurrent in-place updates and stale cached reads are harmless.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_chase(uint32_t *ptr, uint32_t n, int maxhops, uint32_t *flag) {
+// Fallback for pathologically long tile-to-tile chains: bounded hops per pass with path compression; the host
+// repeats while flagged.  Resolves a word as soon as it meets a resolved one.
+__global__ __launch_bounds__(NTHR) void k_chase(uint32_t *lab, uint32_t n, int maxhops, uint32_t *flag) {
   const uint64_t stride = (uint64_t)gridDim.x * NTHR;
   for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
     const uint32_t c = (uint32_t)c64;
-    uint32_t p = ptr[c];
-    if (p == OUTP || p == c) continue;
-    const uint32_t p0 = p;
+    uint32_t v = lab[c];
+    if (!(v & LAB_PEND) || v == OUTP) continue;
+    const uint32_t v0 = v;
     int hops = 0;
     bool unfinished = false;
     for (;;) {
-      const uint32_t q = ptr[p];
-      if (q == OUTP) { p = OUTP; break; }
-      if (q == p) break;
-      p = q;
+      const uint32_t q = lab[v & ~LAB_PEND];
+      v = q;
+      if (!(q & LAB_PEND) || q == OUTP) break;
       if (++hops >= maxhops) { unfinished = true; break; }
     }
-    if (p != p0) ptr[c] = p;
+    if (v != v0) lab[c] = v;
     if (unfinished) *flag = 1;
   }
 }
 
-// Labels per tile: the cells of a 64x64 tile share a handful of distinct pointers (its pits and the ring
-// cells its paths leave through), so the distinct values are collected in an LDS table, each is chased to
-// its pit ONCE (tile-to-tile hops, global gathers), and the 4096 cells read their label from LDS.  lab[pit]
-// must already hold the pit's dense id (k_descent); lab[c] = B for cells draining off the raster.  A chain
-// longer than maxhops raises the flag: the host then falls back to the compressing passes.
+// Labels per tile: the unresolved cells of a 64x64 tile share a handful of distinct pointers (the ring cells its
+// paths leave through), so the distinct values are collected in an LDS table, each is chased to a resolved word
+// ONCE (tile-to-tile hops, global gathers), and the cells read their label from LDS; lab[c] = B for cells draining
+// off the raster.  Cells whose path ends at a pit of their own tile were finished by k_descent and are not written.
+// A chain longer than maxhops raises the flag and leaves (compressed) pending words: the host then falls back to the
+// compressing passes.
 constexpr int LT_SLOTS = 1024;
 constexpr uint32_t LT_EMPTY = 0xFFFFFFFEu;
 
-__device__ __forceinline__ uint32_t chase_to_label(const uint32_t *__restrict__ ptr, const uint32_t *lab, uint32_t p,
-                                                   uint32_t B, int maxhops, uint32_t *flag) {
+__device__ __forceinline__ uint32_t chase_to_label(const uint32_t *lab, uint32_t v, uint32_t B, int maxhops, uint32_t *flag) {
   int hops = 0;
-  for (;;) {
-    const uint32_t q = ptr[p];
+  for (;;) {   // v: a pending word
+    const uint32_t q = lab[v & ~LAB_PEND];
     if (q == OUTP) return B;
-    if (q == p) return lab[p];
-    p = q;
-    if (++hops >= maxhops) { *flag = 1; return B; }
+    if (!(q & LAB_PEND)) return q;
+    v = q;
+    if (++hops >= maxhops) { *flag = 1; return v; }
   }
 }
 
-__global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict__ ptr, uint32_t *lab, int w, int h,
-                                                     uint32_t tilesX, uint32_t ntiles, uint32_t B, int maxhops,
-                                                     uint32_t *flag) {
+__global__ __launch_bounds__(NTHR) void k_tile_label(uint32_t *lab, int w, int h, uint32_t tilesX, uint32_t ntiles,
+                                                     uint32_t B, int maxhops, uint32_t *flag) {
   __shared__ uint32_t tkey[LT_SLOTS];
   __shared__ uint32_t tval[LT_SLOTS];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
@@ -303,20 +313,17 @@ __global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict_
   const int gx = x0 + lx;
   constexpr int CELLS = DH / 4;
   uint32_t pv[CELLS];
-  int16_t sl[CELLS];   // table slot, -1: pit / outside the raster, -2: drains off the raster, -3: table full
+  int16_t sl[CELLS];   // table slot, -1: final already / outside the raster, -2: drains off the raster, -3: table full
 #pragma unroll
-  for (int j = 0; j < CELLS; j++) {   // all pointer loads of the thread in flight together
+  for (int j = 0; j < CELLS; j++) {   // all loads of the thread in flight together
     const int gy = y0 + ly0 + 4 * j;
-    pv[j] = (gx < w && gy < h) ? ptr[(size_t)gy * w + gx] : 0u;
+    pv[j] = (gx < w && gy < h) ? lab[(size_t)gy * w + gx] : 0u;
   }
 #pragma unroll
   for (int j = 0; j < CELLS; j++) {
-    const int gy = y0 + ly0 + 4 * j;
     sl[j] = -1;
-    if (gx >= w || gy >= h) continue;
-    const uint32_t c = (uint32_t)gy * (uint32_t)w + (uint32_t)gx;
     const uint32_t p = pv[j];
-    if (p == c) continue;
+    if (!(p & LAB_PEND)) continue;
     if (p == OUTP) { sl[j] = -2; continue; }
     if (j > 0 && sl[j - 1] >= 0 && pv[j - 1] == p) { sl[j] = sl[j - 1]; continue; }
     uint32_t slot = (p * 0x9E3779B1u) >> 22;
@@ -334,52 +341,45 @@ __global__ __launch_bounds__(NTHR) void k_tile_label(const uint32_t *__restrict_
   {
     // the thread's table slots are chased together: one gather per live chain and trip, all in flight at once
     constexpr int SPT = LT_SLOTS / NTHR;
-    uint32_t p[SPT], res[SPT];
+    uint32_t p[SPT];
     uint32_t live = 0;
 #pragma unroll
     for (int r = 0; r < SPT; r++) {
-      p[r] = tkey[threadIdx.x + r * NTHR];
-      res[r] = B;
+      p[r] = tkey[threadIdx.x + r * NTHR];   // a pending word (or LT_EMPTY)
       if (p[r] != LT_EMPTY) live |= 1u << r;
     }
     for (int hops = 0; live; hops++) {
-      if (hops > maxhops) { *flag = 1; break; }
+      if (hops > maxhops) { *flag = 1; break; }   // the words stay pending (compressed): the fallback finishes them
       uint32_t q[SPT];
 #pragma unroll
-      for (int r = 0; r < SPT; r++) q[r] = (live >> r & 1u) ? ptr[p[r]] : 0u;
+      for (int r = 0; r < SPT; r++) q[r] = (live >> r & 1u) ? lab[p[r] & ~LAB_PEND] : 0u;
 #pragma unroll
       for (int r = 0; r < SPT; r++) {
         if (!(live >> r & 1u)) continue;
-        if (q[r] == OUTP) { res[r] = B; live &= ~(1u << r); }
-        else if (q[r] == p[r]) { res[r] = lab[p[r]]; live &= ~(1u << r); }
+        if (q[r] == OUTP) { p[r] = B; live &= ~(1u << r); }
+        else if (!(q[r] & LAB_PEND)) { p[r] = q[r]; live &= ~(1u << r); }
         else p[r] = q[r];
       }
     }
 #pragma unroll
-    for (int r = 0; r < SPT; r++) tval[threadIdx.x + r * NTHR] = res[r];
+    for (int r = 0; r < SPT; r++) tval[threadIdx.x + r * NTHR] = p[r];
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < CELLS; j++) {
     if (sl[j] == -1) continue;
     const size_t c = (size_t)(y0 + ly0 + 4 * j) * w + gx;
-    lab[c] = sl[j] >= 0 ? tval[sl[j]] : sl[j] == -2 ? B : chase_to_label(ptr, lab, pv[j], B, maxhops, flag);
+    lab[c] = sl[j] >= 0 ? tval[sl[j]] : sl[j] == -2 ? B : chase_to_label(lab, pv[j], B, maxhops, flag);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// 3. per-cell labels after the compressing fallback passes
+// 3. after the compressing fallback passes every word is a basin id or OUTP: lab[c] = B for the latter
 // ------------------------------------------------------------------------------------------
-// lab[c] = basin id of c's pit; B for cells draining off the raster.
-__global__ __launch_bounds__(NTHR) void k_label_cells(const uint32_t *__restrict__ ptr, uint32_t *lab,
-                                                      uint32_t n, uint32_t B) {
+__global__ __launch_bounds__(NTHR) void k_label_cells(uint32_t *lab, uint32_t n, uint32_t B) {
   const uint64_t stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride) {
-    const uint32_t c = (uint32_t)c64;
-    const uint32_t p = ptr[c];
-    if (p == OUTP) lab[c] = B;
-    else if (p != c) lab[c] = lab[p];  // lab[p] of a pit was written by k_descent
-  }
+  for (uint64_t c64 = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c64 < n; c64 += stride)
+    if (lab[c64] == OUTP) lab[c64] = B;
 }
 
 // Stream compaction helper: every thread of the (256-thread) block calls it; ONE global atomic per
@@ -1271,7 +1271,6 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   if (w <= 2 || (!sharded && h <= 2)) { fb.trivial = true; return; }  // every cell is a border cell
 
   Workspace &ws = Workspace::get();
-  uint32_t *ptr = ws.buf<uint32_t>("fill.ptr", n);
   uint32_t *lab = alloc.get<uint32_t>("fill.lab", n);
   fb.lab = lab;
   uint32_t *dflags = ws.buf<uint32_t>("fill.flags", 16);  // [0] chase flag, [1] pit total, [2] root counter
@@ -1280,16 +1279,16 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const uint32_t tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), ntiles = tilesX * tilesY;
   const uint32_t sgrid = std::min(cdiv(n, NTHR), 256u * 32u);  // grid-stride 1-D kernels
 
-  // descent pointers; pits (ptr[c] == c) are final and numbered by the same kernel
+  // descent forest: one word per cell (basin id / pending pointer / off the raster); pits are numbered by the same kernel
   const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
   RD_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(uint32_t), s));
   // naturally aligned quads when every row starts on a quad boundary; the any-width quad loads otherwise
   const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
   if (vec)
-    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
+    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, lab, dflags + 1, w,
               h, dtx, dnt, open_top, open_bottom);
   else
-    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, ptr, lab, dflags + 1, w,
+    RD_LAUNCH("fill.descent", (k_descent<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, lab, dflags + 1, w,
               h, dtx, dnt, open_top, open_bottom);
   RD_HIP(hipMemcpyAsync(hw, dflags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
@@ -1297,8 +1296,7 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   g_stats.basins = B;
   fb.B = B;
   if (B == 0) { fb.trivial = true; return; }  // no pits and no terminals: nothing to raise
-  RD_LAUNCH("fill.tile_label", k_tile_label, dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const uint32_t *)ptr, lab, w, h, dtx,
-            dnt, B, 256, dflags);
+  RD_LAUNCH("fill.tile_label", k_tile_label, dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, lab, w, h, dtx, dnt, B, 256, dflags);
   RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   g_stats.jump_passes = 1;
@@ -1306,13 +1304,13 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
     // pathologically long tile-to-tile chains: compress them (each pass shortens every path >= 32x), relabel
     for (;;) {
       RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
-      RD_LAUNCH("fill.chase", k_chase, dim3(sgrid), dim3(NTHR), 0, s, ptr, n, 32, dflags);
+      RD_LAUNCH("fill.chase", k_chase, dim3(sgrid), dim3(NTHR), 0, s, lab, n, 32, dflags);
       RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
       g_stats.jump_passes++;
       if (hw[0] == 0) break;
     }
-    RD_LAUNCH("fill.label_cells", k_label_cells, dim3(sgrid), dim3(NTHR), 0, s, ptr, lab, n, B);
+    RD_LAUNCH("fill.label_cells", k_label_cells, dim3(sgrid), dim3(NTHR), 0, s, lab, n, B);
   }
 
   uint32_t *cur = alloc.get<uint32_t>("fill.cur", (size_t)B + 1);
