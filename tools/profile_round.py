@@ -81,7 +81,7 @@ def main():
             f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f}\n")
     # per-launch HBM traffic of the fill's kernels, under the names the library's profiler (and bench.py) uses
     names = {"k_scan": "fill.scan", "k_descent": "fill.descent", "k_tile_label": "fill.tile_label",
-             "k_finalize": "fill.finalize", "k_edge_round": "fill.edge_round"}
+             "k_finalize": "fill.finalize", "k_finalize_tiled": "fill.finalize", "k_edge_round": "fill.edge_round"}
     per = {}
     for kern, prof_name in names.items():
         sel = [r for r in rows if r[0].split("<")[0] == "rdgpu::" + kern]
