@@ -84,6 +84,12 @@ RDGPU_DECL_PITMASK(u32, uint32_t)
 RDGPU_DECL_PITMASK(f32, float)
 #undef RDGPU_DECL_PITMASK
 
+/* Environment switches of the fill (read at every call; for tests and A/B timing, results never change):
+ *   RDGPU_FILL_EDGES=0         every contraction round is a raster pass (the r01d engine; default: one raster pass,
+ *                              then rounds on the component-pair list it records)
+ *   RDGPU_FILL_EDGE_CAP=<n>    capacity of that list in records (default min(12 per basin, cells/2)); a list
+ *                              that does not fit falls back to raster passes
+ *   RDGPU_FILL_DEDUP=0         do not merge the list's records per component pair between rounds */
 /* Statistics of the last fill on this process (for DESIGN.md / bench.py reporting). */
 typedef struct rdgpu_fill_stats {
   uint64_t cells;       /* width*height                                   */

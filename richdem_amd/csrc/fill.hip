@@ -846,7 +846,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     }
   }
   // NB: no global "alive tiles" counter here -- ~10^6 same-address atomics serialise at ~12 ns each
-  // (that alone cost 9 ms per pass); k_count_alive sums the flags instead
+  // (that alone cost 9 ms per pass); k_compact_alive turns the flags into the next round's tile list
   if (threadIdx.x == 0) alive_out[t] = alive ? 1 : 0;
 }
 
