@@ -18,11 +18,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FILL_ALG_BYTES_PER_CELL = 8.0  # read z (4 B) + write W (4 B)
-# The fill's raster kernels, each one pass over the DEM: a launch's algorithmic bytes are 8 B x the cells it visits
-# (fill.scan: the tiles it is launched on -- all of them in the single pair pass; the others: every cell).
-RASTER_KERNELS = ("fill.scan", "fill.descent", "fill.tile_label", "fill.finalize")
 
 
 def cpu_baseline(Z, sample: int):
@@ -63,9 +58,20 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE line, the JSON of rank 0.  Libraries print there too (RCCL: "Librccl path : ...",
+    # flushed from the C stdio buffer at exit, on every rank), so file descriptor 1 is pointed at stderr for the
+    # whole run and the JSON line is written to the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
 
     import richdem_amd as rd
+    from richdem_amd.roofline import fill_roofline
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,7 +92,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from richdem_amd.sharded import bench_sharded
 
-        return bench_sharded(args, rank, world)
+        out = bench_sharded(args, rank, world)
+        if out is not None:   # rank 0
+            emit(out)
+        return
 
     n = args.size
     cells = n * n
@@ -117,42 +126,8 @@ def main():
     ms_step = dt * 1e3 / args.steps
     value = cells / 1e6 / (dt / args.steps)
 
-    total_kernel_ms = sum(v[0] for v in prof.values())
-    # the dominant kernel = the raster kernel with the largest share of the step
-    dominant = max(RASTER_KERNELS, key=lambda k: prof.get(k, (0.0, 0))[0])
-    k_ms, k_n = prof.get(dominant, (0.0, 0))
-    roofline = None
-    if k_n:
-        launches = k_n / args.steps
-        if dominant == "fill.scan":   # tiles visited x cells per tile (dead tiles are skipped by raster rounds 2..)
-            visited_cells = stats["scan_tiles"] * stats["tile_cells"]
-        else:
-            visited_cells = cells * launches
-        k_s = k_ms / args.steps / 1e3
-        achieved = visited_cells * FILL_ALG_BYTES_PER_CELL / k_s / 1e9
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            if pt.get("size") == n:
-                traffic = pt.get("GB_per_launch", {}).get(dominant)
-        except OSError:
-            pass
-        roofline = {
-            "bound": "hbm",
-            "kernel": dominant,
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/)" if traffic is not None else None,
-            "avg_launch_ms": round(k_ms / k_n, 4),
-            "launches_per_step": launches,
-            "alg_GB_per_launch": round(visited_cells * FILL_ALG_BYTES_PER_CELL / launches / 1e9, 3),
-            "share_of_kernel_time": round(k_ms / total_kernel_ms, 3) if total_kernel_ms else None,
-            "whole_fill_alg_GBps": round(cells * FILL_ALG_BYTES_PER_CELL / (dt / args.steps) / 1e9, 1),
-        }
+    roofline = fill_roofline(prof, stats, cells, args.steps, dt / args.steps,
+                             os.path.join(ROOT, "profiles", "pmc_traffic.json"), n)
     out = {
         "metric": "Mcells/s Priority-Flood fill, 40k x 40k f32 DEM",
         "value": round(value, 2),
@@ -181,7 +156,7 @@ def main():
     }
     if args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(Z, args.cpu_sample)
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":

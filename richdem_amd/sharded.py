@@ -241,7 +241,7 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
 # ---------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of the BASELINE DEM over N row blocks
 # ---------------------------------------------------------------------------------------------------
-def bench_sharded(args, rank: int, world: int) -> None:
+def bench_sharded(args, rank: int, world: int):
     import torch
     import torch.distributed as dist
 
@@ -299,19 +299,16 @@ def bench_sharded(args, rank: int, world: int) -> None:
                 "parallelism": f"row-block x{world}; 1 all-gather of cut rows + spillover graph per fill",
             },
         }
-        k_ms, k_n = prof.get("fill.scan", (0.0, 0))
-        if k_n:   # the dominant kernel on rank 0's row block: algorithmic bytes of the cells its launches visited
-            visited = stats["scan_tiles"] * stats["tile_cells"]
-            achieved = visited * 8 / (k_ms / args.steps / 1e3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "fill.scan", "achieved": round(achieved, 1), "peak": 8000.0,
-                               "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
-                               "avg_launch_ms": round(k_ms / k_n, 4), "launches_per_step": k_n / args.steps,
-                               "alg_GB_per_launch": round(visited * 8 / (k_n / args.steps) / 1e9, 3), "scope": "rank 0, per GPU"}
+        from .roofline import fill_roofline
+
+        rl = fill_roofline(prof, stats, (r1 - r0) * n, args.steps)   # the dominant kernel on rank 0's row block
+        if rl:
+            rl["scope"] = "rank 0, per GPU"
+            out["roofline"] = rl
             out["kernels_ms_per_step_rank0"] = {k: round(v[0] / args.steps, 3)
                                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:10]}
     dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    return out   # rank 0: the JSON object bench.py prints; None elsewhere
 
 
 # ---------------------------------------------------------------------------------------------------
