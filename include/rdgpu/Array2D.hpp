@@ -99,6 +99,20 @@ public:
   T noData() const { return no_data_; }
   void setNoData(const T &v) { no_data_ = v; }
 
+  // extremes over the cells that are not NoData (reference Array2D.hpp:516-535; numeric_limits when there are none)
+  T min() const {
+    T m = std::numeric_limits<T>::max();
+    for (size_t i = 0, n = (size_t)w_ * (size_t)h_; i < n; i++)
+      if (!(ptr_[i] == no_data_) && ptr_[i] < m) m = ptr_[i];
+    return m;
+  }
+  T max() const {
+    T m = std::numeric_limits<T>::lowest();
+    for (size_t i = 0, n = (size_t)w_ * (size_t)h_; i < n; i++)
+      if (!(ptr_[i] == no_data_) && ptr_[i] > m) m = ptr_[i];
+    return m;
+  }
+
   void setAll(const T &val) { std::fill(ptr_, ptr_ + (size_t)w_ * (size_t)h_, val); }
 
   void resize(xy_t width, xy_t height, const T &val = T()) {

@@ -61,7 +61,10 @@ int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
   inline int c_fa_dinf(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_tarboton_##SUF(p, nd, w, h, a); } \
   inline int c_fa_mfd(const T *p, T nd, int w, int h, int m, double x, double *a) { return rdgpu_fa_mfd_##SUF(p, nd, w, h, m, x, a); } \
   inline int c_rfe(T *p, T nd, int w, int h) { return rdgpu_resolve_flats_epsilon_##SUF(p, nd, w, h); } \
-  inline int c_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_dinf_flowdirs_##SUF(p, nd, w, h, o); }
+  inline int c_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_dinf_flowdirs_##SUF(p, nd, w, h, o); } \
+  inline int c_fm_d8(const T *p, T nd, int w, int h, float *o) { return rdgpu_fm_d8_##SUF(p, nd, w, h, o); } \
+  inline int c_fm_dinf(const T *p, T nd, int w, int h, float *o) { return rdgpu_fm_tarboton_##SUF(p, nd, w, h, o); } \
+  inline int c_fm_mfd(const T *p, T nd, int w, int h, int m, double x, float *o) { return rdgpu_fm_mfd_##SUF(p, nd, w, h, m, x, o); }
 RDGPU_SHIM_STENCIL(u8, uint8_t)
 RDGPU_SHIM_STENCIL(i16, int16_t)
 RDGPU_SHIM_STENCIL(u16, uint16_t)
@@ -84,6 +87,12 @@ template <class T>
 int c_fa_mfd(const T *, T, int, int, int, double, double *) { unsupported("FA_Holmgren / FA_Freeman / FA_Quinn / FA_D4"); }
 template <class T>
 int c_rfe(T *, T, int, int) { unsupported("ResolveFlatsEpsilon"); }
+template <class T>
+int c_fm_d8(const T *, T, int, int, float *) { unsupported("FM_D8"); }
+template <class T>
+int c_fm_dinf(const T *, T, int, int, float *) { unsupported("FM_Tarboton"); }
+template <class T>
+int c_fm_mfd(const T *, T, int, int, int, double, float *) { unsupported("FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4"); }
 
 #define RDGPU_SHIM_PITMASK(SUF, T) \
   inline int c_pitmask(const T *p, T nd, int w, int h, int topo, uint8_t *m) { return rdgpu_pit_mask_##SUF(p, nd, w, h, topo, m); }
@@ -262,6 +271,76 @@ template <class E, class G>
 void FA_OCallaghanD4(const E &elevations, G &accum) { FA_D4(elevations, accum); }
 template <class E, class G>
 void FA_OCallaghanD8(const E &elevations, G &accum) { FA_D8(elevations, accum); }
+
+// ---- flow proportions (the Array3D<float> on-the-wire format of rd.FlowProportions) ----------------------------
+// richdem::FM_D8 / FM_OCallaghan<D8> (flowmet/OCallaghan1984.hpp:13-84), FM_D4 / FM_OCallaghan<D4> (:86),
+// FM_Tarboton / FM_Dinfinity (flowmet/Tarboton1997.hpp:14-144), FM_Holmgren(x) (Holmgren1994.hpp:14),
+// FM_Freeman(x) (Freeman1991.hpp:14), FM_Quinn (Quinn1991.hpp:13).  `props` is sized by the caller (nine float
+// slots per cell, rdgpu::Array3D<float> or richdem::Array3D<float>); its NoData becomes NO_DATA_GEN = -2.
+namespace detail {
+// the slot buffer of a proportions array: richdem::Array3D has getData() (common/Array3D.hpp:165), rdgpu::Array3D data()
+template <class P>
+auto raw3(P &p, int) -> decltype(p.getData()) { return p.getData(); }
+template <class P>
+auto raw3(P &p, long) -> decltype(p.data()) { return p.data(); }
+
+template <class E, class P, class Fn>
+void fm_into(const E &elevations, P &props, Fn fn, const char *who) {
+  static_assert(std::is_same<decltype(raw3(props, 0)), float *>::value, "FM_*: the proportions array must be Array3D<float>");
+  props.setNoData(-2.0f);               // NO_DATA_GEN, common/constants.hpp:85
+  if (props.width() != elevations.width() || props.height() != elevations.height())
+    throw std::runtime_error(std::string(who) + ": proportions array must have the dimensions of the elevations");
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  check(fn(elevations.data(), elevations.noData(), elevations.width(), elevations.height(), raw3(props, 0)), who);
+}
+}  // namespace detail
+template <class E, class P>
+void FM_D8(const E &elevations, P &props) {
+  using T = detail::elem_t<E>;
+  detail::fm_into(elevations, props, [](const T *p, T nd, int w, int h, float *o) { return detail::c_fm_d8(p, nd, w, h, o); }, "FM_D8");
+}
+template <class E, class P>
+void FM_Tarboton(const E &elevations, P &props) {
+  using T = detail::elem_t<E>;
+  detail::fm_into(elevations, props, [](const T *p, T nd, int w, int h, float *o) { return detail::c_fm_dinf(p, nd, w, h, o); }, "FM_Tarboton");
+}
+template <class E, class P>
+void FM_Dinfinity(const E &elevations, P &props) { FM_Tarboton(elevations, props); }
+namespace detail {
+template <class E, class P>
+void fm_mfd(const E &elevations, P &props, int method, double xparam, const char *who) {
+  using T = elem_t<E>;
+  fm_into(elevations, props,
+          [method, xparam](const T *p, T nd, int w, int h, float *o) { return c_fm_mfd(p, nd, w, h, method, xparam, o); }, who);
+}
+}  // namespace detail
+template <class E, class P>
+void FM_Holmgren(const E &elevations, P &props, double xparam) { detail::fm_mfd(elevations, props, 0, xparam, "FM_Holmgren"); }
+template <class E, class P>
+void FM_Freeman(const E &elevations, P &props, double xparam) { detail::fm_mfd(elevations, props, 1, xparam, "FM_Freeman"); }
+template <class E, class P>
+void FM_Quinn(const E &elevations, P &props) { detail::fm_mfd(elevations, props, 2, 1.0, "FM_Quinn"); }
+template <class E, class P>
+void FM_D4(const E &elevations, P &props) { detail::fm_mfd(elevations, props, 3, 1.0, "FM_D4"); }
+// FM_OCallaghan<topo>: Topology::D8 -> FM_D8, Topology::D4 -> FM_D4 (OCallaghan1984.hpp:81-90)
+template <auto topo, class E, class P>
+void FM_OCallaghan(const E &elevations, P &props) {
+  if (detail::topology_code<topo>() == 8) FM_D8(elevations, props);
+  else FM_D4(elevations, props);
+}
+
+// richdem::FlowAccumulation(const Array3D<float>&, Array2D<A>&)   methods/flow_accumulation_generic.hpp:33-100
+// accum is in/out: pre-loaded with the flow each cell generates.
+template <class P, class G>
+void FlowAccumulation(const P &props, G &accum) {
+  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FlowAccumulation: the accumulation array must be Array2D<double>");
+  accum.setNoData(-1.0);                // ACCUM_NO_DATA, :40
+  if (accum.width() != props.width() || accum.height() != props.height())   // :42-43
+    throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
+  if (props.width() == 0 || props.height() == 0) return;
+  const float *p9 = detail::raw3(const_cast<P &>(props), 0);   // (the reference's accessor is non-const; read only)
+  detail::check(rdgpu_flow_accumulation_f64(p9, props.width(), props.height(), accum.data()), "FlowAccumulation");
+}
 
 // richdem::pit_mask<topo>(const Array2D<T>&, Array2D<uint8_t>&)   depressions/Barnes2014.hpp:593-676
 template <auto topo, class E, class M>

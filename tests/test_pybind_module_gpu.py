@@ -1,0 +1,90 @@
+"""`_richdem` on the engine, on the GPU: what the reference's richdem/__init__.py calls (pywrapper.hpp:27-82,
+pywrapper.cpp:50) against the oracle, through the pybind11 module and the C++ shim."""
+import numpy as np
+import pytest
+
+from richdem_amd.synth import fractal_dem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    from richdem_amd import compat
+
+    return compat.load()    # built by build(); no fallback
+
+
+def wrap(R, arr, nodata):
+    name = {"float32": "float", "float64": "double", "int16": "int16_t", "int32": "int32_t", "uint8": "uint8_t",
+            "uint16": "uint16_t", "uint32": "uint32_t", "int64": "int64_t", "uint64": "uint64_t"}[str(arr.dtype)]
+    w = getattr(R, "Array2D_" + name)(arr)
+    w.setNoData(nodata)
+    w.geotransform = np.array([0, 1, 0, 0, 0, -1], dtype="float64")
+    return w
+
+
+def test_fill_in_place_every_type(R, orc):
+    z = fractal_dem(300, 220, seed=5)
+    for dt, scale in ((np.float32, 1.0), (np.float64, 1.0), (np.int32, 0.2), (np.int16, 0.1), (np.uint8, 0.03), (np.uint16, 0.5),
+                      (np.uint32, 2.0), (np.int64, 0.2), (np.uint64, 0.2)):
+        dem = (np.floor((z - z.min()) * scale) if np.issubdtype(dt, np.integer) else z * scale).astype(dt)
+        for fn, topo in ((R.rdFillDepressionsD8, 8), (R.rdFillDepressionsD4, 4)):
+            a = dem.copy()
+            assert fn(wrap(R, a, -9999 if np.issubdtype(dt, np.signedinteger) or dt in (np.float32, np.float64) else 0)) is None
+            assert np.array_equal(a, orc.port.fill(dem, topo)), (dt, topo)   # the numpy array itself was filled
+
+
+def test_accumulation_families(R, orc):
+    raw = fractal_dem(240, 180, 77)
+    nd = np.float32(-9999)
+    raw[50:54, 60:70] = nd
+    dem = orc.port.fill(raw)
+    demw = wrap(R, dem, -9999)
+    wts = np.random.default_rng(1).integers(0, 5, dem.shape).astype(np.float64)
+
+    def run(fn, *extra, weights=None):
+        acc = np.ones(dem.shape, np.float64) if weights is None else weights.copy()
+        accw = R.Array2D_double(acc)
+        fn(demw, accw, *extra)
+        assert accw.noData() == -1                                      # ACCUM_NO_DATA
+        return acc
+
+    assert np.array_equal(run(R.FA_D8), orc.port.fa_d8(dem, nd))
+    assert np.array_equal(run(R.FA_OCallaghanD8), orc.port.fa_d8(dem, nd))
+    assert np.array_equal(run(R.FA_D8, weights=wts), orc.port.fa_d8(dem, nd, wts))
+    for fn, method, x in ((R.FA_Quinn, "Quinn", None), (R.FA_Holmgren, "Holmgren", 1.5), (R.FA_Freeman, "Freeman", 1.1),
+                          (R.FA_D4, "D4", None), (R.FA_OCallaghanD4, "D4", None)):
+        got = run(fn, *(() if x is None else (x,)))
+        assert np.allclose(got, orc.port.fa_mfd(dem, nd, method, 1.0 if x is None else x), rtol=2e-6, atol=0), method
+    for fn in (R.FA_Tarboton, R.FA_Dinfinity):
+        assert np.allclose(run(fn), orc.port.fa_tarboton(dem, nd), rtol=2e-6, atol=0)
+
+    # proportions (Array3D_float: nine slots per cell) and the generic accumulation over them
+    props = np.zeros(dem.shape + (9,), np.float32)
+    pw = R.Array3D_float(props)
+    R.FM_D8(demw, pw)
+    assert pw.noData() == -2 and np.array_equal(props, orc.port.fm_d8(dem, nd))
+    acc = np.ones(dem.shape, np.float64)
+    R.FlowAccumulation(pw, R.Array2D_double(acc))
+    assert np.array_equal(acc, orc.port.fa_d8(dem, nd))
+    R.FM_OCallaghanD8(demw, pw)
+    assert np.array_equal(props, orc.port.fm_d8(dem, nd))
+    for fn, method, x in ((R.FM_Quinn, "Quinn", None), (R.FM_Holmgren, "Holmgren", 2.0), (R.FM_Freeman, "Freeman", 1.1),
+                          (R.FM_D4, "D4", None), (R.FM_OCallaghanD4, "D4", None)):
+        fn(demw, pw, *(() if x is None else (x,)))
+        exp = orc.port.fm_mfd(dem, nd, method, 1.0 if x is None else x)
+        assert np.allclose(props, exp, rtol=3e-7, atol=0), method
+    for fn in (R.FM_Tarboton, R.FM_Dinfinity):
+        fn(demw, pw)
+        assert np.allclose(props, orc.port.fm_tarboton(dem, nd), rtol=3e-7, atol=1e-7)
+    with pytest.raises(RuntimeError, match="dimensions"):
+        R.FM_D8(demw, R.Array3D_float(np.zeros((5, 5, 9), np.float32)))
+
+
+def test_resolve_flats_epsilon(R, orc):
+    z = np.floor(fractal_dem(200, 160, seed=9) * 0.05).astype(np.float32)
+    dem = orc.port.fill(z)
+    a = dem.copy()
+    R.rdResolveFlatsEpsilon(wrap(R, a, -9999))
+    assert np.array_equal(a, orc.port.resolve_flats_epsilon(dem, np.float32(-9999)))
