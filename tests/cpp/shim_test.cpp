@@ -10,15 +10,21 @@
 
 #ifdef RDGPU_TEST_WITH_RICHDEM
 #include <richdem/common/Array2D.hpp>
+#include <richdem/common/Array3D.hpp>
 #include <richdem/common/constants.hpp>
 template <class T>
 using Arr = richdem::Array2D<T>;
+using Arr3 = richdem::Array3D<float>;
 using Topo = richdem::Topology;
+static float *slots(Arr3 &p) { return p.getData(); }
 #else
 #include <rdgpu/Array2D.hpp>
+#include <rdgpu/Array3D.hpp>
 template <class T>
 using Arr = rdgpu::Array2D<T>;
+using Arr3 = rdgpu::Array3D<float>;
 using Topo = rdgpu::Topology;
+static float *slots(Arr3 &p) { return p.data(); }
 #endif
 #include <rdgpu/richdem_gpu.hpp>
 
@@ -35,6 +41,8 @@ void orc_fa_mfd_f32(const float *dem, float nodata, int w, int h, int method, do
 void orc_resolve_flats_epsilon_f32(float *dem, float nodata, int w, int h);
 void orc_pit_mask_f32(const float *dem, float nodata, int w, int h, int topo, uint8_t *mask);
 void orc_fa_d8_f32(const float *, float, int, int, double *);
+void orc_fm_d8_f32(const float *dem, float nodata, int w, int h, float *props9);
+void orc_fm_mfd_f32(const float *dem, float nodata, int w, int h, int method, double xparam, float *props9);
 }
 
 static int failures = 0;
@@ -198,6 +206,39 @@ int main() {
     orc_resolve_flats_epsilon_f32(e.data(), -9999.0f, w, h);
     rdgpu::ResolveFlatsEpsilon(a);
     EXPECT(std::memcmp(a.data(), e.data(), e.size() * 4) == 0);
+  }
+  // rd.FlowProportions / rd.FlowAccumFromProps: FM_*(elevations, Array3D<float>&) then FlowAccumulation(props, accum)
+  {
+    Arr<float> filled(dem);
+    filled.setNoData(-9999.0f);
+    orc_fill_f32(filled.data(), w, h, 8);
+    Arr3 props(filled);
+    rdgpu::FM_D8(filled, props);
+    EXPECT(props.noData() == -2.0f);
+    std::vector<float> e((size_t)w * h * 9);
+    orc_fm_d8_f32(filled.data(), -9999.0f, w, h, e.data());
+    EXPECT(std::memcmp(slots(props), e.data(), e.size() * 4) == 0);
+    Arr<double> accum(filled, 1.0), ea(filled, 1.0);
+    rdgpu::FlowAccumulation(props, accum);
+    orc_fa_d8_f32(filled.data(), -9999.0f, w, h, ea.data());
+    EXPECT(accum.noData() == -1.0);
+    EXPECT(std::memcmp(accum.data(), ea.data(), (size_t)w * h * 8) == 0);
+    rdgpu::FM_OCallaghan<Topo::D8>(filled, props);
+    EXPECT(std::memcmp(slots(props), e.data(), e.size() * 4) == 0);
+    rdgpu::FM_Quinn(filled, props);
+    orc_fm_mfd_f32(filled.data(), -9999.0f, w, h, 2, 1.0, e.data());
+    size_t bad = 0;
+    for (size_t i = 0; i < e.size(); i++)
+      if (std::fabs(slots(props)[i] - e[i]) > 3e-7f * std::fabs(e[i])) bad++;
+    EXPECT(bad == 0);
+    rdgpu::FM_Holmgren(filled, props, 2.0);
+    rdgpu::FM_Freeman(filled, props, 1.1);
+    rdgpu::FM_D4(filled, props);
+    rdgpu::FM_Tarboton(filled, props);
+    Arr<double> wrong(w + 1, h, 1.0);
+    bool threw = false;
+    try { rdgpu::FlowAccumulation(props, wrong); } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw);
   }
   // native raster format round trip (reference saveToCache / Array2D(filename, native=true), Array2D.hpp:209-281)
   {
