@@ -1,5 +1,5 @@
-"""The command-line apps (apps/*.cpp: the reference's rd_depressions_flood / rd_flow_accumulation / rd_d8_flowdirs
-on the GPU engine, native raster files instead of GDAL ones) end to end: file -> Array2D -> rdgpu:: call -> file."""
+"""The command-line apps (apps/*.cpp: the reference's rd_depressions_flood / rd_flow_accumulation / rd_d8_flowdirs /
+rd_depressions_mask on the GPU engine, native raster files instead of GDAL ones) end to end: file -> Array2D -> rdgpu:: call -> file."""
 import os
 import subprocess
 
@@ -36,6 +36,12 @@ def test_apps_on_native_files(rd, orc, tmp_path):
     assert r.returncode == 0, r.stderr
     dirs = rd.LoadNative(out, np.uint8)
     assert np.array_equal(dirs, orc.port.flat_resolution(orc.port.fill(z), np.float32(-9999))) and dirs.no_data == 255
+
+    r = run("rd_depressions_mask", dem, out)
+    assert r.returncode == 0, r.stderr
+    mask = rd.LoadNative(out, np.uint8)
+    assert np.array_equal(mask, orc.port.pit_mask(z, np.float32(-9999))) and mask.no_data == 3 and tuple(mask.geotransform) == gt
+    assert run("rd_depressions_mask", dem, out, "f64").returncode == 1        # pit_mask: 32-bit element types
 
     filled_path = str(tmp_path / "filled.rd")
     rd.SaveNative(filled_path, filled)
