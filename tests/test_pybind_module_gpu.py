@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 def R():
     from richdem_amd import compat
 
-    return compat.load()    # built by build(); no fallback
+    if compat.module_path() is None:   # normally built by __graft_entry__.build() and shipped in-tree
+        compat.build()
+    return compat.load()               # no fallback
 
 
 def wrap(R, arr, nodata):
