@@ -14,7 +14,6 @@ GpuShardEngine (HIP, through the C-ABI); tests pass a numpy model engine.  There
 from __future__ import annotations
 
 import ctypes
-import os
 import time
 
 import numpy as np
