@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Produces the per-round measurement artifacts for profiles/ on the GPU box:
 
-    python tools/profile_round.py <tag> [--steps K]
+    python tools/profile_round.py <tag> [--steps K] [--sq]
 
 runs, back to back and all on the same command (`python bench.py --steps K --warmup 1`):
   1. the plain bench               -> gpurun_out/<tag>_fill40k_bench.json
   2. rocprofv3 --kernel-trace --stats  -> gpurun_out/<tag>_fill40k_kernel_stats.csv
   3. rocprofv3 --pmc FETCH_SIZE  and  4. rocprofv3 --pmc WRITE_SIZE (separate passes, kernel-trace only)
                                    -> gpurun_out/<tag>_fill40k_pmc_summary.csv, gpurun_out/pmc_traffic.json
+  5. (--sq) rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
+     SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS (one more pass, kernel-trace only)
+                                   -> gpurun_out/<tag>_fill40k_sq_summary.csv: where the waves of each kernel spend
+                                      their cycles (parked / issuing / VALU / LDS), as fractions of SQ_WAVE_CYCLES
 Counters are KiB; WRITE_SIZE x1 and FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md; calibrated in r01a on kernels of
 known byte count: k_synth writes exactly 4 B/cell, k_count_pits reads exactly 4 B/cell).  Copy the four files into
 profiles/ and commit them."""
@@ -100,6 +104,26 @@ def main():
         line = json.dumps(d)
         with open(os.path.join(OUT, f"{tag}_fill40k_bench.json"), "w") as f:
             f.write(line + "\n")
+    if "--sq" in sys.argv:
+        names_sq = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                    "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
+        d = os.path.join(OUT, f"{tag}_sq")
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = (["rocprofv3", "--kernel-trace", "--pmc"] + names_sq + ["--output-format", "csv", "-d", d, "-o", "run", "--"]
+               + bench[:2] + ["--steps", "1", "--warmup", "0", "--cpu-sample", "0"])
+        print("sq rc", run(cmd, os.path.join(OUT, f"{tag}_sq.log")))
+        cols = {n: counters(d, n) for n in names_sq}
+        with open(os.path.join(OUT, f"{tag}_fill40k_sq_summary.csv"), "w") as f:
+            f.write(f"# {tag} SQ counters, fill 40000x40000 f32, 1 step (rocprofv3 --kernel-trace --pmc SQ_*; quad-cycle units; "
+                    "fractions of SQ_WAVE_CYCLES)\n")
+            f.write("kernel,launches,wave_cycles,wait_any,wait_inst_any,active_inst_any,active_valu,active_lds,insts_valu,insts_lds\n")
+            for k in sorted(cols["SQ_WAVE_CYCLES"]):
+                wc = cols["SQ_WAVE_CYCLES"][k][1]
+                if not k.startswith("rdgpu::") or wc <= 0:
+                    continue
+                frac = [cols[n][k][1] / wc for n in names_sq[1:6]]
+                f.write(f"{k},{cols['SQ_WAVE_CYCLES'][k][0]},{wc:.4g}," + ",".join(f"{x:.3f}" for x in frac)
+                        + f",{cols['SQ_INSTS_VALU'][k][1]:.4g},{cols['SQ_INSTS_LDS'][k][1]:.4g}\n")
     print(line.strip())
 
 
