@@ -40,8 +40,10 @@ def test_surface_is_complete(R):
     assert R.NO_FLOW == 0 and R.engine == "rdgpu"
     dh = R.depression_hierarchy
     assert (dh.OCEAN, dh.NO_DEP, dh.NO_PARENT, dh.NO_VALUE) == (0, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)
-    d = dh.Depression()
-    assert d.parent == dh.NO_PARENT and d.pit_elev == float("inf") and d.ocean_linked == [] and d.cell_count == 0
+    d = dh.Depression()   # defaults as the reference's own Python test expects (wrappers/pyrichdem/tests/tests.py:8-22)
+    assert d.parent == dh.NO_PARENT and d.pit_elev == float("inf") and d.out_elev == float("inf") and d.ocean_linked == []
+    assert d.out_cell == d.pit_cell == d.odep == d.geolink == d.lchild == d.rchild == dh.NO_VALUE
+    assert d.ocean_parent is False and (d.dep_label, d.cell_count, d.dep_vol, d.water_vol, d.total_elevation) == (0, 0, 0, 0, 0)
     assert isinstance(R.rdHash(), str) and isinstance(R.rdCompileTime(), str)
 
 
