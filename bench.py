@@ -1,11 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- Mcells/s of the Priority-Flood-equivalent fill on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-stages] [--no-host]
 
 A step = one fill (rdgpu_fill_dev_f32 through the C-ABI) of one synthetic float32 DEM, G(seed) of
 SURVEY.md section 8d, already resident in HBM when the timed region starts.  At N=1 the workload is
-BASELINE config "40000x40000 float32 DEM, Priority-Flood fill on 1 MI355X".  One JSON line on rank 0.
+BASELINE configs[2] "40000x40000 float32 DEM, Priority-Flood (+ flat resolution) on 1 MI355X".  One JSON
+line on rank 0.  Besides `value` (the fill) the line carries
+
+  roofline       whole fill first (8 algorithmic bytes per cell ONCE for all of its kernels), then the
+                 dominant raster kernel of the fill with its own launch time (HIP events on the launch stream,
+                 taken in a separate instrumented pass -- the timed steps run without event recording)
+  stages         the rest of the path on the filled DEM (BASELINE configs[2] and [4]): D8 directions,
+                 directions + flat resolution, d8_flow_accum, ResolveFlatsEpsilon, FA_D8 on the epsilon-resolved
+                 DEM -- each with ms, Mcells/s, SURVEY 8d algorithmic bytes and the fraction of 8 TB/s
+  end_to_end_host  rdgpu_fill_f32 on a host array (the drop-in boundary: H2D + fill + D2H), never `value`
+  cpu_baseline   the compiled reference on a bounded window of the same DEM on this box's host
 """
 from __future__ import annotations
 
@@ -18,6 +28,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0
+#: SURVEY.md section 8d, algorithmic bytes per cell
+STAGE_BYTES = {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
+               "resolve_flats_epsilon": 8, "fa_d8": 20}
 
 
 def cpu_baseline(Z, sample: int):
@@ -39,13 +53,93 @@ def cpu_baseline(Z, sample: int):
     out = be.fill(win, 8)
     dt = time.perf_counter() - t0
     assert out.shape == win.shape and np.isfinite(out).all()
-    return {
+    res = {
         "value": round(s * s / 1e6 / dt, 3),
         "unit": "Mcells/s",
         "cores": 1,
         "kind": kind,
         "sample": f"{s}x{s} top-left window of the bench DEM, {what}, {dt:.2f} s",
     }
+    full = os.path.join(ROOT, "profiles", "r02_parity40k.json")   # the whole 40k x 40k DEM, measured once per round
+    try:
+        with open(full) as f:
+            p = json.load(f)
+        res["full_size"] = {k: p[k] for k in ("size", "ref_fill_s", "ref_fill_Mcells_s", "ref_flat_resolution_s",
+                                                "ref_d8_flow_accum_s") if k in p}
+        res["full_size"]["source"] = "profiles/r02_parity40k.json (tools/parity40k.py, same box type)"
+    except (OSError, ValueError):
+        pass
+    return res
+
+
+def _best(fn, reps, sync):
+    best = 1e30
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def stage_entry(seconds: float, cells: int, bytes_per_cell: int, n_gpus: int = 1) -> dict:
+    gbs = cells * bytes_per_cell / seconds / 1e9
+    return {"ms": round(seconds * 1e3, 3), "Mcells_s": round(cells / 1e6 / seconds, 1), "alg_bytes_per_cell": bytes_per_cell,
+            "alg_GBps": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_GBS * n_gpus), 4)}
+
+
+def run_stages(rd, torch, W, nodata: float, reps: int = 2) -> dict:
+    """The path after the fill on one GPU, HBM-resident, through the C-ABI `_dev_` entry points.  W = the filled DEM."""
+    n_cells = W.numel()
+    sync = torch.cuda.synchronize
+    out = {}
+    dirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
+    rd.d8_flow_directions_dev(W, nodata, dirs)                                   # workspace growth: not timed
+    out["d8_flow_directions"] = stage_entry(_best(lambda: rd.d8_flow_directions_dev(W, nodata, dirs), reps, sync), n_cells, 5)
+    rd.d8_flow_directions_dev(W, nodata, dirs, flats=True)
+    out["directions_plus_flat_resolution"] = stage_entry(
+        _best(lambda: rd.d8_flow_directions_dev(W, nodata, dirs, flats=True), reps, sync), n_cells, 6)
+    fs = rd.flat_stats()
+    out["directions_plus_flat_resolution"].update({"noflow_cells": fs["noflow"], "rounds_towards": fs["towards"],
+                                                   "rounds_away": fs["away"]})
+    area = torch.empty(W.shape, dtype=torch.float64, device="cuda")
+    rd.d8_flow_accum_dev(dirs, area)
+    out["d8_flow_accum"] = stage_entry(_best(lambda: rd.d8_flow_accum_dev(dirs, area), reps, sync), n_cells, 9)
+    out["d8_flow_accum"]["input"] = "flat-resolved directions of the filled DEM; float64 out"
+    out["d8_flow_accum"]["max_area"] = float(area.max().item())
+    del dirs
+    E = W.clone()
+    rd.resolve_flats_epsilon_dev(E, nodata)
+    t_rfe = 1e30
+    for _ in range(reps):
+        E.copy_(W)
+        t_rfe = min(t_rfe, _best(lambda: rd.resolve_flats_epsilon_dev(E, nodata), 1, sync))
+    out["resolve_flats_epsilon"] = stage_entry(t_rfe, n_cells, 8)
+    area.fill_(1.0)
+    rd.fa_d8_dev(E, nodata, area)
+    t_fa = 1e30
+    for _ in range(reps):
+        area.fill_(1.0)
+        t_fa = min(t_fa, _best(lambda: rd.fa_d8_dev(E, nodata, area), 1, sync))
+    out["fa_d8"] = stage_entry(t_fa, n_cells, 20)
+    out["fa_d8"]["input"] = "fill -> ResolveFlatsEpsilon output, unit weights"
+    out["fa_d8"]["max_accum"] = float(area.max().item())
+    return out
+
+
+def host_path(rd, torch, Z, reps: int = 2) -> dict:
+    """The drop-in boundary as rd_depressions_flood sees it: rdgpu_fill_f32 on a host array (H2D + fill + D2H)."""
+    host = Z.cpu().numpy()
+    best = 1e30
+    for _ in range(reps):
+        a = host.copy()
+        t0 = time.perf_counter()
+        rd.FillDepressions(a, in_place=True)
+        best = min(best, time.perf_counter() - t0)
+    return {"entry": "rdgpu_fill_f32 (host pointer: H2D + fill + D2H into the same buffer, pageable numpy array)",
+            "ms": round(best * 1e3, 1), "Mcells_s": round(Z.numel() / 1e6 / best, 1),
+            "GB_over_pcie": round(2 * host.nbytes / 1e9, 2)}
 
 
 def main():
@@ -56,6 +150,8 @@ def main():
     ap.add_argument("--size", type=int, default=40000, help="DEM is size x size cells")
     ap.add_argument("--cpu-sample", type=int, default=10000, help="window edge for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--no-stages", action="store_true", help="skip the directions / flat resolution / accumulation stages")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer end-to-end measurement")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE line, the JSON of rank 0.  Libraries print there too (RCCL: "Librccl path : ...",
@@ -110,23 +206,33 @@ def main():
         rd.fill_depressions_dev(scratch)
     torch.cuda.synchronize()
 
-    rd.profile_reset()
-    rd.profile_enable(True)   # HIP events around every kernel, on the stream the kernel is launched on
+    # the timed region: K fills, nothing else (no event recording)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         rd.fill_depressions_dev(bufs[k])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    stats = rd.fill_stats()
+    changed = float((bufs[0] != Z).float().mean())
+    W = bufs[0]                        # the filled DEM: input of the stages below
+    del bufs[1:]
+
+    # per-kernel times: a separate, instrumented pass (HIP events around every launch, on the launch stream)
+    prof_steps = 2
+    rd.profile_reset()
+    rd.profile_enable(True)
+    for _ in range(prof_steps):
+        scratch.copy_(Z)
+        rd.fill_depressions_dev(scratch)
+    torch.cuda.synchronize()
     rd.profile_enable(False)
     prof = rd.profile_totals()
-    stats = rd.fill_stats()
+    del scratch
 
-    changed = float((bufs[0] != Z).float().mean())
     ms_step = dt * 1e3 / args.steps
     value = cells / 1e6 / (dt / args.steps)
-
-    roofline = fill_roofline(prof, stats, cells, args.steps, dt / args.steps,
+    roofline = fill_roofline(prof, stats, cells, prof_steps, dt / args.steps,
                              os.path.join(ROOT, "profiles", "pmc_traffic.json"), n)
     out = {
         "metric": "Mcells/s Priority-Flood fill, 40k x 40k f32 DEM",
@@ -152,8 +258,17 @@ def main():
             "parallelism": "1 GPU",
         },
         "roofline": roofline,
-        "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "kernels_ms_per_step": {k: round(v[0] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
     }
+    if not args.no_stages:
+        out["stages"] = {"fill": stage_entry(dt / args.steps, cells, 8)}
+        out["stages"].update(run_stages(rd, torch, W, -9999.0))
+    if not args.no_host:
+        del W
+        bufs.clear()
+        rd.release_workspace()
+        torch.cuda.empty_cache()
+        out["end_to_end_host"] = host_path(rd, torch, Z)
     if args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(Z, args.cpu_sample)
     emit(out)

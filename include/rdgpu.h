@@ -84,6 +84,31 @@ RDGPU_DECL_PITMASK(u32, uint32_t)
 RDGPU_DECL_PITMASK(f32, float)
 #undef RDGPU_DECL_PITMASK
 
+/* ---- PriorityFloodEpsilon_Barnes2014<topology>(Array2D<T>&) ------------------------------------------------------
+ * Replaces richdem::PriorityFloodEpsilon_Barnes2014 (include/richdem/depressions/Barnes2014.hpp:335-420) =
+ * FillDepressionsEpsilon (depressions/depressions.hpp:23); Python rd.FillDepressions(epsilon=True) ->
+ * rdPFepsilonD8 / rdPFepsilonD4 (wrappers/pyrichdem/src/pywrapper.hpp:34-35).  In place; every depression and flat
+ * gets a gradient of one representable step (std::nextafter) per cell towards its outlet.  Floating-point DEMs only:
+ * the reference throws "Priority-Flood+Epsilon is only available for floating-point data types!" for the integer
+ * types (:424-451) and so does the C++ shim.  NoData cells are never altered and act as outlets of value NoData
+ * (what the reference does with NoData regions that touch the raster border, given its precondition that NoData is
+ * lower than every data value).
+ * The result is the unique surface E = z on the border / NoData, E(c) = max(z(c), nextafter(min over neighbours
+ * E(n))) elsewhere; it equals the reference's output on every DEM in which no two cells of the reference's heap tie
+ * (with ties the reference's output depends on std::priority_queue's pop order; this surface is then <= it). */
+int rdgpu_fill_epsilon_f32(float *dem, float nodata, int width, int height, int topology);
+int rdgpu_fill_epsilon_f64(double *dem, double nodata, int width, int height, int topology);
+int rdgpu_fill_epsilon_dev_f32(float *d_dem, float nodata, int width, int height, int topology, void *hip_stream);
+int rdgpu_fill_epsilon_dev_f64(double *d_dem, double nodata, int width, int height, int topology, void *hip_stream);
+typedef struct rdgpu_epsilon_stats {
+  uint32_t rounds;           /* tile-relaxation rounds, all attempts                                            */
+  uint32_t attempts;         /* 1 unless the assumed slack was too small for the DEM (RDGPU_EPS_SLACK=<steps>)  */
+  uint64_t tile_relaxations; /* tiles relaxed, summed over the rounds                                           */
+  uint64_t slack;            /* the slack the successful attempt ran with, in representable steps               */
+  uint64_t max_lift;         /* largest lift of a cell above the plain fill, in representable steps             */
+} rdgpu_epsilon_stats;
+int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
+
 /* Environment switches of the fill (read at every call; for tests and A/B timing, results never change):
  *   RDGPU_FILL_EDGES=0         every contraction round is a raster pass (the r01d engine; default: one raster pass,
  *                              then rounds on the component-pair list it records)

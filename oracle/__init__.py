@@ -213,6 +213,34 @@ class _Backend:
         self._fn(f"pit_mask_{s}")(_ptr(dem), _CT[s](nodata), w, h, int(topo), _ptr(out))
         return out
 
+    # ---- the other outputs of the Priority-Flood sweep ---------------------------
+    def fill_epsilon(self, dem: np.ndarray, nodata, topo: int = 8) -> np.ndarray:
+        """PriorityFloodEpsilon_Barnes2014<topo> (depressions/Barnes2014.hpp:335-420): float32 / float64 only."""
+        out = np.ascontiguousarray(dem).copy()
+        h, w = out.shape
+        s = _suf(out)
+        if s not in ("f32", "f64"):
+            raise TypeError("Priority-Flood+Epsilon is only available for floating-point data types!")
+        self._fn(f"fill_epsilon_{s}")(_ptr(out), _CT[s](nodata), w, h, int(topo))
+        return out
+
+    def watersheds(self, dem: np.ndarray, nodata, topo: int = 8, alter: bool = False):
+        """PriorityFloodWatersheds_Barnes2014<topo> (:713-807): (labels int32, dem -- filled when alter)."""
+        out = np.ascontiguousarray(dem).copy()
+        h, w = out.shape
+        s = _suf(out)
+        labels = np.empty((h, w), np.int32)
+        self._fn(f"watersheds_{s}")(_ptr(out), _CT[s](nodata), w, h, int(topo), int(bool(alter)), _ptr(labels))
+        return labels, out
+
+    def fill_max_dep(self, dem: np.ndarray, max_dep_size: int, topo: int = 8) -> np.ndarray:
+        """PriorityFlood_Barnes2014_max_dep<topo> (:844-931): only depressions of <= max_dep_size cells are filled."""
+        out = np.ascontiguousarray(dem).copy()
+        h, w = out.shape
+        s = _suf(out)
+        self._fn(f"fill_max_dep_{s}")(_ptr(out), w, h, int(topo), ctypes.c_uint64(int(max_dep_size)))
+        return out
+
     def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)
         h, w = dem.shape

@@ -62,12 +62,18 @@ static const int D4Y[5] = {0, 0, -1, 0, 1};
 #undef SUF
 #define T float
 #define SUF f32
+#define ORC_IS_FLOAT
+#define ORC_NEXTUP(v) nextafterf((v), INFINITY)
 #include "oracle_impl.h"
+#undef ORC_NEXTUP
 #undef T
 #undef SUF
 #define T double
 #define SUF f64
+#define ORC_NEXTUP(v) nextafter((v), (double)INFINITY)
 #include "oracle_impl.h"
+#undef ORC_NEXTUP
+#undef ORC_IS_FLOAT
 #undef T
 #undef SUF
 #define T int64_t

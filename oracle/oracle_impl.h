@@ -535,6 +535,151 @@ void FN(orc_pit_mask)(const T *dem, T nodata, int w, int h, int topo, uint8_t *m
   free(filled);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* the other outputs of the Priority-Flood sweep.               */
+/* Ties: the reference pops equal elevations in the order libstdc++'s         */
+/* std::priority_queue happens to hold them; this heap has its own order.  On */
+/* DEMs without equal elevations among the heap's cells the results agree     */
+/* (tests/test_oracle_pinning.py); DESIGN.md section 3b says what is defined  */
+/* when they do not.                                                          */
+/* ------------------------------------------------------------------------- */
+static void FN(seed_border)(const T *dem, int w, int h, int8_t *closed, FN(hcell) **heap, size_t *hn, size_t *hcap) {
+  for (int x = 0; x < w; x++) {                                /* e.g. Barnes2014.hpp:358-363 */
+    FN(hcell) a = {dem[x], x, 0}, b = {dem[(size_t)(h - 1) * w + x], x, h - 1};
+    FN(heap_push)(heap, hn, hcap, a);
+    FN(heap_push)(heap, hn, hcap, b);
+    closed[x] = 1; closed[(size_t)(h - 1) * w + x] = 1;
+  }
+  for (int y = 1; y < h - 1; y++) {                            /* :364-369 */
+    FN(hcell) a = {dem[(size_t)y * w], 0, y}, b = {dem[(size_t)y * w + w - 1], w - 1, y};
+    FN(heap_push)(heap, hn, hcap, a);
+    FN(heap_push)(heap, hn, hcap, b);
+    closed[(size_t)y * w] = 1; closed[(size_t)y * w + w - 1] = 1;
+  }
+}
+
+#ifdef ORC_IS_FLOAT
+/* PriorityFloodEpsilon_Barnes2014<topo>, depressions/Barnes2014.hpp:335-420 (floating point only, :424-451). */
+void FN(orc_fill_epsilon)(T *dem, T nodata, int w, int h, int topo) {
+  const int *dx = topo == 4 ? D4X : D8X, *dy = topo == 4 ? D4Y : D8Y;
+  const int nmax = topo == 4 ? 4 : 8;
+  size_t N = (size_t)w * h;
+  int8_t *closed = (int8_t *)calloc(N, 1);                     /* :355 */
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  FN(hcell) *pit = (FN(hcell) *)malloc(N * sizeof(FN(hcell)));
+  size_t ph = 0, pt = 0;
+  FN(seed_border)(dem, w, h, closed, &heap, &hn, &hcap);
+  while (hn > 0 || ph < pt) {                                  /* :373-414 */
+    FN(hcell) c;
+    if (ph < pt && hn > 0 && heap[0].z == pit[ph].z) c = FN(heap_pop)(heap, &hn);   /* :375-378 */
+    else if (ph < pt) c = pit[ph++];                                                /* :379-383 */
+    else c = FN(heap_pop)(heap, &hn);                                               /* :384-388 */
+    const T up = ORC_NEXTUP(c.z);                              /* std::nextafter(c.z, +inf) */
+    for (int n = 1; n <= nmax; n++) {
+      int nx = c.x + dx[n], ny = c.y + dy[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      closed[ni] = 1;
+      if (dem[ni] == nodata) {                                 /* :401-402: queued with z = NoData, not altered */
+        FN(hcell) p = {nodata, nx, ny};
+        pit[pt++] = p;
+      } else if (dem[ni] <= up) {                              /* :404-409 */
+        dem[ni] = up;
+        FN(hcell) p = {up, nx, ny};
+        pit[pt++] = p;
+      } else {
+        FN(hcell) o = {dem[ni], nx, ny};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+      }
+    }
+  }
+  free(closed); free(heap); free(pit);
+}
+#endif
+
+/* PriorityFloodWatersheds_Barnes2014<topo>(elevations, labels, alter_elevations), depressions/Barnes2014.hpp:713-807. */
+void FN(orc_watersheds)(T *dem, T nodata, int w, int h, int topo, int alter, int32_t *labels) {
+  const int *dx = topo == 4 ? D4X : D8X, *dy = topo == 4 ? D4Y : D8Y;
+  const int nmax = topo == 4 ? 4 : 8;
+  size_t N = (size_t)w * h;
+  int8_t *closed = (int8_t *)calloc(N, 1);
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  FN(hcell) *pit = (FN(hcell) *)malloc(N * sizeof(FN(hcell)));
+  size_t ph = 0, pt = 0;
+  int32_t clabel = 1;                                          /* :721 */
+  for (size_t i = 0; i < N; i++) labels[i] = -1;               /* :737-738 */
+  FN(seed_border)(dem, w, h, closed, &heap, &hn, &hcap);
+  while (hn > 0 || ph < pt) {                                  /* :760-800 */
+    FN(hcell) c;
+    if (ph < pt) c = pit[ph++];
+    else c = FN(heap_pop)(heap, &hn);
+    size_t ci = (size_t)c.y * w + c.x;
+    if (labels[ci] == -1 && dem[ci] != nodata) labels[ci] = clabel++;   /* :777-778 */
+    for (int n = 1; n <= nmax; n++) {
+      int nx = c.x + dx[n], ny = c.y + dy[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      labels[ni] = labels[ci];                                 /* :789 */
+      closed[ni] = 1;
+      if (dem[ni] <= c.z) {                                    /* :792-796 */
+        if (alter) dem[ni] = c.z;
+        FN(hcell) p = {c.z, nx, ny};
+        pit[pt++] = p;
+      } else {
+        FN(hcell) o = {dem[ni], nx, ny};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+      }
+    }
+  }
+  free(closed); free(heap); free(pit);
+}
+
+/* PriorityFlood_Barnes2014_max_dep<topo>(elevations, max_dep_size), depressions/Barnes2014.hpp:844-931. */
+void FN(orc_fill_max_dep)(T *dem, int w, int h, int topo, uint64_t max_dep_size) {
+  const int *dx = topo == 4 ? D4X : D8X, *dy = topo == 4 ? D4Y : D8Y;
+  const int nmax = topo == 4 ? 4 : 8;
+  size_t N = (size_t)w * h;
+  int8_t *closed = (int8_t *)calloc(N, 1);
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  FN(hcell) *pit = (FN(hcell) *)malloc(N * sizeof(FN(hcell)));
+  size_t ph = 0, pt = 0;
+  size_t *dep = (size_t *)malloc(N * sizeof(size_t));          /* dep_cells, :887 */
+  size_t ndep = 0;
+  T dep_elev = 0;                                              /* :886 */
+  FN(seed_border)(dem, w, h, closed, &heap, &hn, &hcap);
+  while (hn > 0 || ph < pt) {                                  /* :891-927 */
+    FN(hcell) c;
+    if (ph < pt) {
+      c = pit[ph++];
+      dep[ndep++] = (size_t)c.y * w + c.x;                     /* :896 */
+    } else {
+      c = FN(heap_pop)(heap, &hn);
+      if (ndep <= max_dep_size)                                /* :900-903 */
+        for (size_t k = 0; k < ndep; k++) dem[dep[k]] = dep_elev;
+      ndep = 0;                                                /* :903 / :905 */
+    }
+    for (int n = 1; n <= nmax; n++) {
+      int nx = c.x + dx[n], ny = c.y + dy[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      closed[ni] = 1;
+      if (dem[ni] < c.z) {                                     /* :918-921 */
+        FN(hcell) p = {c.z, nx, ny};
+        pit[pt++] = p;
+        dep_elev = c.z;
+      } else {
+        FN(hcell) o = {dem[ni], nx, ny};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+      }
+    }
+  }
+  free(closed); free(heap); free(pit); free(dep);
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

@@ -299,3 +299,47 @@ REF_PM_API(i32, int32_t)
 REF_PM_API(u32, uint32_t)
 REF_PM_API(f32, float)
 REF_PM_API(f64, double)
+
+// ---- the other outputs of the Priority-Flood sweep -------------------------------------------------
+// PriorityFloodEpsilon_Barnes2014<topo> (depressions/Barnes2014.hpp:335-420; floating point only, :424-451)
+template <class T>
+void ref_fill_epsilon(T *dem, T nodata, int w, int h, int topo) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  if (topo == 8) PriorityFloodEpsilon_Barnes2014<Topology::D8>(a);
+  else PriorityFloodEpsilon_Barnes2014<Topology::D4>(a);
+}
+extern "C" void ref_fill_epsilon_f32(float *dem, float nodata, int w, int h, int topo) { ref_fill_epsilon<float>(dem, nodata, w, h, topo); }
+extern "C" void ref_fill_epsilon_f64(double *dem, double nodata, int w, int h, int topo) { ref_fill_epsilon<double>(dem, nodata, w, h, topo); }
+
+// PriorityFloodWatersheds_Barnes2014<topo>(elevations, labels, alter_elevations) (:713-807)
+template <class T>
+void ref_watersheds(T *dem, T nodata, int w, int h, int topo, int alter, int32_t *labels) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  Array2D<int32_t> lab;
+  if (topo == 8) PriorityFloodWatersheds_Barnes2014<Topology::D8>(a, lab, alter != 0);
+  else PriorityFloodWatersheds_Barnes2014<Topology::D4>(a, lab, alter != 0);
+  std::memcpy(labels, lab.data(), (size_t)w * h * sizeof(int32_t));
+}
+// PriorityFlood_Barnes2014_max_dep<topo>(elevations, max_dep_size) (:844-931; apps/rd_depressions_flood.cpp:16-19)
+template <class T>
+void ref_fill_max_dep(T *dem, int w, int h, int topo, uint64_t max_dep_size) {
+  Array2D<T> a(dem, w, h);
+  if (topo == 8) PriorityFlood_Barnes2014_max_dep<Topology::D8>(a, max_dep_size);
+  else PriorityFlood_Barnes2014_max_dep<Topology::D4>(a, max_dep_size);
+}
+#define REF_F2_API(SUF, T)                                                                                                    \
+  extern "C" void ref_watersheds_##SUF(T *dem, T nodata, int w, int h, int topo, int alter, int32_t *labels) {                \
+    ref_watersheds<T>(dem, nodata, w, h, topo, alter, labels);                                                                \
+  }                                                                                                                           \
+  extern "C" void ref_fill_max_dep_##SUF(T *dem, int w, int h, int topo, uint64_t max_dep_size) {                             \
+    ref_fill_max_dep<T>(dem, w, h, topo, max_dep_size);                                                                       \
+  }
+REF_F2_API(u8, uint8_t)
+REF_F2_API(i16, int16_t)
+REF_F2_API(u16, uint16_t)
+REF_F2_API(i32, int32_t)
+REF_F2_API(u32, uint32_t)
+REF_F2_API(f32, float)
+REF_F2_API(f64, double)

@@ -49,6 +49,9 @@ from .api import (  # noqa: F401
     d8_flow_accum_dev,
     fa_d8_dev,
     synth_dem_dev,
+    resolve_flats_epsilon_dev,
+    flat_stats,
+    release_workspace,
 )
 
 __all__ = [
@@ -74,6 +77,9 @@ __all__ = [
     "d8_flow_accum_dev",
     "fa_d8_dev",
     "synth_dem_dev",
+    "resolve_flats_epsilon_dev",
+    "flat_stats",
+    "release_workspace",
     "fill_stats",
     "profile_enable",
     "profile_collect",

@@ -25,6 +25,28 @@ _SUFFIX = {
 _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
 _CT = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "u16": ctypes.c_uint16, "i32": ctypes.c_int32,
        "u32": ctypes.c_uint32, "f32": ctypes.c_float, "f64": ctypes.c_double}
+_NP = {"u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32, "f32": np.float32,
+       "f64": np.float64}
+
+
+def _scalar(s: str, nodata):
+    """ctypes scalar of the DEM's element type from the user's no_data value, converted the way the reference's
+    setNoData(double) does (a C cast to T: fractions truncate towards zero, out-of-range integers wrap as they do
+    on x86-64): rdarray(int16_arr, no_data=-9999.0) works, and so does the common uint8 DEM with no_data=-9999.
+    NaN / infinite values for an integer DEM are an error."""
+    if s in ("f32", "f64"):
+        return _CT[s](float(nodata))
+    try:
+        v = int(float(nodata))
+    except (TypeError, ValueError, OverflowError):
+        raise RdgpuError(f"no_data value {nodata!r} is not representable in the DEM's element type {_NP[s].__name__}") from None
+    bits = 8 * np.dtype(_NP[s]).itemsize
+    v &= (1 << bits) - 1
+    if np.issubdtype(_NP[s], np.signedinteger) and v >= 1 << (bits - 1):
+        v -= 1 << bits
+    return _CT[s](v)
+
+
 _ELEV_SUFFIX = {k: v for k, v in _SUFFIX.items() if v not in ("i64", "u64")}   # stencil / accumulation entry points
 _ACC_SUFFIX = {np.dtype(np.int32): "i32", np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 
@@ -79,7 +101,7 @@ def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
         raise RdgpuError("pit_mask: 64-bit element types are not provided")
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)
-    check(getattr(lib(), f"rdgpu_pit_mask_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, _topo(topology),
+    check(getattr(lib(), f"rdgpu_pit_mask_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, _topo(topology),
                                                 out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_pit_mask")
     return out
 
@@ -100,7 +122,7 @@ def d8_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)
     fn = getattr(lib(), f"rdgpu_d8_flowdirs_{s}")
-    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
           "rdgpu_d8_flowdirs")
     return out
 
@@ -117,14 +139,14 @@ def barnes_flat_resolution_d8(dem: np.ndarray, nodata, alter: bool = False) -> n
         s = "f32" if dem.dtype == np.float32 else "f64"
         out = np.empty((h, w), np.uint8)
         fn = getattr(lib(), f"rdgpu_flat_resolution_d8_alter_{s}")
-        check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+        check(fn(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
               "rdgpu_flat_resolution_d8_alter")
         return out
     dem, s = _elev(dem, "barnes_flat_resolution_d8")
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)
     fn = getattr(lib(), f"rdgpu_flat_resolution_d8_{s}")
-    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),
           "rdgpu_flat_resolution_d8")
     return out
 
@@ -138,7 +160,7 @@ def resolve_flats(dem: np.ndarray, nodata):
     mask = np.empty((h, w), np.int32)
     labels = np.empty((h, w), np.int32)
     fn = getattr(lib(), f"rdgpu_resolve_flats_{s}")
-    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h, dirs.ctypes.data_as(ctypes.c_void_p),
+    check(fn(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, dirs.ctypes.data_as(ctypes.c_void_p),
              mask.ctypes.data_as(ctypes.c_void_p), labels.ctypes.data_as(ctypes.c_void_p)), "rdgpu_resolve_flats")
     return dirs, mask, labels
 
@@ -158,7 +180,7 @@ def resolve_flats_epsilon(dem: np.ndarray, nodata, in_place: bool = False):
     except KeyError:
         raise RdgpuError(f"ResolveFlats: unsupported elevation dtype {out.dtype}") from None
     h, w = out.shape
-    check(getattr(lib(), f"rdgpu_resolve_flats_epsilon_{s}")(out.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h),
+    check(getattr(lib(), f"rdgpu_resolve_flats_epsilon_{s}")(out.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h),
           "rdgpu_resolve_flats_epsilon")
     return None if in_place else out
 
@@ -186,7 +208,7 @@ def dinf_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
     dem, s = _elev(dem, "dinf_flow_directions")
     h, w = dem.shape
     out = np.empty((h, w), np.float32)
-    check(getattr(lib(), f"rdgpu_dinf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _CT[s](nodata), w, h,
+    check(getattr(lib(), f"rdgpu_dinf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
                                                      out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_dinf_flowdirs")
     return out
 
@@ -226,9 +248,9 @@ def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999, exponen
     out = np.empty((h, w, 9), np.float32)
     pd, po = dem.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
     if kind == "mfd":
-        check(getattr(lib(), f"rdgpu_fm_mfd_{s}")(pd, _CT[s](nodata), w, h, code, ctypes.c_double(xp), po), "rdgpu_fm_mfd")
+        check(getattr(lib(), f"rdgpu_fm_mfd_{s}")(pd, _scalar(s, nodata), w, h, code, ctypes.c_double(xp), po), "rdgpu_fm_mfd")
     else:
-        check(getattr(lib(), f"rdgpu_fm_d8_{s}" if kind == "d8" else f"rdgpu_fm_tarboton_{s}")(pd, _CT[s](nodata), w, h, po),
+        check(getattr(lib(), f"rdgpu_fm_d8_{s}" if kind == "d8" else f"rdgpu_fm_tarboton_{s}")(pd, _scalar(s, nodata), w, h, po),
               "rdgpu_fm_" + kind)
     return out
 
@@ -263,9 +285,9 @@ def flow_accumulation_into(dem: np.ndarray, method, nodata, acc: np.ndarray, exp
         raise RdgpuError("Accumulation array must be of type 'float64'!")
     pd, pa = dem.ctypes.data_as(ctypes.c_void_p), acc.ctypes.data_as(ctypes.c_void_p)
     if kind == "mfd":
-        check(getattr(lib(), f"rdgpu_fa_mfd_{s}")(pd, _CT[s](nodata), w, h, code, ctypes.c_double(xp), pa), "rdgpu_fa_mfd")
+        check(getattr(lib(), f"rdgpu_fa_mfd_{s}")(pd, _scalar(s, nodata), w, h, code, ctypes.c_double(xp), pa), "rdgpu_fa_mfd")
     else:
-        check(getattr(lib(), f"rdgpu_fa_d8_{s}" if kind == "d8" else f"rdgpu_fa_tarboton_{s}")(pd, _CT[s](nodata), w, h, pa),
+        check(getattr(lib(), f"rdgpu_fa_d8_{s}" if kind == "d8" else f"rdgpu_fa_tarboton_{s}")(pd, _scalar(s, nodata), w, h, pa),
               "rdgpu_fa_" + kind)
 
 
@@ -353,7 +375,7 @@ def d8_flow_directions_dev(dem, nodata, dirs, flats: bool = False) -> None:
         raise RdgpuError("d8_flow_directions_dev: shape mismatch")
     s = _torch_elev_suffix(dem)
     name = f"rdgpu_flat_resolution_d8_dev_{s}" if flats else f"rdgpu_d8_flowdirs_dev_{s}"
-    check(getattr(lib(), name)(ctypes.c_void_p(dem.data_ptr()), _CT[s](nodata), w, h, ctypes.c_void_p(dirs.data_ptr()),
+    check(getattr(lib(), name)(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h, ctypes.c_void_p(dirs.data_ptr()),
                                _stream_ptr()), name)
 
 
@@ -379,5 +401,30 @@ def fa_d8_dev(dem, nodata, accum) -> None:
     if _dev2d(accum, "fa_d8_dev", torch.float64) != (h, w):
         raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
     s = _torch_elev_suffix(dem)
-    check(getattr(lib(), f"rdgpu_fa_d8_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _CT[s](nodata), w, h,
+    check(getattr(lib(), f"rdgpu_fa_d8_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
                                                  ctypes.c_void_p(accum.data_ptr()), _stream_ptr()), "rdgpu_fa_d8_dev")
+
+
+def resolve_flats_epsilon_dev(dem, nodata) -> None:
+    """In-place ResolveFlatsEpsilon (flats/flats.hpp:21-28) of a contiguous 2-D CUDA tensor, on torch's current stream."""
+    h, w = _dev2d(dem, "resolve_flats_epsilon_dev")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_resolve_flats_epsilon_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+                                                               _stream_ptr()), "rdgpu_resolve_flats_epsilon_dev")
+
+
+class _FlatStats(ctypes.Structure):
+    _fields_ = [("low", ctypes.c_uint64), ("high", ctypes.c_uint64), ("noflow", ctypes.c_uint64),
+                ("away", ctypes.c_uint32), ("towards", ctypes.c_uint32)]
+
+
+def flat_stats() -> dict:
+    """rdgpu_flat_get_stats of the last flat resolution on this process."""
+    st = _FlatStats()
+    check(lib().rdgpu_flat_get_stats(ctypes.byref(st)), "rdgpu_flat_get_stats")
+    return {"low_edges": st.low, "high_edges": st.high, "noflow": st.noflow, "away": st.away, "towards": st.towards}
+
+
+def release_workspace() -> None:
+    """Free the grow-only device workspace cached between calls (rdgpu_release_workspace)."""
+    check(lib().rdgpu_release_workspace(), "rdgpu_release_workspace")

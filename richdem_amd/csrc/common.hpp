@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -32,10 +33,20 @@ void set_last_error(const std::string &m);
                                               " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
+// Every C-ABI entry point runs under ONE process-wide lock: the grow-only workspace, the statistics and the
+// profiler are process globals, so two host threads (e.g. two Python threads calling the `_richdem` module, which
+// releases the GIL around every call) must not be inside the library at the same time.  Calls from different
+// threads are serialised here; when the calling thread changes, the device is synchronised first so that the
+// previous caller's asynchronous `_dev` work has left the shared scratch buffers.
+std::recursive_mutex &api_mutex();
+void api_enter();   // call with api_mutex() held
+
 // Runs fn(), maps exceptions to the C-ABI return code convention.
 template <class F>
 int guarded(F &&fn) {
+  std::lock_guard<std::recursive_mutex> lock(api_mutex());
   try {
+    api_enter();
     fn();
     return RDGPU_OK;
   } catch (const Error &e) {
@@ -53,7 +64,7 @@ int guarded(F &&fn) {
 class Workspace {
 public:
   static Workspace &get();
-  // Returns a device buffer of at least `bytes`, identified by `name`; contents are undefined.
+  // Returns a buffer of at least `bytes` on the CURRENT device, identified by (device, name); contents are undefined.
   void *buf(const char *name, size_t bytes);
   template <class T>
   T *buf(const char *name, size_t count) {

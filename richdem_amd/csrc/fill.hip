@@ -1596,6 +1596,7 @@ struct rdgpu_fill_shard {
   rdgpu::FillBuffers fb;
   std::vector<void *> owned;
   bool cached = false;   // its buffers are the process-wide cached shard workspace (see shard_begin)
+  int device = 0;
   uint32_t *d_edges = nullptr;
   uint32_t nedges = 0;
   rdgpu_fill_stats stats{};
@@ -1616,12 +1617,13 @@ template <> struct DtypeCode<float> { static constexpr int v = 5; };
 // hipMalloc / hipFree of its ~5 B/cell of tables on every call: the first live shard keeps its buffers in the
 // grow-only workspace (under names of their own); shards begun while it is alive own theirs (tests and tools
 // drive many shards from one process).
-static bool g_cached_shard_live = false;
+static bool g_cached_shard_live[64] = {};   // per device: the workspace slots are per device too
 
 static void shard_free(rdgpu_fill_shard *sh) {
   if (!sh) return;
+  std::lock_guard<std::recursive_mutex> lock(api_mutex());
   for (void *p : sh->owned) (void)hipFree(p);
-  if (sh->cached) g_cached_shard_live = false;
+  if (sh->cached) g_cached_shard_live[sh->device & 63] = false;
   delete sh;
 }
 
@@ -1681,8 +1683,9 @@ static rdgpu_fill_shard *shard_begin(T *d_dem, int w, int h, int topology, int o
     sh->w = w; sh->h = h; sh->topology = topology;
     sh->open_top = open_top ? 1 : 0; sh->open_bottom = open_bottom ? 1 : 0;
     sh->stream = s;
-    sh->cached = !g_cached_shard_live;
-    if (sh->cached) g_cached_shard_live = true;
+    RD_HIP(hipGetDevice(&sh->device));
+    sh->cached = !g_cached_shard_live[sh->device & 63];
+    if (sh->cached) g_cached_shard_live[sh->device & 63] = true;
     BufAlloc alloc{!sh->cached, &sh->owned, sh->cached};
     if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
     else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
@@ -1959,6 +1962,7 @@ extern "C" int rdgpu_fill_shard_export(rdgpu_fill_shard *sh, uint32_t *top_keys,
 
 extern "C" int rdgpu_fill_shard_finish(rdgpu_fill_shard *sh, const uint32_t *levels) {
   if (!sh) { set_last_error("rdgpu_fill_shard_finish: null handle"); return RDGPU_ERR_ARG; }
+  std::lock_guard<std::recursive_mutex> lock(api_mutex());
   const int rc = guarded([&] { RD_DISPATCH(sh, shard_finish<T>(sh, levels)); });
   g_stats = sh->stats;
   shard_free(sh);
@@ -1974,6 +1978,7 @@ extern "C" int rdgpu_fill_shard_export_dev(rdgpu_fill_shard *sh, uint32_t *d_key
 
 extern "C" int rdgpu_fill_shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels) {
   if (!sh) { set_last_error("rdgpu_fill_shard_finish_dev: null handle"); return RDGPU_ERR_ARG; }
+  std::lock_guard<std::recursive_mutex> lock(api_mutex());
   const int rc = guarded([&] { RD_DISPATCH(sh, shard_finish_dev<T>(sh, d_levels)); });
   g_stats = sh->stats;
   shard_free(sh);

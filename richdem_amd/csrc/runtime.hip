@@ -2,11 +2,30 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <thread>
 
 namespace rdgpu {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &m) { g_last_error = m; }
+
+std::recursive_mutex &api_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+
+void api_enter() {
+  static std::thread::id last{};
+  static int depth_guard = 0;
+  const std::thread::id me = std::this_thread::get_id();
+  if (last != std::thread::id{} && last != me && depth_guard == 0) {
+    // another host thread used the library last: its asynchronous work may still read the shared scratch
+    depth_guard = 1;
+    (void)hipDeviceSynchronize();
+    depth_guard = 0;
+  }
+  last = me;
+}
 
 // ---- Workspace ----------------------------------------------------------------------------
 Workspace &Workspace::get() {
@@ -15,7 +34,11 @@ Workspace &Workspace::get() {
 }
 
 void *Workspace::buf(const char *name, size_t bytes) {
-  Slot &s = slots_[name];
+  // slots are per device: after rdgpu_set_device(1) (or under a torch.cuda.device context) a call must not launch on
+  // device 1 against scratch that lives in device 0's HBM
+  int dev = 0;
+  RD_HIP(hipGetDevice(&dev));
+  Slot &s = slots_[std::to_string(dev) + ":" + name];
   if (bytes > s.cap) {
     if (s.p) RD_HIP(hipFree(s.p));
     s.p = nullptr;
@@ -34,6 +57,7 @@ uint32_t *Workspace::host_words() {
 }
 
 void Workspace::release() {
+  (void)hipDeviceSynchronize();
   for (auto &kv : slots_)
     if (kv.second.p) (void)hipFree(kv.second.p);
   slots_.clear();

@@ -271,6 +271,9 @@ def bench_sharded(args, rank: int, world: int):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     changed = (bufs[0] != Z).sum().to(torch.float64)
     dist.all_reduce(changed)
+    stages = None
+    if not getattr(args, "no_stages", False):
+        stages = _bench_chain_sharded(bufs[0], n, world)
     out = None
     if rank == 0:
         sec = float(dt.item())
@@ -299,6 +302,8 @@ def bench_sharded(args, rank: int, world: int):
         }
         from .roofline import fill_roofline
 
+        if stages is not None:
+            out["stages"] = stages
         rl = fill_roofline(prof, stats, (r1 - r0) * n, args.steps)   # the dominant kernel on rank 0's row block
         if rl:
             rl["scope"] = "rank 0, per GPU"
@@ -307,6 +312,45 @@ def bench_sharded(args, rank: int, world: int):
                                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:10]}
     dist.destroy_process_group()
     return out   # rank 0: the JSON object bench.py prints; None elsewhere
+
+
+def _bench_chain_sharded(W, n: int, world: int) -> dict:
+    """BASELINE configs[4] on the row blocks: flat-resolved D8 directions and d8_flow_accum of the filled DEM, each
+    timed once after one untimed run (barrier + synchronize on both sides, MAX over ranks), with SURVEY 8d's
+    algorithmic bytes against world x 8 TB/s.  Collective: every rank calls it."""
+    import torch
+    import torch.distributed as dist
+
+    HBM = 8000.0
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return r, float(dt.item())
+
+    def entry(sec, bpc):
+        gbs = n * n * bpc / sec / 1e9
+        return {"ms": round(sec * 1e3, 3), "Mcells_s": round(n * n / 1e6 / sec, 1), "alg_bytes_per_cell": bpc,
+                "alg_GBps": round(gbs, 1), "frac_of_peak": round(gbs / (HBM * world), 4)}
+
+    out = {}
+    d8_flow_directions_sharded(W, -9999.0, flats=True)
+    dirs, sec = timed(lambda: d8_flow_directions_sharded(W, -9999.0, flats=True))
+    out["directions_plus_flat_resolution"] = entry(sec, 6)
+    area = torch.empty(W.shape, dtype=torch.float64, device="cuda")
+    d8_flow_accum_sharded(dirs, area)
+    rounds, sec = timed(lambda: d8_flow_accum_sharded(dirs, area))
+    out["d8_flow_accum"] = entry(sec, 9)
+    out["d8_flow_accum"]["exchanges"] = int(rounds)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_roofline_object():
+def test_roofline_object(tmp_path):
     from richdem_amd.roofline import FILL_ALG_BYTES_PER_CELL, HBM_PEAK_GBS, fill_roofline
 
     cells, steps = 1_600_000_000, 3
@@ -28,12 +28,33 @@ def test_roofline_object():
     r = fill_roofline({"fill.scan": (57.0, 27)}, {"scan_tiles": 3_500_000, "tile_cells": 2048}, cells, steps)
     assert r["launches_per_step"] == 9.0 and abs(r["alg_GB_per_launch"] - 3_500_000 * 2048 * 8 / 9 / 1e9) < 1e-3
     assert fill_roofline({}, stats, cells, steps) is None
-    # traffic comes from the committed PMC summary, per kernel, only for the size it was measured at
-    pt = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    per = json.load(open(pt))
-    r = fill_roofline({"fill.scan": (19.5, 3)}, stats, cells, steps, traffic_file=pt, size=per["size"])
-    assert r["traffic"] == per["GB_per_launch"]["fill.scan"] and r["traffic"] > r["alg_GB_per_launch"] * 0.9
+    # traffic comes from a PMC summary, per kernel, only for the size AND the fill.hip it was measured on
+    from richdem_amd.roofline import engine_sha
+
+    pt = str(tmp_path / "pmc_traffic.json")
+    per = {"size": 40000, "GB_per_launch": {"fill.scan": 15.1}, "GB_per_fill": 59.0, "engine_sha": engine_sha()}
+    json.dump(per, open(pt, "w"))
+    r = fill_roofline({"fill.scan": (19.5, 3)}, stats, cells, steps, step_seconds=0.0222, traffic_file=pt, size=40000)
+    assert r["traffic"] == 15.1 and r["whole_fill_traffic_GB"] == 59.0 and abs(r["whole_fill_pass_count"] - 59.0 / 12.8) < 0.01
+    assert list(r)[:3] == ["bound", "whole_fill_alg_GBps", "whole_fill_frac"]          # the whole fill leads
+    assert abs(r["whole_fill_frac"] - cells * 8 / 0.0222 / 1e9 / 8000.0) < 1e-4
     assert fill_roofline({"fill.scan": (19.5, 3)}, stats, cells, steps, traffic_file=pt, size=123)["traffic"] is None
+    per["engine_sha"] = "0123456789abcdef"                                             # measured on other kernels: stale
+    json.dump(per, open(pt, "w"))
+    assert fill_roofline({"fill.scan": (19.5, 3)}, stats, cells, steps, traffic_file=pt, size=40000)["traffic"] is None
+    committed = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    assert set(json.load(open(committed))) >= {"size", "GB_per_launch", "engine_sha"}
+
+
+def test_stage_entry():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    e = bench.stage_entry(0.181, 1_600_000_000, 6)
+    assert e["ms"] == 181.0 and e["alg_bytes_per_cell"] == 6 and abs(e["alg_GBps"] - 9.6 / 0.181) < 0.1
+    assert abs(e["frac_of_peak"] - 9.6 / 0.181 / 8000) < 1e-4 and abs(e["Mcells_s"] - 1600 / 0.181) < 0.1
+    assert bench.STAGE_BYTES == {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
+                                 "resolve_flats_epsilon": 8, "fa_d8": 20}
 
 
 def test_bench_stdout_is_reserved_for_the_json_line():

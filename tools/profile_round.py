@@ -51,6 +51,9 @@ def main():
     tag = sys.argv[1]
     steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1"]
+    # the profiling passes run the fill only, or (--path) the fill and the stages after it; never the host path
+    prof_tail = ["--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-host"] + ([] if "--path" in sys.argv else ["--no-stages"])
+    what = "path40k" if "--path" in sys.argv else "fill40k"
     os.makedirs(OUT, exist_ok=True)
     log = os.path.join(OUT, f"{tag}_bench.log")
     run(bench, log)
@@ -61,12 +64,12 @@ def main():
                        ("write", ["--kernel-trace", "--pmc", "WRITE_SIZE"])):
         d = os.path.join(OUT, f"{tag}_{sub}")
         shutil.rmtree(d, ignore_errors=True)
-        cmd = ["rocprofv3"] + extra + ["--output-format", "csv", "-d", d, "-o", "run", "--"] + bench[:2] + ["--steps", "1", "--warmup", "0", "--cpu-sample", "0"]
+        cmd = ["rocprofv3"] + extra + ["--output-format", "csv", "-d", d, "-o", "run", "--"] + bench[:2] + prof_tail
         rc = run(cmd, os.path.join(OUT, f"{tag}_{sub}.log"))
         print(sub, "rc", rc)
     ks = glob.glob(os.path.join(OUT, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(OUT, f"{tag}_fill40k_kernel_stats.csv"))
+        shutil.copy(ks[0], os.path.join(OUT, f"{tag}_{what}_kernel_stats.csv"))
     fetch = counters(os.path.join(OUT, f"{tag}_fetch"), "FETCH_SIZE")
     write = counters(os.path.join(OUT, f"{tag}_write"), "WRITE_SIZE")
     rows = []
@@ -77,7 +80,7 @@ def main():
         fg = fetch[k][1] * 1024 * 2 / 1e9 / n
         wg = write[k][1] * 1024 / 1e9 / n
         rows.append((k, n, fg, wg, fg + wg))
-    with open(os.path.join(OUT, f"{tag}_fill40k_pmc_summary.csv"), "w") as f:
+    with open(os.path.join(OUT, f"{tag}_{what}_pmc_summary.csv"), "w") as f:
         f.write(f"# {tag} PMC summary: fill, 40000x40000 f32, 1 step (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)\n")
         f.write("# counters are KiB; WRITE_SIZE x1, FETCH_SIZE x2 (gfx950 half-count; calibration: k_synth writes 6.4e9 B, k_count_pits reads 6.4e9 B)\n")
         f.write("kernel,launches,fetch_GB_per_launch(x2),write_GB_per_launch,total_GB_per_launch\n")
@@ -94,7 +97,16 @@ def main():
             per[prof_name] = round(sum(r[4] * r[1] for r in sel) / cnt, 3)
     if per:
         with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
-            json.dump({"size": 40000, "GB_per_launch": per,
+            sys.path.insert(0, ROOT)
+            from richdem_amd.roofline import engine_sha
+
+            fill_kernels = ("k_descent", "k_tile_label", "k_scan", "k_edge_round", "k_finalize", "k_finalize_tiled", "k_hook",
+                            "k_chase_links", "k_update_basins", "k_compact_roots", "k_best_reset", "k_init_tables",
+                            "k_compact_alive", "k_sum_segments", "k_chase", "k_label_cells")
+            # launches counted by the profiling command's fills (1 timed + the instrumented pass of bench.py)
+            nfill = max(1, sum(r[1] for r in rows if r[0].split("<")[0] == "rdgpu::k_descent"))
+            per_fill = sum(r[4] * r[1] for r in rows if r[0].split("<")[0].replace("rdgpu::", "") in fill_kernels) / nfill
+            json.dump({"size": 40000, "GB_per_launch": per, "GB_per_fill": round(per_fill, 2), "engine_sha": engine_sha(),
                        "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
         # the bench line above was printed before these passes ran: give it this round's traffic figure
         d = json.loads(line)
@@ -110,10 +122,10 @@ def main():
         d = os.path.join(OUT, f"{tag}_sq")
         shutil.rmtree(d, ignore_errors=True)
         cmd = (["rocprofv3", "--kernel-trace", "--pmc"] + names_sq + ["--output-format", "csv", "-d", d, "-o", "run", "--"]
-               + bench[:2] + ["--steps", "1", "--warmup", "0", "--cpu-sample", "0"])
+               + bench[:2] + prof_tail)
         print("sq rc", run(cmd, os.path.join(OUT, f"{tag}_sq.log")))
         cols = {n: counters(d, n) for n in names_sq}
-        with open(os.path.join(OUT, f"{tag}_fill40k_sq_summary.csv"), "w") as f:
+        with open(os.path.join(OUT, f"{tag}_{what}_sq_summary.csv"), "w") as f:
             f.write(f"# {tag} SQ counters, fill 40000x40000 f32, 1 step (rocprofv3 --kernel-trace --pmc SQ_*; quad-cycle units; "
                     "fractions of SQ_WAVE_CYCLES)\n")
             f.write("kernel,launches,wave_cycles,wait_any,wait_inst_any,active_inst_any,active_valu,active_lds,insts_valu,insts_lds\n")
