@@ -106,6 +106,13 @@ RDGPU_SHIM_PITMASK(f32, float)
 template <class T>
 int c_pitmask(const T *, T, int, int, int, uint8_t *) { unsupported("pit_mask"); }
 
+inline int c_fill_eps(float *p, float nd, int w, int h, int t) { return rdgpu_fill_epsilon_f32(p, nd, w, h, t); }
+inline int c_fill_eps(double *p, double nd, int w, int h, int t) { return rdgpu_fill_epsilon_f64(p, nd, w, h, t); }
+template <class T>
+int c_fill_eps(T *, T, int, int, int) {   // depressions/Barnes2014.hpp:424-451
+  throw std::runtime_error("Priority-Flood+Epsilon is only available for floating-point data types!");
+}
+
 inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
 inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
 template <class T>
@@ -145,6 +152,22 @@ void PriorityFlood_Barnes2014(A &dem) {
 template <auto topo, class A>
 void FillDepressions(A &dem) {
   detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()), "FillDepressions");
+}
+
+// richdem::PriorityFloodEpsilon_Barnes2014<topo>(Array2D<T>&)   depressions/Barnes2014.hpp:335-420; integer element
+// types throw std::runtime_error as the reference's specialisations do (:424-451)
+template <auto topo, class A>
+void PriorityFloodEpsilon_Barnes2014(A &dem) {
+  using T = detail::elem_t<A>;
+  if (dem.width() == 0 || dem.height() == 0) return;
+  detail::check(detail::c_fill_eps((T *)dem.data(), dem.noData(), dem.width(), dem.height(), detail::topology_code<topo>()),
+                "PriorityFloodEpsilon_Barnes2014");
+}
+
+// richdem::FillDepressionsEpsilon<topo>(Array2D<T>&)      depressions/depressions.hpp:23
+template <auto topo, class A>
+void FillDepressionsEpsilon(A &dem) {
+  PriorityFloodEpsilon_Barnes2014<topo>(dem);
 }
 
 // ---- flow directions ---------------------------------------------------------------------------

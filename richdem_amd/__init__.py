@@ -50,6 +50,8 @@ from .api import (  # noqa: F401
     fa_d8_dev,
     synth_dem_dev,
     resolve_flats_epsilon_dev,
+    fill_epsilon_dev,
+    epsilon_stats,
     flat_stats,
     release_workspace,
 )

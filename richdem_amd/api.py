@@ -65,12 +65,12 @@ def _topo(topology) -> int:
         raise RdgpuError("Unknown topology!") from None  # depressions.hpp:19-20
 
 
-def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = False, topology="D8", shards: int = 1):
+def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = False, topology="D8", shards: int = 1,
+                    nodata=-9999):
     """Fill all depressions of ``dem`` (reference: ``rd.FillDepressions``,
-    wrappers/pyrichdem/richdem/__init__.py:381-422 -> FillDepressions<topo>, depressions.hpp:13-21).
-    Returns the filled array (or None when ``in_place``)."""
-    if epsilon:
-        raise RdgpuError("FillDepressions(epsilon=True) is not provided: PriorityFloodEpsilon's result depends on the order in which the reference's heap pops equal elevations")
+    wrappers/pyrichdem/richdem/__init__.py:381-422 -> FillDepressions<topo>, depressions.hpp:13-21; ``epsilon=True``
+    -> PriorityFloodEpsilon_Barnes2014<topo>, depressions/Barnes2014.hpp:335-420, floating point only, ``nodata`` cells
+    are left alone).  Returns the filled array (or None when ``in_place``)."""
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("FillDepressions: expected a 2-D numpy array")
     out = dem if in_place else dem.copy()
@@ -79,6 +79,13 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
             raise RdgpuError("FillDepressions(in_place=True) needs a C-contiguous array")
         out = np.ascontiguousarray(out)
     h, w = out.shape
+    if epsilon:
+        if out.dtype not in (np.float32, np.float64):
+            raise RdgpuError("Priority-Flood+Epsilon is only available for floating-point data types!")   # Barnes2014.hpp:424-451
+        s = _suffix(out.dtype)
+        check(getattr(lib(), f"rdgpu_fill_epsilon_{s}")(out.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
+                                                        _topo(topology)), "rdgpu_fill_epsilon")
+        return None if in_place else out
     if shards > 1:   # the multi-GPU row-block protocol, shard after shard on one GPU
         if _suffix(out.dtype) in ("f64", "i64", "u64"):
             raise RdgpuError("FillDepressions(shards=...): the row-block shard engine takes the 32-bit element types")
@@ -428,3 +435,26 @@ def flat_stats() -> dict:
 def release_workspace() -> None:
     """Free the grow-only device workspace cached between calls (rdgpu_release_workspace)."""
     check(lib().rdgpu_release_workspace(), "rdgpu_release_workspace")
+
+
+def fill_epsilon_dev(dem, nodata, topology="D8") -> None:
+    """In-place PriorityFloodEpsilon of a contiguous 2-D float32 / float64 CUDA tensor, on torch's current stream."""
+    import torch
+
+    h, w = _dev2d(dem, "fill_epsilon_dev")
+    if dem.dtype not in (torch.float32, torch.float64):
+        raise RdgpuError("Priority-Flood+Epsilon is only available for floating-point data types!")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_fill_epsilon_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+                                                        _topo(topology), _stream_ptr()), "rdgpu_fill_epsilon_dev")
+
+
+class _EpsStats(ctypes.Structure):
+    _fields_ = [("rounds", ctypes.c_uint32), ("attempts", ctypes.c_uint32), ("tile_relaxations", ctypes.c_uint64),
+                ("slack", ctypes.c_uint64), ("max_lift", ctypes.c_uint64)]
+
+
+def epsilon_stats() -> dict:
+    st = _EpsStats()
+    check(lib().rdgpu_fill_epsilon_get_stats(ctypes.byref(st)), "rdgpu_fill_epsilon_get_stats")
+    return {k: getattr(st, k) for k, _ in _EpsStats._fields_}

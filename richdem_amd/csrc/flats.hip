@@ -38,6 +38,8 @@ __device__ __forceinline__ int fdy(int n) { return (n >= 2 && n <= 4) ? -1 : (n 
 // reverse level order behind a pre-check.
 
 constexpr uint8_t F_LOW = 1, F_HIGH = 2, F_NOFLOW = 4;
+constexpr uint8_t F_NEAR = 8;       // NO_FLOW cell next to an equal-elevation cell WITH a direction (a low edge): towards level 2
+constexpr uint8_t DIR_GHOST_NOFLOW = 254;   // row-block shards: NO_FLOW cell of a ghost row (feeds, is not relaxed here)
 
 // ------------------------------------------------------------------------------------------
 // find_flat_edges (flat_resolution.hpp:381-418) -> one flag byte per cell
@@ -83,15 +85,17 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
       // a cell WITH flow can only be a low edge if some neighbour is NO_FLOW; a NO_FLOW cell is always
       // interior (edge cells always get a direction), so its 8 neighbours exist
       const T e = sz[o];
-      bool hit = false;
+      bool hit = false, near = false;
 #pragma unroll
       for (int k = 1; k <= 8; k++) {
         const uint8_t dn = sdir[o + off[k]];
         if (dn == 255) continue;
         const T zn = sz[o + off[k]];
         hit |= noflow ? (e < zn) : (dn == 0 && zn == e);   // :409-411 / :406-408
+        near |= noflow && dn != 0 && zn == e;              // the neighbour is a low edge of this cell's flat
       }
       if (hit) f |= noflow ? F_HIGH : F_LOW;
+      if (near) f |= F_NEAR;
     }
     flags[(size_t)gy * w + gx] = f;
   }
@@ -386,31 +390,62 @@ __device__ __forceinline__ int32_t from_right(int32_t v, int32_t fill) {
 }
 __device__ __forceinline__ int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
 
-// One active tile to its local fixed point.  Two facts keep the inner loop free of elevation compares and
-// almost free of LDS: (1) two adjacent NO_FLOW cells always have the same elevation (neither has a lower
-// neighbour), so among the cells that are relaxed the flat graph is the plain 8-grid; (2) the cells that are
-// NOT relaxed but hold a distance (low edges, a shard's ghost rows) only feed in, so they are applied once, with
-// the equal-elevation test, before the loop.  A wavefront is one 64-column band of 8 rows: a lane keeps its
-// column strip in registers, sweeps it down and up (Gauss-Seidel), takes the two side columns' vertical
-// 3-minima from the neighbouring lanes with DPP wave shifts, and only the bands' first/last rows go through
-// LDS (double buffered: one barrier per iteration, shared with the "anything changed" vote).
-template <class T>
-__device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_t *__restrict__ dirs, int32_t *D,
-                                           const uint32_t t, uint8_t *next_active, int w, int h, uint32_t tilesX,
-                                           uint32_t tilesY) {
+// Start of the towards field, one 64 x RCH tile per block: low edges hold level 1 (they are not relaxed: they have a
+// direction), the NO_FLOW cells next to a low edge of their own flat level 2 (:262-275: the low edges are the first
+// BFS level), everything else "not reached".  Rows outside [row_lo, row_hi) -- a shard's ghost rows -- are not
+// seeded: their levels arrive from their owners.  A tile with a seed wakes itself and its 8 neighbours.
+__global__ __launch_bounds__(NTHR) void k_flat_init_towards(const uint8_t *__restrict__ flags, int32_t *__restrict__ D,
+                                                            uint8_t *tile_active, int w, int h, int row_lo, int row_hi,
+                                                            uint32_t tilesX, uint32_t tilesY) {
+  const uint32_t t = blockIdx.x;
+  const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
+  const int x0 = tx * CW, y0 = ty * RCH;
+  const int lx = threadIdx.x & (CW - 1), r0 = threadIdx.x >> 6;
+  int seed = 0;
+#pragma unroll
+  for (int j = 0; j < RCH / 4; j++) {
+    const int gx = x0 + lx, gy = y0 + r0 + 4 * j;
+    if (gx >= w || gy >= h) continue;
+    const size_t g = (size_t)gy * w + gx;
+    int32_t v = DINF;
+    if (gy >= row_lo && gy < row_hi) {
+      const uint8_t f = flags[g];
+      if (f & F_LOW) v = 1;
+      else if (f & F_NEAR) { v = 2; seed = 1; }
+    }
+    D[g] = v;
+  }
+  if (__syncthreads_or(seed) && threadIdx.x < 9) {
+    const int ntx = tx + (int)threadIdx.x % 3 - 1, nty = ty + (int)threadIdx.x / 3 - 1;
+    if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) tile_active[nty * tilesX + ntx] = 1;
+  }
+}
+
+// One active tile to its local fixed point d(c) = min(d(c), min over the 8 neighbours d(n) + 1) over its NO_FLOW
+// cells.  Two adjacent NO_FLOW cells always have the same elevation (neither has a lower neighbour), so among the cells
+// that take part the flat graph is the plain 8-grid with the other cells as walls: no elevations are read here at all
+// (the low edges enter through the start values, k_flat_init_towards).  Per cell the kernel reads its level and its
+// direction byte.
+// A wavefront is one 64-column band of ROWS rows: a lane keeps its column strip in registers, sweeps it down and up
+// (Gauss-Seidel), takes the two side columns' vertical 3-minima from the neighbouring lanes with DPP wave shifts, and
+// only the bands' first/last rows go through LDS (double buffered: one barrier per iteration, shared with the "anything
+// changed" vote).  Levels only decrease and stay upper bounds, so the fixed point is the exact BFS level.
+// (Measured and dropped, r02, all correct: min-plus scans along the rows inside this kernel -- a front then crosses the
+// tile width in one trip -- with ds_bpermute shuffles or with DPP row shifts + v_readlane: 2.5-3x SLOWER at S3, because
+// with one stencil step per trip the diagonal fronts of open lakes take 32 trips instead of 8; and one wavefront per
+// tile running chamfer sweeps over rows kept in LDS, no barriers at all: 1.4x slower, 89 + 46 ms against 60 + 33 ms.)
+constexpr int32_t DWALL = DINF + 1;   // LDS only: a cell that does not take part
+__device__ __forceinline__ void relax_tile(const uint8_t *__restrict__ dirs, int32_t *D, const uint32_t t,
+                                           uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY, int row_lo,
+                                           int row_hi) {
   constexpr int RW = CW + 2, RH = RCH + 2, ROWS = RCH / RBANDS;
-  __shared__ T sz[RH * RW];
   __shared__ int32_t sd[RH * RW];
-  __shared__ uint8_t se[RH * RW];
   __shared__ int32_t xrow[2][RBANDS][2][CW];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int x0 = tx * CW, y0 = ty * RCH;
   {
-    // All loads of the thread are issued before the first one is consumed (clamped addresses, branch-free):
-    // item by item the tile paid one memory round trip per loop trip -- nine in a row -- and this kernel is
-    // launched for ~10^6 tiles per gradient.
+    // all loads of the thread are issued before the first one is consumed (clamped addresses, branch-free)
     constexpr int IPT = (RH * RW + RNT - 1) / RNT;
-    T zv[IPT];
     int32_t dv[IPT];
     uint8_t ev[IPT];
 #pragma unroll
@@ -419,7 +454,6 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
       const int ly = i / RW, lxx = i - ly * RW;
       const int gx = min(max(x0 - 1 + lxx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
       const size_t g = (size_t)gy * w + gx;
-      zv[r] = z[g];
       dv[r] = __hip_atomic_load(&D[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // neighbours' tiles write it
       ev[r] = dirs[g];
     }
@@ -430,47 +464,30 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
       const int ly = i / RW, lxx = i - ly * RW;
       const int gx = x0 - 1 + lxx, gy = y0 - 1 + ly;
       const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
-      sz[i] = in ? zv[r] : T();
-      sd[i] = in ? dv[r] : DINF;
-      se[i] = in && ev[r] == 0;   // only NO_FLOW cells are relaxed (:190-191); sources merely hold a distance
+      sd[i] = (in && (ev[r] == 0 || ev[r] == DIR_GHOST_NOFLOW)) ? dv[r] : DWALL;   // only NO_FLOW cells take part (:190-191)
     }
   }
   __syncthreads();
   const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
-  const int off[9] = {0, -1, -RW - 1, -RW, -RW + 1, 1, RW + 1, RW, RW - 1};
   int32_t d[ROWS], d0[ROWS];
-  uint32_t elig = 0;
+  uint32_t elig = 0;   // bit j: the cell is relaxed here (NO_FLOW, inside the raster, in the own rows)
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
-    const int o = (band * ROWS + j + 1) * RW + lx + 1;
-    int32_t v = DINF;
-    if (se[o]) {
-      elig |= 1u << j;
-      v = sd[o];
-      const T e = sz[o];
-#pragma unroll
-      for (int k = 1; k <= 8; k++) {   // feeders: not relaxed themselves, same flat <=> same elevation
-        const int q = o + off[k];
-        if (!se[q] && sz[q] == e) v = imin(v, sd[q] + 1);
-      }
-    }
-    d0[j] = se[o] ? sd[o] : DINF;
-    d[j] = v;
+    const int ly = band * ROWS + j, gy = y0 + ly;
+    d[j] = sd[(ly + 1) * RW + lx + 1];
+    if (d[j] <= DINF && gy >= row_lo && gy < row_hi) elig |= 1u << j;
+    d0[j] = d[j];
   }
   if (!__syncthreads_or(elig != 0)) return;
-  // fixed surroundings of the tile as seen by the loop: relaxed cells of the neighbouring tiles (INF otherwise)
-  auto ring = [&](int ly /* -1..RCH */, int cx /* -1..CW */) -> int32_t {
-    const int q = (ly + 1) * RW + cx + 1;
-    return se[q] ? sd[q] : DINF;
-  };
+  auto ring = [&](int ly /* -1..RCH */, int cx /* -1..CW */) -> int32_t { return sd[(ly + 1) * RW + cx + 1]; };
   int32_t sideL[ROWS], sideR[ROWS];   // vertical 3-minima of the halo columns (lanes 0 and 63 use them)
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     const int ly = band * ROWS + j;
-    sideL[j] = lx == 0 ? imin(ring(ly - 1, -1), imin(ring(ly, -1), ring(ly + 1, -1))) : DINF;
-    sideR[j] = lx == CW - 1 ? imin(ring(ly - 1, CW), imin(ring(ly, CW), ring(ly + 1, CW))) : DINF;
+    sideL[j] = lx == 0 ? imin(ring(ly - 1, -1), imin(ring(ly, -1), ring(ly + 1, -1))) : DWALL;
+    sideR[j] = lx == CW - 1 ? imin(ring(ly - 1, CW), imin(ring(ly, CW), ring(ly + 1, CW))) : DWALL;
   }
-  const int32_t halo_up = band == 0 ? ring(-1, lx) : DINF, halo_dn = band == RBANDS - 1 ? ring(RCH, lx) : DINF;
+  const int32_t halo_up = band == 0 ? ring(-1, lx) : DWALL, halo_dn = band == RBANDS - 1 ? ring(RCH, lx) : DWALL;
   int changed = 1, it = 0;
   for (; it < 256; it++) {
     // Gauss-Seidel along the strip
@@ -487,7 +504,7 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
     const int32_t dn = band == RBANDS - 1 ? halo_dn : xrow[it & 1][band + 1][0][lx];
     // HSTEPS stencil steps per barrier: the sideways exchange is all DPP (registers), so a front crosses HSTEPS
     // columns per trip; the rows above / below the band are one trip stale, which only delays, never breaks,
-    // convergence (distances are upper bounds and only decrease)
+    // convergence (levels are upper bounds and only decrease)
     changed = 0;
 #pragma unroll
     for (int sub = 0; sub < HSTEPS; sub++) {
@@ -525,15 +542,14 @@ __device__ __forceinline__ void relax_tile(const T *__restrict__ z, const uint8_
 // One block per listed tile.  The count lives on the device (rounds are enqueued in batches, the host sizes the
 // grid from the previous batch): blocks past the count leave at once, and tiles past the grid -- the list grew
 // faster than expected -- simply stay active for the next round (relaxation is monotone, order is irrelevant).
-template <class T>
-__global__ __launch_bounds__(RNT) void k_flat_relax(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
-                                                    int32_t *D, const uint32_t *__restrict__ tiles,
-                                                    const uint32_t *__restrict__ count, uint8_t *next_active, int w,
-                                                    int h, uint32_t tilesX, uint32_t tilesY) {
+__global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ dirs, int32_t *D,
+                                                    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
+                                                    uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY,
+                                                    int row_lo, int row_hi) {
   const uint32_t n = *count;
   for (uint32_t i = gridDim.x + blockIdx.x * RNT + threadIdx.x; i < n; i += gridDim.x * RNT) next_active[tiles[i]] = 1;
   if (blockIdx.x >= n) return;
-  relax_tile<T>(z, dirs, D, tiles[blockIdx.x], next_active, w, h, tilesX, tilesY);
+  relax_tile(dirs, D, tiles[blockIdx.x], next_active, w, h, tilesX, tilesY, row_lo, row_hi);
 }
 
 // flat_height[label] = deepest away level of the flat (:181): atomicMax behind a coherent pre-check
@@ -755,9 +771,9 @@ static uint32_t compact_flags(const uint8_t *flags, uint8_t mask, uint64_t n, co
 // Relaxation rounds until no tile is active.  Rounds are enqueued RELAX_BATCH at a time (compact the active
 // tile flags into a list + count on the device, relax that list); the host only reads the counts back once
 // per batch, and the rounds enqueued past the fixed point see an empty list.  Returns the rounds that had work.
-template <class T>
-static uint32_t relax_rounds(const T *d_z, const uint8_t *d_dirs, int32_t *D, uint8_t *tflags, uint32_t *tlist,
-                             uint32_t *ctr /* RELAX_BATCH words */, int w, int h, const char *name, hipStream_t s) {
+static uint32_t relax_rounds(const uint8_t *d_dirs, int32_t *D, uint8_t *tflags, uint32_t *tlist,
+                             uint32_t *ctr /* RELAX_BATCH words */, int w, int h, int row_lo, int row_hi, const char *name,
+                             hipStream_t s) {
   uint32_t *hw = Workspace::get().host_words();
   const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
@@ -767,8 +783,8 @@ static uint32_t relax_rounds(const T *d_z, const uint8_t *d_dirs, int32_t *D, ui
     for (int b = 0; b < RELAX_BATCH; b++) {
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, tflags, ntiles,
                 tlist, ctr + b);
-      RD_LAUNCH(name, (k_flat_relax<T>), dim3(grid), dim3(RNT), 0, s, d_z, d_dirs, D, (const uint32_t *)tlist,
-                (const uint32_t *)(ctr + b), tflags, w, h, tilesX, tilesY);
+      RD_LAUNCH(name, k_flat_relax, dim3(grid), dim3(RNT), 0, s, d_dirs, D, (const uint32_t *)tlist,
+                (const uint32_t *)(ctr + b), tflags, w, h, tilesX, tilesY, row_lo, row_hi);
     }
     RD_HIP(hipMemcpyAsync(hw, ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
@@ -784,19 +800,38 @@ static uint32_t relax_rounds(const T *d_z, const uint8_t *d_dirs, int32_t *D, ui
   }
 }
 
-// Distances from the cells listed in src (level 1) by tile relaxation.  Returns the number of rounds.
-template <class T>
-static uint32_t run_relax(const T *d_z, const uint8_t *d_dirs, int32_t *D, const uint32_t *src, uint32_t nsrc,
-                          const uint32_t *L, const int32_t *fh_filter, int w, int h, const char *name, hipStream_t s) {
+struct RelaxScratch {
+  uint8_t *tflags;
+  uint32_t *tlist, *ctr;
+  uint32_t tilesX, tilesY, ntiles;
+};
+static RelaxScratch relax_scratch(int w, int h) {
   Workspace &ws = Workspace::get();
-  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
-  uint8_t *tflags = ws.buf<uint8_t>("flats.tflags", ntiles);
-  uint32_t *tlist = ws.buf<uint32_t>("flats.tlist", ntiles);
-  uint32_t *ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
-  RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
+  RelaxScratch r;
+  r.tilesX = (w + CW - 1) / CW; r.tilesY = (h + RCH - 1) / RCH; r.ntiles = r.tilesX * r.tilesY;
+  r.tflags = ws.buf<uint8_t>("flats.tflags", r.ntiles);
+  r.tlist = ws.buf<uint32_t>("flats.tlist", r.ntiles);
+  r.ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
+  return r;
+}
+
+// Away levels from the high edges listed in src (level 1) by tile relaxation.  Returns the number of rounds.
+static uint32_t run_relax_away(const uint8_t *d_dirs, int32_t *D, const uint32_t *src, uint32_t nsrc, const uint32_t *L,
+                               const int32_t *fh_filter, int w, int h, hipStream_t s) {
+  const RelaxScratch r = relax_scratch(w, h);
+  RD_HIP(hipMemsetAsync(r.tflags, 0, r.ntiles, s));
   RD_LAUNCH("flats.seed", k_flat_seed, dim3((nsrc + NTHR - 1) / NTHR), dim3(NTHR), 0, s, src, nsrc, L, fh_filter, D,
-            tflags, w, tilesX, tilesY, (const int32_t *)nullptr);
-  return relax_rounds<T>(d_z, d_dirs, D, tflags, tlist, ctr, w, h, name, s);
+            r.tflags, w, r.tilesX, r.tilesY, (const int32_t *)nullptr);
+  return relax_rounds(d_dirs, D, r.tflags, r.tlist, r.ctr, w, h, 0, h, "flats.relax_away", s);
+}
+
+// Towards levels from the low edges (flags: F_LOW level 1, F_NEAR level 2).  D is written in full.
+static uint32_t run_relax_towards(const uint8_t *d_dirs, const uint8_t *flags, int32_t *D, int w, int h, hipStream_t s) {
+  const RelaxScratch r = relax_scratch(w, h);
+  RD_HIP(hipMemsetAsync(r.tflags, 0, r.ntiles, s));
+  RD_LAUNCH("flats.init_towards", k_flat_init_towards, dim3(r.ntiles), dim3(NTHR), 0, s, flags, D, r.tflags, w, h, 0, h, r.tilesX,
+            r.tilesY);
+  return relax_rounds(d_dirs, D, r.tflags, r.tlist, r.ctr, w, h, 0, h, "flats.relax_towards", s);
 }
 
 // Computes flat_mask (M) for the DEM; d_dirs must hold d8_flow_directions output.
@@ -842,13 +877,12 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   if (nhigh_all > 0) {
     A = ws.buf<int32_t>("flats.away", n);
     RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
-    g_fstats.away_levels = run_relax<T>(d_z, d_dirs, A, highall, nhigh_all, L, fh, w, h, "flats.relax_away", s);
+    g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, L, fh, w, h, s);
     RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
               n);
   }
   // towards gradient from every low edge, then the combined mask in place
-  RD_HIP(hipMemsetAsync(M, 0x7F, n * sizeof(int32_t), s));
-  g_fstats.towards_levels = run_relax<T>(d_z, d_dirs, M, low, nlow, L, nullptr, w, h, "flats.relax_towards", s);
+  g_fstats.towards_levels = run_relax_towards(d_dirs, flags, M, w, h, s);
   RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, M, (const int32_t *)A, (const uint32_t *)L,
             (const int32_t *)fh, n);
 }
@@ -980,6 +1014,11 @@ __global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *_
     const int ty = own_row / RCH;
     for (int tx = max(x - 1, 0) / CW; tx <= min(x + 1, w - 1) / CW; tx++) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
   }
+}
+
+__global__ __launch_bounds__(NTHR) void k_fs_ghost_dirs(uint8_t *dirs, uint32_t n) {
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  if (i < n) dirs[i] = dirs[i] == 0 ? DIR_GHOST_NOFLOW : 1;
 }
 
 struct CutRows { int row[4]; };   // ghost above, first own, last own, ghost below (-1: no such row)
@@ -1116,17 +1155,20 @@ static void fs_relax(rdgpu_flat_shard *f, int phase) {
   hipStream_t s = f->stream;
   const int w = f->w, h = f->rows;
   const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH;
-  const T *z = static_cast<const T *>(f->z);
+  const int row_lo = f->gtop, row_hi = h - f->gbot;   // the own rows: ghost rows feed, they are not relaxed here
   int32_t *D = f->D[phase];
   if (!f->seeded[phase]) {
     f->seeded[phase] = true;
-    if (f->nsrc[phase])
-      RD_LAUNCH("flats.seed", k_flat_seed, dim3((f->nsrc[phase] + NTHR - 1) / NTHR), dim3(NTHR), 0, s,
-                (const uint32_t *)f->src[phase], f->nsrc[phase], (const uint32_t *)f->L, (const int32_t *)nullptr, D,
-                f->tflags[phase], w, tilesX, tilesY, phase == 1 ? (const int32_t *)f->D[0] : (const int32_t *)nullptr);
+    if (phase == 0)
+      RD_LAUNCH("flats.init_towards", k_flat_init_towards, dim3(tilesX * tilesY), dim3(NTHR), 0, s, (const uint8_t *)f->flags, D,
+                f->tflags[0], w, h, row_lo, row_hi, tilesX, tilesY);
+    else if (f->nsrc[1])
+      RD_LAUNCH("flats.seed", k_flat_seed, dim3((f->nsrc[1] + NTHR - 1) / NTHR), dim3(NTHR), 0, s,
+                (const uint32_t *)f->src[1], f->nsrc[1], (const uint32_t *)f->L, (const int32_t *)nullptr, D,
+                f->tflags[1], w, tilesX, tilesY, (const int32_t *)f->D[0]);
   }
-  f->rounds[phase] += relax_rounds<T>(z, (const uint8_t *)f->dirs, D, f->tflags[phase], f->tlist, f->ctr, w, h,
-                                      phase ? "flats.relax_away" : "flats.relax_towards", s);
+  f->rounds[phase] += relax_rounds((const uint8_t *)f->dirs, D, f->tflags[phase], f->tlist, f->ctr, w, h, row_lo, row_hi,
+                                   phase ? "flats.relax_away" : "flats.relax_towards", s);
 }
 
 template <class T>
@@ -1190,9 +1232,10 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
         RD_HIP(hipMemcpyAsync(f->src[ph], list, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
       }
     }
-    // ghost cells are never relaxed or given a direction here: mark them as "has a direction"
-    if (gtop) RD_HIP(hipMemsetAsync(f->dirs, 1, (size_t)gtop * w, s));
-    if (gbot) RD_HIP(hipMemsetAsync(f->dirs + (size_t)(rows - gbot) * w, 1, (size_t)gbot * w, s));
+    // ghost cells are never relaxed or given a direction here: their NO_FLOW cells keep feeding (DIR_GHOST_NOFLOW),
+    // the others are marked as "has a direction"
+    if (gtop) RD_LAUNCH("flatshard.ghost_dirs", k_fs_ghost_dirs, dim3(((size_t)gtop * w + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->dirs, (uint32_t)gtop * (uint32_t)w);
+    if (gbot) RD_LAUNCH("flatshard.ghost_dirs", k_fs_ghost_dirs, dim3(((size_t)gbot * w + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->dirs + (size_t)(rows - gbot) * w, (uint32_t)gbot * (uint32_t)w);
     RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles);
     launch_ccl_border<T>(d_z, f->L, w, rows, s);
     RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, f->L, n);

@@ -102,30 +102,31 @@ def _plain(a) -> np.ndarray:
     return np.asarray(a).view(np.ndarray)
 
 
-def FillDepressions(dem, epsilon: bool = False, in_place: bool = False, topology: str = "D8", shards: int = 1):
+def FillDepressions(dem, epsilon: bool = False, in_place: bool = False, topology: str = "D8", shards: int = 1, nodata=None):
     """Fills all depressions in a DEM (reference __init__.py:381-422 -> rdFillDepressionsD8/D4 =
     PriorityFlood_Zhou2016 / PriorityFlood_Barnes2014<D4>, pywrapper.hpp:32-33).
-    rdarray in: returns a new rdarray, or None when ``in_place``.  ``epsilon=True`` is refused: the result of
-    PriorityFloodEpsilon depends on the order in which the reference's heap pops equal elevations."""
+    rdarray in: returns a new rdarray, or None when ``in_place``.  ``epsilon=True`` -> rdPFepsilonD8/D4 =
+    PriorityFloodEpsilon_Barnes2014<topo> (pywrapper.hpp:34-35), floating-point DEMs only."""
     if type(dem) is not rdarray:
         if isinstance(dem, np.ndarray) and type(dem) is np.ndarray:
-            return _api.FillDepressions(dem, epsilon=epsilon, in_place=in_place, topology=topology, shards=shards)
+            return _api.FillDepressions(dem, epsilon=epsilon, in_place=in_place, topology=topology, shards=shards,
+                                        nodata=-9999 if nodata is None else nodata)
         raise Exception("A richdem.rdarray or numpy.ndarray is required!")
     if topology not in ["D8", "D4"]:
         raise Exception("Unknown topology!")
-    if epsilon:
-        raise RdgpuError("FillDepressions(epsilon=True) is not provided (order-dependent in the reference)")
     if not in_place:
         dem = dem.copy()
     elif not dem.flags["C_CONTIGUOUS"]:
         raise RdgpuError("FillDepressions(in_place=True) needs a C-contiguous array")
     _add_analysis(dem, f"FillDepressions(dem, epsilon={epsilon})")
     work = _plain(dem)
+    nd = (_nodata_of(dem) if nodata is None else nodata) if epsilon else -9999
     if not work.flags["C_CONTIGUOUS"]:
-        filled = _api.FillDepressions(np.ascontiguousarray(work), in_place=False, topology=topology, shards=shards)
+        filled = _api.FillDepressions(np.ascontiguousarray(work), epsilon=epsilon, in_place=False, topology=topology,
+                                      shards=shards, nodata=nd)
         work[...] = filled
     else:
-        _api.FillDepressions(work, in_place=True, topology=topology, shards=shards)
+        _api.FillDepressions(work, epsilon=epsilon, in_place=True, topology=topology, shards=shards, nodata=nd)
     if not in_place:
         return dem
     return None

@@ -6,6 +6,10 @@
 * ref_fixtures.npz   -- the reference's OWN golden vectors, transcribed from its ArcInfo-ASCII test files
                         (tests/depressions/testdem1.{dem,all.out}, tests/flow_accum/*.{d8,out};
                         reference tests/tests.cpp:135-146, :233-271) plus its un-asserted inputs data/*.dem.
+* ref_f2.npz         -- SURVEY 8(f2): the reference's max_dep goldens (tests/depressions/testdem1.{1,2}.out,
+                        tests/tests.cpp:273-287) and outputs of the compiled reference's PriorityFloodEpsilon /
+                        PriorityFloodWatersheds / PriorityFlood_Barnes2014_max_dep on seeded DEMs WITHOUT equal
+                        elevations (with ties those three depend on std::priority_queue's pop order).
 * ref_generated.npz  -- outputs of the UNMODIFIED reference headers (oracle/_ref/libref.so) on seeded
                         inputs, for the functions the reference has no golden file for
                         (d8_flow_directions, barnes_flat_resolution_d8, FA_D8, fill on float/int DEMs).
@@ -84,5 +88,54 @@ def main():
     print("wrote", len(fx), "fixture arrays and", len(gen), "generated arrays")
 
 
+def tie_free(dem, nodata=-9999.0):
+    """the same DEM with every repeated data value nudged up by single representable steps until all differ"""
+    out = dem.copy()
+    for _ in range(64):
+        flat = out.ravel()
+        data = np.flatnonzero(flat != nodata)
+        _, first = np.unique(flat[data], return_index=True)
+        dup = np.setdiff1d(np.arange(data.size), first)
+        if dup.size == 0:
+            return out
+        flat[data[dup]] = np.nextafter(flat[data[dup]], np.inf, dtype=flat.dtype)
+    raise AssertionError("could not make the DEM tie free")
+
+
+def f2():
+    oracle.build()
+    R = oracle.ref
+    g = {}
+    for k in (1, 2):
+        out, _ = oracle.read_ascii_grid(f"{REF}/tests/depressions/testdem1.{k}.out", np.int32)
+        g[f"max_dep/testdem1/{k}"] = out
+    rng = np.random.default_rng(2)
+    cases = {"frac_f32": tie_free(fractal_dem(96, 80, 21)), "tilt_f32": tie_free(fractal_dem(70, 50, 22, tilt=3.0)),
+             "rand_f32": (rng.random((60, 75)) * 50).astype(np.float32),
+             "ulps_f32": (np.float32(100.0).view(np.uint32) + rng.permutation(2 * 57 * 49)[: 57 * 49].astype(np.uint32)).view(np.float32).reshape(57, 49),
+             "rand_f64": rng.random((50, 64)) * 1000}
+    edge = fractal_dem(80, 60, 23).copy()
+    edge[:12, :30] = -9999.0     # NoData region touching the raster border
+    edge[:, -2:] = -9999.0
+    cases["nodata_border_f32"] = tie_free(edge)
+    for name, dem in cases.items():
+        data = dem[dem != -9999.0]
+        assert np.unique(data).size == data.size, name
+        g[f"{name}/dem"] = dem
+        for topo in (8, 4):
+            g[f"{name}/epsilon_d{topo}"] = R.fill_epsilon(dem, -9999.0, topo)
+            lab, filled = R.watersheds(dem, -9999.0, topo, True)
+            g[f"{name}/watersheds_d{topo}"] = lab
+            assert np.array_equal(filled, R.fill(dem, topo))
+            for md in (0, 3, 40, 100000):
+                g[f"{name}/max_dep{md}_d{topo}"] = R.fill_max_dep(dem, md, topo)
+    np.savez_compressed(os.path.join(HERE, "ref_f2.npz"), **g)
+    print("wrote", len(g), "f2 arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--f2" in sys.argv:
+        f2()
+    else:
+        main()
+        f2()

@@ -3,6 +3,8 @@
   (2) outputs of the unmodified reference headers on seeded inputs (tests/golden/ref_generated.npz),
   (3) oracle/_ref/libref.so live, where it is present (this container; travels prebuilt to the GPU box).
 CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -119,3 +121,34 @@ def test_config0_beauford_shaped_dem(orc):
     frac = float((exp != z).mean())
     assert 0.05 < frac < 0.9 and (exp >= z).all()
     assert np.array_equal(exp[0], z[0]) and np.array_equal(exp[:, -1], z[:, -1])
+
+
+# ---- PriorityFloodEpsilon / PriorityFloodWatersheds / PriorityFlood_Barnes2014_max_dep -----------------
+@pytest.fixture(scope="module")
+def f2():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_f2.npz"))
+
+
+def test_max_dep_reference_goldens(orc, fixtures, f2):
+    """tests/tests.cpp:273-287: PriorityFlood_Barnes2014_max_dep<D8>(testdem1, 1) == testdem1.1.out, (.., 2) == .2.out"""
+    dem = fixtures["fill/testdem1/dem"]
+    for k in (1, 2):
+        assert np.array_equal(orc.port.fill_max_dep(dem, k, 8), f2[f"max_dep/testdem1/{k}"]), k
+        if orc.ref.available:
+            assert np.array_equal(orc.ref.fill_max_dep(dem, k, 8), f2[f"max_dep/testdem1/{k}"]), k
+
+
+def test_f2_restatements_equal_the_compiled_reference_outputs(orc, f2):
+    """The committed outputs of the compiled reference on DEMs without equal elevations (tests/golden/make_golden.py
+    --f2): with ties these three functions depend on std::priority_queue's pop order, without them they do not."""
+    names = sorted({k.split("/")[0] for k in f2.files if not k.startswith("max_dep/")})
+    assert len(names) >= 6
+    for name in names:
+        dem = f2[f"{name}/dem"]
+        for topo in (8, 4):
+            assert np.array_equal(orc.port.fill_epsilon(dem, -9999.0, topo), f2[f"{name}/epsilon_d{topo}"]), (name, topo)
+            lab, filled = orc.port.watersheds(dem, -9999.0, topo, True)
+            assert np.array_equal(lab, f2[f"{name}/watersheds_d{topo}"]), (name, topo)
+            assert np.array_equal(filled, orc.port.fill(dem, topo))
+            for md in (0, 3, 40, 100000):
+                assert np.array_equal(orc.port.fill_max_dep(dem, md, topo), f2[f"{name}/max_dep{md}_d{topo}"]), (name, topo, md)

@@ -122,12 +122,13 @@ def test_array3d(R):
 
 def test_out_of_scope_functions_raise(R):
     dem = R.Array2D_float(np.zeros((4, 4), np.float32))
-    for name in ("rdPFepsilonD8", "rdPFepsilonD4", "rdBreachDepressionsD8", "TA_slope_degrees", "FA_Rho8", "FM_Rho4",
-                 "generate_perlin_terrain"):
+    for name in ("rdBreachDepressionsD8", "TA_slope_degrees", "FA_Rho8", "FM_Rho4", "generate_perlin_terrain"):
         with pytest.raises(RuntimeError, match="outside the scope"):
             getattr(R, name)(dem)
     with pytest.raises(RuntimeError, match="outside the scope"):
         R.depression_hierarchy.get_depression_hierarchy(dem, dem)
+    with pytest.raises(RuntimeError, match="only available for floating-point"):   # Barnes2014.hpp:424-451
+        R.rdPFepsilonD8(R.Array2D_int32_t(np.zeros((3, 3), np.int32)))
     with pytest.raises(RuntimeError, match="element type not supported"):   # bound for every type, as in the reference
         R.rdFillDepressionsD8(R.Array2D_int8_t(np.zeros((3, 3), np.int8)))
     with pytest.raises(RuntimeError, match="same dimensions"):              # flow_accumulation_generic.hpp:42-43
@@ -157,7 +158,8 @@ def test_the_reference_package_runs_on_it():
         reached = 0
         for fn, kw in ((rd.FillDepressions, {{}}), (rd.FlowAccumulation, {{"method": "D8"}}),
                        (rd.FlowAccumulation, {{"method": "Holmgren", "exponent": 2.0}}),
-                       (rd.FlowProportions, {{"method": "Quinn"}}), (rd.ResolveFlats, {{}})):
+                       (rd.FlowProportions, {{"method": "Quinn"}}), (rd.ResolveFlats, {{}}),
+                       (rd.FillDepressions, {{"epsilon": True}})):
             try:
                 out = fn(dem, **kw)
                 assert out.shape[:2] == dem.shape
@@ -165,8 +167,8 @@ def test_the_reference_package_runs_on_it():
             except RuntimeError as e:
                 assert "hip" in str(e).lower() or "rocm" in str(e).lower(), e
                 reached += 1
-        assert reached == 5
-        for fn, kw in ((rd.FillDepressions, {{"epsilon": True}}), (rd.BreachDepressions, {{}}),
+        assert reached == 6
+        for fn, kw in ((rd.BreachDepressions, {{}}),
                        (rd.TerrainAttribute, {{"attrib": "slope_degrees"}})):
             try:
                 fn(dem, **kw)

@@ -28,8 +28,8 @@ def test_argument_errors_without_gpu(rd):
         rd.FillDepressions([[1, 2], [3, 4]])
     with pytest.raises(Exception, match="Unknown topology"):
         rd.FillDepressions(z, topology="D6")
-    with pytest.raises(rd.RdgpuError):
-        rd.FillDepressions(z, epsilon=True)
+    with pytest.raises(rd.RdgpuError, match="only available for floating-point"):    # Barnes2014.hpp:424-451
+        rd.FillDepressions(rd.rdarray(np.zeros((4, 4), np.int32), no_data=-1), epsilon=True)
     with pytest.raises(Exception, match="Invalid FlowAccumulation method"):
         rd.FlowAccumulation(z, method="Foo")
     with pytest.raises(Exception, match="Invalid FlowAccumulation method"):

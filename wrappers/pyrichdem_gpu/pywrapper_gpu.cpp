@@ -69,6 +69,11 @@ void bind_functions(py::module_ &m) {
         "Fill all depressions, D8 (PriorityFlood_Zhou2016's result).");
   m.def("rdFillDepressionsD4", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Barnes2014<Topology::D4>(dem); }, release(),
         "Fill all depressions, D4 (PriorityFlood_Barnes2014<D4>'s result).");
+  // pywrapper.hpp:34-35 (floating-point element types; the others raise as the reference's specialisations do)
+  m.def("rdPFepsilonD8", [](Array2D<T> &dem) { rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D8>(dem); }, release(),
+        "Fill all depressions with epsilon.");
+  m.def("rdPFepsilonD4", [](Array2D<T> &dem) { rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D4>(dem); }, release(),
+        "Fill all depressions with epsilon.");
   m.def("rdResolveFlatsEpsilon", [](Array2D<T> &dem) { rdgpu::ResolveFlatsEpsilon(dem); }, release(),
         "Raise the cells of drainable flats by the smallest representable steps (ResolveFlatsEpsilon).");
 
@@ -219,7 +224,7 @@ PYBIND11_MODULE(_richdem, m) {
   m.def("rdHash", []() { return std::string(rdgpu_version()); }, "Version of the engine (the reference returns its git hash).");
   m.def("rdCompileTime", []() { return std::string(__DATE__ " " __TIME__); }, "Build time of this module.");
 
-  for (const char *name : {"rdPFepsilonD8", "rdPFepsilonD4", "rdBreachDepressionsD8", "rdBreachDepressionsD4", "TA_SPI", "TA_CTI",
+  for (const char *name : {"rdBreachDepressionsD8", "rdBreachDepressionsD4", "TA_SPI", "TA_CTI",
                            "TA_slope_riserun", "TA_slope_percentage", "TA_slope_degrees", "TA_slope_radians", "TA_aspect",
                            "TA_curvature", "TA_planform_curvature", "TA_profile_curvature", "FA_FairfieldLeymarieD8",
                            "FA_FairfieldLeymarieD4", "FA_Rho8", "FA_Rho4", "FM_FairfieldLeymarieD8", "FM_FairfieldLeymarieD4",
