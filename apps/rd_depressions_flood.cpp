@@ -1,24 +1,37 @@
 // rd_depressions_flood on the GPU engine, native raster files instead of GDAL ones.
-// Mirrors reference apps/rd_depressions_flood.cpp:11-23 (PerformAlgorithm: PriorityFlood_Zhou2016 when no maximum
-// depression size is given); the bounded-depth variant (_max_dep) is order dependent and not provided.
+// Mirrors reference apps/rd_depressions_flood.cpp:11-23 (PerformAlgorithm: PriorityFlood_Zhou2016 when the maximum
+// depression size is 0, PriorityFlood_Barnes2014_max_dep<D8> otherwise) and its usage text (:31-38).
 #include "common.hpp"
+
+#include <cstdlib>
 
 template <class T>
 struct Flood {
-  static int run(const std::string &in, const std::string &out) {
+  static int run(const std::string &in, const std::string &out, uint32_t max_dep_size) {
     apps::Array2D<T> elevation(in, true);
-    rdgpu::PriorityFlood_Zhou2016(elevation);
+    if (max_dep_size == 0) rdgpu::PriorityFlood_Zhou2016(elevation);
+    else rdgpu::PriorityFlood_Barnes2014_max_dep<apps::Topology::D8>(elevation, max_dep_size);
     elevation.saveToCache(out);
     return 0;
   }
 };
 
 static int body(int argc, char **argv) {
-  if (argc < 3 || argc > 4) {
-    std::cerr << "Fill all depressions" << std::endl;
-    std::cerr << argv[0] << " <Input native raster> <Output native raster> [element type: f32]" << std::endl;
+  if (argc < 3 || argc > 5) {
+    std::cerr << "Eliminate all depressions via flooding." << std::endl;
+    std::cerr << argv[0] << " <Input native raster> <Output native raster> [<Maximum Depression Size> = 0] [element type = f32]" << std::endl;
+    std::cerr << "\t<Maximum Depression Size> - Depressions larger than this are not flooded." << std::endl;
+    std::cerr << "                              Use `0` to flood all depressions.            " << std::endl;
     return -1;
   }
-  return apps::route<Flood>(argc == 4 ? argv[3] : "f32", std::string(argv[1]), std::string(argv[2]));
+  // (round 1 took the element type as the third argument: still accepted)
+  std::string type = "f32";
+  uint32_t max_dep_size = 0;
+  for (int i = 3; i < argc; i++) {
+    const std::string a = argv[i];
+    if (!a.empty() && a.find_first_not_of("0123456789") == std::string::npos) max_dep_size = (uint32_t)std::stoul(a);
+    else type = a;
+  }
+  return apps::route<Flood>(type, std::string(argv[1]), std::string(argv[2]), max_dep_size);
 }
 int main(int argc, char **argv) { return apps::guarded_main(body, argc, argv); }

@@ -70,6 +70,24 @@ int rdgpu_fill_dev_f64(double *d_dem, int width, int height, int topology, void 
 int rdgpu_fill_dev_i64(int64_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, void *hip_stream);
 
+/* PriorityFlood_Barnes2014_max_dep<topology>(Array2D<T>&, uint64_t max_dep_size) (depressions/Barnes2014.hpp:844-931;
+ * apps/rd_depressions_flood.cpp:16-19 with a non-zero third argument): only depressions of at most max_dep_size
+ * cells are filled, the others are left as they are.  "Depression" as the reference counts it: the cells below the
+ * level L that one cell of elevation L floods in one run of its pit queue.  Identical to the reference on DEMs without
+ * equal elevations and on the reference's goldens (tests/depressions/testdem1.{1,2}.out); when several cells of
+ * elevation L touch the same pocket the reference's grouping follows std::priority_queue's pop order, this one the
+ * lowest cell index. */
+#define RDGPU_DECL_MAXDEP(SUF, T)                                                                       \
+  int rdgpu_fill_max_dep_##SUF(T *dem, int width, int height, int topology, uint64_t max_dep_size);     \
+  int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int width, int height, int topology, uint64_t max_dep_size, void *hip_stream);
+RDGPU_DECL_MAXDEP(u8, uint8_t)
+RDGPU_DECL_MAXDEP(i16, int16_t)
+RDGPU_DECL_MAXDEP(u16, uint16_t)
+RDGPU_DECL_MAXDEP(i32, int32_t)
+RDGPU_DECL_MAXDEP(u32, uint32_t)
+RDGPU_DECL_MAXDEP(f32, float)
+#undef RDGPU_DECL_MAXDEP
+
 /* pit_mask<topology>(const Array2D<T>&, Array2D<uint8_t>&) (depressions/Barnes2014.hpp:593-676,
  * apps/rd_depressions_mask.cpp:16): 1 = the cell lies in a depression (the fill would raise it), 0 = not,
  * 3 = NoData.  The DEM is not modified. */

@@ -106,6 +106,18 @@ RDGPU_SHIM_PITMASK(f32, float)
 template <class T>
 int c_pitmask(const T *, T, int, int, int, uint8_t *) { unsupported("pit_mask"); }
 
+#define RDGPU_SHIM_MAXDEP(SUF, T) \
+  inline int c_fill_maxdep(T *p, int w, int h, int t, uint64_t m) { return rdgpu_fill_max_dep_##SUF(p, w, h, t, m); }
+RDGPU_SHIM_MAXDEP(u8, uint8_t)
+RDGPU_SHIM_MAXDEP(i16, int16_t)
+RDGPU_SHIM_MAXDEP(u16, uint16_t)
+RDGPU_SHIM_MAXDEP(i32, int32_t)
+RDGPU_SHIM_MAXDEP(u32, uint32_t)
+RDGPU_SHIM_MAXDEP(f32, float)
+#undef RDGPU_SHIM_MAXDEP
+template <class T>
+int c_fill_maxdep(T *, int, int, int, uint64_t) { unsupported("PriorityFlood_Barnes2014_max_dep"); }
+
 inline int c_fill_eps(float *p, float nd, int w, int h, int t) { return rdgpu_fill_epsilon_f32(p, nd, w, h, t); }
 inline int c_fill_eps(double *p, double nd, int w, int h, int t) { return rdgpu_fill_epsilon_f64(p, nd, w, h, t); }
 template <class T>
@@ -152,6 +164,16 @@ void PriorityFlood_Barnes2014(A &dem) {
 template <auto topo, class A>
 void FillDepressions(A &dem) {
   detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()), "FillDepressions");
+}
+
+// richdem::PriorityFlood_Barnes2014_max_dep<topo>(Array2D<T>&, uint64_t max_dep_size)   depressions/Barnes2014.hpp:844-931
+// (apps/rd_depressions_flood.cpp:16-19): only depressions of at most max_dep_size cells are filled
+template <auto topo, class A>
+void PriorityFlood_Barnes2014_max_dep(A &dem, uint64_t max_dep_size) {
+  using T = detail::elem_t<A>;
+  if (dem.width() == 0 || dem.height() == 0) return;
+  detail::check(detail::c_fill_maxdep((T *)dem.data(), dem.width(), dem.height(), detail::topology_code<topo>(), max_dep_size),
+                "PriorityFlood_Barnes2014_max_dep");
 }
 
 // richdem::PriorityFloodEpsilon_Barnes2014<topo>(Array2D<T>&)   depressions/Barnes2014.hpp:335-420; integer element

@@ -97,6 +97,27 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     return None if in_place else out
 
 
+def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bool = False):
+    """PriorityFlood_Barnes2014_max_dep<topo> (depressions/Barnes2014.hpp:844-931; rd_depressions_flood's third
+    argument): only depressions of at most ``max_dep_size`` cells are filled."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("fill_max_dep: expected a 2-D numpy array")
+    out = dem if in_place else dem.copy()
+    if not out.flags["C_CONTIGUOUS"]:
+        if in_place:
+            raise RdgpuError("fill_max_dep(in_place=True) needs a C-contiguous array")
+        out = np.ascontiguousarray(out)
+    s = _suffix(out.dtype)
+    if s in ("f64", "i64", "u64"):
+        raise RdgpuError("fill_max_dep: 64-bit element types are not provided")
+    if int(max_dep_size) < 0:
+        raise RdgpuError("fill_max_dep: max_dep_size must not be negative")
+    h, w = out.shape
+    check(getattr(lib(), f"rdgpu_fill_max_dep_{s}")(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology),
+                                                    ctypes.c_uint64(int(max_dep_size))), "rdgpu_fill_max_dep")
+    return None if in_place else out
+
+
 def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
     """uint8 mask of the cells lying in depressions: 1 = the fill would raise the cell, 0 = not, 3 = NoData
     (reference pit_mask<topo>, depressions/Barnes2014.hpp:593-676; apps/rd_depressions_mask.cpp)."""

@@ -1562,6 +1562,197 @@ static void pit_mask_host(const T *dem, T nodata, int w, int h, int topology, ui
   RD_HIP(hipMemcpy(mask, dm, n, hipMemcpyDeviceToHost));
 }
 
+// ------------------------------------------------------------------------------------------
+// PriorityFlood_Barnes2014_max_dep<topo>(elevations, max_dep_size) (reference depressions/Barnes2014.hpp:844-931;
+// apps/rd_depressions_flood.cpp:16-19 with a non-zero third argument; goldens tests/depressions/testdem1.{1,2}.out,
+// tests/tests.cpp:273-287): the same flood, but a depression is only raised when it has at most max_dep_size cells.
+//
+// What the reference counts as ONE depression is one run of its pit queue (:893-906): the cell c popped from the heap
+// (level L = z(c)) floods every not yet visited cell BELOW L that it can reach through such cells (:918-921), and the
+// run's cells are raised to L together, or not at all, when the next cell is popped from the heap.  In terms of the
+// plain fill W: the run consists of raised cells (z < W = L); adjacent raised cells always have the same W, so the
+// connected components of the raised cells ("pockets") are what can be flooded, each by the FIRST popped cell of
+// elevation exactly L next to it, and a run = the pockets that share that cell.
+//   * pockets: the raised cells of one basin of the descent forest are connected (every raised cell descends to the pit
+//     through lower, hence raised, cells of its basin), so pockets are unions of basins -- a union-find over basins,
+//     united wherever two raised cells of different basins touch (k_md_pockets; it also counts the raised cells per
+//     basin, one atomic per run of equal labels in a wavefront row).
+//   * spawner: the lowest cell index among the un-raised cells of elevation L next to the pocket (k_md_spawn).  When a
+//     DEM has no two cells of equal elevation there is exactly one candidate; with ties the reference takes whichever
+//     std::priority_queue pops first, which this rule cannot promise to reproduce.
+//   * runs: every spawner unites the pockets it spawns (k_md_runs), sizes are summed per run, cells of runs with at
+//     most max_dep_size cells are raised (k_md_apply).
+// (The reference never applies the run started by the LAST cell popped from its heap, :891/:900 -- the loop ends first.
+// On a DEM without equal elevations that cell, the highest un-raised one, cannot have started a run: a pocket has more
+// than one rim cell and all of them would have to be the highest cell.)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t md_find(uint32_t *par, uint32_t x) {
+  uint32_t p = __hip_atomic_load(&par[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (p != x) {
+    x = p;
+    p = __hip_atomic_load(&par[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return x;
+}
+__device__ __forceinline__ void md_unite(uint32_t *par, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = md_find(par, a);
+    b = md_find(par, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }   // hook the larger root under the smaller: acyclic under any interleaving
+    const uint32_t old = atomicMin(&par[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_md_init(uint32_t *par, uint32_t *cnt, uint32_t *spawn, uint32_t *size, uint32_t B) {
+  const uint32_t b = blockIdx.x * NTHR + threadIdx.x;
+  if (b >= B) return;
+  par[b] = b; cnt[b] = 0; spawn[b] = 0xFFFFFFFFu; size[b] = 0;
+}
+
+template <class T, int TOPO>
+__global__ __launch_bounds__(NTHR) void k_md_pockets(const T *__restrict__ z, const uint32_t *__restrict__ lab,
+                                                     const uint32_t *__restrict__ acc, uint32_t *par, uint32_t *cnt, int w,
+                                                     int h, uint32_t B) {
+  // one wavefront per 64-cell row segment (grid-stride over segments)
+  const uint32_t segsX = ((uint32_t)w + 63u) / 64u;
+  const uint64_t nseg = (uint64_t)segsX * (uint64_t)h;
+  const int lane = threadIdx.x & 63;
+  for (uint64_t sgi = (uint64_t)blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6); sgi < nseg; sgi += (uint64_t)gridDim.x * (NTHR / 64)) {
+    const int y = (int)(sgi / segsX), x = (int)(sgi % segsX) * 64 + lane;
+    const bool in = x < w;
+    const size_t c = (size_t)y * w + (in ? x : 0);
+    const uint32_t b = in ? lab[c] : B;
+    const bool raised = in && b != B && acc[b] > Key32<T>::to(z[c]);
+    if (raised) {
+      // forward neighbours: every adjacent pair of raised cells is looked at once
+      const int nx[4] = {1, 1, 0, -1}, ny[4] = {0, 1, 1, 1};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (TOPO == 4 && (k == 1 || k == 3)) continue;
+        const int xx = x + nx[k], yy = y + ny[k];
+        if (xx < 0 || xx >= w || yy >= h) continue;
+        const size_t q = (size_t)yy * w + xx;
+        const uint32_t bq = lab[q];
+        if (bq == b || bq == B) continue;
+        if (acc[bq] > Key32<T>::to(z[q])) md_unite(par, b, bq);
+      }
+    }
+    // raised cells per basin: one atomic per run of equal labels along the row segment
+    const uint32_t key = raised ? b : 0xFFFFFFFFu;
+    const uint32_t left = __shfl_up(key, 1, 64);
+    const bool head = raised && (lane == 0 || left != key);
+    const unsigned long long heads = __ballot(head), rs = __ballot(raised);
+    if (head) {
+      const unsigned long long above = lane < 63 ? (heads >> (lane + 1)) : 0ull;
+      const int next = above ? lane + __ffsll((long long)above) : 64;   // next run head (of any label)
+      // the run ends at the next head or at the first un-raised lane
+      const unsigned long long notr = lane < 63 ? ((~rs) >> (lane + 1)) : 0ull;
+      const int stop = notr ? lane + __ffsll((long long)notr) : 64;
+      const int end = next < stop ? next : stop;
+      atomicAdd(&cnt[b], (uint32_t)(end - lane));
+    }
+  }
+}
+
+template <class T, int TOPO, int PASS>
+__global__ __launch_bounds__(NTHR) void k_md_spawn(const T *__restrict__ z, const uint32_t *__restrict__ lab,
+                                                   const uint32_t *__restrict__ acc, uint32_t *par, uint32_t *spawn, int w,
+                                                   int h, uint32_t B) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const uint32_t b = lab[c];
+    const uint32_t kz = Key32<T>::to(z[c]);
+    if (b != B && acc[b] > kz) continue;   // raised cells are flooded, they do not flood
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (TOPO == 4 && (k & 1)) continue;
+      const int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+      const int xx = x + dx[k], yy = y + dy[k];
+      if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+      const size_t q = (size_t)yy * w + xx;
+      const uint32_t bq = lab[q];
+      if (bq == B) continue;
+      const uint32_t L = acc[bq];
+      if (L != kz || !(L > Key32<T>::to(z[q]))) continue;   // a raised neighbour filled to exactly this cell's elevation
+      const uint32_t r = md_find(par, bq);
+      if (PASS == 0) {
+        if ((uint32_t)c < __hip_atomic_load(&spawn[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&spawn[r], (uint32_t)c);
+      } else if (__hip_atomic_load(&spawn[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)c) {
+        if (first == 0xFFFFFFFFu) first = r;
+        else md_unite(par, first, r);        // the pockets this cell floods are one run
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_md_sizes(uint32_t *par, const uint32_t *__restrict__ cnt, uint32_t *size, uint32_t B) {
+  const uint32_t b = blockIdx.x * NTHR + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t c = cnt[b];
+  if (c) atomicAdd(&size[md_find(par, b)], c);
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_md_apply(T *z, const uint32_t *__restrict__ lab, const uint32_t *__restrict__ acc,
+                                                   uint32_t *par, const uint32_t *__restrict__ size, uint64_t n, uint32_t B,
+                                                   uint64_t max_dep) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const uint32_t b = lab[c];
+    if (b == B) continue;
+    const uint32_t L = acc[b];
+    if (!(L > Key32<T>::to(z[c]))) continue;
+    if ((uint64_t)size[md_find(par, b)] <= max_dep) z[c] = Key32<T>::from(L);
+  }
+}
+
+template <class T, int TOPO>
+static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStream_t s) {
+  FillBuffers fb;
+  BufAlloc ws_alloc{false, nullptr};
+  fill_local_phase<T, TOPO>(d_z, w, h, 0, 0, ws_alloc, fb, s);
+  if (fb.trivial) return;
+  const uint64_t n = (uint64_t)w * h;
+  const uint32_t B = fb.B;
+  Workspace &ws = Workspace::get();
+  uint32_t *par = ws.buf<uint32_t>("maxdep.par", B), *cnt = ws.buf<uint32_t>("maxdep.cnt", B);
+  uint32_t *spawn = ws.buf<uint32_t>("maxdep.spawn", B), *size = ws.buf<uint32_t>("maxdep.size", B);
+  const uint32_t bgrid = cdiv(B, NTHR), sgrid = (uint32_t)std::min<uint64_t>((n + NTHR - 1) / NTHR, 256u * 32u);
+  RD_LAUNCH("maxdep.init", k_md_init, dim3(bgrid), dim3(NTHR), 0, s, par, cnt, spawn, size, B);
+  RD_LAUNCH("maxdep.pockets", (k_md_pockets<T, TOPO>), dim3(256u * 16u), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
+            (const uint32_t *)fb.acc, par, cnt, w, h, B);
+  RD_LAUNCH("maxdep.spawn", (k_md_spawn<T, TOPO, 0>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
+            (const uint32_t *)fb.acc, par, spawn, w, h, B);
+  RD_LAUNCH("maxdep.runs", (k_md_spawn<T, TOPO, 1>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
+            (const uint32_t *)fb.acc, par, spawn, w, h, B);
+  RD_LAUNCH("maxdep.sizes", k_md_sizes, dim3(bgrid), dim3(NTHR), 0, s, par, (const uint32_t *)cnt, size, B);
+  RD_LAUNCH("maxdep.apply", (k_md_apply<T>), dim3(sgrid), dim3(NTHR), 0, s, d_z, (const uint32_t *)fb.lab, (const uint32_t *)fb.acc,
+            par, (const uint32_t *)size, n, B, max_dep);
+}
+
+template <class T>
+static void fill_max_dep_device(T *d_z, int w, int h, int topology, uint64_t max_dep, hipStream_t s) {
+  check_fill_args(d_z, w, h, topology);
+  if (topology == 8) fill_max_dep_device_t<T, 8>(d_z, w, h, max_dep, s);
+  else fill_max_dep_device_t<T, 4>(d_z, w, h, max_dep, s);
+}
+
+template <class T>
+static void fill_max_dep_host(T *dem, int w, int h, int topology, uint64_t max_dep) {
+  check_fill_args(dem, w, h, topology);
+  const size_t bytes = (size_t)w * h * sizeof(T);
+  T *d = Workspace::get().buf<T>("host.dem", (size_t)w * h);
+  RD_HIP(hipMemcpy(d, dem, bytes, hipMemcpyHostToDevice));
+  fill_max_dep_device<T>(d, w, h, topology, max_dep, nullptr);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  RD_HIP(hipMemcpy(dem, d, bytes, hipMemcpyDeviceToHost));
+}
+
 template <class T>
 static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
   check_fill_args(d_z, w, h, topology);
@@ -1909,6 +2100,12 @@ using namespace rdgpu;
   }                                                                                               \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
     return guarded([&] { fill_device<T>(d_dem, w, h, topology, (hipStream_t)stream); });          \
+  }                                                                                               \
+  extern "C" int rdgpu_fill_max_dep_##SUF(T *dem, int w, int h, int topology, uint64_t max_dep_size) { \
+    return guarded([&] { fill_max_dep_host<T>(dem, w, h, topology, max_dep_size); });             \
+  }                                                                                               \
+  extern "C" int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int w, int h, int topology, uint64_t max_dep_size, void *stream) { \
+    return guarded([&] { fill_max_dep_device<T>(d_dem, w, h, topology, max_dep_size, (hipStream_t)stream); }); \
   }                                                                                               \
   extern "C" int rdgpu_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topology, uint8_t *mask) { \
     return guarded([&] { pit_mask_host<T>(dem, nodata, w, h, topology, mask); });                 \

@@ -1,0 +1,91 @@
+"""PriorityFlood_Barnes2014_max_dep<topo> (depressions/Barnes2014.hpp:844-931) on the GPU, through the C-ABI: the
+reference's own goldens (tests/depressions/testdem1.{1,2}.out, tests/tests.cpp:273-287), the committed outputs of the
+compiled reference on tie-free DEMs, and random DEMs against the C restatement."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def f2():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_f2.npz"))
+
+
+def test_max_dep_reference_goldens(rd, fixtures, f2):
+    dem = fixtures["fill/testdem1/dem"]
+    for k in (1, 2):
+        assert rd.fill_max_dep(dem, k).tobytes() == f2[f"max_dep/testdem1/{k}"].tobytes(), k
+    assert rd.fill_max_dep(dem, 10 ** 9).tobytes() == fixtures["fill/testdem1/all_out"].tobytes()
+    assert rd.fill_max_dep(dem, 0).tobytes() == dem.tobytes()
+
+
+def test_max_dep_equals_compiled_reference_outputs(rd, f2):
+    names = sorted({k.split("/")[0] for k in f2.files if not k.startswith("max_dep/") and not k.endswith("f64/dem")})
+    for name in names:
+        dem = f2[f"{name}/dem"]
+        if dem.dtype != np.float32:
+            continue
+        for topo, nm in ((8, "D8"), (4, "D4")):
+            for md in (0, 3, 40, 100000):
+                got = rd.fill_max_dep(dem, md, nm)
+                assert np.array_equal(got, f2[f"{name}/max_dep{md}_d{topo}"]), (name, topo, md)
+
+
+def test_max_dep_random_tie_free(rd, orc):
+    rng = np.random.default_rng(13)
+    for i in range(30):
+        h, w = (int(v) for v in rng.integers(3, 140, 2))
+        z = (rng.random((h, w)) * 100).astype(np.float32)
+        if np.unique(z).size != z.size:
+            continue
+        for topo, nm in ((8, "D8"), (4, "D4")):
+            for md in (1, 2, 7, 30, 500):
+                assert np.array_equal(rd.fill_max_dep(z, md, nm), orc.port.fill_max_dep(z, md, topo)), (i, topo, md)
+
+
+def test_max_dep_integer_dems(rd, orc):
+    """Integer DEMs are full of equal elevations, and then which cell of elevation L floods a pocket -- hence how pockets
+    group into depressions and which groups pass the size test -- follows the pop order of the reference's heap: on
+    these noisy DEMs the C restatement itself (same algorithm, its own heap) differs from the compiled reference in
+    about half of the cases.  What holds whatever the order: every cell is either left alone or raised to the plain
+    fill's level, a raised cell's whole pocket is raised with it, and the two limits (0: nothing, huge: the plain fill)
+    are exact.  Mismatching cases are counted and printed, not hidden."""
+    rng = np.random.default_rng(17)
+    differ = total = 0
+    for i in range(40):
+        h, w = (int(v) for v in rng.integers(4, 80, 2))
+        z = rng.integers(0, 5 + i, (h, w)).astype(np.int32)
+        W = orc.port.fill(z, 8)
+        for md in (1, 3, 10):
+            got = rd.fill_max_dep(z, md)
+            exp = orc.port.fill_max_dep(z, md, 8)
+            assert ((got == z) | (got == W)).all()
+            # all-or-nothing per pocket: two adjacent cells that the plain fill raises are either both raised or both left
+            r = W > z
+            up = got > z
+            assert not (r[:, 1:] & r[:, :-1] & (up[:, 1:] != up[:, :-1])).any()
+            assert not (r[1:, :] & r[:-1, :] & (up[1:, :] != up[:-1, :])).any()
+            assert not (r[1:, 1:] & r[:-1, :-1] & (up[1:, 1:] != up[:-1, :-1])).any()
+            assert not (r[1:, :-1] & r[:-1, 1:] & (up[1:, :-1] != up[:-1, 1:])).any()
+            total += 1
+            differ += not np.array_equal(got, exp)
+        assert np.array_equal(rd.fill_max_dep(z, 0), z) and np.array_equal(rd.fill_max_dep(z, 10 ** 8), W)
+    print(f"max_dep integer DEMs: {differ} of {total} cases differ from the C restatement (ties)")
+
+
+def test_max_dep_sizes_and_types(rd, orc):
+    from richdem_amd.synth import fractal_dem
+
+    z = fractal_dem(700, 500, seed=5)
+    zz = z + (np.arange(z.size, dtype=np.float32).reshape(z.shape) * np.float32(1e-3))   # spread the ties of the generator
+    if np.unique(zz).size == zz.size:
+        for md in (5, 200, 5000):
+            assert np.array_equal(rd.fill_max_dep(zz, md), orc.port.fill_max_dep(zz, md, 8)), md
+    for dt in (np.uint8, np.int16, np.uint16, np.uint32):
+        q = (rng_dem := np.random.default_rng(3).integers(0, 200, (40, 50))).astype(dt)
+        assert np.array_equal(rd.fill_max_dep(q, 10 ** 7), orc.port.fill(q, 8))
+    with pytest.raises(rd.RdgpuError):
+        rd.fill_max_dep(z.astype(np.float64), 3)
