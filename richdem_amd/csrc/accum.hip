@@ -18,6 +18,7 @@
 #include "flowdirs.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace rdgpu {
@@ -45,6 +46,31 @@ __device__ __forceinline__ int64_t flow_target(uint32_t c, int n, int w, int h) 
   const int x = (int)(c % (uint32_t)w) + d8dx(n), y = (int)(c / (uint32_t)w) + d8dy(n);
   if (x < 0 || y < 0 || x >= w || y >= h) return -1;
   return (int64_t)y * w + x;
+}
+
+// Stage a (T+2) x (T+2) window of the direction raster in LDS: every load of the thread is issued before the first one is
+// consumed (load -> store -> load -> ... paid one memory round trip per loop trip, seventeen in a row: it was most of
+// the time of every tile kernel in this file).  Cells outside the raster read as `fill`.
+template <int LW_, int NT_>
+__device__ __forceinline__ void stage_dirs(const uint8_t *__restrict__ dirs, int w, int h, int x0, int y0, uint8_t fill,
+                                           uint8_t *sd) {
+  constexpr int N = LW_ * LW_, IPT = (N + NT_ - 1) / NT_;
+  uint8_t v[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {
+    const int i = min((int)threadIdx.x + r * NT_, N - 1);
+    const int ly = i / LW_, lx = i - ly * LW_;
+    const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);   // clamped: branch-free loads
+    v[r] = dirs[(size_t)gy * w + gx];
+  }
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {
+    const int i = (int)threadIdx.x + r * NT_;
+    if (i >= N) continue;
+    const int ly = i / LW_, lx = i - ly * LW_;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? v[r] : fill;
+  }
 }
 
 // ---- unit weights ---------------------------------------------------------------------------
@@ -111,11 +137,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk(const uint8_t *__rest
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
-  for (int i = threadIdx.x; i < ALH * ALW; i += NTHR) {
-    const int ly = i / ALW, lx = i - ly * ALW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : nodata;
-  }
+  stage_dirs<ALW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
   __syncthreads();
   const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
   // pending inflows (from anywhere) + own area
@@ -141,28 +163,38 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk(const uint8_t *__rest
     if (x0 + lx < w && y0 + ly < h && sd[(ly + 1) * ALW + lx + 1] != nodata && (lw[ly * AW + lx] >> 24) == 0) srcmask |= 1u << j;
   }
   __syncthreads();
-  for (uint32_t m = srcmask; m; m &= m - 1) {
-    const int j = __ffs((int)m) - 1;
-    int cx = lx, cy = ly0 + 4 * j;
-    uint32_t v = 1;
+  {
+    // a lane whose walk has ended takes its next source in the same trip (see k_acc_link_tile)
+    uint32_t m = srcmask, v = 0;
+    bool active = false;
+    int cx = 0, cy = 0;
     for (;;) {
-      const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
-      bool stalled = false;
-      if (d >= 1 && d <= 8) {
-        const int tx = cx + d8dx(d), ty = cy + d8dy(d);
-        const uint8_t dt = sd[(ty + 1) * ALW + tx + 1];      // nodata for cells outside the raster
-        if (dt != nodata) {                                    // else: off the DEM / into NoData: dropped
-          if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
-            // target is strictly inside the tile: all its donors are in this tile -> LDS state is complete
-            const uint32_t old = atomicAdd(&lw[ty * AW + tx], v - LCNT1);
-            if ((old >> 24) == 1) { v = (old & LMASK) + v; cx = tx; cy = ty; continue; }
-          } else {
-            stalled = true;                                    // ring cell or another tile: continue raster-wide
+      if (!active && m) {
+        cx = lx; cy = ly0 + 4 * (__ffs((int)m) - 1);
+        m &= m - 1;
+        v = 1;
+        active = true;
+      }
+      if (!__any(active || m != 0)) break;
+      if (active) {
+        const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
+        bool stalled = false, cont = false;
+        if (d >= 1 && d <= 8) {
+          const int tx = cx + d8dx(d), ty = cy + d8dy(d);
+          const uint8_t dt = sd[(ty + 1) * ALW + tx + 1];      // nodata for cells outside the raster
+          if (dt != nodata) {                                    // else: off the DEM / into NoData: dropped
+            if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
+              // target is strictly inside the tile: all its donors are in this tile -> LDS state is complete
+              const uint32_t old = atomicAdd(&lw[ty * AW + tx], v - LCNT1);
+              if ((old >> 24) == 1) { v = (old & LMASK) + v; cx = tx; cy = ty; cont = true; }
+            } else {
+              stalled = true;                                    // ring cell or another tile: continue raster-wide
+            }
           }
         }
+        if (stalled) lw[cy * AW + cx] = (LSRC << 24) | v;        // completed, still has to pass its total on
+        active = cont;
       }
-      if (stalled) lw[cy * AW + cx] = (LSRC << 24) | v;        // completed, still has to pass its total on
-      break;
     }
   }
   __syncthreads();
@@ -200,6 +232,339 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
   }
 }
 
+// ---- unit weights through tile links -------------------------------------------------------------------------
+// The raster-wide walk above is bound by its critical path: one lane walks each long river cell by cell, one memory
+// round trip per cell (55 ms of the 77 at S3, whose resolved lakes have flow paths of tens of thousands of cells).
+// The reference's tiled program (programs/parallel_d8_accum/main.cpp: per-tile accumulation :373-464, perimeter links
+// FollowPath :270-334, inflow added along the in-tile path FollowPathAdd :344-370; Barnes 2017) shows the way out, here
+// at the granularity of 64 x 64 LDS tiles:
+//   1. k_acc_link_tile   every tile on its own: accumulation of the flow that STAYS inside the tile (last-arriver walk
+//                        in LDS over all of its cells, donors outside the tile ignored) and, by pointer jumping in LDS,
+//                        the cell through which every border cell's path leaves the tile.  Only the tile's 252 border
+//                        cells are written: the local total of each EXIT cell (a cell whose direction leaves the tile)
+//                        and each border cell's exit.
+//   2. the exits form a forest of their own: exit q hands its total to the exit that q's target cell (a border cell of
+//                        the neighbouring tile) leaves ITS tile through.  k_acc_link_edges builds those links and their
+//                        in-degrees, k_acc_link_walk accumulates along them (the same last-arriver walk; its critical
+//                        path is the number of TILES a river crosses, not its cells).
+//   3. k_acc_link_final  every tile again: the inflow a border cell receives from outside is the finished total of its
+//                        outside donors; with that as extra weight the in-tile accumulation is final, written in the
+//                        requested type.
+// Direction loops keep the reference's semantics (d8_methods.hpp:104-131: a cell that never becomes free of
+// dependencies never passes anything on and keeps the inflow that did arrive, without its own 1): an exit that is not
+// complete inside its tile is blocked for good, and a border cell with an unfinished outside donor stays pending.
+constexpr int LT = 64, LLW = LT + 2;
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+constexpr uint16_t LP_TERM = 0xF000u, LP_EXIT = 0xF001u;
+constexpr unsigned long long NOT_A_NODE = 0xFEull;   // count field of a slot that is not an exit
+
+__device__ __forceinline__ int border_slot(int lx, int ly) {
+  if (ly == 0) return lx;
+  if (ly == LT - 1) return LT + lx;
+  if (lx == 0) return 2 * LT + (ly - 1);
+  if (lx == LT - 1) return 2 * LT + (LT - 2) + (ly - 1);
+  return -1;
+}
+
+// stage the tile's directions (+ ring; cells outside the raster read as NoData) and, per cell, its in-tile donors
+// and its in-tile target / LP_EXIT / LP_TERM
+__device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h, int x0, int y0,
+                                           uint8_t *sd, uint16_t *lp) {
+  stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
+  __syncthreads();
+  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
+    const uint8_t d = sd[o];
+    uint16_t p = LP_TERM;
+    if (d != nodata && d >= 1 && d <= 8) {
+      const int tx = lx + d8dx(d), ty = ly + d8dy(d);
+      if (sd[(ty + 1) * LLW + tx + 1] != nodata)   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
+        p = (tx >= 0 && tx < LT && ty >= 0 && ty < LT) ? (uint16_t)(ty * LT + tx) : LP_EXIT;
+    }
+    lp[ly * LT + lx] = p;
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_acc_link_tile(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                        uint32_t tilesX, uint32_t ntiles, unsigned long long *nw,
+                                                        uint32_t *next, uint8_t *rootslot) {
+  __shared__ uint8_t sd[LLW * LLW];
+  __shared__ uint32_t lw[LT * LT];
+  __shared__ uint16_t lp[LT * LT];
+  // one word per cell: pending in-tile donors (bits 28..31) | in-tile target, 0x1FFF for none (bits 15..27) | area;
+  // the returning add of a step also delivers the target of the cell it completed: ONE LDS round trip per step
+  constexpr uint32_t LCNT1 = 1u << 28, LMASK = 0x7FFFu, LNOTGT = 0x1FFFu;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
+  link_stage(dirs, nodata, w, h, x0, y0, sd, lp);
+  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  // pending donors are counted from the donors' side: one (non-returning) LDS add per cell into its target's word,
+  // instead of eight byte reads per cell to look who points at it (LDS instruction issue bounds these kernels)
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const uint16_t tg = lp[ly * LT + lx];
+    lw[ly * LT + lx] = sd[(ly + 1) * LLW + lx + 1] != nodata ? (((tg < LP_TERM ? (uint32_t)tg : LNOTGT) << 15) | 1u) : 0u;
+  }
+  __syncthreads();
+  for (int j = 0; j < LT / 4; j++) {
+    const uint16_t tg = lp[(ly0 + 4 * j) * LT + lx];
+    if (tg < LP_TERM) atomicAdd(&lw[tg], LCNT1);
+  }
+  __syncthreads();
+  uint32_t srcmask = 0;
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    if (sd[(ly + 1) * LLW + lx + 1] != nodata && (lw[ly * LT + lx] >> 28) == 0) srcmask |= 1u << j;
+  }
+  __syncthreads();   // the sources are fixed before any walk completes a cell
+  {
+    // last-arriver walks, confined to the tile.  A lane whose walk has ended takes its next source in the same trip
+    // (with "for every source: walk to the end" a wavefront paid the longest chain of EVERY round of sources: 84 us
+    // per tile at S3)
+    uint32_t m = srcmask, tg = LNOTGT, v = 0;
+    for (;;) {
+      if (tg == LNOTGT && m) {
+        tg = (lw[(ly0 + 4 * (__ffs((int)m) - 1)) * LT + lx] >> 15) & LNOTGT;
+        v = 1;
+        m &= m - 1;
+      }
+      if (!__any(tg != LNOTGT || m != 0)) break;
+      if (tg != LNOTGT) {
+        const uint32_t old = atomicAdd(&lw[tg], v - LCNT1);
+        if ((old >> 28) != 1) tg = LNOTGT;
+        else { v = (old & LMASK) + v; tg = (old >> 15) & LNOTGT; }
+      }
+    }
+  }
+  // the last in-tile cell of every cell's path: pointer jumping (two batches of independent LDS reads per trip);
+  // twelve doublings cover any loop-free path of a 4096-cell tile, what still points at a non-terminal then runs into a loop
+  uint16_t keep[LT / 4];
+#pragma unroll
+  for (int j = 0; j < LT / 4; j++) keep[j] = lp[(ly0 + 4 * j) * LT + lx];   // own entries before they are compressed
+  __syncthreads();
+  for (int it = 0; it < 12; it++) {
+    uint16_t pv[LT / 4], qv[LT / 4];
+#pragma unroll
+    for (int j = 0; j < LT / 4; j++) pv[j] = lp[(ly0 + 4 * j) * LT + lx];
+#pragma unroll
+    for (int j = 0; j < LT / 4; j++) qv[j] = pv[j] < LP_TERM ? lp[pv[j]] : pv[j];
+    int still = 0;
+#pragma unroll
+    for (int j = 0; j < LT / 4; j++)
+      if (pv[j] < LP_TERM && qv[j] < LP_TERM) { lp[(ly0 + 4 * j) * LT + lx] = qv[j]; still = 1; }
+    if (!__syncthreads_or(still)) break;
+  }
+  __syncthreads();
+  // what the border cells publish (252 of the tile's 256 slots; the four spare ones are marked unused)
+  if (threadIdx.x < 4) {
+    const size_t node = (size_t)t * 256 + 252 + threadIdx.x;
+    nw[node] = NOT_A_NODE << 56; next[node] = NO_NODE; rootslot[node] = 255;
+  }
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int slot = border_slot(lx, ly);
+    if (slot < 0) continue;
+    const size_t node = (size_t)t * 256 + slot;
+    const int c = ly * LT + lx;
+    const bool is_exit = keep[j] == LP_EXIT;
+    // root: the cell itself when it is terminal, else the terminal its compressed pointer names
+    uint8_t rs = 255;
+    if (is_exit) rs = (uint8_t)slot;
+    else if (keep[j] < LP_TERM) {
+      const uint16_t p = lp[c];
+      if (p < LP_TERM) {
+        // p is terminal iff its own (uncompressed == compressed) entry is a code
+        const uint16_t code = lp[p];
+        if (code == LP_EXIT) rs = (uint8_t)border_slot(p & (LT - 1), p >> 6);
+      }
+    }
+    rootslot[node] = rs;
+    unsigned long long word = NOT_A_NODE << 56;
+    uint32_t tn = NO_NODE;
+    if (is_exit) {
+      const uint32_t v = lw[c];
+      word = ((unsigned long long)((v >> 28) != 0 ? 1u : 0u) << 56) | (unsigned long long)(v & LMASK);
+      const uint8_t d = sd[(ly + 1) * LLW + lx + 1];
+      const int gx = x0 + lx + d8dx(d), gy = y0 + ly + d8dy(d);
+      tn = ((uint32_t)(gy / LT) * tilesX + (uint32_t)(gx / LT)) * 256u + (uint32_t)border_slot(gx % LT, gy % LT);
+    }
+    nw[node] = word;
+    next[node] = tn;
+  }
+}
+
+// next[q] : the cell q flows to (a border cell of another tile) -> the exit that cell's path leaves its tile through
+__global__ __launch_bounds__(NTHR) void k_acc_link_edges(unsigned long long *nw, uint32_t *next,
+                                                         const uint8_t *__restrict__ rootslot, uint64_t nnodes) {
+  const uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (i >= nnodes) return;
+  const uint32_t tn = next[i];
+  if (tn == NO_NODE) return;
+  const uint8_t r = rootslot[tn];
+  const uint32_t nx = r == 255 ? NO_NODE : ((tn & ~255u) | r);
+  next[i] = nx;
+  if (nx != NO_NODE) atomicAdd(&nw[nx], CNT1);
+}
+
+__global__ __launch_bounds__(NTHR) void k_acc_link_sources(unsigned long long *nw, uint64_t nnodes) {
+  const uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (i >= nnodes) return;
+  const unsigned long long v = nw[i];
+  if ((v >> 56) == 0) nw[i] = v | (SRC << 56);   // an exit nobody hands anything to: a source of the link forest
+}
+
+__global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, const uint32_t *__restrict__ next,
+                                                        uint64_t nnodes) {
+  // lane-refill walk over the exits (see k_acc_walk_unit)
+  const uint64_t wave = ((uint64_t)blockIdx.x * NTHR + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint64_t nxt = wave * WALK_CHUNK;
+  const uint64_t end = nxt + WALK_CHUNK < nnodes ? nxt + WALK_CHUNK : nnodes;
+  if (nxt >= nnodes) return;
+  bool active = false;
+  uint32_t c = 0;
+  unsigned long long v = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (nxt < end && idle) {
+      const uint64_t my = nxt + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && my < end) {
+        const unsigned long long wd = nw[my];   // a source's word is never modified: plain read
+        if ((wd >> 56) == SRC) { active = true; c = (uint32_t)my; v = wd & LOWMASK; }
+      }
+      nxt += (uint64_t)__popcll(idle);
+    } else if (idle == ~0ull) {
+      break;
+    }
+    if (active) {
+      const uint32_t t = next[c];
+      if (t == NO_NODE) active = false;
+      else {
+        const unsigned long long old = atomicAdd(&nw[t], v - CNT1);
+        if ((old >> 56) != 1) active = false;
+        else { v = (old & LOWMASK) + v; c = t; }
+      }
+    }
+  }
+}
+
+template <class A>
+__global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                         uint32_t tilesX, uint32_t ntiles,
+                                                         const unsigned long long *__restrict__ nw, A *__restrict__ area) {
+  __shared__ uint8_t sd[LLW * LLW];
+  // one word per cell: pending donors (bits 56..63) | in-tile target, 0x1FFF for none (bits 43..55) | total (43 bits)
+  __shared__ unsigned long long lw[LT * LT];
+  __shared__ unsigned long long ext_in[NTHR];
+  __shared__ uint8_t ext_blk[NTHR];
+  constexpr unsigned long long TMASK = (1ull << 43) - 1ull, NOTGT = 0x1FFFull;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int tx0 = (int)(t % tilesX), ty0 = (int)(t / tilesX);
+  const int x0 = tx0 * LT, y0 = ty0 * LT;
+  stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
+  __syncthreads();
+  {
+    // what the border cells receive from outside, one border cell per thread (all lookups of the block in flight
+    // together): finished donors bring their total, unfinished ones (direction loops) block the cell for good
+    const int slot = (int)threadIdx.x;
+    unsigned long long inflow = 0;
+    uint32_t blocked = 0;
+    if (slot < 4 * LT - 4) {
+      const int bx = slot < LT ? slot : slot < 2 * LT ? slot - LT : slot < 3 * LT - 2 ? 0 : LT - 1;
+      const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
+      const int o = (by + 1) * LLW + bx + 1;
+      if (sd[o] != nodata) {
+        unsigned long long wv[8];
+        bool use[8];
+#pragma unroll
+        for (int m = 1; m <= 8; m++) {
+          const int nx = bx + d8dx(m), ny = by + d8dy(m);
+          const uint8_t dn = sd[o + d8dy(m) * LLW + d8dx(m)];
+          use[m - 1] = !(nx >= 0 && nx < LT && ny >= 0 && ny < LT) && dn != nodata && dn == (m <= 4 ? m + 4 : m - 4);
+          wv[m - 1] = 0;
+          if (use[m - 1]) {
+            const int gx = x0 + nx, gy = y0 + ny;
+            wv[m - 1] = nw[((size_t)(gy / LT) * tilesX + (size_t)(gx / LT)) * 256 + (size_t)border_slot(gx % LT, gy % LT)];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          if (!use[m]) continue;
+          const unsigned long long cnt = wv[m] >> 56;
+          if (cnt == 0 || cnt == SRC) inflow += wv[m] & LOWMASK;
+          else blocked++;
+        }
+      }
+    }
+    ext_in[slot] = inflow;
+    ext_blk[slot] = (uint8_t)blocked;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  uint32_t tgs[LT / 4];   // in-tile target of the thread's cells (NOTGT: none)
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
+    unsigned long long v = 0;
+    const uint8_t d = sd[o];
+    tgs[j] = (uint32_t)NOTGT;
+    if (d != nodata) {
+      unsigned long long k = 0, inflow = 0;
+      if (d >= 1 && d <= 8) {
+        const int tx = lx + d8dx(d), ty = ly + d8dy(d);
+        if (tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata) tgs[j] = (uint32_t)(ty * LT + tx);
+      }
+      const int slot = border_slot(lx, ly);
+      if (slot >= 0) { inflow = ext_in[slot]; k = ext_blk[slot]; }
+      v = (k << 56) | ((unsigned long long)tgs[j] << 43) | (1ull + inflow);
+    }
+    lw[ly * LT + lx] = v;
+  }
+  __syncthreads();
+  for (int j = 0; j < LT / 4; j++)   // pending donors, counted from the donors' side (see k_acc_link_tile)
+    if (tgs[j] != (uint32_t)NOTGT) atomicAdd(&lw[tgs[j]], CNT1);
+  __syncthreads();
+  uint32_t srcmask = 0;
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    if (sd[(ly + 1) * LLW + lx + 1] != nodata && (lw[ly * LT + lx] >> 56) == 0) srcmask |= 1u << j;
+  }
+  __syncthreads();   // the sources are fixed before any walk completes a cell
+  {
+    uint32_t m = srcmask;
+    unsigned long long tg = NOTGT, v = 0;
+    for (;;) {   // a lane whose walk has ended takes its next source in the same trip (see k_acc_link_tile)
+      if (tg == NOTGT && m) {
+        const unsigned long long own = lw[(ly0 + 4 * (__ffs((int)m) - 1)) * LT + lx];
+        tg = (own >> 43) & NOTGT;
+        v = own & TMASK;
+        m &= m - 1;
+      }
+      if (!__any(tg != NOTGT || m != 0)) break;
+      if (tg != NOTGT) {
+        const unsigned long long old = atomicAdd(&lw[tg], v - CNT1);
+        if ((old >> 56) != 1) tg = NOTGT;
+        else { v = (old & TMASK) + v; tg = (old >> 43) & NOTGT; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    A out = (A)-1;                                                  // area.noData() == -1, d8_methods.hpp:64,:72-75
+    if (sd[(ly + 1) * LLW + lx + 1] != nodata) {
+      const unsigned long long v = lw[ly * LT + lx];
+      // cells downstream of a direction loop are never completed by the reference either: they keep the sum of the
+      // inflows that did arrive, without their own +1 (d8_methods.hpp:104-131)
+      out = (A)((v >> 56) != 0 ? (v & TMASK) - 1ull : (v & TMASK));
+    }
+    area[(size_t)gy * w + gx] = out;
+  }
+}
+
 // ---- f64 weights ----------------------------------------------------------------------------
 // Tile pre-walk for f64 weights: k_acc_tile_prewalk's scheme with the totals as doubles in LDS.  It also
 // replaces a separate inflow-counting pass: the pending words written here are what the raster-wide walk
@@ -215,11 +580,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk_f64(const uint8_t *__
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
-  for (int i = threadIdx.x; i < ALH * ALW; i += NTHR) {
-    const int ly = i / ALW, lx = i - ly * ALW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : 255;
-  }
+  stage_dirs<ALW, NTHR>(dirs, w, h, x0, y0, (uint8_t)255, sd);
   const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
   {
     double wv[AH / 4];
@@ -249,31 +610,42 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk_f64(const uint8_t *__
     lc[ly * AW + lx] = v;
   }
   __syncthreads();
-  for (uint32_t m = srcmask; m; m &= m - 1) {
-    const int j = __ffs((int)m) - 1;
-    int cx = lx, cy = ly0 + 4 * j;
-    double v = lt[cy * AW + cx];
+  {
+    // a lane whose walk has ended takes its next source in the same trip (see k_acc_link_tile)
+    uint32_t m = srcmask;
+    bool active = false;
+    int cx = 0, cy = 0;
+    double v = 0;
     for (;;) {
-      const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
-      bool stalled = false;
-      if (d >= 1 && d <= 8) {
-        const int tx = cx + d8dx(d), ty = cy + d8dy(d);
-        if (sd[(ty + 1) * ALW + tx + 1] != 255) {                // else: off the DEM / into NoData: dropped
-          if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
-            atomicAdd(&lt[ty * AW + tx], v);
-            const uint32_t old = atomicSub(&lc[ty * AW + tx], 1u);
-            if ((old & 0xFFu) == 1) {
-              v = __hip_atomic_load(&lt[ty * AW + tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              cx = tx; cy = ty;
-              continue;
+      if (!active && m) {
+        cx = lx; cy = ly0 + 4 * (__ffs((int)m) - 1);
+        m &= m - 1;
+        v = lt[cy * AW + cx];
+        active = true;
+      }
+      if (!__any(active || m != 0)) break;
+      if (active) {
+        const uint8_t d = sd[(cy + 1) * ALW + cx + 1];
+        bool stalled = false, cont = false;
+        if (d >= 1 && d <= 8) {
+          const int tx = cx + d8dx(d), ty = cy + d8dy(d);
+          if (sd[(ty + 1) * ALW + tx + 1] != 255) {                // else: off the DEM / into NoData: dropped
+            if (tx >= 1 && tx < AW - 1 && ty >= 1 && ty < AH - 1) {
+              atomicAdd(&lt[ty * AW + tx], v);
+              const uint32_t old = atomicSub(&lc[ty * AW + tx], 1u);
+              if ((old & 0xFFu) == 1) {
+                v = __hip_atomic_load(&lt[ty * AW + tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                cx = tx; cy = ty;
+                cont = true;
+              }
+            } else {
+              stalled = true;                                      // ring cell or another tile: continue raster-wide
             }
-          } else {
-            stalled = true;                                      // ring cell or another tile: continue raster-wide
           }
         }
+        if (stalled) lc[cy * AW + cx] = (lc[cy * AW + cx] & ~0xFFu) | SRC32;   // complete, still has to pass its total on
+        active = cont;
       }
-      if (stalled) lc[cy * AW + cx] = (lc[cy * AW + cx] & ~0xFFu) | SRC32;   // complete, still has to pass its total on
-      break;
     }
   }
   __syncthreads();
@@ -357,6 +729,27 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
   if (!d_dirs || !d_area) throw Error(RDGPU_ERR_ARG, "rdgpu_d8_flow_accum: null pointer");
   check_dims(w, h, "rdgpu_d8_flow_accum");
   const uint64_t n = (uint64_t)w * h;
+  const char *env = getenv("RDGPU_ACCUM_LINKS");   // =0: the raster-wide walk (what the row-block shards run); A/B and tests
+  if (!(env && env[0] == '0')) {
+    const uint32_t tilesX = (w + LT - 1) / LT, ntiles = tilesX * ((h + LT - 1) / LT);
+    const uint64_t nnodes = (uint64_t)ntiles * 256;
+    if (nnodes < 0xFFFFFF00ull) {
+      Workspace &ws = Workspace::get();
+      unsigned long long *nw = ws.buf<unsigned long long>("accum.link_word", nnodes);
+      uint32_t *next = ws.buf<uint32_t>("accum.link_next", nnodes);
+      uint8_t *rootslot = ws.buf<uint8_t>("accum.link_root", nnodes);
+      const uint32_t ngrid = (uint32_t)((nnodes + NTHR - 1) / NTHR);
+      RD_LAUNCH("accum.link_tile", k_acc_link_tile, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h, tilesX, ntiles,
+                nw, next, rootslot);
+      RD_LAUNCH("accum.link_edges", k_acc_link_edges, dim3(ngrid), dim3(NTHR), 0, s, nw, next, (const uint8_t *)rootslot, nnodes);
+      RD_LAUNCH("accum.link_sources", k_acc_link_sources, dim3(ngrid), dim3(NTHR), 0, s, nw, nnodes);
+      RD_LAUNCH("accum.link_walk", k_acc_link_walk, dim3((uint32_t)(((nnodes + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR),
+                0, s, nw, (const uint32_t *)next, nnodes);
+      RD_LAUNCH("accum.link_final", (k_acc_link_final<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h, tilesX,
+                ntiles, (const unsigned long long *)nw, d_area);
+      return;
+    }
+  }
   unsigned long long *word = Workspace::get().buf<unsigned long long>("accum.word", n);
   {
     const uint32_t tilesX = (w + AW - 1) / AW, ntiles = tilesX * ((h + AH - 1) / AH);
