@@ -127,6 +127,25 @@ typedef struct rdgpu_epsilon_stats {
 } rdgpu_epsilon_stats;
 int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
 
+/* ---- PriorityFloodWatersheds_Barnes2014<topology>(Array2D<T>&, Array2D<int32_t>& labels, bool alter_elevations) ----
+ * Replaces richdem::PriorityFloodWatersheds_Barnes2014 (include/richdem/depressions/Barnes2014.hpp:713-807): labels[i] =
+ * the watershed the cell drains to (every data cell of the raster border, and every data cell next to a NoData region
+ * connected to it, starts a watershed; labels are numbered from 1 in the order the reference pops their first cell,
+ * i.e. by elevation; cells that are never labelled -- NoData connected to the border -- hold -1 = labels.noData()).
+ * alter != 0: the DEM is filled as by PriorityFlood_Barnes2014 (:793-794).  Identical to the reference, numbering
+ * included, on DEMs without equal elevations among the cells of its heap; with ties the reference's partition follows
+ * std::priority_queue's pop order. */
+#define RDGPU_DECL_WS(SUF, T)                                                                                          \
+  int rdgpu_watersheds_##SUF(T *dem, T nodata, int width, int height, int topology, int alter, int32_t *labels);      \
+  int rdgpu_watersheds_dev_##SUF(T *d_dem, T nodata, int width, int height, int topology, int alter, int32_t *d_labels, void *hip_stream);
+RDGPU_DECL_WS(u8, uint8_t)
+RDGPU_DECL_WS(i16, int16_t)
+RDGPU_DECL_WS(u16, uint16_t)
+RDGPU_DECL_WS(i32, int32_t)
+RDGPU_DECL_WS(u32, uint32_t)
+RDGPU_DECL_WS(f32, float)
+#undef RDGPU_DECL_WS
+
 /* Environment switches of the fill (read at every call; for tests and A/B timing, results never change):
  *   RDGPU_FILL_EDGES=0         every contraction round is a raster pass (the r01d engine; default: one raster pass,
  *                              then rounds on the component-pair list it records)

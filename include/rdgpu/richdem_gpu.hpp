@@ -118,6 +118,18 @@ RDGPU_SHIM_MAXDEP(f32, float)
 template <class T>
 int c_fill_maxdep(T *, int, int, int, uint64_t) { unsupported("PriorityFlood_Barnes2014_max_dep"); }
 
+#define RDGPU_SHIM_WS(SUF, T) \
+  inline int c_watersheds(T *p, T nd, int w, int h, int t, int alter, int32_t *l) { return rdgpu_watersheds_##SUF(p, nd, w, h, t, alter, l); }
+RDGPU_SHIM_WS(u8, uint8_t)
+RDGPU_SHIM_WS(i16, int16_t)
+RDGPU_SHIM_WS(u16, uint16_t)
+RDGPU_SHIM_WS(i32, int32_t)
+RDGPU_SHIM_WS(u32, uint32_t)
+RDGPU_SHIM_WS(f32, float)
+#undef RDGPU_SHIM_WS
+template <class T>
+int c_watersheds(T *, T, int, int, int, int, int32_t *) { unsupported("PriorityFloodWatersheds_Barnes2014"); }
+
 inline int c_fill_eps(float *p, float nd, int w, int h, int t) { return rdgpu_fill_epsilon_f32(p, nd, w, h, t); }
 inline int c_fill_eps(double *p, double nd, int w, int h, int t) { return rdgpu_fill_epsilon_f64(p, nd, w, h, t); }
 template <class T>
@@ -174,6 +186,20 @@ void PriorityFlood_Barnes2014_max_dep(A &dem, uint64_t max_dep_size) {
   if (dem.width() == 0 || dem.height() == 0) return;
   detail::check(detail::c_fill_maxdep((T *)dem.data(), dem.width(), dem.height(), detail::topology_code<topo>(), max_dep_size),
                 "PriorityFlood_Barnes2014_max_dep");
+}
+
+// richdem::PriorityFloodWatersheds_Barnes2014<topo>(Array2D<T>&, Array2D<int32_t>&, bool alter_elevations)
+// depressions/Barnes2014.hpp:713-807: labels resized to the DEM, NoData -1 (:737-738)
+template <auto topo, class A, class L>
+void PriorityFloodWatersheds_Barnes2014(A &elevations, L &labels, bool alter_elevations) {
+  using T = detail::elem_t<A>;
+  static_assert(std::is_same<detail::elem_t<L>, int32_t>::value, "PriorityFloodWatersheds_Barnes2014: labels must be Array2D<int32_t>");
+  labels.resize(elevations.width(), elevations.height(), -1);
+  labels.setNoData(-1);
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_watersheds((T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(),
+                                     detail::topology_code<topo>(), alter_elevations ? 1 : 0, labels.data()),
+                "PriorityFloodWatersheds_Barnes2014");
 }
 
 // richdem::PriorityFloodEpsilon_Barnes2014<topo>(Array2D<T>&)   depressions/Barnes2014.hpp:335-420; integer element

@@ -39,6 +39,7 @@ from .pyrichdem import (  # noqa: F401
 from .api import (  # noqa: F401
     pit_mask,
     fill_max_dep,
+    watersheds,
     dinf_flow_directions,
     d8_flow_directions,
     d8_flow_accum,

@@ -118,6 +118,23 @@ def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bo
     return None if in_place else out
 
 
+def watersheds(dem: np.ndarray, nodata=-9999, topology="D8", alter: bool = False):
+    """PriorityFloodWatersheds_Barnes2014<topo> (depressions/Barnes2014.hpp:713-807): int32 watershed labels (1.. in the
+    order the watersheds' first cells are flooded, -1 for NoData connected to the border); with ``alter`` also the filled
+    DEM: returns labels, or (labels, filled)."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("watersheds: expected a 2-D numpy array")
+    work = np.ascontiguousarray(dem).copy()
+    s = _suffix(work.dtype)
+    if s in ("f64", "i64", "u64"):
+        raise RdgpuError("watersheds: 64-bit element types are not provided")
+    h, w = work.shape
+    labels = np.empty((h, w), np.int32)
+    check(getattr(lib(), f"rdgpu_watersheds_{s}")(work.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, _topo(topology),
+                                                  1 if alter else 0, labels.ctypes.data_as(ctypes.c_void_p)), "rdgpu_watersheds")
+    return (labels, work) if alter else labels
+
+
 def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
     """uint8 mask of the cells lying in depressions: 1 = the fill would raise the cell, 0 = not, 3 = NoData
     (reference pit_mask<topo>, depressions/Barnes2014.hpp:593-676; apps/rd_depressions_mask.cpp)."""

@@ -90,10 +90,35 @@ struct CKey<double> {
   }
 };
 
-// one representable step up (saturating at +infinity; "not reached" stays not reached)
+// The field a relaxation works on: key type, "not reached", the largest key that still steps, and per cell its floor
+// (the value it can never go below) and whether it is fixed besides the raster border.
 template <class T>
-__device__ __forceinline__ typename CKey<T>::K step_up(typename CKey<T>::K m) {
-  return m + (m < CKey<T>::POSINF ? 1 : 0);
+struct EpsField {   // the epsilon surface of a float / double DEM: floor = the cell's own elevation, NoData cells fixed
+  using K = typename CKey<T>::K;
+  static constexpr K INF = CKey<T>::INF, POSINF = CKey<T>::POSINF;
+  const T *z;
+  T nodata;
+  __device__ __forceinline__ K key(size_t g, bool &fixed) const {
+    const T zz = z[g];
+    fixed = zz == nodata;
+    return CKey<T>::to(zz);
+  }
+};
+template <class T>
+struct ShedField {   // (level of the plain fill W, steps from where the flood entered the cell's lake or flat): watersheds
+  using K = uint64_t;
+  static constexpr K INF = 0xFFFFFFFFFFFFFFF0ull, POSINF = 0xFFFFFFFFFFFFFF00ull;
+  const T *W;
+  __device__ __forceinline__ K key(size_t g, bool &fixed) const {
+    fixed = false;
+    return (uint64_t)Key32<T>::to(W[g]) << 32;
+  }
+};
+
+// one representable step up (saturating at +infinity; "not reached" stays not reached)
+template <class P>
+__device__ __forceinline__ typename P::K step_up(typename P::K m) {
+  return m + (m < P::POSINF ? 1 : 0);
 }
 
 __device__ __forceinline__ uint32_t dpp_left(uint32_t v, uint32_t fill) {   // lane l receives lane l-1's value
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
     const int o = (ly + 1) * RW + lx + 1;
     K lo = kmin(kmin(sd[o - RW], sd[o + RW]), kmin(sd[o - 1], sd[o + 1]));
     if (TOPO == 8) lo = kmin(lo, kmin(kmin(sd[o - RW - 1], sd[o - RW + 1]), kmin(sd[o + RW - 1], sd[o + RW + 1])));
-    const K f = kmax(CKey<T>::to(zz), step_up<T>(lo));
+    const K f = kmax(CKey<T>::to(zz), step_up<EpsField<T>>(lo));
     const K d = sd[o];
     if (d != f) nbad++;
     const K wk = CKey<T>::to(W[g]);
@@ -239,12 +264,12 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
 }
 
 // ---- one active tile to its local fixed point ----------------------------------------------------------------------
-template <class T, int TOPO>
-__global__ __launch_bounds__(NT) void k_eps_relax(const T *__restrict__ z, T nodata, typename CKey<T>::K *D,
+template <class P, int TOPO>
+__global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
                                                   const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
                                                   uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
-  using K = typename CKey<T>::K;
-  constexpr K KINF = CKey<T>::INF;
+  using K = typename P::K;
+  constexpr K KINF = P::INF;
   __shared__ K sd[RH * RW];
   __shared__ K xrow[2][RBANDS][2][CW];
   const uint32_t nact = *count;
@@ -284,9 +309,9 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const T *__restrict__ z, T nod
     const int gy = y0 + band * ROWS + j;
     zk[j] = 0;
     if (gx < w && gy < h) {
-      const T zz = z[(size_t)gy * w + gx];
-      zk[j] = CKey<T>::to(zz);
-      if (!(gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || zz == nodata)) free_ |= 1u << j;
+      bool fixed;
+      zk[j] = p.key((size_t)gy * w + gx, fixed);
+      if (!(gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || fixed)) free_ |= 1u << j;
     }
   }
   __syncthreads();
@@ -329,10 +354,10 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const T *__restrict__ z, T nod
     // Gauss-Seidel along the strip (vertical neighbours: both topologies)
 #pragma unroll
     for (int j = 1; j < ROWS; j++)
-      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<T>(d[j - 1])));
+      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j - 1])));
 #pragma unroll
     for (int j = ROWS - 2; j >= 0; j--)
-      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<T>(d[j + 1])));
+      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j + 1])));
     xrow[it & 1][band][0][lx] = d[0];
     xrow[it & 1][band][1][lx] = d[ROWS - 1];
     if (!__syncthreads_or(changed)) break;
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const T *__restrict__ z, T nod
       neigh_min(up, dn, mn);
 #pragma unroll
       for (int j = 0; j < ROWS; j++) {
-        const K cand = kmax(zk[j], step_up<T>(mn[j]));
+        const K cand = kmax(zk[j], step_up<P>(mn[j]));
         if ((free_ & (1u << j)) && cand < d[j]) { d[j] = cand; changed = 1; }
       }
     }
@@ -391,6 +416,35 @@ struct Stats {
 };
 static Stats g_stats;
 
+// Rounds until no tile is active: compact the active-tile flags into a list + count on the device, relax that list;
+// BATCH rounds are enqueued per host read-back, the rounds enqueued past the fixed point see an empty list.
+template <class P, int TOPO>
+static void relax_until_quiet(const P p, typename P::K *D, uint8_t *tflags, uint32_t *tlist, uint32_t *ctr /* BATCH words */, int w,
+                              int h, const char *name, hipStream_t s) {
+  uint32_t *hw = Workspace::get().host_words();
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
+  uint32_t grid = ntiles;
+  for (bool done = false; !done;) {
+    RD_HIP(hipMemsetAsync(ctr, 0, BATCH * sizeof(uint32_t), s));
+    for (int b = 0; b < BATCH; b++) {
+      RD_LAUNCH("eps.tiles_compact", k_tiles_compact, dim3((ntiles + NT - 1) / NT), dim3(NT), 0, s, tflags, ntiles, tlist, ctr + b);
+      RD_LAUNCH(name, (k_eps_relax<P, TOPO>), dim3(grid), dim3(NT), 0, s, p, D, (const uint32_t *)tlist,
+                (const uint32_t *)(ctr + b), tflags, w, h, tilesX, tilesY);
+    }
+    RD_HIP(hipMemcpyAsync(hw, ctr, BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    uint32_t most = 0;
+    for (int b = 0; b < BATCH; b++) {
+      if (hw[b] == 0) { done = true; break; }
+      most = std::max(most, hw[b]);
+      g_stats.rounds++;
+      g_stats.tile_relaxations += hw[b];
+    }
+    grid = std::min<uint32_t>(ntiles, std::max<uint32_t>(1024u, 2u * most));
+    if (g_stats.rounds > (1u << 24)) throw Error(RDGPU_ERR_HIP, "rdgpu: tile relaxation did not terminate");
+  }
+}
+
 template <class T, int TOPO>
 static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
   using K = typename CKey<T>::K;
@@ -413,26 +467,7 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     RD_HIP(hipMemsetAsync(ctr + BATCH, 0, 8 * sizeof(uint32_t), s));
     RD_LAUNCH("eps.init", (k_eps_init<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, X, D, tflags,
               w, h, tilesX, ntiles);
-    uint32_t grid = ntiles;
-    for (bool done = false; !done;) {
-      RD_HIP(hipMemsetAsync(ctr, 0, BATCH * sizeof(uint32_t), s));
-      for (int b = 0; b < BATCH; b++) {
-        RD_LAUNCH("eps.tiles_compact", k_tiles_compact, dim3((ntiles + NT - 1) / NT), dim3(NT), 0, s, tflags, ntiles, tlist, ctr + b);
-        RD_LAUNCH("eps.relax", (k_eps_relax<T, TOPO>), dim3(grid), dim3(NT), 0, s, (const T *)d_z, nodata, D, (const uint32_t *)tlist,
-                  (const uint32_t *)(ctr + b), tflags, w, h, tilesX, tilesY);
-      }
-      RD_HIP(hipMemcpyAsync(hw, ctr, BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      uint32_t most = 0;
-      for (int b = 0; b < BATCH; b++) {
-        if (hw[b] == 0) { done = true; break; }
-        most = std::max(most, hw[b]);
-        g_stats.rounds++;
-        g_stats.tile_relaxations += hw[b];
-      }
-      grid = std::min<uint32_t>(ntiles, std::max<uint32_t>(1024u, 2u * most));
-      if (g_stats.rounds > (1u << 24)) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_epsilon: relaxation did not terminate");
-    }
+    relax_until_quiet<EpsField<T>, TOPO>(EpsField<T>{d_z, nodata}, D, tflags, tlist, ctr, w, h, "eps.relax", s);
     RD_LAUNCH("eps.check", (k_eps_check<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, (const K *)D, w,
               h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2));
     RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -483,6 +518,283 @@ static void fill_epsilon_host(T *dem, T nodata, int w, int h, int topology) {
 }
 
 }  // namespace eps
+
+// ------------------------------------------------------------------------------------------------------------------
+// PriorityFloodWatersheds_Barnes2014<topo>(elevations, labels, alter_elevations) (reference
+// depressions/Barnes2014.hpp:713-807).  The reference labels every cell with the label of the cell that CLOSED it -- the
+// first of its neighbours to be processed -- and hands out a new label to every data cell that is popped without one
+// (:777-778: the cells of the raster border and the data cells next to a NoData region that is connected to it).
+// Cells are processed in the order of the level the flood has when it reaches them (the plain fill's W), and the cells
+// of one lake in breadth-first order from the cell the flood entered it through (the pit queue is a FIFO, :762-764).
+// So with  P(c) = (W(c), steps from the lake's entry)  -- the fixed point of the SAME relaxation as the epsilon fill on
+// 64-bit keys, floor (W << 32): a cell with a lower neighbour holds (W, 0), a lake or flat cell one more than its
+// lowest neighbour -- the cell that closed c is a neighbour of smallest P, and all such neighbours carry the same
+// label.  Labels then are: parent(c) = the lowest-P neighbour, label = the nearest ancestor that starts a label
+// (pointer chasing with path compression), numbered in the order of the starters' elevations (their pop order).
+// Identical to the reference (labels AND numbering) on DEMs without equal elevations among the heap's cells; with ties
+// the partition of the reference depends on std::priority_queue's pop order.
+// ------------------------------------------------------------------------------------------------------------------
+namespace shed {
+using namespace eps;
+
+constexpr uint32_t TERM = 0x80000000u;        // link word: a terminal; low bits = the cell that starts the label
+constexpr uint32_t NONE = 0x7FFFFFFFu;        // ... or none (the label stays -1)
+
+template <class T, int TOPO>
+__global__ __launch_bounds__(NT) void k_ws_init(const T *__restrict__ W, uint64_t *__restrict__ D, uint8_t *tile_active, int w,
+                                                int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint32_t sw[RH * RW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * CW, y0 = (int)(t / tilesX) * RCH;
+  for (int i = threadIdx.x; i < RH * RW; i += NT) {
+    const int ly = i / RW, lx = i - ly * RW;
+    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+    sw[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? Key32<T>::to(W[(size_t)gy * w + gx]) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
+  int anyinf = 0;
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int ly = band * ROWS + j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const int o = (ly + 1) * RW + lx + 1;
+    const uint32_t k = sw[o];
+    uint64_t d = (uint64_t)k << 32;
+    if (!(gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1)) {
+      uint32_t lo = kmin(kmin(sw[o - RW], sw[o + RW]), kmin(sw[o - 1], sw[o + 1]));
+      if (TOPO == 8) lo = kmin(lo, kmin(kmin(sw[o - RW - 1], sw[o - RW + 1]), kmin(sw[o + RW - 1], sw[o + RW + 1])));
+      if (!(lo < k)) { d = ShedField<T>::INF; anyinf = 1; }   // lake / flat cell: its level comes from the relaxation
+    }
+    D[(size_t)gy * w + gx] = d;
+  }
+  if (__syncthreads_or(anyinf) && threadIdx.x == 0) tile_active[t] = 1;
+}
+
+// link[c]: the lowest-P neighbour (lowest index among equals), or a terminal: TERM | c for a cell that starts a label,
+// TERM | NONE for a cell that stays unlabelled.  Without NoData cells the starters are exactly the border cells.
+template <class T, int TOPO>
+__global__ __launch_bounds__(NT) void k_ws_parent(const T *__restrict__ z, T nodata, const uint64_t *__restrict__ D,
+                                                  uint32_t *__restrict__ link, int w, int h, uint32_t *any_nodata) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  int nd = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    const bool isnd = z[c] == nodata;
+    nd |= isnd;
+    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {
+      link[c] = TERM | (isnd ? NONE : (uint32_t)c);   // :777: a border data cell starts a label, a NoData one none
+      continue;
+    }
+    uint64_t best = ~0ull;
+    uint32_t arg = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {   // raster order: the lowest index wins among equals
+      if (k == 4) continue;
+      const int dx = k % 3 - 1, dy = k / 3 - 1;
+      if (TOPO == 4 && dx != 0 && dy != 0) continue;
+      const uint64_t q = c + (int64_t)dy * w + dx;
+      const uint64_t v = D[q];
+      if (v < best) { best = v; arg = (uint32_t)q; }
+    }
+    link[c] = arg;
+  }
+  if (__any(nd) && (threadIdx.x & 63) == 0) *any_nodata = 1;
+}
+
+// bounded pointer chase with path compression: link[c] <- the terminal word its chain ends in (or a pointer further up
+// the chain when the hop budget runs out: the host repeats while flagged)
+__global__ __launch_bounds__(NT) void k_ws_chase(uint32_t *link, uint64_t n, int maxhops, uint32_t *flag) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    uint32_t v = link[c];
+    if (v & TERM) continue;
+    const uint32_t v0 = v;
+    bool unfinished = true;
+    for (int hops = 0; hops < maxhops; hops++) {
+      const uint32_t q = link[v];
+      v = q;
+      if (q & TERM) { unfinished = false; break; }
+    }
+    if (v != v0) link[c] = v;
+    if (unfinished) *flag = 1;
+  }
+}
+
+// NoData present.  Pass A (ua): for a NoData cell, does its chain of parents run through NoData cells to a NoData cell
+// of the border (then it is never labelled, and a data cell it closes starts a label)?  ua[c] = TERM | 1 yes, TERM | 0
+// no (data cells, and what a data cell closed), else the parent.
+template <class T>
+__global__ __launch_bounds__(NT) void k_ws_nodata_links(const T *__restrict__ z, T nodata, const uint32_t *__restrict__ link,
+                                                        uint32_t *__restrict__ ua, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t l = link[c];
+    if (z[c] != nodata) ua[c] = TERM | 0u;
+    else ua[c] = (l & TERM) ? (TERM | 1u) : l;    // a NoData border cell / an interior NoData cell: ask its parent
+  }
+}
+// Pass B: the final links.  A data cell whose parent is never labelled starts a label; a NoData cell that is never
+// labelled is a terminal without one.
+template <class T>
+__global__ __launch_bounds__(NT) void k_ws_seed_links(const T *__restrict__ z, T nodata, const uint32_t *__restrict__ ua,
+                                                      uint32_t *__restrict__ link, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t l = link[c];
+    if (l & TERM) continue;                                   // border cells are done
+    if (z[c] == nodata) { if (ua[c] == (TERM | 1u)) link[c] = TERM | NONE; }
+    else if (ua[l] == (TERM | 1u)) link[c] = TERM | (uint32_t)c;   // (ua of a data parent is TERM | 0)
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(NT) void k_ws_collect(const T *__restrict__ z, const uint32_t *__restrict__ link, uint64_t n,
+                                                   uint64_t *keys, uint32_t *count, uint32_t cap) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c0 = (uint64_t)blockIdx.x * NT; c0 < n; c0 += stride) {   // whole blocks: block_append has barriers
+    const uint64_t c = c0 + threadIdx.x;
+    const bool hit = c < n && link[c] == (TERM | (uint32_t)c);
+    const uint32_t slot = block_append(hit, count);
+    if (hit && slot < cap) keys[slot] = ((uint64_t)Key32<T>::to(z[c]) << 32) | (uint64_t)c;
+    __syncthreads();   // block_append's LDS words are free again
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_ws_number(const uint64_t *__restrict__ sorted, uint32_t nseeds, int32_t *labels) {
+  const uint32_t i = blockIdx.x * NT + threadIdx.x;
+  if (i < nseeds) labels[(uint32_t)sorted[i]] = (int32_t)i + 1;   // clabel starts at 1, :721
+}
+
+__global__ __launch_bounds__(NT) void k_ws_apply(const uint32_t *__restrict__ link, int32_t *labels, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t t = link[c] & ~TERM;
+    if (t == NONE) labels[c] = -1;                 // labels.noData(), :737-738
+    else if (t != (uint32_t)c) labels[c] = labels[t];
+  }
+}
+
+}  // namespace shed
+}  // namespace rdgpu
+
+#include <hipcub/hipcub.hpp>
+
+#define RD_WS_FILL(SUF, T) extern "C" int rdgpu_fill_dev_##SUF(T *, int, int, int, void *);
+RD_WS_FILL(u8, uint8_t)
+RD_WS_FILL(i16, int16_t)
+RD_WS_FILL(u16, uint16_t)
+RD_WS_FILL(i32, int32_t)
+RD_WS_FILL(u32, uint32_t)
+#undef RD_WS_FILL
+
+namespace rdgpu {
+namespace shed {
+static int fill_of(uint8_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_u8(p, w, h, t, s); }
+static int fill_of(int16_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_i16(p, w, h, t, s); }
+static int fill_of(uint16_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_u16(p, w, h, t, s); }
+static int fill_of(int32_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_i32(p, w, h, t, s); }
+static int fill_of(uint32_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_u32(p, w, h, t, s); }
+static int fill_of(float *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_f32(p, w, h, t, s); }
+
+template <class T, int TOPO>
+static void run(T *d_z, T nodata, const T *d_W, int w, int h, int32_t *d_labels, hipStream_t s) {
+  const uint64_t n = (uint64_t)w * h;
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH, ntiles = tilesX * tilesY;
+  uint64_t *D = ws.buf<uint64_t>("shed.D", n);
+  uint8_t *tflags = ws.buf<uint8_t>("eps.tflags", ntiles);
+  uint32_t *tlist = ws.buf<uint32_t>("eps.tlist", ntiles);
+  uint32_t *ctr = ws.buf<uint32_t>("eps.ctr", BATCH + 8);
+  g_stats = Stats();
+  g_stats.attempts = 1;
+  RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
+  RD_HIP(hipMemsetAsync(ctr + BATCH, 0, 8 * sizeof(uint32_t), s));
+  RD_LAUNCH("shed.init", (k_ws_init<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, d_W, D, tflags, w, h, tilesX, ntiles);
+  relax_until_quiet<ShedField<T>, TOPO>(ShedField<T>{d_W}, D, tflags, tlist, ctr, w, h, "shed.relax", s);
+  const uint32_t sgrid = (uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 32u);
+  uint32_t *link = ws.buf<uint32_t>("shed.link", n);
+  RD_LAUNCH("shed.parent", (k_ws_parent<T, TOPO>), dim3(sgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const uint64_t *)D, link, w,
+            h, ctr + BATCH);
+  RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  auto chase = [&](uint32_t *lk) {
+    for (;;) {
+      RD_HIP(hipMemsetAsync(ctr + BATCH + 1, 0, sizeof(uint32_t), s));
+      RD_LAUNCH("shed.chase", k_ws_chase, dim3(sgrid), dim3(NT), 0, s, lk, n, 32, ctr + BATCH + 1);
+      RD_HIP(hipMemcpyAsync(hw, ctr + BATCH + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (hw[0] == 0) break;
+    }
+  };
+  if (hw[0]) {   // NoData cells: who is never labelled, and which data cells start a label next to them
+    uint32_t *ua = ws.buf<uint32_t>("shed.ua", n);
+    RD_LAUNCH("shed.nodata_links", (k_ws_nodata_links<T>), dim3(sgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const uint32_t *)link,
+              ua, n);
+    chase(ua);
+    RD_LAUNCH("shed.seed_links", (k_ws_seed_links<T>), dim3(sgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const uint32_t *)ua, link,
+              n);
+  }
+  chase(link);
+  // the cells that start a label, in the order of their elevations (= the order the reference pops them in)
+  RD_HIP(hipMemsetAsync(ctr + BATCH + 2, 0, sizeof(uint32_t), s));
+  uint32_t cap = (uint32_t)std::min<uint64_t>(n, (uint64_t)4 * (w + h) + 1024);
+  uint64_t *keys = nullptr;
+  uint32_t nseeds = 0;
+  for (;;) {
+    keys = ws.buf<uint64_t>("shed.keys", (size_t)2 * cap);
+    RD_LAUNCH("shed.collect", (k_ws_collect<T>), dim3(sgrid), dim3(NT), 0, s, (const T *)d_z, (const uint32_t *)link, n, keys,
+              ctr + BATCH + 2, cap);
+    RD_HIP(hipMemcpyAsync(hw, ctr + BATCH + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    nseeds = hw[0];
+    if (nseeds <= cap) break;
+    cap = nseeds;   // NoData regions made more starters than the border has cells: once more with room for all
+    RD_HIP(hipMemsetAsync(ctr + BATCH + 2, 0, sizeof(uint32_t), s));
+  }
+  uint64_t *sorted = keys + cap;
+  if (nseeds) {
+    size_t tmp_bytes = 0;
+    RD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys, sorted, (int)nseeds, 0, 64, s));
+    void *tmp = ws.buf<uint8_t>("shed.sorttmp", tmp_bytes);
+    RD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, sorted, (int)nseeds, 0, 64, s));
+    RD_LAUNCH("shed.number", k_ws_number, dim3((nseeds + NT - 1) / NT), dim3(NT), 0, s, (const uint64_t *)sorted, nseeds, d_labels);
+  }
+  RD_LAUNCH("shed.apply", k_ws_apply, dim3(sgrid), dim3(NT), 0, s, (const uint32_t *)link, d_labels, n);
+}
+
+template <class T>
+static void watersheds_device(T *d_z, T nodata, int w, int h, int topology, int alter, int32_t *d_labels, hipStream_t s) {
+  if (!d_z || !d_labels) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: width and height must be positive");
+  if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: topology must be 8 or 4");
+  if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: raster too large");
+  const size_t n = (size_t)w * h;
+  T *W = Workspace::get().buf<T>("eps.W", n);
+  RD_HIP(hipMemcpyAsync(W, d_z, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+  if (fill_of(W, w, h, topology, s) != RDGPU_OK) throw Error(RDGPU_ERR_HIP, std::string("rdgpu_watersheds: ") + rdgpu_last_error());
+  if (topology == 8) run<T, 8>(d_z, nodata, W, w, h, d_labels, s);
+  else run<T, 4>(d_z, nodata, W, w, h, d_labels, s);
+  if (alter) RD_HIP(hipMemcpyAsync(d_z, W, n * sizeof(T), hipMemcpyDeviceToDevice, s));   // :793-794: as PriorityFlood_Barnes2014
+}
+
+template <class T>
+static void watersheds_host(T *dem, T nodata, int w, int h, int topology, int alter, int32_t *labels) {
+  if (!dem || !labels) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: width and height must be positive");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  int32_t *dl = Workspace::get().buf<int32_t>("host.labels", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  watersheds_device<T>(d, nodata, w, h, topology, alter, dl, nullptr);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  RD_HIP(hipMemcpy(labels, dl, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (alter) RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
+}  // namespace shed
 }  // namespace rdgpu
 
 using namespace rdgpu;
@@ -508,3 +820,18 @@ extern "C" int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out) {
   out->max_lift = eps::g_stats.max_lift;
   return RDGPU_OK;
 }
+
+#define RD_WS_API(SUF, T)                                                                                              \
+  extern "C" int rdgpu_watersheds_##SUF(T *dem, T nodata, int w, int h, int topology, int alter, int32_t *labels) {  \
+    return guarded([&] { shed::watersheds_host<T>(dem, nodata, w, h, topology, alter, labels); });                    \
+  }                                                                                                                    \
+  extern "C" int rdgpu_watersheds_dev_##SUF(T *d_dem, T nodata, int w, int h, int topology, int alter, int32_t *d_labels, \
+                                            void *stream) {                                                            \
+    return guarded([&] { shed::watersheds_device<T>(d_dem, nodata, w, h, topology, alter, d_labels, (hipStream_t)stream); }); \
+  }
+RD_WS_API(u8, uint8_t)
+RD_WS_API(i16, int16_t)
+RD_WS_API(u16, uint16_t)
+RD_WS_API(i32, int32_t)
+RD_WS_API(u32, uint32_t)
+RD_WS_API(f32, float)
