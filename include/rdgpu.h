@@ -14,9 +14,10 @@
  *   rdgpu_<op>_dev_<dtype>(device pointers...) HBM-resident variant (bench.py,
  *                                              multi-GPU shards, chaining stages)
  *
- * dtype suffixes: u8 i16 u16 i32 u32 f32 everywhere; f64 additionally for the fill (exact: through the f32 engine
- * when the values fit, through dense value ranks otherwise), the stencil stages, flat resolution and the
- * accumulations; i64 u64 for the fill only.  The row-block shard entry points of the fill take the 32-bit types.
+ * dtype suffixes: i8 u8 i16 u16 i32 u32 f32 everywhere; f64 i64 u64 additionally for the fill (exact: f64 through the f32
+ * engine when the values fit, 64-bit values through dense value ranks otherwise), for d8_flow_directions, flat
+ * resolution, ResolveFlatsEpsilon and FA_D8 / FM_D8 (these compare elevations in their own type); the D-infinity / MFD
+ * families take i8 ... f64.  The row-block shard entry points of the fill take the 8 / 16 / 32-bit types.
  *
  * Threading: one host thread at a time per process (the reference functions
  * are not internally re-entrant on shared arrays either).
@@ -54,6 +55,7 @@ int rdgpu_fill_u16(uint16_t *dem, int width, int height, int topology);
 int rdgpu_fill_i32(int32_t *dem, int width, int height, int topology);
 int rdgpu_fill_u32(uint32_t *dem, int width, int height, int topology);
 int rdgpu_fill_f32(float *dem, int width, int height, int topology);
+int rdgpu_fill_i8(int8_t *dem, int width, int height, int topology);
 /* 64-bit element types: exact as well -- f64 DEMs whose values fit f32 run the f32 engine, everything
  * else is filled on dense ranks of the values (csrc/fill64.hip). */
 int rdgpu_fill_f64(double *dem, int width, int height, int topology);
@@ -66,6 +68,7 @@ int rdgpu_fill_dev_u16(uint16_t *d_dem, int width, int height, int topology, voi
 int rdgpu_fill_dev_i32(int32_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u32(uint32_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_f32(float *d_dem, int width, int height, int topology, void *hip_stream);
+int rdgpu_fill_dev_i8(int8_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_f64(double *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_i64(int64_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, void *hip_stream);
@@ -86,6 +89,7 @@ RDGPU_DECL_MAXDEP(u16, uint16_t)
 RDGPU_DECL_MAXDEP(i32, int32_t)
 RDGPU_DECL_MAXDEP(u32, uint32_t)
 RDGPU_DECL_MAXDEP(f32, float)
+RDGPU_DECL_MAXDEP(i8, int8_t)
 #undef RDGPU_DECL_MAXDEP
 
 /* pit_mask<topology>(const Array2D<T>&, Array2D<uint8_t>&) (depressions/Barnes2014.hpp:593-676,
@@ -100,6 +104,7 @@ RDGPU_DECL_PITMASK(u16, uint16_t)
 RDGPU_DECL_PITMASK(i32, int32_t)
 RDGPU_DECL_PITMASK(u32, uint32_t)
 RDGPU_DECL_PITMASK(f32, float)
+RDGPU_DECL_PITMASK(i8, int8_t)
 #undef RDGPU_DECL_PITMASK
 
 /* ---- PriorityFloodEpsilon_Barnes2014<topology>(Array2D<T>&) ------------------------------------------------------
@@ -144,6 +149,7 @@ RDGPU_DECL_WS(u16, uint16_t)
 RDGPU_DECL_WS(i32, int32_t)
 RDGPU_DECL_WS(u32, uint32_t)
 RDGPU_DECL_WS(f32, float)
+RDGPU_DECL_WS(i8, int8_t)
 #undef RDGPU_DECL_WS
 
 /* Environment switches of the fill (read at every call; for tests and A/B timing, results never change):
@@ -195,6 +201,7 @@ int rdgpu_fill_shard_begin_u16(uint16_t *d_rows, int width, int rows, int topolo
 int rdgpu_fill_shard_begin_i32(int32_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
 int rdgpu_fill_shard_begin_u32(uint32_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
 int rdgpu_fill_shard_begin_f32(float *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
+int rdgpu_fill_shard_begin_i8(int8_t *d_rows, int width, int rows, int topology, int open_top, int open_bottom, void *hip_stream, rdgpu_fill_shard **out);
 int rdgpu_fill_shard_edge_count(rdgpu_fill_shard *shard, uint32_t *n_edges);
 int rdgpu_fill_shard_export(rdgpu_fill_shard *shard, uint32_t *top_keys, uint32_t *bottom_keys, uint32_t *edges);
 int rdgpu_fill_shard_finish(rdgpu_fill_shard *shard, const uint32_t *levels);
@@ -212,12 +219,26 @@ int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, const uint3
                                const uint32_t *d_edges_all, const uint32_t *d_counts, uint32_t cap,
                                uint32_t *d_levels_all, void *hip_stream);
 int rdgpu_fill_shard_finish_dev(rdgpu_fill_shard *shard, const uint32_t *d_levels);
+/* One process, several devices (the reference's tiled driver, programs/parallel_priority_flood/main.cpp:276-330,
+ * :401-547, as a library call): row block s of the host raster goes to devices[s] over that device's own PCIe link,
+ * is filled locally there, the cut rows and spillover graphs are joined and solved on the host, every device raises its
+ * block and returns it.  Same result as rdgpu_fill_<T>, bit for bit.  A device id may be listed more than once.
+ * rdgpu_fill_<T> itself takes this path when the environment holds RDGPU_DEVICES=<id>,<id>,... with two or more ids,
+ * so rdgpu::FillDepressions(Array2D&) and apps/rd_depressions_flood use several GPUs without a change of signature. */
+int rdgpu_fill_multi_u8(uint8_t *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_i16(int16_t *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_u16(uint16_t *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_i32(int32_t *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_u32(uint32_t *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_f32(float *dem, int width, int height, int topology, const int *devices, int ndevices);
+int rdgpu_fill_multi_i8(int8_t *dem, int width, int height, int topology, const int *devices, int ndevices);
 int rdgpu_fill_sharded_u8(uint8_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_i16(int16_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_u16(uint16_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_i32(int32_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_u32(uint32_t *dem, int width, int height, int topology, int nshards);
 int rdgpu_fill_sharded_f32(float *dem, int width, int height, int topology, int nshards);
+int rdgpu_fill_sharded_i8(int8_t *dem, int width, int height, int topology, int nshards);
 
 /* ---- d8_flow_directions(const Array2D<T>&, Array2D<uint8_t>&) ------------------------------
  * Replaces richdem::d8_flow_directions / d8_FlowDir (include/richdem/flowmet/d8_flowdirs.hpp:96-123,
@@ -230,6 +251,9 @@ int rdgpu_d8_flowdirs_i32(const int32_t *dem, int32_t nodata, int width, int hei
 int rdgpu_d8_flowdirs_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs);
 int rdgpu_d8_flowdirs_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs);
 int rdgpu_d8_flowdirs_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_i8(const int8_t *dem, int8_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_i64(const int64_t *dem, int64_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_d8_flowdirs_u64(const uint64_t *dem, uint64_t nodata, int width, int height, uint8_t *dirs);
 int rdgpu_d8_flowdirs_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_d8_flowdirs_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_d8_flowdirs_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
@@ -237,6 +261,9 @@ int rdgpu_d8_flowdirs_dev_i32(const int32_t *d_dem, int32_t nodata, int width, i
 int rdgpu_d8_flowdirs_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_d8_flowdirs_dev_f32(const float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_d8_flowdirs_dev_f64(const double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_i8(const int8_t *d_dem, int8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_i64(const int64_t *d_dem, int64_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_d8_flowdirs_dev_u64(const uint64_t *d_dem, uint64_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 
 /* ---- barnes_flat_resolution_d8(Array2D<T>& elevations, Array2D<uint8_t>& flowdirs, alter=false) --
  * Replaces richdem::barnes_flat_resolution_d8 (include/richdem/flats/flat_resolution.hpp:587-605) with
@@ -253,6 +280,9 @@ int rdgpu_flat_resolution_d8_i32(const int32_t *dem, int32_t nodata, int width, 
 int rdgpu_flat_resolution_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs);
 int rdgpu_flat_resolution_d8_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs);
 int rdgpu_flat_resolution_d8_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_i8(const int8_t *dem, int8_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_i64(const int64_t *dem, int64_t nodata, int width, int height, uint8_t *dirs);
+int rdgpu_flat_resolution_d8_u64(const uint64_t *dem, uint64_t nodata, int width, int height, uint8_t *dirs);
 int rdgpu_flat_resolution_d8_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_flat_resolution_d8_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_flat_resolution_d8_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
@@ -260,6 +290,9 @@ int rdgpu_flat_resolution_d8_dev_i32(const int32_t *d_dem, int32_t nodata, int w
 int rdgpu_flat_resolution_d8_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_flat_resolution_d8_dev_f32(const float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_flat_resolution_d8_dev_f64(const double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_i8(const int8_t *d_dem, int8_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_i64(const int64_t *d_dem, int64_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+int rdgpu_flat_resolution_d8_dev_u64(const uint64_t *d_dem, uint64_t nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
 int rdgpu_resolve_flats_u8(const uint8_t *dem, uint8_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 int rdgpu_resolve_flats_i16(const int16_t *dem, int16_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 int rdgpu_resolve_flats_u16(const uint16_t *dem, uint16_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
@@ -267,6 +300,9 @@ int rdgpu_resolve_flats_i32(const int32_t *dem, int32_t nodata, int width, int h
 int rdgpu_resolve_flats_u32(const uint32_t *dem, uint32_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 int rdgpu_resolve_flats_f32(const float *dem, float nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 int rdgpu_resolve_flats_f64(const double *dem, double nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_i8(const int8_t *dem, int8_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_i64(const int64_t *dem, int64_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
+int rdgpu_resolve_flats_u64(const uint64_t *dem, uint64_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 
 /* alter == true (flat_resolution.hpp:597-600 + d8_flats_alter_dem :545-582): the DEM is raised in place by
  * flat_mask increments of nextafterf inside drainable flats, then plain D8 directions are taken on it.
@@ -299,6 +335,9 @@ RDGPU_DECL_RFE(i32, int32_t)
 RDGPU_DECL_RFE(u32, uint32_t)
 RDGPU_DECL_RFE(f32, float)
 RDGPU_DECL_RFE(f64, double)
+RDGPU_DECL_RFE(i8, int8_t)
+RDGPU_DECL_RFE(i64, int64_t)
+RDGPU_DECL_RFE(u64, uint64_t)
 #undef RDGPU_DECL_RFE
 
 /* ---- flat resolution over row-block shards ---------------------------
@@ -319,6 +358,9 @@ int rdgpu_flat_shard_begin_i32(const int32_t *d_rows, int32_t nodata, int width,
 int rdgpu_flat_shard_begin_u32(const uint32_t *d_rows, uint32_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
 int rdgpu_flat_shard_begin_f32(const float *d_rows, float nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
 int rdgpu_flat_shard_begin_f64(const double *d_rows, double nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_i8(const int8_t *d_rows, int8_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_i64(const int64_t *d_rows, int64_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
+int rdgpu_flat_shard_begin_u64(const uint64_t *d_rows, uint64_t nodata, int width, int rows, int ghost_top, int ghost_bottom, void *hip_stream, rdgpu_flat_shard **out);
 int rdgpu_flat_shard_relax(rdgpu_flat_shard *shard, int phase);
 int rdgpu_flat_shard_boundary(rdgpu_flat_shard *shard, int phase, int32_t *d_out_2w);
 int rdgpu_flat_shard_inject(rdgpu_flat_shard *shard, int phase, const int32_t *d_row_above, const int32_t *d_row_below);
@@ -377,6 +419,9 @@ int rdgpu_fa_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, d
 int rdgpu_fa_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, double *accum);
 int rdgpu_fa_d8_f32(const float *dem, float nodata, int width, int height, double *accum);
 int rdgpu_fa_d8_f64(const double *dem, double nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_i8(const int8_t *dem, int8_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_i64(const int64_t *dem, int64_t nodata, int width, int height, double *accum);
+int rdgpu_fa_d8_u64(const uint64_t *dem, uint64_t nodata, int width, int height, double *accum);
 /* FM_D8 alone (richdem::FM_D8, flowmet/OCallaghan1984.hpp:81-84) as the 9-float proportions array */
 int rdgpu_fm_d8_u8(const uint8_t *dem, uint8_t nodata, int width, int height, float *props9);
 int rdgpu_fm_d8_i16(const int16_t *dem, int16_t nodata, int width, int height, float *props9);
@@ -385,6 +430,9 @@ int rdgpu_fm_d8_i32(const int32_t *dem, int32_t nodata, int width, int height, f
 int rdgpu_fm_d8_u32(const uint32_t *dem, uint32_t nodata, int width, int height, float *props9);
 int rdgpu_fm_d8_f32(const float *dem, float nodata, int width, int height, float *props9);
 int rdgpu_fm_d8_f64(const double *dem, double nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_i8(const int8_t *dem, int8_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_i64(const int64_t *dem, int64_t nodata, int width, int height, float *props9);
+int rdgpu_fm_d8_u64(const uint64_t *dem, uint64_t nodata, int width, int height, float *props9);
 int rdgpu_fa_d8_dev_u8(const uint8_t *d_dem, uint8_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_i16(const int16_t *d_dem, int16_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_u16(const uint16_t *d_dem, uint16_t nodata, int width, int height, double *d_accum, void *hip_stream);
@@ -392,6 +440,9 @@ int rdgpu_fa_d8_dev_i32(const int32_t *d_dem, int32_t nodata, int width, int hei
 int rdgpu_fa_d8_dev_u32(const uint32_t *d_dem, uint32_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_f32(const float *d_dem, float nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_f64(const double *d_dem, double nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_i8(const int8_t *d_dem, int8_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_i64(const int64_t *d_dem, int64_t nodata, int width, int height, double *d_accum, void *hip_stream);
+int rdgpu_fa_d8_dev_u64(const uint64_t *d_dem, uint64_t nodata, int width, int height, double *d_accum, void *hip_stream);
 
 /* ---- D-infinity (Tarboton 1997) and the generic FlowAccumulation ---------------------------------
  * rdgpu_dinf_flowdirs_<T>   replaces richdem::dinf_flow_directions (include/richdem/flowmet/dinf_flowdirs.hpp
@@ -418,6 +469,7 @@ RDGPU_DECL_MFD(i32, int32_t)
 RDGPU_DECL_MFD(u32, uint32_t)
 RDGPU_DECL_MFD(f32, float)
 RDGPU_DECL_MFD(f64, double)
+RDGPU_DECL_MFD(i8, int8_t)
 #undef RDGPU_DECL_MFD
 /* FM_Holmgren(x) / FM_Freeman(x) / FM_Quinn / FM_D4 proportions and the matching FA_* accumulations
  * (flowmet/Holmgren1994.hpp:14, Freeman1991.hpp:14, Quinn1991.hpp:13, OCallaghan1984.hpp:86;
@@ -435,6 +487,7 @@ RDGPU_DECL_MFD2(i32, int32_t)
 RDGPU_DECL_MFD2(u32, uint32_t)
 RDGPU_DECL_MFD2(f32, float)
 RDGPU_DECL_MFD2(f64, double)
+RDGPU_DECL_MFD2(i8, int8_t)
 #undef RDGPU_DECL_MFD2
 int rdgpu_flow_accumulation_f64(const float *props9, int width, int height, double *accum);
 int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int width, int height, double *d_accum, void *hip_stream);

@@ -50,6 +50,7 @@ RDGPU_SHIM_ELEV(f32, float)
 RDGPU_SHIM_ELEV(f64, double)
 RDGPU_SHIM_ELEV(i64, int64_t)
 RDGPU_SHIM_ELEV(u64, uint64_t)
+RDGPU_SHIM_ELEV(i8, int8_t)
 #undef RDGPU_SHIM_ELEV
 template <class T>
 int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
@@ -72,7 +73,17 @@ RDGPU_SHIM_STENCIL(i32, int32_t)
 RDGPU_SHIM_STENCIL(u32, uint32_t)
 RDGPU_SHIM_STENCIL(f32, float)
 RDGPU_SHIM_STENCIL(f64, double)
+RDGPU_SHIM_STENCIL(i8, int8_t)
 #undef RDGPU_SHIM_STENCIL
+#define RDGPU_SHIM_STENCIL64(SUF, T)                                                                       \
+  inline int c_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_d8_flowdirs_##SUF(p, nd, w, h, o); } \
+  inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
+  inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
+  inline int c_rfe(T *p, T nd, int w, int h) { return rdgpu_resolve_flats_epsilon_##SUF(p, nd, w, h); } \
+  inline int c_fm_d8(const T *p, T nd, int w, int h, float *o) { return rdgpu_fm_d8_##SUF(p, nd, w, h, o); }
+RDGPU_SHIM_STENCIL64(i64, int64_t)
+RDGPU_SHIM_STENCIL64(u64, uint64_t)
+#undef RDGPU_SHIM_STENCIL64
 template <class T>
 int c_flowdirs(const T *, T, int, int, uint8_t *) { unsupported("d8_flow_directions"); }
 template <class T>
@@ -102,6 +113,7 @@ RDGPU_SHIM_PITMASK(u16, uint16_t)
 RDGPU_SHIM_PITMASK(i32, int32_t)
 RDGPU_SHIM_PITMASK(u32, uint32_t)
 RDGPU_SHIM_PITMASK(f32, float)
+RDGPU_SHIM_PITMASK(i8, int8_t)
 #undef RDGPU_SHIM_PITMASK
 template <class T>
 int c_pitmask(const T *, T, int, int, int, uint8_t *) { unsupported("pit_mask"); }
@@ -114,6 +126,7 @@ RDGPU_SHIM_MAXDEP(u16, uint16_t)
 RDGPU_SHIM_MAXDEP(i32, int32_t)
 RDGPU_SHIM_MAXDEP(u32, uint32_t)
 RDGPU_SHIM_MAXDEP(f32, float)
+RDGPU_SHIM_MAXDEP(i8, int8_t)
 #undef RDGPU_SHIM_MAXDEP
 template <class T>
 int c_fill_maxdep(T *, int, int, int, uint64_t) { unsupported("PriorityFlood_Barnes2014_max_dep"); }
@@ -126,6 +139,7 @@ RDGPU_SHIM_WS(u16, uint16_t)
 RDGPU_SHIM_WS(i32, int32_t)
 RDGPU_SHIM_WS(u32, uint32_t)
 RDGPU_SHIM_WS(f32, float)
+RDGPU_SHIM_WS(i8, int8_t)
 #undef RDGPU_SHIM_WS
 template <class T>
 int c_watersheds(T *, T, int, int, int, int, int32_t *) { unsupported("PriorityFloodWatersheds_Barnes2014"); }

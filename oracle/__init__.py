@@ -22,6 +22,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 _SUFFIX = {
+    np.dtype(np.int8): "i8",
     np.dtype(np.uint8): "u8",
     np.dtype(np.int16): "i16",
     np.dtype(np.uint16): "u16",
@@ -33,6 +34,7 @@ _SUFFIX = {
     np.dtype(np.uint64): "u64",
 }
 _CT = {
+    "i8": ctypes.c_int8,
     "u8": ctypes.c_uint8,
     "i16": ctypes.c_int16,
     "u16": ctypes.c_uint16,

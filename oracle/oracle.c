@@ -40,6 +40,11 @@ static const int D4Y[5] = {0, 0, -1, 0, 1};
 #include "oracle_impl.h"
 #undef T
 #undef SUF
+#define T int8_t
+#define SUF i8
+#include "oracle_impl.h"
+#undef T
+#undef SUF
 #define T int16_t
 #define SUF i16
 #include "oracle_impl.h"

@@ -199,6 +199,7 @@ void ref_fa_tarboton(const T *dem, T nodata, int w, int h, double *accum) {
   }
 
 REF_ELEV_API(u8, uint8_t)
+REF_ELEV_API(i8, int8_t)
 REF_ELEV_API(i16, int16_t)
 REF_ELEV_API(u16, uint16_t)
 REF_ELEV_API(i32, int32_t)
@@ -273,6 +274,9 @@ void ref_resolve_flats_epsilon(T *dem, T nodata, int w, int h) {
 #define REF_RFE_API(SUF, T) \
   extern "C" void ref_resolve_flats_epsilon_##SUF(T *dem, T nodata, int w, int h) { ref_resolve_flats_epsilon<T>(dem, nodata, w, h); }
 REF_RFE_API(u8, uint8_t)
+REF_RFE_API(i8, int8_t)
+REF_RFE_API(i64, int64_t)
+REF_RFE_API(u64, uint64_t)
 REF_RFE_API(i16, int16_t)
 REF_RFE_API(u16, uint16_t)
 REF_RFE_API(i32, int32_t)
@@ -293,6 +297,7 @@ void ref_pit_mask(const T *dem, T nodata, int w, int h, int topo, uint8_t *out) 
 #define REF_PM_API(SUF, T) \
   extern "C" void ref_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topo, uint8_t *out) { ref_pit_mask<T>(dem, nodata, w, h, topo, out); }
 REF_PM_API(u8, uint8_t)
+REF_PM_API(i8, int8_t)
 REF_PM_API(i16, int16_t)
 REF_PM_API(u16, uint16_t)
 REF_PM_API(i32, int32_t)
@@ -337,6 +342,7 @@ void ref_fill_max_dep(T *dem, int w, int h, int topo, uint64_t max_dep_size) {
     ref_fill_max_dep<T>(dem, w, h, topo, max_dep_size);                                                                       \
   }
 REF_F2_API(u8, uint8_t)
+REF_F2_API(i8, int8_t)
 REF_F2_API(i16, int16_t)
 REF_F2_API(u16, uint16_t)
 REF_F2_API(i32, int32_t)

@@ -12,6 +12,7 @@ import numpy as np
 from ._lib import RdgpuError, check, lib
 
 _SUFFIX = {
+    np.dtype(np.int8): "i8",
     np.dtype(np.uint8): "u8",
     np.dtype(np.int16): "i16",
     np.dtype(np.uint16): "u16",
@@ -23,10 +24,10 @@ _SUFFIX = {
     np.dtype(np.uint64): "u64",
 }
 _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
-_CT = {"u8": ctypes.c_uint8, "i16": ctypes.c_int16, "u16": ctypes.c_uint16, "i32": ctypes.c_int32,
-       "u32": ctypes.c_uint32, "f32": ctypes.c_float, "f64": ctypes.c_double}
-_NP = {"u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32, "f32": np.float32,
-       "f64": np.float64}
+_CT = {"i8": ctypes.c_int8, "u8": ctypes.c_uint8, "i16": ctypes.c_int16, "u16": ctypes.c_uint16, "i32": ctypes.c_int32,
+       "u32": ctypes.c_uint32, "f32": ctypes.c_float, "f64": ctypes.c_double, "i64": ctypes.c_int64, "u64": ctypes.c_uint64}
+_NP = {"i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32, "f32": np.float32,
+       "f64": np.float64, "i64": np.int64, "u64": np.uint64}
 
 
 def _scalar(s: str, nodata):
@@ -47,7 +48,8 @@ def _scalar(s: str, nodata):
     return _CT[s](v)
 
 
-_ELEV_SUFFIX = {k: v for k, v in _SUFFIX.items() if v not in ("i64", "u64")}   # stencil / accumulation entry points
+_ELEV_SUFFIX = dict(_SUFFIX)   # d8 directions, flat resolution, ResolveFlatsEpsilon, FA_D8 / FM_D8: every element type
+_MFD_SUFFIX = {k: v for k, v in _SUFFIX.items() if v not in ("i64", "u64")}   # D-infinity and the MFD families
 _ACC_SUFFIX = {np.dtype(np.int32): "i32", np.dtype(np.float32): "f32", np.dtype(np.float64): "f64"}
 
 
@@ -151,12 +153,12 @@ def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
     return out
 
 
-def _elev(dem, who):
+def _elev(dem, who, mfd: bool = False):
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError(f"{who}: expected a 2-D numpy array")
     dem = np.ascontiguousarray(dem)
     try:
-        return dem, _ELEV_SUFFIX[dem.dtype]
+        return dem, (_MFD_SUFFIX if mfd else _ELEV_SUFFIX)[dem.dtype]
     except KeyError:
         raise RdgpuError(f"{who}: unsupported elevation dtype {dem.dtype}") from None
 
@@ -250,7 +252,7 @@ def d8_flow_accum(dirs: np.ndarray, nodata: int = 255, dtype=np.float64) -> np.n
 
 def dinf_flow_directions(dem: np.ndarray, nodata) -> np.ndarray:
     """float32 D-infinity angles (reference dinf_flow_directions, flowmet/dinf_flowdirs.hpp:128-152)."""
-    dem, s = _elev(dem, "dinf_flow_directions")
+    dem, s = _elev(dem, "dinf_flow_directions", mfd=True)
     h, w = dem.shape
     out = np.empty((h, w), np.float32)
     check(getattr(lib(), f"rdgpu_dinf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
@@ -288,7 +290,7 @@ def FlowProportions(dem: np.ndarray, method: str = "Dinf", nodata=-9999, exponen
     """[h, w, 9] float32 flow proportions (reference ``rd.FlowProportions`` -> FM_Tarboton / FM_D8 /
     FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4, flowmet/*.hpp)."""
     kind, code, xp = _method("FlowProportions", method, exponent)
-    dem, s = _elev(dem, "FlowProportions")
+    dem, s = _elev(dem, "FlowProportions", mfd=kind != "d8")
     h, w = dem.shape
     out = np.empty((h, w, 9), np.float32)
     pd, po = dem.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
@@ -322,7 +324,7 @@ def flow_accumulation_into(dem: np.ndarray, method, nodata, acc: np.ndarray, exp
     """FA_<method>(dem, acc): acc (float64, C-contiguous, dem's shape) holds the flow generated per cell on
     entry and the accumulation on return (methods/flow_accumulation.hpp:16-28)."""
     kind, code, xp = _method("FlowAccumulation", method, exponent)
-    dem, s = _elev(dem, "FlowAccumulation")
+    dem, s = _elev(dem, "FlowAccumulation", mfd=kind != "d8")
     h, w = dem.shape
     if acc.shape != dem.shape:                     # flow_accumulation_generic.hpp:42-43
         raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
@@ -356,8 +358,8 @@ def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights:
 def _torch_suffix(t) -> str:
     import torch
 
-    m = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32", torch.float64: "f64",
-         torch.int64: "i64"}
+    m = {torch.int8: "i8", torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
+         torch.float64: "f64", torch.int64: "i64"}
     if t.dtype not in m:
         raise RdgpuError(f"unsupported tensor dtype {t.dtype}")
     return m[t.dtype]
@@ -404,7 +406,8 @@ def _dev2d(t, who, dtype=None):
 def _torch_elev_suffix(t) -> str:
     import torch
 
-    m = {torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32", torch.float64: "f64"}
+    m = {torch.int8: "i8", torch.uint8: "u8", torch.int16: "i16", torch.int32: "i32", torch.float32: "f32",
+         torch.float64: "f64", torch.int64: "i64"}
     if t.dtype not in m:
         raise RdgpuError(f"unsupported tensor dtype {t.dtype}")
     return m[t.dtype]

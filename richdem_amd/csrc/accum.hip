@@ -1125,3 +1125,6 @@ RD_FA_API(i32, int32_t)
 RD_FA_API(u32, uint32_t)
 RD_FA_API(f32, float)
 RD_FA_API(f64, double)
+RD_FA_API(i8, int8_t)
+RD_FA_API(i64, int64_t)
+RD_FA_API(u64, uint64_t)

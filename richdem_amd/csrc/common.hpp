@@ -164,6 +164,11 @@ struct Key32<uint16_t> {
   __host__ __device__ static inline uint16_t from(uint32_t k) { return (uint16_t)k; }
 };
 template <>
+struct Key32<int8_t> {
+  __host__ __device__ static inline uint32_t to(int8_t v) { return (uint32_t)((int32_t)v + 128); }
+  __host__ __device__ static inline int8_t from(uint32_t k) { return (int8_t)((int32_t)k - 128); }
+};
+template <>
 struct Key32<uint8_t> {
   __host__ __device__ static inline uint32_t to(uint8_t v) { return v; }
   __host__ __device__ static inline uint8_t from(uint32_t k) { return (uint8_t)k; }

@@ -687,11 +687,13 @@ RD_WS_FILL(i16, int16_t)
 RD_WS_FILL(u16, uint16_t)
 RD_WS_FILL(i32, int32_t)
 RD_WS_FILL(u32, uint32_t)
+RD_WS_FILL(i8, int8_t)
 #undef RD_WS_FILL
 
 namespace rdgpu {
 namespace shed {
 static int fill_of(uint8_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_u8(p, w, h, t, s); }
+static int fill_of(int8_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_i8(p, w, h, t, s); }
 static int fill_of(int16_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_i16(p, w, h, t, s); }
 static int fill_of(uint16_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_u16(p, w, h, t, s); }
 static int fill_of(int32_t *p, int w, int h, int t, hipStream_t s) { return rdgpu_fill_dev_i32(p, w, h, t, s); }
@@ -835,3 +837,4 @@ RD_WS_API(u16, uint16_t)
 RD_WS_API(i32, int32_t)
 RD_WS_API(u32, uint32_t)
 RD_WS_API(f32, float)
+RD_WS_API(i8, int8_t)

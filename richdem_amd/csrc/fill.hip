@@ -1780,7 +1780,7 @@ static void fill_host(T *dem, int w, int h, int topology) {
 // shard handle (C-ABI object)
 // ------------------------------------------------------------------------------------------
 struct rdgpu_fill_shard {
-  int dtype = 0;   // 0 u8, 1 i16, 2 u16, 3 i32, 4 u32, 5 f32
+  int dtype = 0;   // 0 u8, 1 i16, 2 u16, 3 i32, 4 u32, 5 f32, 6 i8
   void *d_dem = nullptr;
   int w = 0, h = 0, topology = 8, open_top = 0, open_bottom = 0;
   hipStream_t stream = nullptr;
@@ -1803,6 +1803,7 @@ template <> struct DtypeCode<uint16_t> { static constexpr int v = 2; };
 template <> struct DtypeCode<int32_t> { static constexpr int v = 3; };
 template <> struct DtypeCode<uint32_t> { static constexpr int v = 4; };
 template <> struct DtypeCode<float> { static constexpr int v = 5; };
+template <> struct DtypeCode<int8_t> { static constexpr int v = 6; };
 
 // One shard per process is the multi-GPU case (one rank, one GPU, one row block), and there a fill must not pay
 // hipMalloc / hipFree of its ~5 B/cell of tables on every call: the first live shard keeps its buffers in the
@@ -2094,8 +2095,29 @@ static void shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels2w) {
 
 using namespace rdgpu;
 
+// RDGPU_DEVICES=0,1,2,...: the host-pointer fill (what rdgpu::FillDepressions(Array2D&) and rd_depressions_flood call)
+// spreads its row blocks over these devices (rdgpu_fill_multi_*); unset or one id: the current device
+static std::vector<int> env_devices() {
+  std::vector<int> v;
+  const char *e = getenv("RDGPU_DEVICES");
+  if (!e) return v;
+  for (const char *p = e; *p;) {
+    char *end = nullptr;
+    const long id = strtol(p, &end, 10);
+    if (end == p) break;
+    v.push_back((int)id);
+    p = *end == ',' ? end + 1 : end;
+    if (*end != ',' ) break;
+  }
+  return v;
+}
+
 #define RD_FILL_API(SUF, T)                                                                       \
+  extern "C" int rdgpu_fill_multi_##SUF(T *, int, int, int, const int *, int);                    \
   extern "C" int rdgpu_fill_##SUF(T *dem, int w, int h, int topology) {                           \
+    const std::vector<int> devs = env_devices();                                                  \
+    if (devs.size() > 1 && h >= 2 * (int)devs.size())                                             \
+      return rdgpu_fill_multi_##SUF(dem, w, h, topology, devs.data(), (int)devs.size());          \
     return guarded([&] { fill_host<T>(dem, w, h, topology); });                                   \
   }                                                                                               \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
@@ -2127,6 +2149,7 @@ RD_FILL_API(u16, uint16_t)
 RD_FILL_API(i32, int32_t)
 RD_FILL_API(u32, uint32_t)
 RD_FILL_API(f32, float)
+RD_FILL_API(i8, int8_t)
 
 #define RD_DISPATCH(sh, CALL)                                                  \
   switch ((sh)->dtype) {                                                       \
@@ -2135,6 +2158,7 @@ RD_FILL_API(f32, float)
     case 2: { using T = uint16_t; CALL; } break;                               \
     case 3: { using T = int32_t; CALL; } break;                                \
     case 4: { using T = uint32_t; CALL; } break;                               \
+    case 6: { using T = int8_t; CALL; } break;                                 \
     default: { using T = float; CALL; } break;                                 \
   }
 

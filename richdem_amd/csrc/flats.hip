@@ -1406,6 +1406,7 @@ static void resolve_flats_epsilon_host(T *dem, T nodata, int w, int h) {
 
 #define RD_INST(T) template void flat_resolution_device<T>(const T *, T, int, int, uint8_t *, hipStream_t);
 RD_INST(uint8_t) RD_INST(int16_t) RD_INST(uint16_t) RD_INST(int32_t) RD_INST(uint32_t) RD_INST(float) RD_INST(double)
+RD_INST(int8_t) RD_INST(int64_t) RD_INST(uint64_t)
 #undef RD_INST
 
 }  // namespace rdgpu
@@ -1431,6 +1432,9 @@ RD_FLATS_API(i32, int32_t)
 RD_FLATS_API(u32, uint32_t)
 RD_FLATS_API(f32, float)
 RD_FLATS_API(f64, double)
+RD_FLATS_API(i8, int8_t)
+RD_FLATS_API(i64, int64_t)
+RD_FLATS_API(u64, uint64_t)
 
 #define RD_FLATS_ALTER_API(SUF, T)                                                                             \
   extern "C" int rdgpu_flat_resolution_d8_alter_##SUF(T *dem, T nodata, int w, int h, uint8_t *dirs) {         \
@@ -1458,6 +1462,9 @@ RD_RFE_API(i32, int32_t)
 RD_RFE_API(u32, uint32_t)
 RD_RFE_API(f32, float)
 RD_RFE_API(f64, double)
+RD_RFE_API(i8, int8_t)
+RD_RFE_API(i64, int64_t)
+RD_RFE_API(u64, uint64_t)
 
 #define RD_FLATSHARD_API(SUF, T)                                                                                       \
   extern "C" int rdgpu_flat_shard_begin_##SUF(const T *d_rows, T nodata, int w, int rows, int ghost_top,               \
@@ -1474,6 +1481,9 @@ RD_FLATSHARD_API(i32, int32_t)
 RD_FLATSHARD_API(u32, uint32_t)
 RD_FLATSHARD_API(f32, float)
 RD_FLATSHARD_API(f64, double)
+RD_FLATSHARD_API(i8, int8_t)
+RD_FLATSHARD_API(i64, int64_t)
+RD_FLATSHARD_API(u64, uint64_t)
 
 extern "C" int rdgpu_flat_shard_relax(rdgpu_flat_shard *f, int phase) {
   return guarded([&] { fs_check(f, phase, "rdgpu_flat_shard_relax"); f->relax_fn(f, phase); });

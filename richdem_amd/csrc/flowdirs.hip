@@ -97,6 +97,7 @@ void flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, int 
 
 #define RD_INST(T) template void flowdirs_device<T>(const T *, T, int, int, uint8_t *, int, hipStream_t);
 RD_INST(uint8_t) RD_INST(int16_t) RD_INST(uint16_t) RD_INST(int32_t) RD_INST(uint32_t) RD_INST(float) RD_INST(double)
+RD_INST(int8_t) RD_INST(int64_t) RD_INST(uint64_t)
 #undef RD_INST
 
 template <class T>
@@ -131,3 +132,6 @@ RD_FLOWDIRS_API(i32, int32_t)
 RD_FLOWDIRS_API(u32, uint32_t)
 RD_FLOWDIRS_API(f32, float)
 RD_FLOWDIRS_API(f64, double)
+RD_FLOWDIRS_API(i8, int8_t)
+RD_FLOWDIRS_API(i64, int64_t)
+RD_FLOWDIRS_API(u64, uint64_t)

@@ -586,6 +586,7 @@ RD_MFD_API(i32, int32_t)
 RD_MFD_API(u32, uint32_t)
 RD_MFD_API(f32, float)
 RD_MFD_API(f64, double)
+RD_MFD_API(i8, int8_t)
 
 #define RD_MFD2_API(SUF, T)                                                                                     \
   extern "C" int rdgpu_fm_mfd_dev_##SUF(const T *d_dem, T nodata, int w, int h, int method, double xparam,      \
@@ -643,6 +644,7 @@ RD_MFD2_API(i32, int32_t)
 RD_MFD2_API(u32, uint32_t)
 RD_MFD2_API(f32, float)
 RD_MFD2_API(f64, double)
+RD_MFD2_API(i8, int8_t)
 
 // FlowAccumulation(const Array3D<float>&, Array2D<double>&), methods/flow_accumulation_generic.hpp:33-100
 extern "C" int rdgpu_flow_accumulation_dev_f64(const float *d_props9, int w, int h, double *d_accum, void *st) {

@@ -156,6 +156,74 @@ static void fill_sharded_host(T *dem, int w, int h, int topology, int nshards, B
   RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));
 }
 
+// The same protocol over SEVERAL devices driven by this one process (the role of the reference's
+// programs/parallel_priority_flood producer + consumers, main.cpp:276-330, :401-547): row block s lives on devices[s],
+// is uploaded over that device's own PCIe link, filled locally there, the cut rows and spillover graphs meet on the
+// host, the solved levels go back, and every device raises and returns its block.  A device may be listed more than
+// once (its blocks are then handled one after the other: what the one-GPU tests do).
+template <class T, class Begin>
+static void fill_multi_host(T *dem, int w, int h, int topology, const int *devices, int ndev, Begin begin) {
+  if (!dem || w <= 0 || h <= 0 || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: bad arguments");
+  if (ndev < 1 || (ndev > 1 && h / ndev < 2)) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: need >= 2 rows per device");
+  int ndevices = 0, home = 0;
+  RD_HIP(hipGetDeviceCount(&ndevices));
+  RD_HIP(hipGetDevice(&home));
+  for (int s = 0; s < ndev; s++)
+    if (devices[s] < 0 || devices[s] >= ndevices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: no such device");
+  std::vector<rdgpu_fill_shard *> sh(ndev, nullptr);
+  std::vector<T *> blk(ndev, nullptr);
+  std::vector<hipStream_t> st(ndev, nullptr);
+  std::vector<int> r0(ndev + 1);
+  for (int s = 0; s <= ndev; s++) r0[s] = (int)((int64_t)h * s / ndev);
+  auto cleanup = [&]() {
+    for (int s = 0; s < ndev; s++) {
+      (void)hipSetDevice(devices[s]);
+      if (sh[s]) rdgpu_fill_shard_free(sh[s]);
+      if (st[s]) { (void)hipStreamSynchronize(st[s]); (void)hipStreamDestroy(st[s]); }
+    }
+    (void)hipSetDevice(home);
+  };
+  try {
+    const size_t per = (size_t)2 * w;
+    std::vector<uint32_t> keys((size_t)ndev * per, 0), levels((size_t)ndev * per, 0), edges;
+    std::vector<uint64_t> offs(ndev + 1, 0);
+    // uploads first, every block on its device's own stream (they overlap when the caller's buffer is pinned) ...
+    for (int s = 0; s < ndev; s++) {
+      RD_HIP(hipSetDevice(devices[s]));
+      const size_t cells = (size_t)(r0[s + 1] - r0[s]) * w;
+      blk[s] = Workspace::get().buf<T>(("multi.block." + std::to_string(s)).c_str(), cells);
+      RD_HIP(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
+      RD_HIP(hipMemcpyAsync(blk[s], dem + (size_t)r0[s] * w, cells * sizeof(T), hipMemcpyHostToDevice, st[s]));
+    }
+    // ... then the local phases
+    for (int s = 0; s < ndev; s++) {
+      RD_HIP(hipSetDevice(devices[s]));
+      const int rc = begin(blk[s], w, r0[s + 1] - r0[s], topology, s > 0, s + 1 < ndev, st[s], &sh[s]);
+      if (rc) throw Error(rc, rdgpu_last_error());
+      uint32_t ne = 0;
+      rdgpu_fill_shard_edge_count(sh[s], &ne);
+      offs[s + 1] = offs[s] + ne;
+      edges.resize((size_t)offs[s + 1] * 3);
+      const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
+                                              ne ? &edges[(size_t)offs[s] * 3] : nullptr);
+      if (rc2) throw Error(rc2, rdgpu_last_error());
+    }
+    graph_solve(ndev, w, topology, keys.data(), edges.data(), offs.data(), levels.data());
+    for (int s = 0; s < ndev; s++) {
+      RD_HIP(hipSetDevice(devices[s]));
+      rdgpu_fill_shard *p = sh[s];
+      sh[s] = nullptr;
+      const int rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);   // synchronises the block's stream
+      if (rc) throw Error(rc, rdgpu_last_error());
+      RD_HIP(hipMemcpyAsync(dem + (size_t)r0[s] * w, blk[s], (size_t)(r0[s + 1] - r0[s]) * w * sizeof(T), hipMemcpyDeviceToHost, st[s]));
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
 }  // namespace rdgpu
 
 using namespace rdgpu;
@@ -175,9 +243,29 @@ extern "C" int rdgpu_fill_graph_solve(int nshards, int width, int topology, cons
                            });                                                                              \
     });                                                                                                     \
   }
+#undef RD_SHARDED_API
+#define RD_SHARDED_API(SUF, T)                                                                              \
+  extern "C" int rdgpu_fill_shard_begin_##SUF(T *, int, int, int, int, int, void *, rdgpu_fill_shard **);   \
+  extern "C" int rdgpu_fill_sharded_##SUF(T *dem, int w, int h, int topology, int nshards) {                \
+    return guarded([&] {                                                                                    \
+      fill_sharded_host<T>(dem, w, h, topology, nshards,                                                    \
+                           [](T *d, int w_, int h_, int t, int ot, int ob, rdgpu_fill_shard **o) {          \
+                             return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, nullptr, o);         \
+                           });                                                                              \
+    });                                                                                                     \
+  }                                                                                                         \
+  extern "C" int rdgpu_fill_multi_##SUF(T *dem, int w, int h, int topology, const int *devices, int ndev) { \
+    return guarded([&] {                                                                                    \
+      fill_multi_host<T>(dem, w, h, topology, devices, ndev,                                                \
+                         [](T *d, int w_, int h_, int t, int ot, int ob, hipStream_t st, rdgpu_fill_shard **o) { \
+                           return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, (void *)st, o);        \
+                         });                                                                                \
+    });                                                                                                     \
+  }
 RD_SHARDED_API(u8, uint8_t)
 RD_SHARDED_API(i16, int16_t)
 RD_SHARDED_API(u16, uint16_t)
 RD_SHARDED_API(i32, int32_t)
 RD_SHARDED_API(u32, uint32_t)
 RD_SHARDED_API(f32, float)
+RD_SHARDED_API(i8, int8_t)

@@ -256,12 +256,38 @@ int main() {
     EXPECT(threw);
     std::remove(path.c_str());
   }
-  // unsupported element type -> std::runtime_error, the reference's error convention
+  // int8_t DEMs (bound by the reference, wrappers/pyrichdem/src/pywrapper.cpp:25-45) run; what the engine does not take
+  // -> std::runtime_error, the reference's error convention (Priority-Flood+Epsilon on integers: Barnes2014.hpp:424-451)
   {
     Arr<int8_t> d(8, 8, 1);
+    d(3, 3) = -5;
+    rdgpu::FillDepressions<Topo::D8>(d);
+    EXPECT(d(3, 3) == 1);
     bool threw = false;
-    try { rdgpu::FillDepressions<Topo::D8>(d); } catch (const std::runtime_error &) { threw = true; }
+    try { rdgpu::PriorityFloodEpsilon_Barnes2014<Topo::D8>(d); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
+    Arr<int64_t> e(8, 8, 1);
+    Arr<uint8_t> m;
+    threw = false;
+    try { rdgpu::pit_mask<Topo::D8>(e, m); } catch (const std::runtime_error &) { threw = true; }
+    EXPECT(threw);
+  }
+  // the other outputs of the sweep through the shim: epsilon fill, bounded depressions, watershed labels
+  {
+    Arr<float> d(9, 9, 10.0f);
+    d(4, 4) = 1.0f; d(4, 5) = 2.0f;
+    Arr<float> e = d;
+    rdgpu::PriorityFloodEpsilon_Barnes2014<Topo::D8>(e);
+    EXPECT(e(4, 4) > 10.0f && e(4, 5) > 10.0f && e(0, 0) == 10.0f);
+    Arr<float> f = d;
+    rdgpu::PriorityFlood_Barnes2014_max_dep<Topo::D8>(f, 1);      // the pit has two cells: left alone
+    EXPECT(f(4, 4) == 1.0f);
+    rdgpu::PriorityFlood_Barnes2014_max_dep<Topo::D8>(f, 2);
+    EXPECT(f(4, 4) == 10.0f && f(4, 5) == 10.0f);
+    Arr<int32_t> lab;
+    Arr<float> g = d;
+    rdgpu::PriorityFloodWatersheds_Barnes2014<Topo::D8>(g, lab, true);
+    EXPECT(lab.width() == 9 && lab.noData() == -1 && lab(0, 0) >= 1 && g(4, 4) == 10.0f);
   }
   std::printf(failures ? "shim_test: %d FAILURES\n" : "shim_test: all checks passed\n", failures);
   return failures ? 1 : 0;

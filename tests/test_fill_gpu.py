@@ -386,3 +386,31 @@ def test_pair_list_rounds_equal_raster_rounds(rd, orc, topo):
         assert np.array_equal(got, exp) and st["edge_records"] == 0, st
         got, st = _with_env(rd, {"RDGPU_FILL_EDGE_CAP": "64"}, dem, topo)  # far too small: overflow -> raster rounds
         assert np.array_equal(got, exp) and st["edge_records"] == 0, st
+
+
+def test_multi_device_entry_on_one_gpu(rd, orc, monkeypatch):
+    """rdgpu_fill_multi_<T> (one process, a list of devices; the reference's tiled driver as a library call): with device
+    0 listed several times the row blocks go through exactly the multi-device code -- per-block streams, the host graph
+    solve, the per-block finish -- and the result equals the single-block fill bit for bit.  RDGPU_DEVICES routes the
+    plain host entry (what rdgpu::FillDepressions(Array2D&) calls) the same way."""
+    import ctypes
+
+    from richdem_amd._lib import check, lib
+
+    z = fractal_dem(700, 530, seed=41)
+    exp = orc.port.fill(z, 8)
+    for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        a = z.copy()
+        arr = (ctypes.c_int * len(devs))(*devs)
+        check(lib().rdgpu_fill_multi_f32(a.ctypes.data_as(ctypes.c_void_p), 700, 530, 8, arr, len(devs)), "rdgpu_fill_multi_f32")
+        assert np.array_equal(a, exp), devs
+    q = np.floor((z - z.min()) * 0.05).astype(np.int16)
+    a = q.copy()
+    arr = (ctypes.c_int * 3)(0, 0, 0)
+    check(lib().rdgpu_fill_multi_i16(a.ctypes.data_as(ctypes.c_void_p), 700, 530, 4, arr, 3), "rdgpu_fill_multi_i16")
+    assert a.tobytes() == orc.port.fill(q, 4).tobytes()
+    monkeypatch.setenv("RDGPU_DEVICES", "0,0,0")
+    assert np.array_equal(rd.FillDepressions(z), exp)
+    monkeypatch.delenv("RDGPU_DEVICES")
+    arr = (ctypes.c_int * 2)(0, 99)
+    assert lib().rdgpu_fill_multi_f32(z.copy().ctypes.data_as(ctypes.c_void_p), 700, 530, 8, arr, 2) != 0

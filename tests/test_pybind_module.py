@@ -130,7 +130,7 @@ def test_out_of_scope_functions_raise(R):
     with pytest.raises(RuntimeError, match="only available for floating-point"):   # Barnes2014.hpp:424-451
         R.rdPFepsilonD8(R.Array2D_int32_t(np.zeros((3, 3), np.int32)))
     with pytest.raises(RuntimeError, match="element type not supported"):   # bound for every type, as in the reference
-        R.rdFillDepressionsD8(R.Array2D_int8_t(np.zeros((3, 3), np.int8)))
+        R.FA_Quinn(R.Array2D_int64_t(np.zeros((3, 3), np.int64)), R.Array2D_double(np.ones((3, 3))))
     with pytest.raises(RuntimeError, match="same dimensions"):              # flow_accumulation_generic.hpp:42-43
         R.FA_D8(dem, R.Array2D_double(np.ones((4, 5))))
     with pytest.raises(TypeError):                                            # accumulation is Array2D<double> only
