@@ -190,23 +190,38 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   // independent LDS reads (the latency of a dependent read chain per cell was what bounded this loop).
   // Two hops per trip (c -> p -> q -> r): the barrier, not the LDS reads, is what a trip costs, and the hop distance
   // triples instead of doubling per trip.
+  // A cell is finished for good once its pointer names a tile root (or it is one itself); a ROW of the wavefront's band
+  // whose 64 cells are all finished is skipped with one scalar test -- this loop is instruction-issue bound (r02a SQ
+  // counters: 2.4 k VALU instructions per wavefront, half of them here), and after two or three trips most rows are done.
+  uint32_t act = 0;   // bit j: the cell of row ly0 + j may still move
+#pragma unroll
+  for (int j = 0; j < DH / 4; j++) act |= (lp[(ly0 + j) * DW + lx] < LTERM_BASE ? 1u : 0u) << j;
   for (int it = 0; it < 12; it++) {
-    uint16_t pv[DH / 4], qv[DH / 4], rv[DH / 4];
-#pragma unroll
-    for (int j = 0; j < DH / 4; j++) pv[j] = lp[(ly0 + j) * DW + lx];
-#pragma unroll
-    for (int j = 0; j < DH / 4; j++) qv[j] = lp[pv[j] < LTERM_BASE ? pv[j] : (ly0 + j) * DW + lx];
-#pragma unroll
-    for (int j = 0; j < DH / 4; j++) rv[j] = lp[qv[j] < LTERM_BASE ? qv[j] : (ly0 + j) * DW + lx];
     int still = 0;
 #pragma unroll
-    for (int j = 0; j < DH / 4; j++)
-      if (pv[j] < LTERM_BASE && qv[j] < LTERM_BASE) {
-        // q is not the tile root of the path yet?  then r is a cell further down: jump there and come back
-        const bool more = rv[j] < LTERM_BASE;
-        lp[(ly0 + j) * DW + lx] = more ? rv[j] : qv[j];
-        still |= more ? 1 : 0;
+    for (int g = 0; g < DH / 16; g++) {   // groups of four rows: batched LDS reads inside, one scalar test outside
+      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;   // wave uniform
+      uint16_t pv[4], qv[4], rv[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LTERM_BASE ? pv[e] : (ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LTERM_BASE ? qv[e] : (ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * g + e;
+        if (pv[e] < LTERM_BASE && qv[e] < LTERM_BASE) {
+          // q is not the tile root of the path yet?  then r is a cell further down: jump there and come back
+          const bool more = rv[e] < LTERM_BASE;
+          lp[(ly0 + j) * DW + lx] = more ? rv[e] : qv[e];
+          if (more) still = 1;
+          else act &= ~(1u << j);
+        } else {
+          act &= ~(1u << j);
+        }
       }
+    }
     if (!__syncthreads_or(still)) break;
   }
   // Pits (and a shard's cut-row terminals) -- the cells that are their own root -- get their dense basin id here:
