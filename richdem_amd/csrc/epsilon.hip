@@ -369,12 +369,15 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
 #pragma unroll
     for (int sub = 0; sub < HSTEPS; sub++) {
       K mn[ROWS];
+      int moved = 0;
       neigh_min(up, dn, mn);
 #pragma unroll
       for (int j = 0; j < ROWS; j++) {
         const K cand = kmax(zk[j], step_up<P>(mn[j]));
-        if ((free_ & (1u << j)) && cand < d[j]) { d[j] = cand; changed = 1; }
+        if ((free_ & (1u << j)) && cand < d[j]) { d[j] = cand; moved = 1; }
       }
+      changed |= moved;
+      if (!__any(moved)) break;   // the remaining steps of this trip would compute the same values
     }
   }
   if (it == IT_CAP && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
