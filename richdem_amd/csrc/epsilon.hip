@@ -49,7 +49,7 @@ namespace eps {
 constexpr int NT = 256;
 constexpr int CW = 64, RCH = 32, RBANDS = NT / 64, ROWS = RCH / RBANDS;
 constexpr int RW = CW + 2, RH = RCH + 2;
-constexpr int HSTEPS = 4;
+constexpr int HSTEPS = 8;
 constexpr int BATCH = 8;
 
 // ---- contiguous order-preserving keys -------------------------------------------------------------------------

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_mark_low(const uint32_t *__restri
 // ------------------------------------------------------------------------------------------
 constexpr int32_t DINF = 0x7F7F7F7F;   // memset-able "not reached"
 constexpr int RCH = 32;                // relaxation tiles are CW x RCH (the labelling tiles CW x CH)
-constexpr int HSTEPS = 4;              // stencil steps per barrier inside a relaxation tile
+constexpr int HSTEPS = 8;              // stencil steps per barrier inside a relaxation tile (a step without a move ends them early)
 constexpr int RNT = 256, RBANDS = RNT / 64;   // one wavefront per band of RCH / RBANDS rows
 constexpr int RELAX_BATCH = 8;         // relaxation rounds enqueued per host read-back
 
@@ -435,7 +435,9 @@ __global__ __launch_bounds__(NTHR) void k_flat_init_towards(const uint8_t *__res
 // (Measured and dropped, r02, all correct: min-plus scans along the rows inside this kernel -- a front then crosses the
 // tile width in one trip -- with ds_bpermute shuffles or with DPP row shifts + v_readlane: 2.5-3x SLOWER at S3, because
 // with one stencil step per trip the diagonal fronts of open lakes take 32 trips instead of 8; and one wavefront per
-// tile running chamfer sweeps over rows kept in LDS, no barriers at all: 1.4x slower, 89 + 46 ms against 60 + 33 ms.)
+// tile running chamfer sweeps over rows kept in LDS, no barriers at all: 1.4x slower, 89 + 46 ms against 60 + 33 ms; a
+// block that follows the front -- goes on with the tile across a changed edge, up to four tiles per launch, minimum
+// writes -- saved 7 % of the rounds and doubled the relaxations of the full rounds: 76 + 48 ms against 54 + 26 ms.)
 constexpr int32_t DWALL = DINF + 1;   // LDS only: a cell that does not take part
 __device__ __forceinline__ void relax_tile(const uint8_t *__restrict__ dirs, int32_t *D, const uint32_t t,
                                            uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY, int row_lo,
