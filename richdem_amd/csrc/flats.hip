@@ -23,6 +23,8 @@
 #include "flowdirs.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <climits>
 #include <cstring>
 
 namespace rdgpu {
@@ -643,6 +645,75 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs(const T *__restrict__ z, con
   }
 }
 
+// Directions straight from the two level fields (the directions-only path of barnes_flat_resolution_d8): inside one flat
+// flat_mask = (flat_height - away) + 2 * towards differs from 2 * towards - away by the flat's constant, low edges
+// (towards level 1) hold mask 2 -- below every NO_FLOW cell of their flat, whose towards level is at least 2 -- and
+// d8_masked_FlowDir (:42-65) only COMPARES masks of cells of one flat.  So neither the flat heights nor the labels
+// behind them (k_ccl_*, k_flat_height, k_flat_combine: 45 ms of the stage at S3) are needed for the directions.
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__ z, const int32_t *__restrict__ TW,
+                                                           const int32_t *__restrict__ AW, uint8_t *dirs, int w, int h,
+                                                           uint32_t tilesX, uint32_t ntiles) {
+  __shared__ T sz[SLH * SLW];
+  __shared__ int32_t sm[SLH * SLW];
+  constexpr int32_t LOWEDGE = INT32_MIN, NOTFLAT = INT32_MAX;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
+  {
+    constexpr int IPT = (SLH * SLW + NTHR - 1) / NTHR;
+    T zv[IPT];
+    int32_t tv[IPT], av[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {   // all loads of the thread in flight together (clamped addresses)
+      const int i = min((int)threadIdx.x + r * NTHR, SLH * SLW - 1);
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
+      const size_t g = (size_t)gy * w + gx;
+      zv[r] = z[g];
+      tv[r] = TW[g];
+      av[r] = AW ? AW[g] : DINF;
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i >= SLH * SLW) continue;
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      sz[i] = in ? zv[r] : T();
+      sm[i] = (!in || tv[r] >= DINF) ? NOTFLAT : tv[r] == 1 ? LOWEDGE : 2 * tv[r] - (av[r] < DINF ? av[r] : 0);
+    }
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
+  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+#pragma unroll
+  for (int j = 0; j < SH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) continue;   // interior only (:108-109)
+    const int o = (ly + 1) * SLW + lx + 1;
+    const int32_t mc = sm[o];
+    if (mc == NOTFLAT || mc == LOWEDGE) continue;     // not a NO_FLOW cell of a drainable flat (low edges keep their direction, :112)
+    const T e = sz[o];
+    int32_t m = mc;
+    int dir = 0;
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {
+      if (!(sz[o + off[k]] == e)) continue;                         // labels(n) != labels(c), :56-57
+      const int32_t v = sm[o + off[k]];
+      if (v == NOTFLAT) continue;                                   // (an equal neighbour outside the flat cannot occur: kept safe)
+      if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1)) {
+        m = v;
+        dir = k;
+      }
+    }
+    dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+  }
+}
+
 static inline uint32_t stencil_tiles(int w, int h, uint32_t *tilesX) {
   *tilesX = (uint32_t)((w + SW - 1) / SW);
   return *tilesX * (uint32_t)((h + SH - 1) / SH);
@@ -903,11 +974,41 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8: width and height must be positive");
   if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8: raster too large");
   flowdirs_device<T>(d_z, nodata, w, h, d_dirs, MODE_D8, s);
-  int32_t *M, *fh;
-  uint32_t *L;
-  resolve_flats_device<T>(d_z, d_dirs, w, h, &M, &L, &fh, s);
-  if (L)   // there is at least one low edge
-    launch_masked_dirs<T>(d_z, M, d_dirs, w, h, s);
+  const char *env = getenv("RDGPU_FLAT_FULLMASK");   // =1: through the full flat_mask (labels, flat heights): A/B and tests
+  if (env && env[0] == '1') {
+    int32_t *M, *fh;
+    uint32_t *L;
+    resolve_flats_device<T>(d_z, d_dirs, w, h, &M, &L, &fh, s);
+    if (L)   // there is at least one low edge
+      launch_masked_dirs<T>(d_z, M, d_dirs, w, h, s);
+    return;
+  }
+  // directions only: the two level fields suffice (k_flat_dirs_levels)
+  const uint64_t n = (uint64_t)w * h;
+  Workspace &ws = Workspace::get();
+  g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
+  uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
+  launch_classify<T>(d_z, d_dirs, w, h, flags, s);
+  uint32_t *low = nullptr, *highall = nullptr;
+  uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
+  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s);
+  g_fstats.low_edges = nlow;
+  g_fstats.noflow_cells = nnoflow;
+  g_fstats.high_edges = nhigh_all;
+  if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
+  int32_t *TWd = ws.buf<int32_t>("flats.mask", n), *A = nullptr;
+  if (nhigh_all > 0) {
+    // every high edge seeds (the flats without an outlet are not filtered out: that would need their labels; their
+    // cells are never reached by the towards field, so they get no direction either way)
+    A = ws.buf<int32_t>("flats.away", n);
+    RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
+    g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, nullptr, nullptr, w, h, s);
+  }
+  g_fstats.towards_levels = run_relax_towards(d_dirs, flags, TWd, w, h, s);
+  uint32_t tilesX;
+  const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+  RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
+            (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
 }
 
 template <class T>
@@ -920,6 +1021,12 @@ static void flat_resolution_host(const T *dem, T nodata, int w, int h, uint8_t *
   uint8_t *dd = Workspace::get().buf<uint8_t>("host.dirs", n);
   RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
   hipStream_t s = nullptr;
+  if (!mask && !labels) {   // directions only: the path without labels and flat heights
+    flat_resolution_device<T>(d, nodata, w, h, dd, s);
+    RD_HIP(hipStreamSynchronize(s));
+    RD_HIP(hipMemcpy(dirs, dd, n, hipMemcpyDeviceToHost));
+    return;
+  }
   flowdirs_device<T>(d, nodata, w, h, dd, MODE_D8, s);
   int32_t *M, *fh;
   uint32_t *L;
