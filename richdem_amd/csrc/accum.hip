@@ -762,7 +762,39 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
 }
 
 // d_dirs uses 255 as NoData marker (output of flowdirs_device); d_acc holds the per-cell weights on entry.
+__global__ __launch_bounds__(NTHR) void k_acc_not_all_ones(const double *__restrict__ acc, uint64_t n, uint32_t *flag) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  bool other = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < n; i += stride) other |= acc[i] != 1.0;
+  if (__any(other) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+template <class A>
+void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A *d_area, hipStream_t s);
+
+// Weighted accumulation over FM_D8 directions (255 = NoData), in place in d_acc.
+// Every weight 1 -- what FA_D8 is called with unless the caller has weights (the Python wrapper's and the apps'
+// accum.setAll(1)): the directions come from a DEM, so they are loop-free and the sums are d8_flow_accum's cell counts,
+// integers, exact in a double; that goes through the tile links (56 ms instead of 85 at S3).  One read of the weights
+// decides.  Anything else: tile prewalk + raster-wide walk on doubles.  (Tile links on doubles were measured too: three
+// LDS arrays per tile leave 2-3 blocks per CU, 112 ms at S3 -- not kept.)
 void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, hipStream_t s) {
+  {
+    const uint64_t n = (uint64_t)w * h;
+    const char *unit = getenv("RDGPU_ACCUM_UNIT");   // =0: always the weighted path (A/B and tests)
+    if (!(unit && unit[0] == '0')) {
+      uint32_t *flag = Workspace::get().buf<uint32_t>("accum.unit_flag", 1);
+      RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+      RD_LAUNCH("accum.unit_check", k_acc_not_all_ones, dim3(sgrid(n)), dim3(NTHR), 0, s, (const double *)d_acc, n, flag);
+      uint32_t other = 1;
+      RD_HIP(hipMemcpyAsync(&other, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (!other) {
+        d8_flow_accum_device<double>(d_dirs, (uint8_t)255, w, h, d_acc, s);
+        return;
+      }
+    }
+  }
   const uint64_t n = (uint64_t)w * h;
   uint32_t *pending = Workspace::get().buf<uint32_t>("accum.pending", n);
   {

@@ -106,6 +106,24 @@ def test_fa_d8_weights(rd, orc):
         rd.FlowAccumulation(z, "D8", weights=np.ones((3, 3)))
 
 
+def test_fa_d8_unit_weights_take_the_counting_path_with_the_same_result(rd, orc, monkeypatch):
+    """All weights 1 (FA_D8's default) is detected on the device and counted through the tile links; the weighted engine
+    on the same input gives the same doubles, NoData cells and cells draining into NoData included."""
+    z = fractal_dem(900, 700, seed=29)
+    z[300:340, 100:180] = -9999.0
+    z[:, -3:] = -9999.0
+    for dem in (z, orc.port.fill(z)):
+        exp = orc.port.fa_d8(dem, np.float32(-9999))
+        fast = rd.FlowAccumulation(dem, "D8", nodata=-9999)
+        monkeypatch.setenv("RDGPU_ACCUM_UNIT", "0")
+        slow = rd.FlowAccumulation(dem, "D8", nodata=-9999)
+        monkeypatch.delenv("RDGPU_ACCUM_UNIT")
+        assert np.array_equal(fast, exp) and np.array_equal(slow, exp)
+    one_off = np.ones(z.shape)
+    one_off[450, 350] = 1.0 + 2.0 ** -40    # a single weight that is not 1: the weighted path, exactly representable sums
+    assert np.array_equal(rd.FlowAccumulation(z, "D8", nodata=-9999, weights=one_off), orc.port.fa_d8(z, np.float32(-9999), one_off))
+
+
 def test_large_accumulation_exact(rd, orc):
     """3000x3000 filled DEM: long cross-XCD flow paths; exact equality with the oracle for both engines
     (packed-u64 unit path and f64 release/acquire path)."""
