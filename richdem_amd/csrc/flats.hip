@@ -532,22 +532,35 @@ __device__ __forceinline__ void relax_tile(const uint8_t *__restrict__ dirs, int
     }
   }
   if (it == 256 && threadIdx.x == 0) next_active[t] = 1;   // iteration cap hit: finish this tile next round
-  // write back and wake the tiles across every edge that changed
-  int top = 0, bot = 0, lef = 0, rig = 0;
+  // Write back, and wake a neighbouring tile only if a cell that moved here can still lower one of ITS cells: the ring
+  // staged at the start holds that tile's edge levels, and a ring cell at most one above the new level has nothing to
+  // gain (levels only decrease, so a stale ring value can only wake a tile needlessly, never miss one).  Waking on
+  // every changed edge made two tiles that merely agree on their common edge wake each other for another round.
+  __shared__ uint32_t wake;
+  if (threadIdx.x == 0) wake = 0;
+  __syncthreads();
+  uint32_t mine = 0;   // bit (dy + 1) * 3 + (dx + 1): the tile at (tx + dx, ty + dy)
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     if (!(elig & (1u << j)) || d[j] >= d0[j]) continue;
     const int ly = band * ROWS + j;
     const int gx = x0 + lx, gy = y0 + ly;
     __hip_atomic_store(&D[(size_t)gy * w + gx], d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    top |= ly == 0; bot |= ly == RCH - 1; lef |= lx == 0; rig |= lx == CW - 1;
+    if (ly != 0 && ly != RCH - 1 && lx != 0 && lx != CW - 1) continue;
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int ny = ly + dy, nx = lx + dx;
+        const int sy = ny < 0 ? -1 : ny >= RCH ? 1 : 0, sx = nx < 0 ? -1 : nx >= CW ? 1 : 0;
+        if (!sy && !sx) continue;
+        const int32_t r = ring(ny, nx);
+        if (r <= DINF && r > d[j] + 1) mine |= 1u << ((sy + 1) * 3 + sx + 1);
+      }
   }
-  top = __syncthreads_or(top); bot = __syncthreads_or(bot); lef = __syncthreads_or(lef); rig = __syncthreads_or(rig);
-  if (threadIdx.x < 9 && threadIdx.x != 4) {
-    const int dx = (int)threadIdx.x % 3 - 1, dy = (int)threadIdx.x / 3 - 1;
-    const bool need = (dy < 0 ? top : dy > 0 ? bot : 1) && (dx < 0 ? lef : dx > 0 ? rig : 1) && (top | bot | lef | rig);
-    const int ntx = tx + dx, nty = ty + dy;
-    if (need && ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
+  if (mine) atomicOr(&wake, mine);
+  __syncthreads();
+  if (threadIdx.x < 9 && threadIdx.x != 4 && (wake >> threadIdx.x & 1u)) {
+    const int ntx = tx + (int)threadIdx.x % 3 - 1, nty = ty + (int)threadIdx.x / 3 - 1;
+    if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
   }
 }
 
