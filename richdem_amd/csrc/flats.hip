@@ -577,6 +577,317 @@ __global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ 
   relax_tile(dirs, D, tiles[blockIdx.x], next_active, w, h, tilesX, tilesY, row_lo, row_hi);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same fixed point by breadth-first search on BITMAPS, one wavefront per 64 x 64 tile (single-device path; the
+// row-block shards keep k_flat_relax, whose ghost rows are cells with levels that feed but are not relaxed).
+// Lane r holds row r of the tile as 64-bit masks: the cells that take part (M), those not yet reached (A), the current
+// front (F).  One BFS level is   N = dilate8(F) & A   =   two DPP row shifts, two bit shifts and a few ORs for the whole
+// tile -- against ~100 VALU instructions per wavefront and stencil step in k_flat_relax, which r02's traces showed to be
+// what bounds the stage (instruction issue in the full rounds, a lone wavefront's dependent chain in the ~500 tail
+// rounds).  Levels are recorded bit-sliced (plane j collects the cells whose level has bit j set) relative to a base,
+// and turned back into one int per cell when the tile is stored.
+// Sources of a visit: the tile's seeds (a bitmap, from the flags) and the ring of cells around the tile with the levels
+// they hold now -- each is injected at its own level, so the search also runs from several fronts at different depths,
+// skipping the gaps between them.  The levels of the tile's own cells are not read at all: they were computed from
+// older (higher or equal) ring levels, so recomputing from the current ring can only reproduce or lower them.
+// ------------------------------------------------------------------------------------------
+constexpr int BT = 64;   // bitmap tiles are BT x BT
+constexpr int BPLANES = 8;   // level planes: 256 levels per flush
+struct BitsScratch {
+  unsigned long long *mbits, *sbits;   // per tile and row: cells that take part / seeds of the current field
+  uint8_t *tflags;
+  uint32_t *tlist, *ctr, *counts;
+  uint32_t tilesX, tilesY, ntiles;
+};
+
+__device__ __forceinline__ uint32_t dpp_up(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t dpp_dn(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+// lane r receives lane r-1's / lane r+1's mask (0 past the ends)
+__device__ __forceinline__ unsigned long long row_above(unsigned long long v) {
+  return ((unsigned long long)dpp_up((uint32_t)(v >> 32)) << 32) | dpp_up((uint32_t)v);
+}
+__device__ __forceinline__ unsigned long long row_below(unsigned long long v) {
+  return ((unsigned long long)dpp_dn((uint32_t)(v >> 32)) << 32) | dpp_dn((uint32_t)v);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+// val in the lanes whose bit is set in the wave-uniform mask, 0 elsewhere: one v_cndmask on the scalar pair
+__device__ __forceinline__ uint32_t lanes_of(unsigned long long smask, uint32_t val) {
+  uint32_t out;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(out) : "v"(val), "s"(smask));
+  return out;
+}
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = imin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const int32_t u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+  return v;
+}
+
+// Per tile and row: the bitmaps of a field, the start of its levels, the tiles to visit first, and the edge counts.
+// TOWARDS: seeds = F_NEAR (level 2), D = 1 on the low edges; else seeds = F_HIGH (level 1; with L / fh only those of
+// flats that have an outlet, :491-500).  One block per tile, a wavefront per 16 rows, a lane per column.
+template <bool TOWARDS, bool WRITE_M>
+__global__ __launch_bounds__(NTHR) void k_bits_prepare(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ L,
+                                                       const int32_t *__restrict__ fh, int32_t *__restrict__ D,
+                                                       unsigned long long *mbits, unsigned long long *sbits,
+                                                       uint8_t *tile_active, uint32_t *counts, int w, int h, uint32_t tilesX,
+                                                       uint32_t tilesY) {
+  const uint32_t t = blockIdx.x;
+  const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gx = tx * BT + lane;
+  unsigned long long mrow = 0, srow = 0;   // lane j: the masks of row wv * 16 + j
+  uint32_t nlow = 0, nhigh = 0, nnoflow = 0;
+  uint8_t f[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int gy = ty * BT + wv * 16 + j;
+    f[j] = (gx < w && gy < h) ? flags[(size_t)gy * w + gx] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int gy = ty * BT + wv * 16 + j;
+    const bool in = gx < w && gy < h;
+    bool seed = TOWARDS ? (f[j] & F_NEAR) != 0 : (f[j] & F_HIGH) != 0;
+    if (!TOWARDS && fh && seed) seed = fh[L[(size_t)gy * w + gx]] >= 0;
+    const unsigned long long mb = __ballot((f[j] & F_NOFLOW) != 0), sb = __ballot(seed);
+    if (lane == j) { mrow = mb; srow = sb; }
+    if (counts) {
+      const unsigned long long lb = __ballot((f[j] & F_LOW) != 0), hb = __ballot((f[j] & F_HIGH) != 0);
+      nnoflow += (uint32_t)__popcll(mb);   // (wave uniform sums; lane 0 reports them)
+      nlow += (uint32_t)__popcll(lb);
+      nhigh += (uint32_t)__popcll(hb);
+    }
+    if (in) D[(size_t)gy * w + gx] = (TOWARDS && (f[j] & F_LOW)) ? 1 : DINF;
+  }
+  if (lane < 16) {
+    const size_t o = (size_t)t * BT + wv * 16 + lane;
+    if (WRITE_M) mbits[o] = mrow;
+    sbits[o] = srow;
+  }
+  const int any = __syncthreads_or(srow != 0);
+  if (any && threadIdx.x < 9) {
+    const int ntx = tx + (int)threadIdx.x % 3 - 1, nty = ty + (int)threadIdx.x / 3 - 1;
+    if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) tile_active[nty * tilesX + ntx] = 1;
+  }
+  if (counts && lane == 0 && (nlow | nhigh | nnoflow)) {   // striped: same-address atomics serialise
+    uint32_t *c = counts + 3 * ((t * 4 + wv) & 255u);
+    if (nlow) atomicAdd(c, nlow);
+    if (nhigh) atomicAdd(c + 1, nhigh);
+    if (nnoflow) atomicAdd(c + 2, nnoflow);
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void k_bits_counts(const uint32_t *__restrict__ counts, unsigned long long *out) {
+  __shared__ unsigned long long acc[3];
+  if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+  __syncthreads();
+  for (int k = 0; k < 3; k++) atomicAdd(&acc[k], (unsigned long long)counts[3 * threadIdx.x + k]);
+  __syncthreads();
+  if (threadIdx.x < 3) out[threadIdx.x] = acc[threadIdx.x];
+}
+
+template <int SEED_LEVEL>
+__global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *__restrict__ mbits,
+                                                     const unsigned long long *__restrict__ sbits, int32_t *D,
+                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
+                                                     uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
+  const uint32_t n = *count;
+  for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
+  const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = tiles[wi];
+  const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
+  const int x0 = tx * BT, y0 = ty * BT;
+  const bool hasL = tx > 0, hasR = tx + 1 < (int)tilesX, hasT = ty > 0, hasB = ty + 1 < (int)tilesY;
+  const size_t tb = (size_t)t * BT;
+  const unsigned long long M = mbits[tb + lane];
+  const unsigned long long S = sbits[tb + lane] & M;
+  // which ring cells take part: the facing rows / columns / corners of the eight neighbouring tiles' masks
+  const unsigned long long mT = hasT ? mbits[tb - (size_t)tilesX * BT + (BT - 1)] : 0ull;   // (wave uniform)
+  const unsigned long long mB = hasB ? mbits[tb + (size_t)tilesX * BT] : 0ull;
+  const unsigned long long mL = hasL ? mbits[tb - BT + lane] : 0ull;
+  const unsigned long long mR = hasR ? mbits[tb + BT + lane] : 0ull;
+  const bool eTL = hasT && hasL && (mbits[tb - (size_t)tilesX * BT - BT + (BT - 1)] >> 63 & 1ull);
+  const bool eTR = hasT && hasR && (mbits[tb - (size_t)tilesX * BT + BT + (BT - 1)] & 1ull);
+  const bool eBL = hasB && hasL && (mbits[tb + (size_t)tilesX * BT - BT] >> 63 & 1ull);
+  const bool eBR = hasB && hasR && (mbits[tb + (size_t)tilesX * BT + BT] & 1ull);
+  // ring levels (clamped addresses, all loads in flight together) and the tile's own edge levels as they are now
+  const int cx = min(x0 + lane, w - 1), cy = min(y0 + lane, h - 1);
+  const int yT = max(y0 - 1, 0), yB = min(y0 + BT, h - 1), xL = max(x0 - 1, 0), xR = min(x0 + BT, w - 1);
+  const int yl = min(y0 + BT - 1, h - 1), xl = min(x0 + BT - 1, w - 1);
+  int32_t tv = D[(size_t)yT * w + cx], bv = D[(size_t)yB * w + cx], lv = D[(size_t)cy * w + xL], rv = D[(size_t)cy * w + xR];
+  int32_t tl = D[(size_t)yT * w + xL], tr = D[(size_t)yT * w + xR], bl = D[(size_t)yB * w + xL], br = D[(size_t)yB * w + xR];
+  int32_t oldT = D[(size_t)y0 * w + cx], oldB = D[(size_t)yl * w + cx], oldL = D[(size_t)cy * w + x0], oldR = D[(size_t)cy * w + xl];
+  if (!(mT >> lane & 1ull)) tv = DINF;
+  if (!(mB >> lane & 1ull)) bv = DINF;
+  if (!(mL >> 63 & 1ull)) lv = DINF;
+  if (!(mR & 1ull)) rv = DINF;
+  if (!eTL) tl = DINF;
+  if (!eTR) tr = DINF;
+  if (!eBL) bl = DINF;
+  if (!eBR) br = DINF;
+  tl = __builtin_amdgcn_readfirstlane(tl); tr = __builtin_amdgcn_readfirstlane(tr);
+  bl = __builtin_amdgcn_readfirstlane(bl); br = __builtin_amdgcn_readfirstlane(br);
+  // (a cell that does not take part is never stored: its "new" level stays its "old" one)
+  int32_t newT = oldT, newB = oldB, newL = oldL, newR = oldR;
+  const int32_t corner_min = imin(imin(tl, tr), imin(bl, br));
+  const int32_t hmin = __builtin_amdgcn_readfirstlane(imin(wave_min_i32(imin(imin(tv, bv), imin(lv, rv))), corner_min));
+  int32_t hmax;
+  {
+    auto fin = [](int32_t v) { return v < DINF ? v : -1; };
+    int32_t m = fin(tv);
+    m = max(m, fin(bv)); m = max(m, fin(lv)); m = max(m, fin(rv));
+    m = max(m, fin(tl)); m = max(m, fin(tr)); m = max(m, fin(bl)); m = max(m, fin(br));
+    hmax = __builtin_amdgcn_readfirstlane(wave_max_i32(m));
+  }
+  const bool seeds = __any(S != 0);
+  int32_t level = seeds ? SEED_LEVEL : DINF;               // the level being assigned
+  if (hmin < DINF) level = imin(level, hmin + 1);
+  if (level >= DINF) return;                               // no source reaches this tile (yet)
+  unsigned long long A = M, F = 0, Rec = 0;
+  unsigned long long P[BPLANES];
+#pragma unroll
+  for (int j = 0; j < BPLANES; j++) P[j] = 0;
+  int32_t base = level, relmax = 0;
+  const uint32_t bitv[BPLANES] = {1u, 2u, 4u, 8u, 16u, 32u, 64u, 128u};
+
+  // store the cells recorded since the last flush; keeps the new edge levels for the wake test
+  auto flush = [&]() {
+    const int np = 32 - __clz(relmax | 1);
+    for (int r = 0; r < BT; r++) {
+      const unsigned long long rec = readlane64(Rec, r);
+      if (!rec) continue;
+      uint32_t val = 0;
+#pragma unroll
+      for (int j = 0; j < BPLANES; j++)
+        if (j < np) val |= lanes_of(readlane64(P[j], r), bitv[j]);
+      if (lanes_of(rec, 1u)) {
+        const int32_t v = base + (int32_t)val;
+        D[(size_t)(y0 + r) * w + x0 + lane] = v;
+        if (r == 0) newT = v;
+        if (r == BT - 1) newB = v;
+      }
+    }
+    if (Rec & 1ull) {
+      uint32_t val = 0;
+#pragma unroll
+      for (int j = 0; j < BPLANES; j++) val |= (uint32_t)(P[j] & 1ull) << j;
+      newL = base + (int32_t)val;
+    }
+    if (Rec >> 63 & 1ull) {
+      uint32_t val = 0;
+#pragma unroll
+      for (int j = 0; j < BPLANES; j++) val |= (uint32_t)(P[j] >> 63) << j;
+      newR = base + (int32_t)val;
+    }
+    Rec = 0;
+#pragma unroll
+    for (int j = 0; j < BPLANES; j++) P[j] = 0;
+    relmax = 0;
+  };
+
+  for (;;) {
+    unsigned long long N = F | row_above(F) | row_below(F);
+    N = N | (N << 1) | (N >> 1);
+    if (level == SEED_LEVEL) N |= S;
+    const int32_t sv = level - 1;   // ring cells holding this level reach their neighbours in the tile now
+    if (sv >= hmin && sv <= hmax) {
+      unsigned long long T = __ballot(tv == sv), B = __ballot(bv == sv), Lm = __ballot(lv == sv), Rm = __ballot(rv == sv);
+      T = T | (T << 1) | (T >> 1);
+      B = B | (B << 1) | (B >> 1);
+      if (tl == sv) T |= 1ull;
+      if (tr == sv) T |= 1ull << 63;
+      if (bl == sv) B |= 1ull;
+      if (br == sv) B |= 1ull << 63;
+      Lm = Lm | (Lm << 1) | (Lm >> 1);
+      Rm = Rm | (Rm << 1) | (Rm >> 1);
+      if (lane == 0) N |= T;
+      if (lane == BT - 1) N |= B;
+      N |= (unsigned long long)lanes_of(Lm, 1u);
+      N |= (unsigned long long)lanes_of(Rm, 0x80000000u) << 32;
+    }
+    N &= A;
+    if (__any(N != 0)) {
+      if (level - base >= (1 << BPLANES)) { flush(); base = level; }
+      const int32_t rel = level - base;
+      relmax = rel;
+      A &= ~N;
+      Rec |= N;
+#pragma unroll
+      for (int j = 0; j < BPLANES; j++)
+        if (rel >> j & 1) P[j] |= N;
+      F = N;
+      level++;
+      continue;
+    }
+    // the front died: on to the next ring level that can still start one, if any cell is left
+    if (!__any(A != 0) || level > hmax) break;
+    auto pend = [&](int32_t v) { return v >= level && v < DINF ? v : DINF; };
+    int32_t nx = imin(imin(pend(tv), pend(bv)), imin(pend(lv), pend(rv)));
+    nx = __builtin_amdgcn_readfirstlane(wave_min_i32(nx));   // (wave uniform, and the compiler should know)
+    nx = imin(nx, imin(imin(pend(tl), pend(tr)), imin(pend(bl), pend(br))));
+    if (nx >= DINF) break;
+    level = nx + 1;
+    F = 0;
+  }
+  if (__any(Rec != 0)) flush();
+  // Wake a neighbouring tile only if an edge cell that moved here can still lower one of ITS cells (see k_flat_relax).
+  // Edge cell (r, c) with new level v against the ring cells next to it, whose levels were read at the start.
+  uint32_t wake = 0;   // bit (dy + 1) * 3 + dx + 1
+  {
+    // top / bottom edge rows: lane = column
+    const int32_t tvl = __shfl_up(tv, 1, 64), tvr = __shfl_down(tv, 1, 64), bvl = __shfl_up(bv, 1, 64), bvr = __shfl_down(bv, 1, 64);
+    auto gain = [](int32_t ring, int32_t v) { return ring > v + 1; };   // (asked only of ring cells that take part)
+    const bool movedT = newT < oldT, movedB = newB < oldB, movedL = newL < oldL, movedR = newR < oldR;
+    const bool eT = mT >> lane & 1ull, eB = mB >> lane & 1ull;
+    const bool eTl = lane > 0 ? (mT >> (lane - 1) & 1ull) : eTL, eTr = lane < 63 ? (mT >> (lane + 1) & 1ull) : eTR;
+    const bool eBl = lane > 0 ? (mB >> (lane - 1) & 1ull) : eBL, eBr = lane < 63 ? (mB >> (lane + 1) & 1ull) : eBR;
+    const int32_t tL = lane > 0 ? tvl : tl, tR = lane < 63 ? tvr : tr, bL = lane > 0 ? bvl : bl, bR = lane < 63 ? bvr : br;
+    if (movedT) {
+      if (eT && gain(tv, newT)) wake |= 1u << 1;
+      if (eTl && gain(tL, newT)) wake |= lane > 0 ? 1u << 1 : 1u << 0;
+      if (eTr && gain(tR, newT)) wake |= lane < 63 ? 1u << 1 : 1u << 2;
+    }
+    if (movedB) {
+      if (eB && gain(bv, newB)) wake |= 1u << 7;
+      if (eBl && gain(bL, newB)) wake |= lane > 0 ? 1u << 7 : 1u << 6;
+      if (eBr && gain(bR, newB)) wake |= lane < 63 ? 1u << 7 : 1u << 8;
+    }
+    // left / right edge columns: lane = row (the corner cells' neighbours above / below the tile are the top / bottom rows' business)
+    const int32_t lvu = __shfl_up(lv, 1, 64), lvd = __shfl_down(lv, 1, 64), rvu = __shfl_up(rv, 1, 64), rvd = __shfl_down(rv, 1, 64);
+    const unsigned long long eLm = __ballot(mL >> 63 & 1ull), eRm = __ballot(mR & 1ull);
+    const bool eL = eLm >> lane & 1ull, eR = eRm >> lane & 1ull;
+    const bool eLu = lane > 0 ? (eLm >> (lane - 1) & 1ull) : eTL, eLd = lane < 63 ? (eLm >> (lane + 1) & 1ull) : eBL;
+    const bool eRu = lane > 0 ? (eRm >> (lane - 1) & 1ull) : eTR, eRd = lane < 63 ? (eRm >> (lane + 1) & 1ull) : eBR;
+    const int32_t lU = lane > 0 ? lvu : tl, lD = lane < 63 ? lvd : bl, rU = lane > 0 ? rvu : tr, rD = lane < 63 ? rvd : br;
+    if (movedL) {
+      if (eL && gain(lv, newL)) wake |= 1u << 3;
+      if (eLu && gain(lU, newL)) wake |= lane > 0 ? 1u << 3 : 1u << 0;
+      if (eLd && gain(lD, newL)) wake |= lane < 63 ? 1u << 3 : 1u << 6;
+    }
+    if (movedR) {
+      if (eR && gain(rv, newR)) wake |= 1u << 5;
+      if (eRu && gain(rU, newR)) wake |= lane > 0 ? 1u << 5 : 1u << 2;
+      if (eRd && gain(rD, newR)) wake |= lane < 63 ? 1u << 5 : 1u << 8;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wake |= __shfl_xor(wake, o, 64);
+  if (lane < 9 && lane != 4 && (wake >> lane & 1u)) {
+    const int ntx = tx + lane % 3 - 1, nty = ty + lane / 3 - 1;
+    if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
+  }
+}
+
 // flat_height[label] = deepest away level of the flat (:181): atomicMax behind a coherent pre-check
 __global__ __launch_bounds__(NTHR) void k_flat_height(const int32_t *__restrict__ A, const uint32_t *__restrict__ L,
                                                       int32_t *fh, uint64_t n) {
@@ -928,6 +1239,89 @@ static uint32_t run_relax_towards(const uint8_t *d_dirs, const uint8_t *flags, i
   return relax_rounds(d_dirs, D, r.tflags, r.tlist, r.ctr, w, h, 0, h, "flats.relax_towards", s);
 }
 
+// ---- the bitmap engine's rounds (same protocol as relax_rounds: batches of rounds, counts read back per batch) ----
+static BitsScratch bits_scratch(int w, int h) {
+  Workspace &ws = Workspace::get();
+  BitsScratch b;
+  b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
+  b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT);
+  b.sbits = ws.buf<unsigned long long>("flats.sbits", (size_t)b.ntiles * BT);
+  b.tflags = ws.buf<uint8_t>("flats.btflags", b.ntiles);
+  b.tlist = ws.buf<uint32_t>("flats.btlist", b.ntiles);
+  b.ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
+  b.counts = ws.buf<uint32_t>("flats.bcounts", 3 * 256 + 8);
+  return b;
+}
+
+template <int SEED_LEVEL>
+static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s) {
+  uint32_t *hw = Workspace::get().host_words();
+  const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
+  uint32_t rounds = 0, grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
+  for (;;) {
+    RD_HIP(hipMemsetAsync(b.ctr, 0, RELAX_BATCH * sizeof(uint32_t), s));
+    for (int k = 0; k < RELAX_BATCH; k++) {
+      RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
+                b.tlist, b.ctr + k);
+      RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
+                (const unsigned long long *)b.sbits, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h,
+                b.tilesX, b.tilesY);
+    }
+    RD_HIP(hipMemcpyAsync(hw, b.ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    uint32_t most = 0;
+    for (int k = 0; k < RELAX_BATCH; k++) {
+      if (trace) fprintf(stderr, "%s round %u nact %u (grid %u)\n", name, rounds, hw[k], grid);
+      if (hw[k] == 0) return rounds;
+      most = std::max(most, hw[k]);
+      rounds++;
+    }
+    grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
+    if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
+  }
+}
+
+// Towards levels from the low edges, D written in full; write_m: also the bitmap of the cells that take part (shared
+// with the away field); counts3 (optional, host): low edges, high edges, NO_FLOW cells.
+static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m, unsigned long long *counts3, int w, int h,
+                                 hipStream_t s) {
+  const BitsScratch b = bits_scratch(w, h);
+  RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  uint32_t *cnt = counts3 ? b.counts : nullptr;
+  if (cnt) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
+  if (write_m)
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
+              (const int32_t *)nullptr, D, b.mbits, b.sbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+  else
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
+              (const int32_t *)nullptr, D, b.mbits, b.sbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+  if (cnt) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(cnt + 3 * 256 + 2);
+    RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)cnt, out);
+    RD_HIP(hipMemcpyAsync(counts3, out, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // (read after the rounds' sync)
+  }
+  return relax_rounds_bits<2>(b, D, w, h, "flats.relax_towards", s);
+}
+
+// Away levels from the high edges (with L / fh: only those of flats that have an outlet), D written in full.
+static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int32_t *fh, int32_t *D, bool write_m, int w, int h,
+                              hipStream_t s) {
+  const BitsScratch b = bits_scratch(w, h);
+  RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  if (write_m)
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits, b.sbits,
+              b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+  else
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits, b.sbits,
+              b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+  return relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s);
+}
+
+static bool use_bits_engine() {
+  const char *env = getenv("RDGPU_FLAT_BITS");   // =0: the stencil relaxation (what the row-block shards run): A/B and tests
+  return !(env && env[0] == '0');
+}
+
 // Computes flat_mask (M) for the DEM; d_dirs must hold d8_flow_directions output.
 // Returns device pointers (workspace) to M, L, fh through the out parameters.
 template <class T>
@@ -970,13 +1364,18 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   int32_t *A = nullptr;
   if (nhigh_all > 0) {
     A = ws.buf<int32_t>("flats.away", n);
-    RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
-    g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, L, fh, w, h, s);
+    if (use_bits_engine()) {
+      g_fstats.away_levels = run_bits_away(flags, L, fh, A, true, w, h, s);
+    } else {
+      RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
+      g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, L, fh, w, h, s);
+    }
     RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
               n);
   }
   // towards gradient from every low edge, then the combined mask in place
-  g_fstats.towards_levels = run_relax_towards(d_dirs, flags, M, w, h, s);
+  g_fstats.towards_levels = use_bits_engine() ? run_bits_towards(flags, M, nhigh_all == 0, nullptr, w, h, s)
+                                              : run_relax_towards(d_dirs, flags, M, w, h, s);
   RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, M, (const int32_t *)A, (const uint32_t *)L,
             (const int32_t *)fh, n);
 }
@@ -1002,22 +1401,36 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   launch_classify<T>(d_z, d_dirs, w, h, flags, s);
-  uint32_t *low = nullptr, *highall = nullptr;
-  uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
-  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s);
-  g_fstats.low_edges = nlow;
-  g_fstats.noflow_cells = nnoflow;
-  g_fstats.high_edges = nhigh_all;
-  if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
   int32_t *TWd = ws.buf<int32_t>("flats.mask", n), *A = nullptr;
-  if (nhigh_all > 0) {
-    // every high edge seeds (the flats without an outlet are not filtered out: that would need their labels; their
-    // cells are never reached by the towards field, so they get no direction either way)
-    A = ws.buf<int32_t>("flats.away", n);
-    RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
-    g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, nullptr, nullptr, w, h, s);
+  if (use_bits_engine()) {
+    // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
+    unsigned long long c3[3] = {0, 0, 0};
+    g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s);
+    g_fstats.low_edges = c3[0];
+    g_fstats.high_edges = c3[1];
+    g_fstats.noflow_cells = c3[2];
+    if (c3[0] == 0) return;   // no flats, or none with an outlet (:475-481)
+    if (c3[1] > 0) {
+      A = ws.buf<int32_t>("flats.away", n);
+      g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
+    }
+  } else {
+    uint32_t *low = nullptr, *highall = nullptr;
+    uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
+    compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s);
+    g_fstats.low_edges = nlow;
+    g_fstats.noflow_cells = nnoflow;
+    g_fstats.high_edges = nhigh_all;
+    if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
+    if (nhigh_all > 0) {
+      // every high edge seeds (the flats without an outlet are not filtered out: that would need their labels; their
+      // cells are never reached by the towards field, so they get no direction either way)
+      A = ws.buf<int32_t>("flats.away", n);
+      RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
+      g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, nullptr, nullptr, w, h, s);
+    }
+    g_fstats.towards_levels = run_relax_towards(d_dirs, flags, TWd, w, h, s);
   }
-  g_fstats.towards_levels = run_relax_towards(d_dirs, flags, TWd, w, h, s);
   uint32_t tilesX;
   const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
   RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
