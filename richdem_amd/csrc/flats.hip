@@ -739,37 +739,47 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
   bl = __builtin_amdgcn_readfirstlane(bl); br = __builtin_amdgcn_readfirstlane(br);
   // (a cell that does not take part is never stored: its "new" level stays its "old" one)
   int32_t newT = oldT, newB = oldB, newL = oldL, newR = oldR;
-  const int32_t corner_min = imin(imin(tl, tr), imin(bl, br));
-  const int32_t hmin = __builtin_amdgcn_readfirstlane(imin(wave_min_i32(imin(imin(tv, bv), imin(lv, rv))), corner_min));
-  int32_t hmax;
+  // The level at which each EDGE cell of the tile is reached from the ring: 1 + the lowest of its (up to three, at a
+  // corner five) ring neighbours.  Computed once, so a level of the search only compares against these four vectors.
+  const int32_t tvl = __shfl_up(tv, 1, 64), tvr = __shfl_down(tv, 1, 64), bvl = __shfl_up(bv, 1, 64), bvr = __shfl_down(bv, 1, 64);
+  const int32_t lvu = __shfl_up(lv, 1, 64), lvd = __shfl_down(lv, 1, 64), rvu = __shfl_up(rv, 1, 64), rvd = __shfl_down(rv, 1, 64);
+  const int32_t tL = lane > 0 ? tvl : tl, tR = lane < 63 ? tvr : tr, bL = lane > 0 ? bvl : bl, bR = lane < 63 ? bvr : br;
+  const int32_t lU = lane > 0 ? lvu : tl, lD = lane < 63 ? lvd : bl, rU = lane > 0 ? rvu : tr, rD = lane < 63 ? rvd : br;
+  auto reach = [](int32_t a, int32_t b, int32_t c) { const int32_t m = imin(a, imin(b, c)); return m < DINF ? m + 1 : DINF; };
+  const int32_t iT = reach(tL, tv, tR), iB = reach(bL, bv, bR), iL = reach(lU, lv, lD), iR = reach(rU, rv, rD);
+  const int32_t imin_ = __builtin_amdgcn_readfirstlane(wave_min_i32(imin(imin(iT, iB), imin(iL, iR))));
+  int32_t imax_;
   {
     auto fin = [](int32_t v) { return v < DINF ? v : -1; };
-    int32_t m = fin(tv);
-    m = max(m, fin(bv)); m = max(m, fin(lv)); m = max(m, fin(rv));
-    m = max(m, fin(tl)); m = max(m, fin(tr)); m = max(m, fin(bl)); m = max(m, fin(br));
-    hmax = __builtin_amdgcn_readfirstlane(wave_max_i32(m));
+    imax_ = __builtin_amdgcn_readfirstlane(wave_max_i32(max(max(fin(iT), fin(iB)), max(fin(iL), fin(iR)))));
   }
   const bool seeds = __any(S != 0);
-  int32_t level = seeds ? SEED_LEVEL : DINF;               // the level being assigned
-  if (hmin < DINF) level = imin(level, hmin + 1);
-  if (level >= DINF) return;                               // no source reaches this tile (yet)
+  int32_t level = imin(seeds ? SEED_LEVEL : DINF, imin_);   // the level being assigned
+  if (level >= DINF) return;                                // no source reaches this tile (yet)
   unsigned long long A = M, F = 0, Rec = 0;
-  unsigned long long P[BPLANES];
+  unsigned long long Sinj = level == SEED_LEVEL ? S : 0ull;   // (ring levels are >= SEED_LEVEL: the seeds come first or never)
+  uint32_t Plo[BPLANES], Phi[BPLANES];
 #pragma unroll
-  for (int j = 0; j < BPLANES; j++) P[j] = 0;
+  for (int j = 0; j < BPLANES; j++) Plo[j] = Phi[j] = 0;
   int32_t base = level, relmax = 0;
   const uint32_t bitv[BPLANES] = {1u, 2u, 4u, 8u, 16u, 32u, 64u, 128u};
 
   // store the cells recorded since the last flush; keeps the new edge levels for the wake test
   auto flush = [&]() {
     const int np = 32 - __clz(relmax | 1);
-    for (int r = 0; r < BT; r++) {
+    unsigned long long rows = __ballot(Rec != 0);
+    while (rows) {
+      const int r = __ffsll((long long)rows) - 1;
+      rows &= rows - 1;
       const unsigned long long rec = readlane64(Rec, r);
-      if (!rec) continue;
       uint32_t val = 0;
 #pragma unroll
       for (int j = 0; j < BPLANES; j++)
-        if (j < np) val |= lanes_of(readlane64(P[j], r), bitv[j]);
+        if (j < np) {
+          const unsigned long long pj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Phi[j], r) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)Plo[j], r);
+          val |= lanes_of(pj, bitv[j]);
+        }
       if (lanes_of(rec, 1u)) {
         const int32_t v = base + (int32_t)val;
         D[(size_t)(y0 + r) * w + x0 + lane] = v;
@@ -780,42 +790,40 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
     if (Rec & 1ull) {
       uint32_t val = 0;
 #pragma unroll
-      for (int j = 0; j < BPLANES; j++) val |= (uint32_t)(P[j] & 1ull) << j;
+      for (int j = 0; j < BPLANES; j++) val |= (Plo[j] & 1u) << j;
       newL = base + (int32_t)val;
     }
     if (Rec >> 63 & 1ull) {
       uint32_t val = 0;
 #pragma unroll
-      for (int j = 0; j < BPLANES; j++) val |= (uint32_t)(P[j] >> 63) << j;
+      for (int j = 0; j < BPLANES; j++) val |= (Phi[j] >> 31) << j;
       newR = base + (int32_t)val;
     }
     Rec = 0;
 #pragma unroll
-    for (int j = 0; j < BPLANES; j++) P[j] = 0;
+    for (int j = 0; j < BPLANES; j++) Plo[j] = Phi[j] = 0;
     relmax = 0;
   };
 
   for (;;) {
-    unsigned long long N = F | row_above(F) | row_below(F);
-    N = N | (N << 1) | (N >> 1);
-    if (level == SEED_LEVEL) N |= S;
-    const int32_t sv = level - 1;   // ring cells holding this level reach their neighbours in the tile now
-    if (sv >= hmin && sv <= hmax) {
-      unsigned long long T = __ballot(tv == sv), B = __ballot(bv == sv), Lm = __ballot(lv == sv), Rm = __ballot(rv == sv);
-      T = T | (T << 1) | (T >> 1);
-      B = B | (B << 1) | (B >> 1);
-      if (tl == sv) T |= 1ull;
-      if (tr == sv) T |= 1ull << 63;
-      if (bl == sv) B |= 1ull;
-      if (br == sv) B |= 1ull << 63;
-      Lm = Lm | (Lm << 1) | (Lm >> 1);
-      Rm = Rm | (Rm << 1) | (Rm >> 1);
-      if (lane == 0) N |= T;
-      if (lane == BT - 1) N |= B;
-      N |= (unsigned long long)lanes_of(Lm, 1u);
-      N |= (unsigned long long)lanes_of(Rm, 0x80000000u) << 32;
+    // one level: the cells next to the front, plus what the ring and the seeds start at this level, that are still free
+    uint32_t nlo, nhi;
+    {
+      const unsigned long long v = F | row_above(F) | row_below(F);
+      const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+      nlo = lo | (lo << 1) | __builtin_amdgcn_alignbit(hi, lo, 1);
+      nhi = hi | (hi >> 1) | __builtin_amdgcn_alignbit(hi, lo, 31);
     }
-    N &= A;
+    nlo |= (uint32_t)Sinj; nhi |= (uint32_t)(Sinj >> 32);
+    Sinj = 0;
+    if (level <= imax_) {
+      const unsigned long long T = __ballot(iT == level), B = __ballot(iB == level);
+      const unsigned long long tb_ = lane == 0 ? T : lane == BT - 1 ? B : 0ull;
+      nlo |= (uint32_t)tb_ | (iL == level ? 1u : 0u);
+      nhi |= (uint32_t)(tb_ >> 32) | (iR == level ? 0x80000000u : 0u);
+    }
+    nlo &= (uint32_t)A; nhi &= (uint32_t)(A >> 32);
+    const unsigned long long N = ((unsigned long long)nhi << 32) | nlo;
     if (__any(N != 0)) {
       if (level - base >= (1 << BPLANES)) { flush(); base = level; }
       const int32_t rel = level - base;
@@ -823,20 +831,21 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
       A &= ~N;
       Rec |= N;
 #pragma unroll
-      for (int j = 0; j < BPLANES; j++)
-        if (rel >> j & 1) P[j] |= N;
+      for (int j = 0; j < BPLANES; j++) {   // branch-free: the mask is all ones when the level has bit j set
+        const uint32_t m = (uint32_t)(-(int32_t)((uint32_t)rel >> j & 1u));
+        Plo[j] |= nlo & m;
+        Phi[j] |= nhi & m;
+      }
       F = N;
       level++;
       continue;
     }
-    // the front died: on to the next ring level that can still start one, if any cell is left
-    if (!__any(A != 0) || level > hmax) break;
-    auto pend = [&](int32_t v) { return v >= level && v < DINF ? v : DINF; };
-    int32_t nx = imin(imin(pend(tv), pend(bv)), imin(pend(lv), pend(rv)));
-    nx = __builtin_amdgcn_readfirstlane(wave_min_i32(nx));   // (wave uniform, and the compiler should know)
-    nx = imin(nx, imin(imin(pend(tl), pend(tr)), imin(pend(bl), pend(br))));
+    // the front died: on to the next level at which the ring starts one, if any cell is left
+    if (!__any(A != 0) || level >= imax_) break;
+    auto pend = [&](int32_t v) { return v > level ? v : DINF; };   // (DINF itself: never)
+    const int32_t nx = __builtin_amdgcn_readfirstlane(wave_min_i32(imin(imin(pend(iT), pend(iB)), imin(pend(iL), pend(iR)))));
     if (nx >= DINF) break;
-    level = nx + 1;
+    level = nx;
     F = 0;
   }
   if (__any(Rec != 0)) flush();
@@ -845,13 +854,11 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
   uint32_t wake = 0;   // bit (dy + 1) * 3 + dx + 1
   {
     // top / bottom edge rows: lane = column
-    const int32_t tvl = __shfl_up(tv, 1, 64), tvr = __shfl_down(tv, 1, 64), bvl = __shfl_up(bv, 1, 64), bvr = __shfl_down(bv, 1, 64);
     auto gain = [](int32_t ring, int32_t v) { return ring > v + 1; };   // (asked only of ring cells that take part)
     const bool movedT = newT < oldT, movedB = newB < oldB, movedL = newL < oldL, movedR = newR < oldR;
     const bool eT = mT >> lane & 1ull, eB = mB >> lane & 1ull;
     const bool eTl = lane > 0 ? (mT >> (lane - 1) & 1ull) : eTL, eTr = lane < 63 ? (mT >> (lane + 1) & 1ull) : eTR;
     const bool eBl = lane > 0 ? (mB >> (lane - 1) & 1ull) : eBL, eBr = lane < 63 ? (mB >> (lane + 1) & 1ull) : eBR;
-    const int32_t tL = lane > 0 ? tvl : tl, tR = lane < 63 ? tvr : tr, bL = lane > 0 ? bvl : bl, bR = lane < 63 ? bvr : br;
     if (movedT) {
       if (eT && gain(tv, newT)) wake |= 1u << 1;
       if (eTl && gain(tL, newT)) wake |= lane > 0 ? 1u << 1 : 1u << 0;
@@ -863,12 +870,10 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
       if (eBr && gain(bR, newB)) wake |= lane < 63 ? 1u << 7 : 1u << 8;
     }
     // left / right edge columns: lane = row (the corner cells' neighbours above / below the tile are the top / bottom rows' business)
-    const int32_t lvu = __shfl_up(lv, 1, 64), lvd = __shfl_down(lv, 1, 64), rvu = __shfl_up(rv, 1, 64), rvd = __shfl_down(rv, 1, 64);
     const unsigned long long eLm = __ballot(mL >> 63 & 1ull), eRm = __ballot(mR & 1ull);
     const bool eL = eLm >> lane & 1ull, eR = eRm >> lane & 1ull;
     const bool eLu = lane > 0 ? (eLm >> (lane - 1) & 1ull) : eTL, eLd = lane < 63 ? (eLm >> (lane + 1) & 1ull) : eBL;
     const bool eRu = lane > 0 ? (eRm >> (lane - 1) & 1ull) : eTR, eRd = lane < 63 ? (eRm >> (lane + 1) & 1ull) : eBR;
-    const int32_t lU = lane > 0 ? lvu : tl, lD = lane < 63 ? lvd : bl, rU = lane > 0 ? rvu : tr, rD = lane < 63 ? rvd : br;
     if (movedL) {
       if (eL && gain(lv, newL)) wake |= 1u << 3;
       if (eLu && gain(lU, newL)) wake |= lane > 0 ? 1u << 3 : 1u << 0;

@@ -7,7 +7,7 @@ f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
 python - "$f" <<PY
 import csv,sys,os
 rows=list(csv.DictReader(open(sys.argv[1])))
-keys=("k_flat_relax","k_tiles_compact","k_flat_init_towards","k_flat_seed","k_relax_bits","k_relax_prepare")
+keys=("k_flat_relax","k_tiles_compact","k_flat_init_towards","k_flat_seed","k_relax_bits","k_bits_prepare")
 rel=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"],r.get("Grid_Size_X") or r.get("Grid_Size")) for r in rows if any(k in r["Kernel_Name"] for k in keys)]
 rel.sort()
 os.makedirs(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out",exist_ok=True)
