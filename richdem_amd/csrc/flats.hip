@@ -594,8 +594,8 @@ __global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ 
 constexpr int BT = 64;   // bitmap tiles are BT x BT
 constexpr int BPLANES = 8;   // level planes: 256 levels per flush
 struct BitsScratch {
-  unsigned long long *mbits, *sbits;   // per tile and row: cells that take part / seeds of the current field
-  uint8_t *tflags;
+  unsigned long long *mbits;   // per tile and row: the cells that take part
+  uint8_t *tflags, *expanded;  // tile is active next round / has been visited in this field
   uint32_t *tlist, *ctr, *counts;
   uint32_t tilesX, tilesY, ntiles;
 };
@@ -630,15 +630,15 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
   return v;
 }
 
-// Per tile and row: the bitmaps of a field, the start of its levels, the tiles to visit first, and the edge counts.
+// Per tile and row: the bitmap of the cells that take part; the start of a field's levels (the seeds hold theirs, all
+// other cells "not reached"), the tiles to visit first, and the edge counts.
 // TOWARDS: seeds = F_NEAR (level 2), D = 1 on the low edges; else seeds = F_HIGH (level 1; with L / fh only those of
 // flats that have an outlet, :491-500).  One block per tile, a wavefront per 16 rows, a lane per column.
 template <bool TOWARDS, bool WRITE_M>
 __global__ __launch_bounds__(NTHR) void k_bits_prepare(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ L,
                                                        const int32_t *__restrict__ fh, int32_t *__restrict__ D,
-                                                       unsigned long long *mbits, unsigned long long *sbits,
-                                                       uint8_t *tile_active, uint32_t *counts, int w, int h, uint32_t tilesX,
-                                                       uint32_t tilesY) {
+                                                       unsigned long long *mbits, uint8_t *tile_active, uint32_t *counts,
+                                                       int w, int h, uint32_t tilesX, uint32_t tilesY) {
   const uint32_t t = blockIdx.x;
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -665,13 +665,9 @@ __global__ __launch_bounds__(NTHR) void k_bits_prepare(const uint8_t *__restrict
       nlow += (uint32_t)__popcll(lb);
       nhigh += (uint32_t)__popcll(hb);
     }
-    if (in) D[(size_t)gy * w + gx] = (TOWARDS && (f[j] & F_LOW)) ? 1 : DINF;
+    if (in) D[(size_t)gy * w + gx] = (TOWARDS && (f[j] & F_LOW)) ? 1 : seed ? (TOWARDS ? 2 : 1) : DINF;
   }
-  if (lane < 16) {
-    const size_t o = (size_t)t * BT + wv * 16 + lane;
-    if (WRITE_M) mbits[o] = mrow;
-    sbits[o] = srow;
-  }
+  if (WRITE_M && lane < 16) mbits[(size_t)t * BT + wv * 16 + lane] = mrow;
   const int any = __syncthreads_or(srow != 0);
   if (any && threadIdx.x < 9) {
     const int ntx = tx + (int)threadIdx.x % 3 - 1, nty = ty + (int)threadIdx.x / 3 - 1;
@@ -695,8 +691,7 @@ __global__ __launch_bounds__(NTHR) void k_bits_counts(const uint32_t *__restrict
 }
 
 template <int SEED_LEVEL>
-__global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *__restrict__ mbits,
-                                                     const unsigned long long *__restrict__ sbits, int32_t *D,
+__global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
                                                      uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
   const uint32_t n = *count;
@@ -710,7 +705,6 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
   const bool hasL = tx > 0, hasR = tx + 1 < (int)tilesX, hasT = ty > 0, hasB = ty + 1 < (int)tilesY;
   const size_t tb = (size_t)t * BT;
   const unsigned long long M = mbits[tb + lane];
-  const unsigned long long S = sbits[tb + lane] & M;
   // which ring cells take part: the facing rows / columns / corners of the eight neighbouring tiles' masks
   const unsigned long long mT = hasT ? mbits[tb - (size_t)tilesX * BT + (BT - 1)] : 0ull;   // (wave uniform)
   const unsigned long long mB = hasB ? mbits[tb + (size_t)tilesX * BT] : 0ull;
@@ -747,17 +741,45 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
   const int32_t lU = lane > 0 ? lvu : tl, lD = lane < 63 ? lvd : bl, rU = lane > 0 ? rvu : tr, rD = lane < 63 ? rvd : br;
   auto reach = [](int32_t a, int32_t b, int32_t c) { const int32_t m = imin(a, imin(b, c)); return m < DINF ? m + 1 : DINF; };
   const int32_t iT = reach(tL, tv, tR), iB = reach(bL, bv, bR), iL = reach(lU, lv, lD), iR = reach(rU, rv, rD);
-  const int32_t imin_ = __builtin_amdgcn_readfirstlane(wave_min_i32(imin(imin(iT, iB), imin(iL, iR))));
   int32_t imax_;
   {
     auto fin = [](int32_t v) { return v < DINF ? v : -1; };
     imax_ = __builtin_amdgcn_readfirstlane(wave_max_i32(max(max(fin(iT), fin(iB)), max(fin(iL), fin(iR)))));
   }
-  const bool seeds = __any(S != 0);
-  int32_t level = imin(seeds ? SEED_LEVEL : DINF, imin_);   // the level being assigned
-  if (level >= DINF) return;                                // no source reaches this tile (yet)
-  unsigned long long A = M, F = 0, Rec = 0;
-  unsigned long long Sinj = level == SEED_LEVEL ? S : 0ull;   // (ring levels are >= SEED_LEVEL: the seeds come first or never)
+  // Where to start.  Whatever this visit changes lies at or above the lowest level at which the ring now reaches an
+  // edge cell earlier than the cell's own level says (a source acts at its level and later, never before); below that
+  // the stored levels stand.  A tile visited for the first time also has its seeds to expand.  The cells below the
+  // start are read back as "reached", those one below it are the front, and the search goes on from there -- a visit
+  // that corrects the top of a tile's range costs that part, not the whole tile.
+  const unsigned long long m0 = readlane64(M, 0), m63 = readlane64(M, BT - 1);
+  int32_t chg = DINF;
+  if ((m0 >> lane & 1ull) && iT < oldT) chg = iT;
+  if ((m63 >> lane & 1ull) && iB < oldB) chg = imin(chg, iB);
+  if ((M & 1ull) && iL < oldL) chg = imin(chg, iL);
+  if ((M >> 63 & 1ull) && iR < oldR) chg = imin(chg, iR);
+  int32_t level = __builtin_amdgcn_readfirstlane(wave_min_i32(chg));   // the level being assigned
+  if (!__builtin_amdgcn_readfirstlane((int)expanded[t])) {
+    level = imin(level, SEED_LEVEL + 1);
+    if (lane == 0) expanded[t] = 1;
+  }
+  if (level >= DINF) return;   // nothing new reaches this tile
+  unsigned long long A, F, Rec = 0;
+  {
+    unsigned long long reached = 0, front = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < BT; r0 += 16) {
+      int32_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = D[(size_t)min(y0 + r0 + j, h - 1) * w + cx];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const unsigned long long rb = __ballot(v[j] < level), fb = __ballot(v[j] == level - 1);
+        if (lane == r0 + j) { reached = rb; front = fb; }
+      }
+    }
+    A = M & ~reached;
+    F = M & front;
+  }
   uint32_t Plo[BPLANES], Phi[BPLANES];
 #pragma unroll
   for (int j = 0; j < BPLANES; j++) Plo[j] = Phi[j] = 0;
@@ -814,8 +836,6 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
       nlo = lo | (lo << 1) | __builtin_amdgcn_alignbit(hi, lo, 1);
       nhi = hi | (hi >> 1) | __builtin_amdgcn_alignbit(hi, lo, 31);
     }
-    nlo |= (uint32_t)Sinj; nhi |= (uint32_t)(Sinj >> 32);
-    Sinj = 0;
     if (level <= imax_) {
       const unsigned long long T = __ballot(iT == level), B = __ballot(iB == level);
       const unsigned long long tb_ = lane == 0 ? T : lane == BT - 1 ? B : 0ull;
@@ -1250,7 +1270,7 @@ static BitsScratch bits_scratch(int w, int h) {
   BitsScratch b;
   b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
   b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT);
-  b.sbits = ws.buf<unsigned long long>("flats.sbits", (size_t)b.ntiles * BT);
+  b.expanded = ws.buf<uint8_t>("flats.bexp", b.ntiles);
   b.tflags = ws.buf<uint8_t>("flats.btflags", b.ntiles);
   b.tlist = ws.buf<uint32_t>("flats.btlist", b.ntiles);
   b.ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
@@ -1269,7 +1289,7 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
       RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
-                (const unsigned long long *)b.sbits, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h,
+                b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h,
                 b.tilesX, b.tilesY);
     }
     RD_HIP(hipMemcpyAsync(hw, b.ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1292,14 +1312,15 @@ static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m,
                                  hipStream_t s) {
   const BitsScratch b = bits_scratch(w, h);
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
   uint32_t *cnt = counts3 ? b.counts : nullptr;
   if (cnt) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
   if (write_m)
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
-              (const int32_t *)nullptr, D, b.mbits, b.sbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
   else
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
-              (const int32_t *)nullptr, D, b.mbits, b.sbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
   if (cnt) {
     unsigned long long *out = reinterpret_cast<unsigned long long *>(cnt + 3 * 256 + 2);
     RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)cnt, out);
@@ -1313,11 +1334,12 @@ static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int
                               hipStream_t s) {
   const BitsScratch b = bits_scratch(w, h);
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
   if (write_m)
-    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits, b.sbits,
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
               b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
   else
-    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits, b.sbits,
+    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
               b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
   return relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s);
 }
