@@ -48,58 +48,80 @@ constexpr uint8_t DIR_GHOST_NOFLOW = 254;   // row-block shards: NO_FLOW cell of
 // ------------------------------------------------------------------------------------------
 constexpr int SW = 64, SH = 16, SLW = SW + 2, SLH = SH + 2;   // stencil tiles (classification, masked directions)
 
+// 64 x 32 tiles; a wavefront owns a band of 8 consecutive rows, a lane one column, and the 3 x 3 windows of elevations
+// and directions slide down the column in registers (6 LDS reads per cell instead of 18: the LDS, not HBM, bounded the
+// first version of this kernel -- 7.9 ms at S3 for 9.6 GB).
+constexpr int KLH = 32, KLLH = KLH + 2;
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z, const uint8_t *__restrict__ dirs,
                                                         int w, int h, uint8_t *__restrict__ flags, uint32_t tilesX,
                                                         uint32_t ntiles) {
-  __shared__ T sz[SLH * SLW];
-  __shared__ uint8_t sdir[SLH * SLW];
+  __shared__ T sz[KLLH * SLW];
+  __shared__ uint8_t sdir[KLLH * SLW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
-  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
-  for (int i = threadIdx.x; i < SLH * SLW; i += NTHR) {
-    const int ly = i / SLW, lx = i - ly * SLW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    T v = T();
-    uint8_t d = 255;   // outside the raster: skipped like NoData
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-      const size_t g = (size_t)gy * w + gx;
-      v = z[g];
-      d = dirs[g];
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
+  {
+    constexpr int IPT = (KLLH * SLW + NTHR - 1) / NTHR;
+    T zv[IPT];
+    uint8_t dv[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {   // all loads of the thread in flight together (clamped addresses)
+      const int i = min((int)threadIdx.x + r * NTHR, KLLH * SLW - 1);
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
+      zv[r] = z[(size_t)gy * w + gx];
+      dv[r] = dirs[(size_t)gy * w + gx];
     }
-    sz[i] = v;
-    sdir[i] = d;
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i >= KLLH * SLW) continue;
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      sz[i] = zv[r];
+      sdir[i] = in ? dv[r] : (uint8_t)255;   // outside the raster: skipped like NoData
+    }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
-  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+  const int lx = threadIdx.x & (SW - 1), yb = (int)(threadIdx.x >> 6) * (KLH / 4);
+  const int gx = x0 + lx;
+  T z0[3], z1[3], z2[3];
+  uint8_t d0[3], d1[3], d2[3];
 #pragma unroll
-  for (int j = 0; j < SH / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    const int o = (ly + 1) * SLW + lx + 1;
+  for (int e = 0; e < 3; e++) {
+    z0[e] = sz[yb * SLW + lx + e]; z1[e] = sz[(yb + 1) * SLW + lx + e];
+    d0[e] = sdir[yb * SLW + lx + e]; d1[e] = sdir[(yb + 1) * SLW + lx + e];
+  }
+#pragma unroll
+  for (int j = 0; j < KLH / 4; j++) {
+    const int ly = yb + j, gy = y0 + ly;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { z2[e] = sz[(ly + 2) * SLW + lx + e]; d2[e] = sdir[(ly + 2) * SLW + lx + e]; }
     uint8_t f = 0;
-    const uint8_t d = sdir[o];
+    const uint8_t d = d1[1];
     if (d != 255) {
       const bool noflow = d == 0;
       if (noflow) f = F_NOFLOW;
       // a cell WITH flow can only be a low edge if some neighbour is NO_FLOW; a NO_FLOW cell is always
       // interior (edge cells always get a direction), so its 8 neighbours exist
-      const T e = sz[o];
+      const T e = z1[1];
       bool hit = false, near = false;
-#pragma unroll
-      for (int k = 1; k <= 8; k++) {
-        const uint8_t dn = sdir[o + off[k]];
-        if (dn == 255) continue;
-        const T zn = sz[o + off[k]];
+      auto nb = [&](T zn, uint8_t dn) {
+        if (dn == 255) return;
         hit |= noflow ? (e < zn) : (dn == 0 && zn == e);   // :409-411 / :406-408
         near |= noflow && dn != 0 && zn == e;              // the neighbour is a low edge of this cell's flat
-      }
+      };
+      nb(z0[0], d0[0]); nb(z0[1], d0[1]); nb(z0[2], d0[2]);
+      nb(z1[0], d1[0]); nb(z1[2], d1[2]);
+      nb(z2[0], d2[0]); nb(z2[1], d2[1]); nb(z2[2], d2[2]);
       if (hit) f |= noflow ? F_HIGH : F_LOW;
       if (near) f |= F_NEAR;
     }
-    flags[(size_t)gy * w + gx] = f;
+    if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; }
   }
 }
 
@@ -590,6 +612,9 @@ __global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ 
 // they hold now -- each is injected at its own level, so the search also runs from several fronts at different depths,
 // skipping the gaps between them.  The levels of the tile's own cells are not read at all: they were computed from
 // older (higher or equal) ring levels, so recomputing from the current ring can only reproduce or lower them.
+// (Measured, r02: holding back tiles whose start level runs ahead of 64..320 levels per round changed nothing -- the
+// sweep already is level ordered, one tile per round: at S3 the deepest level is ~2e4 and the towards field takes 349
+// rounds; per round a visit's ~35 us of dependent instruction issue is the floor, whatever the number of tiles.)
 // ------------------------------------------------------------------------------------------
 constexpr int BT = 64;   // bitmap tiles are BT x BT
 constexpr int BPLANES = 8;   // level planes: 256 levels per flush
@@ -1086,8 +1111,7 @@ static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((
 
 template <class T>
 static void launch_classify(const T *d_z, const uint8_t *d_dirs, int w, int h, uint8_t *flags, hipStream_t s) {
-  uint32_t tilesX;
-  const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+  const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
   RD_LAUNCH("flats.classify", (k_flat_classify<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, d_dirs, w, h, flags, tilesX,
             ntiles);
 }
