@@ -12,8 +12,10 @@
 
 namespace rdgpu {
 
-constexpr int TW = 64, TH = 16, LW = TW + 2, LH = TH + 2, NTHR = 256;
+constexpr int TW = 64, TH = 32, LW = TW + 2, LH = TH + 2, NTHR = 256;
 
+// 64 x 32 tiles (+1 halo) staged in LDS with every load of a thread in flight together; a wavefront owns a band of 8
+// consecutive rows, a lane one column, and the 3 x 3 window slides down the column in registers (3 LDS reads per cell).
 template <class T, int MODE>
 __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T nodata, uint8_t *__restrict__ dirs,
                                                    int w, int h, uint32_t tilesX, uint32_t ntiles) {
@@ -21,24 +23,36 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
-  for (int i = threadIdx.x; i < LH * LW; i += NTHR) {
-    const int ly = i / LW, lx = i - ly * LW;
-    const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    T v = nodata;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = z[(size_t)gy * w + gx];
-    sz[i] = v;
+  {
+    constexpr int IPT = (LH * LW + NTHR - 1) / NTHR;
+    T zv[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {   // clamped addresses: a cell outside the raster is never used as a neighbour
+      const int i = min((int)threadIdx.x + r * NTHR, LH * LW - 1);
+      const int ly = i / LW, lx = i - ly * LW;
+      const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
+      zv[r] = z[(size_t)gy * w + gx];
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i < LH * LW) sz[i] = zv[r];
+    }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (TW - 1), ly0 = threadIdx.x >> 6;
-  // LDS offsets of neighbours 1..8 in the 234/105/876 numbering (reference common/constants.hpp:44-45)
-  const int off[9] = {0, -1, -LW - 1, -LW, -LW + 1, 1, LW + 1, LW, LW - 1};
+  const int lx = threadIdx.x & (TW - 1), yb = (int)(threadIdx.x >> 6) * (TH / 4);
+  const int gx = x0 + lx;
+  T r0[3], r1[3], r2[3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) { r0[e] = sz[yb * LW + lx + e]; r1[e] = sz[(yb + 1) * LW + lx + e]; }
 #pragma unroll
   for (int j = 0; j < TH / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    const int o = (ly + 1) * LW + lx + 1;
-    const T e = sz[o];
+    const int gy = y0 + yb + j;
+#pragma unroll
+    for (int e = 0; e < 3; e++) r2[e] = sz[(yb + j + 2) * LW + lx + e];
+    // neighbours 1..8 in the 234/105/876 numbering (reference common/constants.hpp:44-45)
+    const T nbv[9] = {r1[1], r1[0], r0[0], r0[1], r0[2], r1[2], r2[2], r2[1], r2[0]};
+    const T e = r1[1];
     int dir = 0;  // NO_FLOW (constants.hpp:80)
     const bool edge = gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1;
     if (e == nodata) {
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
         T m = e;
 #pragma unroll
         for (int n = 1; n <= 8; n++) {
-          const T v = sz[o + off[n]];
+          const T v = nbv[n];
           if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (n & 1) == 1)) {
             m = v;
             dir = n;
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
         T m = e;
 #pragma unroll
         for (int n = 1; n <= 8; n++) {
-          const T v = sz[o + off[n]];
+          const T v = nbv[n];
           if (v == nodata) continue;
           if (v < m) {  // first strictly-lowest neighbour below the centre
             m = v;
@@ -78,7 +92,9 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
         }
       }
     }
-    dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+    if (gx < w && gy < h) dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+#pragma unroll
+    for (int e2 = 0; e2 < 3; e2++) { r0[e2] = r1[e2]; r1[e2] = r2[e2]; }
   }
 }
 
