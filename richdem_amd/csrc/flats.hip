@@ -1028,19 +1028,19 @@ template <class T>
 __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__ z, const int32_t *__restrict__ TW,
                                                            const int32_t *__restrict__ AW, uint8_t *dirs, int w, int h,
                                                            uint32_t tilesX, uint32_t ntiles) {
-  __shared__ T sz[SLH * SLW];
-  __shared__ int32_t sm[SLH * SLW];
+  __shared__ T sz[KLLH * SLW];
+  __shared__ int32_t sm[KLLH * SLW];
   constexpr int32_t LOWEDGE = INT32_MIN, NOTFLAT = INT32_MAX;
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
-  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * SH;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
   {
-    constexpr int IPT = (SLH * SLW + NTHR - 1) / NTHR;
+    constexpr int IPT = (KLLH * SLW + NTHR - 1) / NTHR;
     T zv[IPT];
     int32_t tv[IPT], av[IPT];
 #pragma unroll
     for (int r = 0; r < IPT; r++) {   // all loads of the thread in flight together (clamped addresses)
-      const int i = min((int)threadIdx.x + r * NTHR, SLH * SLW - 1);
+      const int i = min((int)threadIdx.x + r * NTHR, KLLH * SLW - 1);
       const int ly = i / SLW, lx = i - ly * SLW;
       const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
       const size_t g = (size_t)gy * w + gx;
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__
 #pragma unroll
     for (int r = 0; r < IPT; r++) {
       const int i = (int)threadIdx.x + r * NTHR;
-      if (i >= SLH * SLW) continue;
+      if (i >= KLLH * SLW) continue;
       const int ly = i / SLW, lx = i - ly * SLW;
       const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
       const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
@@ -1060,31 +1060,44 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__
     }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (SW - 1), ly0 = threadIdx.x >> 6;
-  const int off[9] = {0, -1, -SLW - 1, -SLW, -SLW + 1, 1, SLW + 1, SLW, SLW - 1};
+  // a wavefront owns a band of 8 consecutive rows, a lane one column; the 3 x 3 windows slide down in registers
+  const int lx = threadIdx.x & (SW - 1), yb = (int)(threadIdx.x >> 6) * (KLH / 4);
+  const int gx = x0 + lx;
+  T z0[3], z1[3], z2[3];
+  int32_t m0[3], m1[3], m2[3];
 #pragma unroll
-  for (int j = 0; j < SH / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= w || gy >= h) continue;
-    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) continue;   // interior only (:108-109)
-    const int o = (ly + 1) * SLW + lx + 1;
-    const int32_t mc = sm[o];
-    if (mc == NOTFLAT || mc == LOWEDGE) continue;     // not a NO_FLOW cell of a drainable flat (low edges keep their direction, :112)
-    const T e = sz[o];
-    int32_t m = mc;
-    int dir = 0;
+  for (int e = 0; e < 3; e++) {
+    z0[e] = sz[yb * SLW + lx + e]; z1[e] = sz[(yb + 1) * SLW + lx + e];
+    m0[e] = sm[yb * SLW + lx + e]; m1[e] = sm[(yb + 1) * SLW + lx + e];
+  }
 #pragma unroll
-    for (int k = 1; k <= 8; k++) {
-      if (!(sz[o + off[k]] == e)) continue;                         // labels(n) != labels(c), :56-57
-      const int32_t v = sm[o + off[k]];
-      if (v == NOTFLAT) continue;                                   // (an equal neighbour outside the flat cannot occur: kept safe)
-      if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1)) {
-        m = v;
-        dir = k;
+  for (int j = 0; j < KLH / 4; j++) {
+    const int gy = y0 + yb + j;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { z2[e] = sz[(yb + j + 2) * SLW + lx + e]; m2[e] = sm[(yb + j + 2) * SLW + lx + e]; }
+    const int32_t mc = m1[1];
+    // interior only (:108-109); a NO_FLOW cell of a drainable flat (low edges keep their direction, :112)
+    if (gx > 0 && gy > 0 && gx < w - 1 && gy < h - 1 && mc != NOTFLAT && mc != LOWEDGE) {
+      // neighbours 1..8 in the 234/105/876 numbering
+      const T zn[9] = {z1[1], z1[0], z0[0], z0[1], z0[2], z1[2], z2[2], z2[1], z2[0]};
+      const int32_t mn[9] = {m1[1], m1[0], m0[0], m0[1], m0[2], m1[2], m2[2], m2[1], m2[0]};
+      const T e = z1[1];
+      int32_t m = mc;
+      int dir = 0;
+#pragma unroll
+      for (int k = 1; k <= 8; k++) {
+        if (!(zn[k] == e)) continue;                                  // labels(n) != labels(c), :56-57
+        const int32_t v = mn[k];
+        if (v == NOTFLAT) continue;                                   // (an equal neighbour outside the flat cannot occur: kept safe)
+        if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1)) {
+          m = v;
+          dir = k;
+        }
       }
+      dirs[(size_t)gy * w + gx] = (uint8_t)dir;
     }
-    dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; m0[e] = m1[e]; m1[e] = m2[e]; }
   }
 }
 
@@ -1482,8 +1495,7 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
     }
     g_fstats.towards_levels = run_relax_towards(d_dirs, flags, TWd, w, h, s);
   }
-  uint32_t tilesX;
-  const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
+  const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
   RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
             (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
 }
