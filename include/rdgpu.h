@@ -397,6 +397,23 @@ typedef struct rdgpu_accum_shard rdgpu_accum_shard;
 int rdgpu_accum_shard_begin(const uint8_t *d_dirs_rows, uint8_t dir_nodata, int width, int rows,
                             const uint8_t *d_row_above, const uint8_t *d_row_below, void *hip_stream,
                             rdgpu_accum_shard **out);
+/* One exchange instead of one per cut crossing (the protocol of programs/parallel_d8_accum/main.cpp:270-464), for
+ * directions without loops (every direction raster derived from a DEM):
+ *   begin_local  pending counts from the block's own cells only: every cell completes, the outboxes hold what the
+ *                block's own cells send across each cut
+ *   links        d_links[2][width]: where the flow ENTERING at each cell of the first / last row leaves the block
+ *                again -- (1 << 31 if across the lower cut) | receiving column, or -1; *d_pending: cells the local
+ *                phase could not complete (a direction loop: fall back to begin / outbox / inject)
+ *   (one all-gather of outbox + links; every rank solves the forest over the cut-row cells:
+ *    richdem_amd/sharded.py accum_link_solve)
+ *   add_paths    the inflow of each entry cell is added along its path inside the block
+ *   finish       as above. */
+int rdgpu_accum_shard_begin_local(const uint8_t *d_dirs_rows, uint8_t dir_nodata, int width, int rows,
+                                  const uint8_t *d_row_above, const uint8_t *d_row_below, void *hip_stream,
+                                  rdgpu_accum_shard **out);
+int rdgpu_accum_shard_links(rdgpu_accum_shard *shard, int32_t *d_links, unsigned long long *d_pending);
+int rdgpu_accum_shard_add_paths(rdgpu_accum_shard *shard, const unsigned long long *d_in_top,
+                                const unsigned long long *d_in_bottom);
 int rdgpu_accum_shard_outbox(rdgpu_accum_shard *shard, unsigned long long *d_out);
 int rdgpu_accum_shard_inject(rdgpu_accum_shard *shard, const unsigned long long *d_from_above,
                              const unsigned long long *d_from_below);

@@ -857,12 +857,13 @@ struct AccShard {
   unsigned long long *word, *out_top, *out_bottom;
   int w, h;
   uint8_t nodata;
+  uint8_t local;   // 1: the one-exchange protocol -- pending counts ignore the donors across the cuts
 };
 
 __device__ __forceinline__ uint8_t accs_dir(const AccShard &s, int x, int y) {
   if (x < 0 || x >= s.w) return s.nodata;            // treated as "never flows in"
-  if (y < 0) return s.above ? s.above[x] : s.nodata;
-  if (y >= s.h) return s.below ? s.below[x] : s.nodata;
+  if (y < 0) return s.above && !s.local ? s.above[x] : s.nodata;
+  if (y >= s.h) return s.below && !s.local ? s.below[x] : s.nodata;
   return s.dirs[(size_t)y * s.w + x];
 }
 
@@ -991,6 +992,77 @@ __global__ __launch_bounds__(NTHR) void k_accs_out(AccShard s, A *area) {
   }
 }
 
+// ---- one exchange (reference programs/parallel_d8_accum/main.cpp: :373-464 the tile's own accumulation, :270-334 where the
+// flow entering at a perimeter cell leaves the tile again, :344-370 FollowPathAdd) -------------------------------------
+// With local pending counts every cell of a loop-free block completes in begin, and the outboxes hold what the block's
+// own cells send across each cut.  What is missing is the flow that ENTERS at a cut-row cell; it travels down that
+// cell's path and leaves again at a known place -- its link.  The ranks gather (outbox, links) once, every rank solves
+// the small forest over the cut-row cells, and the inflow of each entry is added along its path.
+// link of a cut-row cell: (leaves across the lower cut ? 1 << 31 : 0) | receiving column, or -1 (the path ends inside).
+__global__ __launch_bounds__(NTHR) void k_accs_links(AccShard s, int32_t *links) {
+  const int i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= 2 * s.w) return;
+  int x = i % s.w, y = i < s.w ? 0 : s.h - 1;
+  int32_t link = -1;
+  uint8_t d = s.dirs[(size_t)y * s.w + x];
+  if (d != s.nodata) {
+    for (uint64_t steps = 0, cap = (uint64_t)s.w * s.h + 1; steps < cap; steps++) {
+      if (d < 1 || d > 8) break;
+      const int nx = x + d8dx(d), ny = y + d8dy(d);
+      if (nx < 0 || nx >= s.w) break;
+      if (ny < 0) { if (s.above && s.above[nx] != s.nodata) link = nx; break; }
+      if (ny >= s.h) { if (s.below && s.below[nx] != s.nodata) link = (int32_t)(0x80000000u | (uint32_t)nx); break; }
+      const uint8_t dn = s.dirs[(size_t)ny * s.w + nx];
+      if (dn == s.nodata) break;
+      // an incomplete cell lies on or below a direction loop: stop (the protocol falls back anyway) instead of circling
+      const unsigned long long k = s.word[(size_t)ny * s.w + nx] >> 56;
+      if (k != 0 && k != SRC) break;
+      x = nx; y = ny; d = dn;
+    }
+  }
+  links[i] = link;
+}
+
+__global__ __launch_bounds__(NTHR) void k_accs_count_pending(AccShard s, unsigned long long *count) {
+  const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
+  uint32_t mine = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const unsigned long long k = s.word[c] >> 56;
+    mine += (s.dirs[c] != s.nodata && k != 0 && k != SRC) ? 1u : 0u;
+  }
+  const unsigned long long b = __ballot(mine != 0);
+  if (b) {   // rare: direction loops only
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)mine);
+  }
+}
+
+// in_top[x] / in_bottom[x]: the flow entering at cell x of the first / last row from outside; added to every cell of
+// that cell's path inside the block (all cells are complete: plain sums, any order)
+__global__ __launch_bounds__(NTHR) void k_accs_add_paths(AccShard s, const unsigned long long *__restrict__ in_top,
+                                                         const unsigned long long *__restrict__ in_bottom) {
+  const int i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= 2 * s.w) return;
+  const unsigned long long *in = i < s.w ? in_top : in_bottom;
+  if (!in) return;
+  int x = i % s.w, y = i < s.w ? 0 : s.h - 1;
+  const unsigned long long v = in[x] & LOWMASK;
+  if (v == 0) return;
+  uint8_t d = s.dirs[(size_t)y * s.w + x];
+  if (d == s.nodata) return;
+  for (uint64_t steps = 0, cap = (uint64_t)s.w * s.h + 1; steps < cap; steps++) {
+    atomicAdd(&s.word[(size_t)y * s.w + x], v);
+    if (d < 1 || d > 8) return;
+    const int nx = x + d8dx(d), ny = y + d8dy(d);
+    if (nx < 0 || nx >= s.w || ny < 0 || ny >= s.h) return;
+    const uint8_t dn = s.dirs[(size_t)ny * s.w + nx];
+    if (dn == s.nodata) return;
+    const unsigned long long k = s.word[(size_t)ny * s.w + nx] >> 56;
+    if (k != 0 && k != SRC) return;   // (never with loop-free directions, the only ones this entry is for)
+    x = nx; y = ny; d = dn;
+  }
+}
+
 }  // namespace rdgpu
 
 struct rdgpu_accum_shard {
@@ -1008,7 +1080,7 @@ static void accs_free(rdgpu_accum_shard *a) {
 }
 
 static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int w, int h, const uint8_t *d_above,
-                                     const uint8_t *d_below, hipStream_t st) {
+                                     const uint8_t *d_below, hipStream_t st, bool local = false) {
   if (!d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_begin: null pointer");
   check_dims(w, h, "rdgpu_accum_shard_begin");
   rdgpu_accum_shard *a = new rdgpu_accum_shard();
@@ -1022,7 +1094,7 @@ static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int 
       return p;
     };
     a->s = AccShard{d_dirs, d_above, d_below, (unsigned long long *)alloc(n * 8), (unsigned long long *)alloc((size_t)w * 8),
-                    (unsigned long long *)alloc((size_t)w * 8), w, h, nodata};
+                    (unsigned long long *)alloc((size_t)w * 8), w, h, nodata, (uint8_t)(local ? 1 : 0)};
     RD_HIP(hipMemsetAsync(a->s.out_top, 0, (size_t)w * 8, st));
     RD_HIP(hipMemsetAsync(a->s.out_bottom, 0, (size_t)w * 8, st));
     RD_LAUNCH("accum.shard_init", k_accs_init, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
@@ -1044,6 +1116,38 @@ extern "C" int rdgpu_accum_shard_begin(const uint8_t *d_dirs, uint8_t dir_nodata
   return guarded([&] {
     if (!out) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_begin: null output handle");
     *out = accs_begin(d_dirs, dir_nodata, w, h, d_row_above, d_row_below, (hipStream_t)stream);
+  });
+}
+
+// One-exchange protocol: local pending counts, then outbox as usual, rdgpu_accum_shard_links, one gather, the solve
+// (richdem_amd/sharded.py accum_link_solve), rdgpu_accum_shard_add_paths, finish.
+extern "C" int rdgpu_accum_shard_begin_local(const uint8_t *d_dirs, uint8_t dir_nodata, int w, int h, const uint8_t *d_row_above,
+                                             const uint8_t *d_row_below, void *stream, rdgpu_accum_shard **out) {
+  return guarded([&] {
+    if (!out) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_begin_local: null output handle");
+    *out = accs_begin(d_dirs, dir_nodata, w, h, d_row_above, d_row_below, (hipStream_t)stream, true);
+  });
+}
+
+// d_links[2][w] <- where the flow entering at each cell of the first / last row leaves the block again;
+// *d_pending <- the number of cells the local phase could not complete (direction loops: use the iterated protocol)
+extern "C" int rdgpu_accum_shard_links(rdgpu_accum_shard *a, int32_t *d_links, unsigned long long *d_pending) {
+  return guarded([&] {
+    if (!a || !d_links || !d_pending) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_links: null pointer");
+    const uint64_t n = (uint64_t)a->s.w * a->s.h;
+    RD_HIP(hipMemsetAsync(d_pending, 0, sizeof(unsigned long long), a->stream));
+    RD_LAUNCH("accum.shard_links", k_accs_links, dim3((2 * a->s.w + NTHR - 1) / NTHR), dim3(NTHR), 0, a->stream, a->s, d_links);
+    RD_LAUNCH("accum.shard_pending", k_accs_count_pending, dim3(sgrid(n)), dim3(NTHR), 0, a->stream, a->s, d_pending);
+  });
+}
+
+// d_in_top[w] / d_in_bottom[w] (NULL: none): the flow entering at the first / last row from outside
+extern "C" int rdgpu_accum_shard_add_paths(rdgpu_accum_shard *a, const unsigned long long *d_in_top,
+                                           const unsigned long long *d_in_bottom) {
+  return guarded([&] {
+    if (!a) throw Error(RDGPU_ERR_ARG, "rdgpu_accum_shard_add_paths: null handle");
+    RD_LAUNCH("accum.shard_add_paths", k_accs_add_paths, dim3((2 * a->s.w + NTHR - 1) / NTHR), dim3(NTHR), 0, a->stream, a->s,
+              d_in_top, d_in_bottom);
   });
 }
 

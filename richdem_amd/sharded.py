@@ -561,7 +561,7 @@ def flat_resolution_blocks(dem, nodata, world: int, shard_factory=None, solve=No
 class GpuAccumShard:
     """rdgpu_accum_shard_* over CUDA tensors."""
 
-    def begin(self, dirs_block, nodata: int, row_above, row_below):
+    def begin(self, dirs_block, nodata: int, row_above, row_below, entry: str = "rdgpu_accum_shard_begin"):
         import torch
 
         if not (dirs_block.is_cuda and dirs_block.dtype == torch.uint8 and dirs_block.is_contiguous()):
@@ -570,13 +570,34 @@ class GpuAccumShard:
         self._keep = (dirs_block, row_above.contiguous() if row_above is not None else None,
                       row_below.contiguous() if row_below is not None else None)
         handle = ctypes.c_void_p()
-        check(lib().rdgpu_accum_shard_begin(
+        check(getattr(lib(), entry)(
             ctypes.c_void_p(dirs_block.data_ptr()), ctypes.c_uint8(nodata), self._w, self._h,
             ctypes.c_void_p(self._keep[1].data_ptr()) if self._keep[1] is not None else None,
             ctypes.c_void_p(self._keep[2].data_ptr()) if self._keep[2] is not None else None,
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(handle)), "rdgpu_accum_shard_begin")
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(handle)), entry)
         self._handle = handle
         self._dev = dirs_block.device
+
+    def begin_local(self, dirs_block, nodata: int, row_above, row_below):
+        """one-exchange protocol: pending counts from the block's own cells only (rdgpu_accum_shard_begin_local)"""
+        self.begin(dirs_block, nodata, row_above, row_below, entry="rdgpu_accum_shard_begin_local")
+
+    def links(self):
+        """([2, w] int32 links of the cut-row cells, [1] int64 number of cells the local phase left incomplete)"""
+        import torch
+
+        links = torch.empty((2, self._w), dtype=torch.int32, device=self._dev)
+        pending = torch.empty((1,), dtype=torch.int64, device=self._dev)
+        check(lib().rdgpu_accum_shard_links(self._handle, ctypes.c_void_p(links.data_ptr()), ctypes.c_void_p(pending.data_ptr())),
+              "rdgpu_accum_shard_links")
+        return links, pending
+
+    def add_paths(self, in_top, in_bottom) -> None:
+        it = in_top.contiguous() if in_top is not None else None
+        ib = in_bottom.contiguous() if in_bottom is not None else None
+        check(lib().rdgpu_accum_shard_add_paths(self._handle, ctypes.c_void_p(it.data_ptr()) if it is not None else None,
+                                                ctypes.c_void_p(ib.data_ptr()) if ib is not None else None),
+              "rdgpu_accum_shard_add_paths")
 
     def outbox(self):
         import torch
@@ -625,9 +646,75 @@ def accum_exchange_loop(shard, rank: int, world: int, group, to_tensor, from_ten
         shard.inject(above, below)
 
 
-def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None, shard=None) -> int:
+_LOW56 = (1 << 56) - 1
+
+
+def accum_link_solve(boxes, links, world: int, w: int):
+    """The forest over the cut-row cells (reference programs/parallel_d8_accum/main.cpp:270-334, the producer's
+    perimeter graph).  boxes [world, 2, w] int64: what every rank's OWN cells send up / down (packed outboxes);
+    links [world, 2, w] int32: where the flow entering at a first / last row cell leaves its block again.
+    Returns [world, 2, w] int64 -- the flow entering every first / last row cell from outside its block -- or None
+    when the links form a loop across the cuts (then the iterated protocol applies).  torch ops only: runs on the
+    device the gathered tensors live on; the graph has 2 * w * world nodes."""
+    import torch
+
+    dev = boxes.device
+    n = world * 2 * w
+    sums = boxes & _LOW56
+    total = torch.zeros((world, 2, w), dtype=torch.int64, device=dev)
+    if world > 1:
+        total[1:, 0] = sums[:-1, 1]      # my first row receives what the rank above sent down
+        total[:-1, 1] = sums[1:, 0]      # my last row receives what the rank below sent up
+    total = total.reshape(n)
+    lk = links.reshape(world, 2, w).to(torch.int64)
+    has = lk != -1
+    down = has & (lk < 0)
+    col = lk & 0x7FFFFFFF
+    r = torch.arange(world, device=dev, dtype=torch.int64).view(world, 1, 1).expand(world, 2, w)
+    dst = torch.where(down, ((r + 1) * 2 + 0) * w + col, ((r - 1) * 2 + 1) * w + col)
+    dst = torch.where(has, dst, torch.full_like(dst, -1)).reshape(n)
+    alive = dst >= 0
+    indeg = torch.zeros(n, dtype=torch.int64, device=dev)
+    indeg.index_add_(0, dst[alive], torch.ones(int(alive.sum()), dtype=torch.int64, device=dev))
+    while True:   # Kahn, a level per trip: as many trips as the longest path crosses cuts
+        idx = (alive & (indeg == 0)).nonzero().reshape(-1)
+        if idx.numel() == 0:
+            break
+        d = dst[idx]
+        total.index_add_(0, d, total[idx])
+        indeg.index_add_(0, d, torch.full((idx.numel(),), -1, dtype=torch.int64, device=dev))
+        alive[idx] = False
+    if bool(alive.any()):
+        return None
+    return total.reshape(world, 2, w)
+
+
+def accum_one_exchange(shard, rank: int, world: int, group, to_tensor, from_tensor) -> bool:
+    """After shard.begin_local: ONE all-gather (outboxes + links + incomplete-cell counts of every rank), the solve,
+    the inflows added along their paths.  False: the directions contain a loop -- nothing was added, use the iterated
+    protocol."""
+    import torch
+
+    box = to_tensor(shard.outbox())
+    links, pending = shard.links()
+    links, pending = to_tensor(links), to_tensor(pending)
+    w = box.shape[1]
+    mine = torch.cat([box.reshape(-1), links.reshape(-1).to(torch.int64), pending.reshape(-1).to(torch.int64)])
+    allv = _all_gather_stack(mine, group)                       # [world, 4w + 1]
+    if bool((allv[:, 4 * w] != 0).any()):
+        return False
+    inflow = accum_link_solve(allv[:, : 2 * w].reshape(world, 2, w), allv[:, 2 * w : 4 * w].reshape(world, 2, w).to(torch.int32),
+                              world, w)
+    if inflow is None:
+        return False
+    shard.add_paths(from_tensor(inflow[rank, 0]) if rank > 0 else None, from_tensor(inflow[rank, 1]) if rank + 1 < world else None)
+    return True
+
+
+def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None, shard=None, protocol: str = "links") -> int:
     """d8_flow_accum of the whole raster, computed on row blocks: area_block <- accumulation of this rank's
-    rows.  Collective.  Returns the number of exchanges."""
+    rows.  Collective.  Returns the number of exchanges: 1 with the link protocol (every loop-free direction raster);
+    directions with loops, or protocol="rounds", take one exchange per cut crossing of the longest path."""
     import torch
     import torch.distributed as dist
 
@@ -640,10 +727,19 @@ def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None,
     above = from_t(rows[rank - 1, 1]) if rank > 0 else None
     below = from_t(rows[rank + 1, 0]) if rank + 1 < world else None
     try:
+        extra = 0
+        if protocol == "links" and hasattr(eng, "begin_local"):
+            eng.begin_local(dirs_block, nodata, above, below)
+            if accum_one_exchange(eng, rank, world, group, to_t, from_t):
+                eng.finish(area_block)
+                return 1
+            if hasattr(eng, "abort"):
+                eng.abort()
+            extra = 1
         eng.begin(dirs_block, nodata, above, below)
         rounds = accum_exchange_loop(eng, rank, world, group, to_t, from_t)
         eng.finish(area_block)
-        return rounds
+        return rounds + extra
     except BaseException:
         if hasattr(eng, "abort"):
             eng.abort()

@@ -104,7 +104,60 @@ class NumpyAccumShard:
     DX = [0, -1, -1, 0, 1, 1, 1, 0, -1]
     DY = [0, 0, -1, -1, -1, 0, 1, 1, 1]
 
-    def begin(self, dirs, nodata, above, below):
+    def begin_local(self, dirs, nodata, above, below):
+        """rdgpu_accum_shard_begin_local: the donors across the cuts are not counted"""
+        self.begin(dirs, nodata, above, below, local=True)
+
+    def links(self):
+        """rdgpu_accum_shard_links: ([2, w] int32 links, [1] int64 incomplete cells)"""
+        links = np.full((2, self.w), -1, np.int32)
+        for k, y0 in ((0, 0), (1, self.h - 1)):
+            for x0 in range(self.w):
+                x, y = x0, y0
+                if int(self.d[y, x]) == self.nd:
+                    continue
+                for _ in range(self.w * self.h + 1):
+                    d = int(self.d[y, x])
+                    if d < 1 or d > 8:
+                        break
+                    nx, ny = x + self.DX[d], y + self.DY[d]
+                    if nx < 0 or nx >= self.w:
+                        break
+                    if ny < 0:
+                        if self.above is not None and int(self.above[nx]) != self.nd:
+                            links[k, x0] = nx
+                        break
+                    if ny >= self.h:
+                        if self.below is not None and int(self.below[nx]) != self.nd:
+                            links[k, x0] = np.int32(np.uint32(0x80000000 | nx).astype(np.int32))
+                        break
+                    if int(self.d[ny, nx]) == self.nd:
+                        break
+                    x, y = nx, ny
+        pending = np.array([int(((self.d != self.nd) & ~self.done).sum())], np.int64)
+        return links, pending
+
+    def add_paths(self, in_top, in_bottom):
+        """rdgpu_accum_shard_add_paths"""
+        for y0, box in ((0, in_top), (self.h - 1, in_bottom)):
+            if box is None:
+                continue
+            for x0 in range(self.w):
+                v = int(box[x0]) & self.LOW
+                if v == 0 or int(self.d[y0, x0]) == self.nd:
+                    continue
+                x, y = x0, y0
+                for _ in range(self.w * self.h + 1):
+                    self.total[y, x] += v
+                    d = int(self.d[y, x])
+                    if d < 1 or d > 8:
+                        break
+                    nx, ny = x + self.DX[d], y + self.DY[d]
+                    if nx < 0 or nx >= self.w or ny < 0 or ny >= self.h or int(self.d[ny, nx]) == self.nd:
+                        break
+                    x, y = nx, ny
+
+    def begin(self, dirs, nodata, above, below, local=False):
         self.d, self.nd, self.above, self.below = dirs, int(nodata), above, below
         h, w = dirs.shape
         self.h, self.w = h, w
@@ -117,9 +170,9 @@ class NumpyAccumShard:
             if x < 0 or x >= w:
                 return self.nd
             if y < 0:
-                return int(above[x]) if above is not None else self.nd
+                return int(above[x]) if above is not None and not local else self.nd
             if y >= h:
-                return int(below[x]) if below is not None else self.nd
+                return int(below[x]) if below is not None and not local else self.nd
             return int(dirs[y, x])
 
         for y in range(h):

@@ -97,42 +97,81 @@ def test_model_engine_matches_oracle_single_process(orc):
         assert np.array_equal(np.concatenate(blocks, axis=0), orc.port.fill(dem, 8)), world
 
 
-def _accum_worker(rank, world, port, outdir):
+def _accum_dirs(case):
+    import oracle
+
+    dem = oracle.port.fill(_make_dem("f32"))
+    dirs = oracle.port.flat_resolution(dem, np.float32(-9999))
+    dirs[20:24, 30:34] = 255                      # a NoData hole straddling nothing in particular
+    if case == "loop":                            # hand-made: a 2-cycle across the first cut of a 3-way split
+        h = dirs.shape[0]
+        y = h // 3 + (1 if h % 3 else 0)          # first row of the second block (row_split)
+        dirs[y - 1, 40], dirs[y, 40] = 7, 3       # south / north: they point at each other
+    return dirs
+
+
+def _accum_worker(rank, world, port, case, protocol, outdir):
     import torch.distributed as dist
 
-    import oracle
     from richdem_amd.sharded import d8_flow_accum_sharded, row_split
     from shard_model import NumpyAccumShard
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dem = oracle.port.fill(_make_dem("f32"))
-    dirs = oracle.port.flat_resolution(dem, np.float32(-9999))
-    dirs[20:24, 30:34] = 255                      # a NoData hole straddling nothing in particular
+    dirs = _accum_dirs(case)
     r0, r1 = row_split(dirs.shape[0], world)[rank]
     block = np.ascontiguousarray(dirs[r0:r1])
     area = np.zeros(block.shape, np.float64)
-    rounds = d8_flow_accum_sharded(block, area, 255, shard=NumpyAccumShard())
+    rounds = d8_flow_accum_sharded(block, area, 255, shard=NumpyAccumShard(), protocol=protocol)
     np.save(os.path.join(outdir, f"area{rank}.npy"), area)
     np.save(os.path.join(outdir, f"rounds{rank}.npy"), np.array([rounds]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_sharded_accumulation_matches_oracle(orc, tmp_path, world):
-    """The outbox / all-gather / inject loop of d8_flow_accum_sharded (product code) around a Python model
-    of the shard engine: tiling invariance of D8 accumulation (reference parallel_d8_accum/test_small.sh)."""
+@pytest.mark.parametrize("world,case,protocol", [(2, "dem", "links"), (3, "dem", "links"), (3, "dem", "rounds"), (3, "loop", "links")])
+def test_gloo_sharded_accumulation_matches_oracle(orc, tmp_path, world, case, protocol):
+    """d8_flow_accum_sharded (product code: the one-exchange link protocol, its solve, the fallback to the outbox /
+    all-gather / inject loop) around a Python model of the shard engine: tiling invariance of D8 accumulation
+    (reference parallel_d8_accum/test_small.sh).  Loop-free directions take exactly ONE exchange; a direction loop
+    across a cut is detected by the solve and handled by the iterated protocol with the reference's partial sums."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_accum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_accum_worker, args=(world, _free_port(), case, protocol, str(tmp_path)), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"area{r}.npy") for r in range(world)], axis=0)
-    dem = orc.port.fill(_make_dem("f32"))
-    dirs = orc.port.flat_resolution(dem, np.float32(-9999))
-    dirs[20:24, 30:34] = 255
+    dirs = _accum_dirs(case)
     assert np.array_equal(got, orc.port.d8_flow_accum(dirs, 255, np.float64))
-    assert int(np.load(tmp_path / "rounds0.npy")[0]) >= 2   # flow really crossed the cuts
+    rounds = int(np.load(tmp_path / "rounds0.npy")[0])
+    if case == "dem" and protocol == "links":
+        assert rounds == 1
+    else:
+        assert rounds >= 2   # flow really crossed the cuts, exchange by exchange
+
+
+def test_accum_link_solve_chain_and_cycle():
+    """The cut-row forest on hand-made links: a path that crosses three cuts accumulates along the chain; two entries
+    that lead into each other are reported as a loop."""
+    import torch
+
+    from richdem_amd.sharded import accum_link_solve
+
+    world, w = 4, 5
+    boxes = torch.zeros((world, 2, w), dtype=torch.int64)
+    links = torch.full((world, 2, w), -1, dtype=torch.int32)
+    DOWN = -(1 << 31)
+    boxes[0, 1, 2] = (1 << 56) | 7          # rank 0 sends 7 down to column 2 of rank 1's first row
+    links[1, 0, 2] = DOWN | 3               # what enters there leaves rank 1 downwards at column 3
+    boxes[1, 1, 3] = (1 << 56) | 10         # rank 1's own cells also send 10 to that cell
+    links[2, 0, 3] = DOWN | 1
+    boxes[3, 0, 4] = (2 << 56) | 5          # rank 3 sends 5 up to column 4 of rank 2's last row
+    links[2, 1, 4] = 0                      # ... which leaves rank 2 upwards at column 0
+    inflow = accum_link_solve(boxes, links, world, w)
+    assert inflow[1, 0, 2] == 7 and inflow[2, 0, 3] == 17 and inflow[3, 0, 1] == 17
+    assert inflow[2, 1, 4] == 5 and inflow[1, 1, 0] == 5 and int(inflow.sum()) == 7 + 17 + 17 + 5 + 5
+    links[1, 1, 0] = DOWN | 4               # rank 1's last row cell 0 sends it back down to column 4 of rank 2's first row ...
+    links[2, 0, 4] = 0                      # ... whose path leaves upwards at column 0 again: a loop across the cut
+    assert accum_link_solve(boxes, links, world, w) is None
 
 
 def _flat_dem(case):
