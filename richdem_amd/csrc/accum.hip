@@ -15,6 +15,8 @@
 //      one atomicAdd(word, area - (1<<56)) per step; integer, exact, order independent.
 //  f64 weights (FA_D8): f64 atomicAdd on the total + release/acquire decrement of a separate counter.
 #include "common.hpp"
+
+#include <string>
 #include "flowdirs.hpp"
 
 #include <algorithm>
@@ -1068,14 +1070,21 @@ __global__ __launch_bounds__(NTHR) void k_accs_add_paths(AccShard s, const unsig
 struct rdgpu_accum_shard {
   rdgpu::AccShard s;
   hipStream_t stream = nullptr;
-  std::vector<void *> owned;
+  int slot = -1;   // which set of workspace buffers this shard holds (several shards may be alive on one device)
 };
 
 namespace rdgpu {
 
+// The per-cell words live in the workspace (a hipMalloc / hipFree of 8 B per cell around every accumulation cost more
+// than the accumulation's own exchange); a live shard owns one numbered set of buffers until finish / free.
+static std::vector<bool> &accs_slots() {
+  static std::vector<bool> v;
+  return v;
+}
+
 static void accs_free(rdgpu_accum_shard *a) {
   if (!a) return;
-  for (void *p : a->owned) (void)hipFree(p);
+  if (a->slot >= 0 && (size_t)a->slot < accs_slots().size()) accs_slots()[a->slot] = false;
   delete a;
 }
 
@@ -1087,11 +1096,16 @@ static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int 
   try {
     a->stream = st;
     const uint64_t n = (uint64_t)w * h;
+    std::vector<bool> &slots = accs_slots();
+    size_t k = 0;
+    while (k < slots.size() && slots[k]) k++;
+    if (k == slots.size()) slots.push_back(false);
+    slots[k] = true;
+    a->slot = (int)k;
+    int nbuf = 0;
     auto alloc = [&](size_t bytes) {
-      void *p = nullptr;
-      RD_HIP(hipMalloc(&p, bytes));
-      a->owned.push_back(p);
-      return p;
+      const std::string name = "accum.shard" + std::to_string(k) + "." + std::to_string(nbuf++);
+      return Workspace::get().buf(name.c_str(), bytes);
     };
     a->s = AccShard{d_dirs, d_above, d_below, (unsigned long long *)alloc(n * 8), (unsigned long long *)alloc((size_t)w * 8),
                     (unsigned long long *)alloc((size_t)w * 8), w, h, nodata, (uint8_t)(local ? 1 : 0)};
