@@ -19,8 +19,13 @@
  * resolution, ResolveFlatsEpsilon and FA_D8 / FM_D8 (these compare elevations in their own type); the D-infinity / MFD
  * families take i8 ... f64.  The row-block shard entry points of the fill take the 8 / 16 / 32-bit types.
  *
- * Threading: one host thread at a time per process (the reference functions
- * are not internally re-entrant on shared arrays either).
+ * Threading: every entry point takes a process-wide lock, so calls from several host threads (e.g. Python threads with
+ * the GIL released by the wrapper) are safe and run one after the other; when the calling thread changes, the device is
+ * synchronised first, because all calls share one grow-only workspace per device.
+ * Streams: the `_dev_` entry points enqueue on the stream they are given and use that shared per-device workspace for
+ * their scratch.  Issue all `_dev_` calls of a process on ONE stream per device, or synchronise between calls issued on
+ * different streams -- two calls in flight on two streams would overwrite each other's scratch.  (The handle-based shard
+ * entry points keep their state in buffers of their own.)
  */
 #ifndef RDGPU_H_
 #define RDGPU_H_

@@ -25,7 +25,16 @@ _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
 
 def row_split(height: int, world: int):
     """Row r0..r1 of every rank: rank s owns rows [h*s/N, h*(s+1)/N)."""
+    if height < world:
+        raise RdgpuError(f"row_split: {height} rows cannot be split over {world} ranks (every rank needs at least one row)")
     return [(height * s // world, height * (s + 1) // world) for s in range(world)]
+
+
+def _check_block(block, who: str) -> None:
+    """The collective drivers index block[0] / block[-1] before any engine call: an empty row block (a raster with
+    fewer rows than ranks) is reported here, by name, instead of as an index error on one rank and a hang on the others."""
+    if len(block.shape) != 2 or block.shape[0] < 1 or block.shape[1] < 1:
+        raise RdgpuError(f"{who}: every rank needs a row block with at least one row and one column (got {tuple(block.shape)})")
 
 
 class GpuShardEngine:
@@ -204,6 +213,7 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
     if topo is None:
         raise RdgpuError("Unknown topology!")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    _check_block(block, "fill_depressions_sharded")
     if hasattr(block, "is_cuda") and block.is_cuda:
         import torch
 
@@ -386,6 +396,7 @@ def d8_flow_directions_sharded(block, nodata, group=None, flats: bool = False):
     from .api import d8_flow_directions_dev
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    _check_block(block, "d8_flow_directions_sharded")
     if flats and world > 1:
         return flat_resolution_sharded(block, nodata, group)
     h, w = block.shape
@@ -719,6 +730,7 @@ def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None,
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    _check_block(dirs_block, "d8_flow_accum_sharded")
     eng = shard if shard is not None else GpuAccumShard()
     is_np = isinstance(dirs_block, np.ndarray)
     to_t = (lambda a: torch.from_numpy(np.ascontiguousarray(a))) if is_np else (lambda a: a)

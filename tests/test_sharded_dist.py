@@ -243,3 +243,13 @@ def test_flat_model_blocks_single_process(orc):
             assert np.array_equal(got.numpy(), orc.port.flat_resolution(dem, nd)), (case, world, ex)
             if case == "snake" and world == 7:
                 assert ex[0] > 3      # the towards levels crossed the cuts repeatedly
+
+
+def test_row_split_rejects_more_ranks_than_rows(rd):
+    from richdem_amd.sharded import _check_block, row_split
+
+    assert row_split(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    with pytest.raises(rd.RdgpuError, match="cannot be split"):
+        row_split(2, 3)
+    with pytest.raises(rd.RdgpuError, match="at least one row"):
+        _check_block(np.zeros((0, 5), np.float32), "fill_depressions_sharded")
