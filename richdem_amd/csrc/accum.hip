@@ -17,6 +17,7 @@
 #include "common.hpp"
 
 #include <string>
+#include <type_traits>
 #include "flowdirs.hpp"
 
 #include <algorithm>
@@ -229,6 +230,10 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
     // cells downstream of a direction loop are never completed by the reference either: they keep the
     // sum of the inflows that did arrive, without their own +1 (d8_methods.hpp:104-131)
     const unsigned long long cnt = v >> 56;
+    if (std::is_same<A, unsigned long long>::value) {   // a shard's words: the total, an incomplete cell keeps a count
+      area[c] = (A)(((cnt != 0 && cnt != SRC) ? CNT1 : 0ull) | (v & AREAMASK));
+      continue;
+    }
     const unsigned long long a = (cnt != 0 && cnt != SRC) ? (v & AREAMASK) - 1 : (v & AREAMASK);
     area[c] = (A)a;
   }
@@ -562,6 +567,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
       // cells downstream of a direction loop are never completed by the reference either: they keep the sum of the
       // inflows that did arrive, without their own +1 (d8_methods.hpp:104-131)
       out = (A)((v >> 56) != 0 ? (v & TMASK) - 1ull : (v & TMASK));
+      if (std::is_same<A, unsigned long long>::value) out = (A)(((v >> 56) != 0 ? CNT1 : 0ull) | (v & TMASK));   // a shard's words
     }
     area[(size_t)gy * w + gx] = out;
   }
@@ -1025,6 +1031,22 @@ __global__ __launch_bounds__(NTHR) void k_accs_links(AccShard s, int32_t *links)
   links[i] = link;
 }
 
+// what the block's own (complete) cut-row cells send across the cuts, in the outbox format of the walk
+__global__ __launch_bounds__(NTHR) void k_accs_local_outbox(AccShard s) {
+  const int i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= 2 * s.w) return;
+  if (s.h == 1 && i >= s.w) return;   // a single row is the first and the last row: once
+  const int x = i % s.w, y = i < s.w ? 0 : s.h - 1;
+  const uint8_t d = s.dirs[(size_t)y * s.w + x];
+  if (d == s.nodata || d < 1 || d > 8) return;
+  const int nx = x + d8dx(d), ny = y + d8dy(d);
+  if (nx < 0 || nx >= s.w || (ny >= 0 && ny < s.h)) return;
+  const unsigned long long v = s.word[(size_t)y * s.w + x];
+  if ((v >> 56) != 0) return;   // incomplete (a direction loop upstream): never handed on
+  if (ny < 0) { if (s.above && s.above[nx] != s.nodata) atomicAdd(&s.out_top[nx], (v & LOWMASK) + CNT1); }
+  else if (s.below && s.below[nx] != s.nodata) atomicAdd(&s.out_bottom[nx], (v & LOWMASK) + CNT1);
+}
+
 __global__ __launch_bounds__(NTHR) void k_accs_count_pending(AccShard s, unsigned long long *count) {
   const uint64_t n = (uint64_t)s.w * s.h, stride = (uint64_t)gridDim.x * NTHR;
   uint32_t mine = 0;
@@ -1111,6 +1133,12 @@ static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int 
                     (unsigned long long *)alloc((size_t)w * 8), w, h, nodata, (uint8_t)(local ? 1 : 0)};
     RD_HIP(hipMemsetAsync(a->s.out_top, 0, (size_t)w * 8, st));
     RD_HIP(hipMemsetAsync(a->s.out_bottom, 0, (size_t)w * 8, st));
+    if (local) {
+      // the block on its own is a raster like any other: the tile links of d8_flow_accum, written as words
+      d8_flow_accum_device<unsigned long long>(d_dirs, nodata, w, h, a->s.word, st);
+      RD_LAUNCH("accum.shard_outbox", k_accs_local_outbox, dim3((2 * w + NTHR - 1) / NTHR), dim3(NTHR), 0, st, a->s);
+      return a;
+    }
     RD_LAUNCH("accum.shard_init", k_accs_init, dim3(sgrid(n)), dim3(NTHR), 0, st, a->s);
     RD_LAUNCH("accum.shard_walk", k_accs_walk_sources, dim3((uint32_t)(((n + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)),
               dim3(NTHR), 0, st, a->s);
