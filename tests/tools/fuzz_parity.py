@@ -32,7 +32,36 @@ def main():
 
     import oracle
     import richdem_amd as rd
-    from richdem_amd.sharded import flat_resolution_blocks
+    from richdem_amd.sharded import GpuAccumShard, accum_link_solve, flat_resolution_blocks, row_split
+
+    def accum_one_exchange(dirs_np, world, adt):
+        """the one-exchange protocol block after block on this GPU; None when it reports a loop"""
+        tdt = {np.float64: torch.float64, np.float32: torch.float32, np.int32: torch.int32}[adt]
+        dirs = torch.from_numpy(dirs_np).cuda()
+        blocks = [dirs[a:b].contiguous() for a, b in row_split(dirs.shape[0], world)]
+        shards, boxes, links, pend = [], [], [], []
+        for k, blk in enumerate(blocks):
+            sh = GpuAccumShard()
+            sh.begin_local(blk, 255, blocks[k - 1][-1] if k > 0 else None, blocks[k + 1][0] if k + 1 < world else None)
+            shards.append(sh)
+            boxes.append(sh.outbox())
+            lk, pn = sh.links()
+            links.append(lk)
+            pend.append(pn)
+        inflow = None
+        if int(torch.cat(pend).sum().item()) == 0:
+            inflow = accum_link_solve(torch.stack(boxes), torch.stack(links), world, dirs.shape[1])
+        if inflow is None:
+            for sh in shards:
+                sh.abort()
+            return None
+        out = []
+        for k, (sh, blk) in enumerate(zip(shards, blocks)):
+            sh.add_paths(inflow[k, 0] if k > 0 else None, inflow[k, 1] if k + 1 < world else None)
+            a = torch.empty(blk.shape, dtype=tdt, device="cuda")
+            sh.finish(a)
+            out.append(a)
+        return torch.cat(out, 0).cpu().numpy()
     from richdem_amd.synth import fractal_dem
 
     oracle.build()
@@ -44,6 +73,8 @@ def main():
         h, w = int(rng.integers(1, 260)), int(rng.integers(1, 300))
         if rng.random() < 0.2:
             h, w = int(rng.integers(1, 6)), int(rng.integers(1, 200))
+        elif rng.random() < 0.12:   # many 64 x 64 tiles: the tile-to-tile paths of the flat search and the tile links
+            h, w = int(rng.integers(260, 700)), int(rng.integers(300, 900))
         dt = dtypes[int(rng.integers(len(dtypes)))]
         style = int(rng.integers(5))
         if style == 0:
@@ -96,7 +127,16 @@ def main():
             d2 = dirs.copy()
             if rng.random() < 0.3:
                 d2[rng.random(d2.shape) < 0.05] = rng.integers(0, 9)      # arbitrary directions, loops included
-            chk("d8_accum", np.array_equal(rd.d8_flow_accum(d2, 255, adt), P.d8_flow_accum(d2, 255, adt)))
+            exp_acc = P.d8_flow_accum(d2, 255, adt)
+            chk("d8_accum", np.array_equal(rd.d8_flow_accum(d2, 255, adt), exp_acc))
+            if h >= 2:
+                world = int(rng.integers(2, min(h, 12) + 1))
+                got = accum_one_exchange(d2, world, adt)
+                if got is not None:   # (None: a direction loop was reported -- the iterated protocol's case)
+                    chk(f"accum_one_exchange{world}", np.array_equal(got, exp_acc))
+                elif d2 is dirs or np.array_equal(d2, dirs):
+                    chk("accum_one_exchange_loopfree_reported_loop", False)
+            chk("fa_d8_unit", np.array_equal(rd.FlowAccumulation(src, "D8", nodata=nd), P.fa_d8(src, nd)))
             wts = rng.integers(0, 7, (h, w)).astype(np.float64)
             chk("fa_d8", np.array_equal(rd.FlowAccumulation(src, "D8", nodata=nd, weights=wts), P.fa_d8(src, nd, wts)))
             m, x = [("Quinn", None), ("Holmgren", 2.0), ("Freeman", 1.1), ("D4", None), ("Holmgren", 0.7)][int(rng.integers(5))]
