@@ -876,7 +876,8 @@ __global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *_
       A &= ~N;
       Rec |= N;
 #pragma unroll
-      for (int j = 0; j < BPLANES; j++) {   // branch-free: the mask is all ones when the level has bit j set
+      for (int j = 0; j < BPLANES; j++) {   // branch-free: the mask is all ones when the level has bit j set (a Gray-coded
+        // counter per cell -- one plane flip a level, picked by a scalar if-chain -- was measured SLOWER: 31.4 vs 29.7 ms)
         const uint32_t m = (uint32_t)(-(int32_t)((uint32_t)rel >> j & 1u));
         Plo[j] |= nlo & m;
         Phi[j] |= nhi & m;
