@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=40000, help="DEM is size x size cells")
-    ap.add_argument("--cpu-sample", type=int, default=10000, help="window edge for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=14000, help="window edge for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-stages", action="store_true", help="skip the directions / flat resolution / accumulation stages")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer end-to-end measurement")
