@@ -716,7 +716,7 @@ __global__ __launch_bounds__(NTHR) void k_bits_counts(const uint32_t *__restrict
 }
 
 template <int SEED_LEVEL>
-__global__ __launch_bounds__(NTHR) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
+__global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
                                                      uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
   const uint32_t n = *count;
