@@ -107,17 +107,21 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
       // a cell WITH flow can only be a low edge if some neighbour is NO_FLOW; a NO_FLOW cell is always
       // interior (edge cells always get a direction), so its 8 neighbours exist
       const T e = z1[1];
-      bool hit = false, near = false;
+      // three questions about the 8 neighbours, accumulated without branches (the per-neighbour early-outs compiled
+      // into ~14 exec-mask branches and ~130 scalar mask operations per cell): is one of them higher (:409-411), is
+      // one an equal NO_FLOW cell (:406-408), is one an equal cell WITH a direction (a low edge of this cell's flat)
+      int higher = 0, eq_noflow = 0, eq_flow = 0;
       auto nb = [&](T zn, uint8_t dn) {
-        if (dn == 255) return;
-        hit |= noflow ? (e < zn) : (dn == 0 && zn == e);   // :409-411 / :406-408
-        near |= noflow && dn != 0 && zn == e;              // the neighbour is a low edge of this cell's flat
+        const int valid = dn != 255, eq = zn == e;
+        higher |= valid & (int)(e < zn);
+        eq_noflow |= valid & eq & (int)(dn == 0);
+        eq_flow |= valid & eq & (int)(dn != 0);
       };
       nb(z0[0], d0[0]); nb(z0[1], d0[1]); nb(z0[2], d0[2]);
       nb(z1[0], d1[0]); nb(z1[2], d1[2]);
       nb(z2[0], d2[0]); nb(z2[1], d2[1]); nb(z2[2], d2[2]);
-      if (hit) f |= noflow ? F_HIGH : F_LOW;
-      if (near) f |= F_NEAR;
+      if (noflow ? higher : eq_noflow) f |= noflow ? F_HIGH : F_LOW;
+      if (noflow && eq_flow) f |= F_NEAR;
     }
     if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
 #pragma unroll
