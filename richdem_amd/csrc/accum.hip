@@ -280,16 +280,18 @@ __device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uin
   stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
   __syncthreads();
   const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+#pragma unroll 4
   for (int j = 0; j < LT / 4; j++) {
+    // branch-free (a cell without a direction "targets" itself for the lookup): these kernels are bound by instruction
+    // issue, and a divergent branch costs more than the handful of selects it guards
     const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
     const uint8_t d = sd[o];
-    uint16_t p = LP_TERM;
-    if (d != nodata && d >= 1 && d <= 8) {
-      const int tx = lx + d8dx(d), ty = ly + d8dy(d);
-      if (sd[(ty + 1) * LLW + tx + 1] != nodata)   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
-        p = (tx >= 0 && tx < LT && ty >= 0 && ty < LT) ? (uint16_t)(ty * LT + tx) : LP_EXIT;
-    }
-    lp[ly * LT + lx] = p;
+    const bool flows = d != nodata && d >= 1 && d <= 8;
+    const int dd = flows ? d : 0;
+    const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
+    const bool into_data = sd[(ty + 1) * LLW + tx + 1] != nodata;   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
+    const bool inside = tx >= 0 && tx < LT && ty >= 0 && ty < LT;
+    lp[ly * LT + lx] = !(flows && into_data) ? LP_TERM : inside ? (uint16_t)(ty * LT + tx) : LP_EXIT;
   }
 }
 
@@ -329,15 +331,18 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
     lw[ly * LT + lx] = (datamask >> j & 1u) ? (((tg < LP_TERM ? (uint32_t)tg : LNOTGT) << 15) | 1u) : 0u;
   }
   __syncthreads();
-  for (int j = 0; j < LT / 4; j++) {
-    const uint16_t tg = lp[(ly0 + 4 * j) * LT + lx];
-    if (tg < LP_TERM) atomicAdd(&lw[tg], LCNT1);
+#pragma unroll 4
+  for (int j = 0; j < LT / 4; j++) {   // (a cell without an in-tile target adds 0 to its own word: no branch)
+    const int c = (ly0 + 4 * j) * LT + lx;
+    const uint16_t tg = lp[c];
+    atomicAdd(&lw[tg < LP_TERM ? tg : c], tg < LP_TERM ? LCNT1 : 0u);
   }
   __syncthreads();
   uint32_t srcmask = 0;
+#pragma unroll
   for (int j = 0; j < LT / 4; j++) {
     const int ly = ly0 + 4 * j;
-    if ((datamask >> j & 1u) && (lw[ly * LT + lx] >> 28) == 0) srcmask |= 1u << j;
+    srcmask |= ((datamask >> j & 1u) & ((lw[ly * LT + lx] >> 28) == 0 ? 1u : 0u)) << j;
   }
   __syncthreads();   // the sources are fixed before any walk completes a cell
   {
@@ -370,11 +375,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
 #pragma unroll
     for (int j = 0; j < LT / 4; j++) pv[j] = lp[(ly0 + 4 * j) * LT + lx];
 #pragma unroll
-    for (int j = 0; j < LT / 4; j++) qv[j] = pv[j] < LP_TERM ? lp[pv[j]] : pv[j];
+    for (int j = 0; j < LT / 4; j++) {   // (a terminal code reads its own slot: no branch around the LDS read)
+      const uint16_t q = lp[pv[j] < LP_TERM ? pv[j] : (ly0 + 4 * j) * LT + lx];
+      qv[j] = pv[j] < LP_TERM ? q : pv[j];
+    }
     int still = 0;
 #pragma unroll
-    for (int j = 0; j < LT / 4; j++)
-      if (pv[j] < LP_TERM && qv[j] < LP_TERM) { lp[(ly0 + 4 * j) * LT + lx] = qv[j]; still = 1; }
+    for (int j = 0; j < LT / 4; j++) {
+      const bool move = pv[j] < LP_TERM && qv[j] < LP_TERM;
+      lp[(ly0 + 4 * j) * LT + lx] = move ? qv[j] : pv[j];   // (rewriting the own slot with its own value is harmless)
+      still |= move;
+    }
     if (!__syncthreads_or(still)) break;
   }
   __syncthreads();
