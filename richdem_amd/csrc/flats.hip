@@ -240,11 +240,11 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
     if (gx < w && gy < h) {
       const T e = sz[ly * CW + lx];
 #pragma unroll
-      for (int k = 1; k <= 8; k++) {
+      for (int k = 1; k <= 8; k++) {   // clamped lookups and a mask, no branches (see k_flat_classify)
         const int nlx = lx + fdx(k), nly = ly + fdy(k);
-        if (nlx < 0 || nlx >= CW || nly < 0 || nly >= CH) continue;
-        if (x0 + nlx >= w || y0 + nly >= h) continue;
-        if (sz[nly * CW + nlx] == e) m |= 1u << (k - 1);
+        const bool in = (nlx >= 0) & (nlx < CW) & (nly >= 0) & (nly < CH) & (x0 + nlx < w) & (y0 + nly < h);
+        const int cx = min(max(nlx, 0), CW - 1), cy = min(max(nly, 0), CH - 1);
+        m |= (uint32_t)(in & (sz[cy * CW + cx] == e)) << (k - 1);
       }
     }
     msk[j] = m;
@@ -1090,14 +1090,12 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__
       int32_t m = mc;
       int dir = 0;
 #pragma unroll
-      for (int k = 1; k <= 8; k++) {
-        if (!(zn[k] == e)) continue;                                  // labels(n) != labels(c), :56-57
+      for (int k = 1; k <= 8; k++) {   // selects, no branches (see k_flat_classify)
         const int32_t v = mn[k];
-        if (v == NOTFLAT) continue;                                   // (an equal neighbour outside the flat cannot occur: kept safe)
-        if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1)) {
-          m = v;
-          dir = k;
-        }
+        const bool same = (zn[k] == e) & (v != NOTFLAT);   // labels(n) == labels(c), :56-57 (an equal neighbour outside the flat cannot occur: kept safe)
+        const bool take = same & ((v < m) | ((v == m) & (dir > 0) & ((dir & 1) == 0) & ((k & 1) == 1)));
+        m = take ? v : m;
+        dir = take ? k : dir;
       }
       dirs[(size_t)gy * w + gx] = (uint8_t)dir;
     }

@@ -72,10 +72,9 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
 #pragma unroll
         for (int n = 1; n <= 8; n++) {
           const T v = nbv[n];
-          if (v < m || (v == m && dir > 0 && (dir & 1) == 0 && (n & 1) == 1)) {
-            m = v;
-            dir = n;
-          }
+          const bool take = (v < m) | ((v == m) & (dir > 0) & ((dir & 1) == 0) & ((n & 1) == 1));
+          m = take ? v : m;
+          dir = take ? n : dir;
         }
       }
     } else {  // MODE_FM, OCallaghan1984.hpp:42-74: edges never flow, NoData neighbours are skipped
@@ -84,11 +83,9 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
 #pragma unroll
         for (int n = 1; n <= 8; n++) {
           const T v = nbv[n];
-          if (v == nodata) continue;
-          if (v < m) {  // first strictly-lowest neighbour below the centre
-            m = v;
-            dir = n;
-          }
+          const bool take = !(v == nodata) & (v < m);   // first strictly-lowest neighbour below the centre
+          m = take ? v : m;
+          dir = take ? n : dir;
         }
       }
     }
