@@ -145,38 +145,39 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       const int ly = ly0 + j, gy = y0 + ly;
 #pragma unroll
       for (int e = 0; e < 3; e++) k2[e] = sk[(ly + 2) * DLW + lx + e];
-      uint16_t l = LTERM_BASE;
-      if (gx < w && gy < h) {
-        if (gx == 0 || gx == w - 1 || (gy == 0 && !open_top) || (gy == h - 1 && !open_bottom)) l = LTERM_BASE | 9;  // true border
-        else if (gy == 0 || gy == h - 1) l = LTERM_BASE;   // cut row of a row-block shard: frozen terminal
-        else {
-          // lowest (key, index) neighbour: visited in increasing index order and compared with strict '<',
-          // so the lowest index wins among equal keys; a neighbour of EQUAL key is taken only if its index is lower
-          const uint32_t kc = k1[1];
-          uint32_t bk;
-          int n = 0;   // 3x3 raster position of the best neighbour
-          if (TOPO == 8) {
-            bk = k0[0];
-            if (k0[1] < bk) { bk = k0[1]; n = 1; }
-            if (k0[2] < bk) { bk = k0[2]; n = 2; }
-            if (k1[0] < bk) { bk = k1[0]; n = 3; }
-            if (k1[2] < bk) { bk = k1[2]; n = 5; }
-            if (k2[0] < bk) { bk = k2[0]; n = 6; }
-            if (k2[1] < bk) { bk = k2[1]; n = 7; }
-            if (k2[2] < bk) { bk = k2[2]; n = 8; }
-          } else {
-            bk = k0[1]; n = 1;
-            if (k1[0] < bk) { bk = k1[0]; n = 3; }
-            if (k1[2] < bk) { bk = k1[2]; n = 5; }
-            if (k2[1] < bk) { bk = k2[1]; n = 7; }
-          }
-          if ((bk < kc) || (bk == kc && n < 4)) {
-            const int tx = lx + n % 3 - 1, ty = ly + n / 3 - 1;
-            if (tx >= 0 && tx < DW && ty >= 0 && ty < DH) l = (uint16_t)(ty * DW + tx);
-            else l = LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n);
-          }
-        }
+      // Branch-free: every case is computed and the pointer is chosen by selects (the nested ifs compiled into five
+      // levels of exec-mask branches per cell; this kernel is bound by instruction issue).
+      // lowest (key, index) neighbour: visited in increasing index order and compared with strict '<', so the lowest
+      // index wins among equal keys; a neighbour of EQUAL key is taken only if its index is lower.  q packs the
+      // neighbour's 3x3 position n with its row n / 3 (bits 4-5) and column n % 3 (bits 6-7).
+#define RD_Q(n) ((n) | (((n) / 3) << 4) | (((n) % 3) << 6))
+      const uint32_t kc = k1[1];
+      uint32_t bk, q;
+      if (TOPO == 8) {
+        bk = k0[0]; q = RD_Q(0);
+        { const bool t = k0[1] < bk; bk = t ? k0[1] : bk; q = t ? RD_Q(1) : q; }
+        { const bool t = k0[2] < bk; bk = t ? k0[2] : bk; q = t ? RD_Q(2) : q; }
+        { const bool t = k1[0] < bk; bk = t ? k1[0] : bk; q = t ? RD_Q(3) : q; }
+        { const bool t = k1[2] < bk; bk = t ? k1[2] : bk; q = t ? RD_Q(5) : q; }
+        { const bool t = k2[0] < bk; bk = t ? k2[0] : bk; q = t ? RD_Q(6) : q; }
+        { const bool t = k2[1] < bk; bk = t ? k2[1] : bk; q = t ? RD_Q(7) : q; }
+        { const bool t = k2[2] < bk; bk = t ? k2[2] : bk; q = t ? RD_Q(8) : q; }
+      } else {
+        bk = k0[1]; q = RD_Q(1);
+        { const bool t = k1[0] < bk; bk = t ? k1[0] : bk; q = t ? RD_Q(3) : q; }
+        { const bool t = k1[2] < bk; bk = t ? k1[2] : bk; q = t ? RD_Q(5) : q; }
+        { const bool t = k2[1] < bk; bk = t ? k2[1] : bk; q = t ? RD_Q(7) : q; }
       }
+#undef RD_Q
+      const int n = (int)(q & 15u);
+      const bool drains = (bk < kc) | ((bk == kc) & (n < 4));
+      const int tx = lx + (int)(q >> 6 & 3u) - 1, ty = ly + (int)(q >> 4 & 3u) - 1;
+      const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
+      const uint16_t ldrain = inside ? (uint16_t)(ty * DW + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
+      const bool incell = (gx < w) & (gy < h);
+      const bool border = (gx == 0) | (gx == w - 1) | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);   // true border
+      const bool cutrow = (gy == 0) | (gy == h - 1);   // (not a border: the cut row of a row-block shard, a frozen terminal)
+      const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : (cutrow | !drains) ? LTERM_BASE : ldrain;
       lp[ly * DW + lx] = l;
 #pragma unroll
       for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
@@ -261,19 +262,16 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
   for (int j = 0; j < DH / 4; j++) {
     const int ly = ly0 + j, gy = y0 + ly;
     if (gx >= w || gy >= h) continue;
-    uint16_t p = lp[ly * DW + lx];
-    int r = ly * DW + lx;
-    if (p < LTERM_BASE) { r = p; p = lp[p]; }
+    const uint16_t p0 = lp[ly * DW + lx];
+    const int r = p0 < LTERM_BASE ? (int)p0 : ly * DW + lx;   // the tile root of the cell's path (itself when it is one)
+    const uint16_t p = lp[r];                                  // (its own entry again when the cell is a root: no branch)
     const int code = p & 15;
-    uint32_t word;
-    if (code == 9) word = OUTP;
-    else if (code == 0) word = pid[r];
-    else {
-      const int rx = r & (DW - 1), ry = r >> 6;
-      const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour
-      word = LAB_PEND | ((uint32_t)(y0 + ry + n / 3 - 1) * (uint32_t)w + (uint32_t)(x0 + rx + n % 3 - 1));
-    }
-    lab[(size_t)gy * w + gx] = word;
+    const uint32_t basin = pid[r];                             // (only meaningful for code 0; any slot is readable)
+    const int rx = r & (DW - 1), ry = r >> 6;
+    const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour (codes 1..8)
+    const int nr = n >= 6 ? 2 : n >= 3 ? 1 : 0, nc = n - 3 * nr;
+    const uint32_t pend = LAB_PEND | ((uint32_t)(y0 + ry + nr - 1) * (uint32_t)w + (uint32_t)(x0 + rx + nc - 1));
+    lab[(size_t)gy * w + gx] = code == 9 ? OUTP : code == 0 ? basin : pend;
   }
 }
 
