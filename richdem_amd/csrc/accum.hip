@@ -298,78 +298,36 @@ __device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uin
 __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
                                                         uint32_t tilesX, uint32_t ntiles, unsigned long long *nw,
                                                         uint32_t *next, uint8_t *rootslot) {
-  // The staged directions are only needed until every cell knows its target; their 4.3 KB then become part of the
-  // words (24.6 instead of 28.9 KB of LDS: a sixth block per CU).  A thread keeps the direction bytes of its own
-  // sixteen cells in registers (four per VGPR) for the "is data" tests and the exits' directions.
-  __shared__ uint32_t lw[LT * LT];
+  // What this pass has to deliver is, per EXIT cell, the number of tile cells whose path leaves the tile through it, and
+  // per border cell the exit its path ends at.  Both follow from "the last in-tile cell of every cell's path" (pointer
+  // jumping): the exit totals are a histogram over those roots -- one LDS add per cell -- and no accumulation walk is
+  // needed here at all (r02c ran the full last-arriver walk in this pass too: 20 of the stage's 47 ms).  Cells that
+  // drain into a direction loop inside the tile have no root and are counted nowhere, as in the reference.
+  // The staged directions are only needed until every cell knows its target; their 4.3 KB then hold the counters.
+  __shared__ uint32_t cnt[LT * LT];
   __shared__ uint16_t lp[LT * LT];
-  uint8_t *const sd = reinterpret_cast<uint8_t *>(lw);
-  static_assert(LLW * LLW <= LT * LT * 4, "the staged directions fit into the words' storage");
-  // one word per cell: pending in-tile donors (bits 28..31) | in-tile target, 0x1FFF for none (bits 15..27) | area;
-  // the returning add of a step also delivers the target of the cell it completed: ONE LDS round trip per step
-  constexpr uint32_t LCNT1 = 1u << 28, LMASK = 0x7FFFu, LNOTGT = 0x1FFFu;
+  uint8_t *const sd = reinterpret_cast<uint8_t *>(cnt);
+  static_assert(LLW * LLW <= LT * LT * 4, "the staged directions fit into the counters' storage");
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
   link_stage(dirs, nodata, w, h, x0, y0, sd, lp);
   const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
-  uint32_t dpk[LT / 16];   // the thread's own direction bytes
-  uint32_t datamask = 0;
+  uint32_t dpk[LT / 16];   // the thread's own direction bytes (four per VGPR): the exits' directions
 #pragma unroll
   for (int j = 0; j < LT / 4; j++) {
     const uint8_t d = sd[(ly0 + 4 * j + 1) * LLW + lx + 1];
     if ((j & 3) == 0) dpk[j >> 2] = 0;
     dpk[j >> 2] |= (uint32_t)d << (8 * (j & 3));
-    datamask |= (d != nodata ? 1u : 0u) << j;
-  }
-  __syncthreads();   // every thread has read what it needs of sd: the words may overwrite it
-  // pending donors are counted from the donors' side: one (non-returning) LDS add per cell into its target's word,
-  // instead of eight byte reads per cell to look who points at it (LDS instruction issue bounds these kernels)
-  for (int j = 0; j < LT / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const uint16_t tg = lp[ly * LT + lx];
-    lw[ly * LT + lx] = (datamask >> j & 1u) ? (((tg < LP_TERM ? (uint32_t)tg : LNOTGT) << 15) | 1u) : 0u;
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int j = 0; j < LT / 4; j++) {   // (a cell without an in-tile target adds 0 to its own word: no branch)
-    const int c = (ly0 + 4 * j) * LT + lx;
-    const uint16_t tg = lp[c];
-    atomicAdd(&lw[tg < LP_TERM ? tg : c], tg < LP_TERM ? LCNT1 : 0u);
-  }
-  __syncthreads();
-  uint32_t srcmask = 0;
-#pragma unroll
-  for (int j = 0; j < LT / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    srcmask |= ((datamask >> j & 1u) & ((lw[ly * LT + lx] >> 28) == 0 ? 1u : 0u)) << j;
-  }
-  __syncthreads();   // the sources are fixed before any walk completes a cell
-  {
-    // last-arriver walks, confined to the tile.  A lane whose walk has ended takes its next source in the same trip
-    // (with "for every source: walk to the end" a wavefront paid the longest chain of EVERY round of sources: 84 us
-    // per tile at S3)
-    uint32_t m = srcmask, tg = LNOTGT, v = 0;
-    for (;;) {
-      if (tg == LNOTGT && m) {
-        tg = (lw[(ly0 + 4 * (__ffs((int)m) - 1)) * LT + lx] >> 15) & LNOTGT;
-        v = 1;
-        m &= m - 1;
-      }
-      if (!__any(tg != LNOTGT || m != 0)) break;
-      if (tg != LNOTGT) {
-        const uint32_t old = atomicAdd(&lw[tg], v - LCNT1);
-        if ((old >> 28) != 1) tg = LNOTGT;
-        else { v = (old & LMASK) + v; tg = (old >> 15) & LNOTGT; }
-      }
-    }
   }
   // the last in-tile cell of every cell's path: pointer jumping (two batches of independent LDS reads per trip);
   // twelve doublings cover any loop-free path of a 4096-cell tile, what still points at a non-terminal then runs into a loop
   uint16_t keep[LT / 4];
 #pragma unroll
   for (int j = 0; j < LT / 4; j++) keep[j] = lp[(ly0 + 4 * j) * LT + lx];   // own entries before they are compressed
-  __syncthreads();
+  __syncthreads();   // (also: every thread has read what it needs of sd)
+#pragma unroll
+  for (int j = 0; j < LT / 4; j++) cnt[(ly0 + 4 * j) * LT + lx] = 0;
   for (int it = 0; it < 12; it++) {
     uint16_t pv[LT / 4], qv[LT / 4];
 #pragma unroll
@@ -387,6 +345,16 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
       still |= move;
     }
     if (!__syncthreads_or(still)) break;
+  }
+  __syncthreads();
+  // every cell adds itself to the exit its path ends at (an exit to itself); anything else adds 0 to its own counter
+#pragma unroll 4
+  for (int j = 0; j < LT / 4; j++) {
+    const int c = (ly0 + 4 * j) * LT + lx;
+    const uint16_t p = lp[c];
+    const uint16_t code = lp[p < LP_TERM ? p : c];   // p is terminal iff its own (uncompressed == compressed) entry is a code
+    const bool self_exit = keep[j] == LP_EXIT, via = keep[j] < LP_TERM && p < LP_TERM && code == LP_EXIT;
+    atomicAdd(&cnt[via ? p : c], (self_exit || via) ? 1u : 0u);
   }
   __syncthreads();
   // what the border cells publish (252 of the tile's 256 slots; the four spare ones are marked unused)
@@ -407,7 +375,6 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
     else if (keep[j] < LP_TERM) {
       const uint16_t p = lp[c];
       if (p < LP_TERM) {
-        // p is terminal iff its own (uncompressed == compressed) entry is a code
         const uint16_t code = lp[p];
         if (code == LP_EXIT) rs = (uint8_t)border_slot(p & (LT - 1), p >> 6);
       }
@@ -416,8 +383,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
     unsigned long long word = NOT_A_NODE << 56;
     uint32_t tn = NO_NODE;
     if (is_exit) {
-      const uint32_t v = lw[c];
-      word = ((unsigned long long)((v >> 28) != 0 ? 1u : 0u) << 56) | (unsigned long long)(v & LMASK);
+      word = (unsigned long long)cnt[c];   // complete by construction: every cell counted has a path to it
       const uint8_t d = (uint8_t)(dpk[j >> 2] >> (8 * (j & 3)));
       const int gx = x0 + lx + d8dx(d), gy = y0 + ly + d8dy(d);
       tn = ((uint32_t)(gy / LT) * tilesX + (uint32_t)(gx / LT)) * 256u + (uint32_t)border_slot(gx % LT, gy % LT);
