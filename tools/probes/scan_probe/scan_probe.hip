@@ -1,3 +1,4 @@
+// hipcc --offload-arch=gfx950 -O3 scan_probe.hip -o scan_probe && gpurun -- tools/probes/scan_probe/scan_probe
 // checks the DPP prefix / suffix minimum over 64 lanes used by the open-water chamfer sweeps
 #include <hip/hip_runtime.h>
 #include <cstdio>
