@@ -341,6 +341,14 @@ __global__ __launch_bounds__(NTHR) void k_ccl_flatten(uint32_t *L, uint64_t n) {
 }
 
 // fh[root] = -1: flat without a low edge (label 0 in the reference, :483-487); >= 0: labelled.
+// the same from the flag bytes (no edge list): every low edge marks its flat as having an outlet
+__global__ __launch_bounds__(NTHR) void k_flat_mark_low_flags(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ L,
+                                                              int32_t *fh, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride)
+    if (flags[c] & F_LOW) fh[L[c]] = 0;
+}
+
 __global__ __launch_bounds__(NTHR) void k_flat_mark_low(const uint32_t *__restrict__ low, uint32_t nlow,
                                                         const uint32_t *__restrict__ L, int32_t *fh) {
   const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
@@ -1194,14 +1202,34 @@ __global__ __launch_bounds__(NTHR) void k_flag_fill2(const uint8_t *__restrict__
   }
 }
 
+// totals of the three per-block count arrays (the counts-only case needs no offsets: one launch instead of three scans)
+__global__ __launch_bounds__(NTHR) void k_flag_totals(const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cn,
+                                                      const uint32_t *__restrict__ ch, uint32_t nblk, uint32_t *tot) {
+  uint32_t a = 0, b = 0, c = 0;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nblk; i += gridDim.x * NTHR) { a += cl[i]; b += cn[i]; c += ch[i]; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(tot, a); atomicAdd(tot + 1, b); atomicAdd(tot + 2, c); }
+}
+
 static void compact_edges(const uint8_t *flags, uint64_t n, uint32_t **low, uint32_t *nlow, uint32_t **high, uint32_t *nhigh,
-                          uint32_t *nnoflow, hipStream_t s) {
+                          uint32_t *nnoflow, hipStream_t s, bool lists = true) {
   Workspace &ws = Workspace::get();
   uint32_t *hw = ws.host_words();
   const uint32_t nblk = (uint32_t)((n + CPB - 1) / CPB);
   uint32_t *counts = ws.buf<uint32_t>("flats.counts3", 3 * ((size_t)nblk + 1));
   uint32_t *cl = counts, *cn = counts + (nblk + 1), *ch = counts + 2 * ((size_t)nblk + 1);
   RD_LAUNCH("flats.flag_count", k_flag_count3, dim3(nblk), dim3(NTHR), 0, s, flags, n, cl, cn, ch);
+  if (!lists) {
+    uint32_t *tot = ws.buf<uint32_t>("flats.totals3", 4);
+    RD_HIP(hipMemsetAsync(tot, 0, 3 * sizeof(uint32_t), s));
+    RD_LAUNCH("flats.flag_totals", k_flag_totals, dim3(64), dim3(NTHR), 0, s, (const uint32_t *)cl, (const uint32_t *)cn,
+              (const uint32_t *)ch, nblk, tot);
+    RD_HIP(hipMemcpyAsync(hw, tot, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    *nlow = hw[0]; *nnoflow = hw[1]; *nhigh = hw[2];
+    *low = *high = nullptr;
+    return;
+  }
   RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, cl, nblk, cl + nblk);
   RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, cn, nblk, cn + nblk);
   RD_LAUNCH("flats.flag_scan", k_flag_scan, dim3(1), dim3(1024), 0, s, ch, nblk, ch + nblk);
@@ -1211,7 +1239,7 @@ static void compact_edges(const uint8_t *flags, uint64_t n, uint32_t **low, uint
   RD_HIP(hipStreamSynchronize(s));
   *nlow = hw[0]; *nnoflow = hw[1]; *nhigh = hw[2];
   *low = *high = nullptr;
-  if (*nlow == 0) return;   // nothing will be resolved: the lists are not needed
+  if (*nlow == 0 || !lists) return;   // nothing will be resolved / the bitmap engine takes its seeds from the flags: counts only
   *low = ws.buf<uint32_t>("flats.low", *nlow);
   *high = ws.buf<uint32_t>("flats.highall", std::max<uint32_t>(*nhigh, 1u));
   RD_LAUNCH("flats.flag_fill", k_flag_fill2, dim3(nblk), dim3(NTHR), 0, s, flags, n, (const uint32_t *)cl, (const uint32_t *)ch,
@@ -1393,7 +1421,7 @@ static bool use_bits_engine() {
 // Returns device pointers (workspace) to M, L, fh through the out parameters.
 template <class T>
 static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int h, int32_t **outM, uint32_t **outL,
-                                 int32_t **outFh, hipStream_t s) {
+                                 int32_t **outFh, hipStream_t s, const int32_t **outA = nullptr) {
   const uint64_t n = (uint64_t)w * h;
   Workspace &ws = Workspace::get();
   int32_t *M = ws.buf<int32_t>("flats.mask", n);
@@ -1407,7 +1435,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   uint32_t *low = nullptr, *highall = nullptr;
   uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
-  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s);
+  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s, !use_bits_engine());
   g_fstats.low_edges = nlow;
   g_fstats.noflow_cells = nnoflow;
   g_fstats.high_edges = nhigh_all;
@@ -1424,8 +1452,12 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   launch_ccl_border<T>(d_z, L, w, h, s);
   RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, L, n);
   RD_HIP(hipMemsetAsync(fh, 0xFF, n * sizeof(int32_t), s));        // -1 everywhere
-  RD_LAUNCH("flats.mark_low", k_flat_mark_low, dim3((nlow + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)low,
-            nlow, (const uint32_t *)L, fh);
+  if (low)
+    RD_LAUNCH("flats.mark_low", k_flat_mark_low, dim3((nlow + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)low,
+              nlow, (const uint32_t *)L, fh);
+  else
+    RD_LAUNCH("flats.mark_low", k_flat_mark_low_flags, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint8_t *)flags, (const uint32_t *)L,
+              fh, n);
 
   // away gradient: sources = high edges whose flat has a low edge
   int32_t *A = nullptr;
@@ -1443,6 +1475,10 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   // towards gradient from every low edge, then the combined mask in place
   g_fstats.towards_levels = use_bits_engine() ? run_bits_towards(flags, M, nhigh_all == 0, nullptr, w, h, s)
                                               : run_relax_towards(d_dirs, flags, M, w, h, s);
+  if (outA) {   // the caller combines on the fly (k_flat_epsilon): M holds the towards levels
+    *outA = A;
+    return;
+  }
   RD_LAUNCH("flats.combine", k_flat_combine, dim3(sgrid(n)), dim3(NTHR), 0, s, M, (const int32_t *)A, (const uint32_t *)L,
             (const int32_t *)fh, n);
 }
@@ -1972,10 +2008,15 @@ template <>
 __device__ __forceinline__ double epsilon_steps<double>(double v, uint32_t m) { return next_up_n64(v, m); }
 
 template <class T>
-__global__ __launch_bounds__(NTHR) void k_flat_epsilon(T *z, const int32_t *__restrict__ M, int w, int h) {
+// TW: the towards levels; the mask (k_flat_combine's formula) is formed here, so it is neither written nor read back
+__global__ __launch_bounds__(NTHR) void k_flat_epsilon(T *z, const int32_t *__restrict__ TW, const int32_t *__restrict__ A,
+                                                       const uint32_t *__restrict__ L, const int32_t *__restrict__ fh, int w, int h) {
   const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
   for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    const int32_t m = M[c];
+    const int32_t t = TW[c];
+    if (t >= DINF) continue;   // not in a drainable flat: mask 0
+    const int32_t a = A ? A[c] : DINF;
+    const int32_t m = (a < DINF ? fh[L[c]] - a : 0) + 2 * t;   // a low edge has t = 1 and no away level: 2
     if (m <= 0) continue;   // unlabelled cells, and labelled cells outside the flat proper (mask 0)
     const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
     if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;    // Barnes2014.hpp:511-512 interior only
@@ -1997,8 +2038,11 @@ void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s)
   }
   int32_t *M, *fh;
   uint32_t *L;
-  resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s);
-  if (L) RD_LAUNCH("flats.epsilon", (k_flat_epsilon<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, w, h);
+  const int32_t *A = nullptr;
+  resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s, &A);
+  if (L)
+    RD_LAUNCH("flats.epsilon", (k_flat_epsilon<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, A,
+              (const uint32_t *)L, (const int32_t *)fh, w, h);
 }
 
 template <class T>
