@@ -503,11 +503,13 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
   __syncthreads();
   const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
   uint32_t tgs[LT / 4];   // in-tile target of the thread's cells (NOTGT: none)
+  uint32_t datamask = 0;
   for (int j = 0; j < LT / 4; j++) {
     const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
     unsigned long long v = 0;
     const uint8_t d = sd[o];
     tgs[j] = (uint32_t)NOTGT;
+    datamask |= (d != nodata ? 1u : 0u) << j;
     if (d != nodata) {
       unsigned long long k = 0, inflow = 0;
       if (d >= 1 && d <= 8) {
@@ -525,26 +527,29 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
     if (tgs[j] != (uint32_t)NOTGT) atomicAdd(&lw[tgs[j]], CNT1);
   __syncthreads();
   uint32_t srcmask = 0;
-  for (int j = 0; j < LT / 4; j++) {
+#pragma unroll
+  for (int j = 0; j < LT / 4; j++) {   // (selects on registers: no branch per cell)
     const int ly = ly0 + 4 * j;
-    if (sd[(ly + 1) * LLW + lx + 1] != nodata && (lw[ly * LT + lx] >> 56) == 0) srcmask |= 1u << j;
+    srcmask |= ((datamask >> j & 1u) & ((uint32_t)(lw[ly * LT + lx] >> 56) == 0 ? 1u : 0u)) << j;
   }
   __syncthreads();   // the sources are fixed before any walk completes a cell
   {
-    uint32_t m = srcmask;
-    unsigned long long tg = NOTGT, v = 0;
+    constexpr uint32_t NT = (uint32_t)NOTGT;
+    uint32_t m = srcmask, tg = NT;   // (the target as a 32-bit value: the 64-bit compares and moves doubled the loop's bookkeeping)
+    unsigned long long v = 0;
     for (;;) {   // a lane whose walk has ended takes its next source in the same trip (see k_acc_link_tile)
-      if (tg == NOTGT && m) {
+      if (tg == NT && m) {
         const unsigned long long own = lw[(ly0 + 4 * (__ffs((int)m) - 1)) * LT + lx];
-        tg = (own >> 43) & NOTGT;
+        tg = (uint32_t)(own >> 43) & NT;
         v = own & TMASK;
         m &= m - 1;
       }
-      if (!__any(tg != NOTGT || m != 0)) break;
-      if (tg != NOTGT) {
+      if (!__any(tg != NT || m != 0)) break;
+      if (tg != NT) {
         const unsigned long long old = atomicAdd(&lw[tg], v - CNT1);
-        if ((old >> 56) != 1) tg = NOTGT;
-        else { v = (old & TMASK) + v; tg = (old >> 43) & NOTGT; }
+        const bool last = (uint32_t)(old >> 56) == 1u;
+        v = last ? (old & TMASK) + v : v;
+        tg = last ? (uint32_t)(old >> 43) & NT : NT;
       }
     }
   }
