@@ -504,23 +504,25 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
   const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
   uint32_t tgs[LT / 4];   // in-tile target of the thread's cells (NOTGT: none)
   uint32_t datamask = 0;
-  for (int j = 0; j < LT / 4; j++) {
+#pragma unroll 4
+  for (int j = 0; j < LT / 4; j++) {   // every cell without branches (see link_stage); the border cells' inflow follows
     const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
-    unsigned long long v = 0;
     const uint8_t d = sd[o];
-    tgs[j] = (uint32_t)NOTGT;
-    datamask |= (d != nodata ? 1u : 0u) << j;
-    if (d != nodata) {
-      unsigned long long k = 0, inflow = 0;
-      if (d >= 1 && d <= 8) {
-        const int tx = lx + d8dx(d), ty = ly + d8dy(d);
-        if (tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata) tgs[j] = (uint32_t)(ty * LT + tx);
-      }
-      const int slot = border_slot(lx, ly);
-      if (slot >= 0) { inflow = ext_in[slot]; k = ext_blk[slot]; }
-      v = (k << 56) | ((unsigned long long)tgs[j] << 43) | (1ull + inflow);
-    }
-    lw[ly * LT + lx] = v;
+    const bool data = d != nodata, flows = data && d >= 1 && d <= 8;
+    const int dd = flows ? d : 0;
+    const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
+    const bool in_tile = flows && tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata;
+    tgs[j] = in_tile ? (uint32_t)(ty * LT + tx) : (uint32_t)NOTGT;
+    datamask |= (data ? 1u : 0u) << j;
+    lw[ly * LT + lx] = data ? (((unsigned long long)tgs[j] << 43) | 1ull) : 0ull;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * LT - 4) {   // one border cell per thread: what it receives from outside, and what blocks it
+    const int slot = (int)threadIdx.x;
+    const int bx = slot < LT ? slot : slot < 2 * LT ? slot - LT : slot < 3 * LT - 2 ? 0 : LT - 1;
+    const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
+    const unsigned long long add = ((unsigned long long)ext_blk[slot] << 56) | ext_in[slot];
+    if (add && lw[by * LT + bx] != 0) lw[by * LT + bx] += add;   // (a NoData border cell receives nothing: its gather found no donor)
   }
   __syncthreads();
   for (int j = 0; j < LT / 4; j++)   // pending donors, counted from the donors' side (see k_acc_link_tile)
