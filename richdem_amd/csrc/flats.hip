@@ -834,7 +834,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
       uint32_t val = 0;
 #pragma unroll
       for (int j = 0; j < BPLANES; j++)
-        if (j < np) {
+        if (j < 5 || np > 5) {   // (five planes or all eight: one uniform test per row instead of one per plane)
           const unsigned long long pj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Phi[j], r) << 32) |
                                         (uint32_t)__builtin_amdgcn_readlane((int)Plo[j], r);
           val |= lanes_of(pj, bitv[j]);
@@ -864,6 +864,10 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     relmax = 0;
   };
 
+  // Segments of at most 256 levels: the inner loop leaves when the planes are full (or the search is over), the flush
+  // happens out here -- inlined INSIDE the level loop it made the compiler copy all sixteen plane registers on every
+  // level (phi copies around the rare branch).
+  for (bool searching = true; searching;) {
   for (;;) {
     // one level: the cells next to the front, plus what the ring and the seeds start at this level, that are still free
     uint32_t nlo, nhi;
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     nlo &= (uint32_t)A; nhi &= (uint32_t)(A >> 32);
     const unsigned long long N = ((unsigned long long)nhi << 32) | nlo;
     if (__any(N != 0)) {
-      if (level - base >= (1 << BPLANES)) { flush(); base = level; }
+      if (level - base >= (1 << BPLANES)) break;   // planes full: flush, then this level again
       const int32_t rel = level - base;
       relmax = rel;
       A &= ~N;
@@ -899,14 +903,16 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
       continue;
     }
     // the front died: on to the next level at which the ring starts one, if any cell is left
-    if (!__any(A != 0) || level >= imax_) break;
+    if (!__any(A != 0) || level >= imax_) { searching = false; break; }
     auto pend = [&](int32_t v) { return v > level ? v : DINF; };   // (DINF itself: never)
     const int32_t nx = __builtin_amdgcn_readfirstlane(wave_min_i32(imin(imin(pend(iT), pend(iB)), imin(pend(iL), pend(iR)))));
-    if (nx >= DINF) break;
+    if (nx >= DINF) { searching = false; break; }
     level = nx;
     F = 0;
   }
   if (__any(Rec != 0)) flush();
+  base = level;
+  }
   // Wake a neighbouring tile only if an edge cell that moved here can still lower one of ITS cells (see k_flat_relax).
   // Edge cell (r, c) with new level v against the ring cells next to it, whose levels were read at the start.
   uint32_t wake = 0;   // bit (dy + 1) * 3 + dx + 1
