@@ -869,6 +869,8 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   // level (phi copies around the rare branch).
   for (bool searching = true; searching;) {
   for (;;) {
+    if (level - base >= (1 << BPLANES)) break;   // planes full: flush, then on with this level (tested up here so that
+                                                 // the body has ONE path that updates the planes in place)
     // one level: the cells next to the front, plus what the ring and the seeds start at this level, that are still free
     uint32_t nlo, nhi;
     {
@@ -886,7 +888,6 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     nlo &= (uint32_t)A; nhi &= (uint32_t)(A >> 32);
     const unsigned long long N = ((unsigned long long)nhi << 32) | nlo;
     if (__any(N != 0)) {
-      if (level - base >= (1 << BPLANES)) break;   // planes full: flush, then this level again
       const int32_t rel = level - base;
       relmax = rel;
       A &= ~N;
