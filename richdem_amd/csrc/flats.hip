@@ -656,16 +656,19 @@ __device__ __forceinline__ uint32_t lanes_of(unsigned long long smask, uint32_t 
   asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(out) : "v"(val), "s"(smask));
   return out;
 }
+// minimum / maximum over the 64 lanes, in every lane: a DPP prefix scan (row shifts + row broadcasts) whose last lane
+// holds the result -- six VALU instructions and a v_readlane instead of six LDS permutes
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = imin(v, __shfl_xor(v, o, 64));
-  return v;
+  constexpr int32_t I = INT32_MAX;
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { const int32_t u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
-  return v;
-}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return -wave_min_i32(-v); }   // (values here are > INT32_MIN)
 
 // Per tile and row: the bitmap of the cells that take part; the start of a field's levels (the seeds hold theirs, all
 // other cells "not reached"), the tiles to visit first, and the edge counts.
@@ -772,10 +775,9 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   int32_t newT = oldT, newB = oldB, newL = oldL, newR = oldR;
   // The level at which each EDGE cell of the tile is reached from the ring: 1 + the lowest of its (up to three, at a
   // corner five) ring neighbours.  Computed once, so a level of the search only compares against these four vectors.
-  const int32_t tvl = __shfl_up(tv, 1, 64), tvr = __shfl_down(tv, 1, 64), bvl = __shfl_up(bv, 1, 64), bvr = __shfl_down(bv, 1, 64);
-  const int32_t lvu = __shfl_up(lv, 1, 64), lvd = __shfl_down(lv, 1, 64), rvu = __shfl_up(rv, 1, 64), rvd = __shfl_down(rv, 1, 64);
-  const int32_t tL = lane > 0 ? tvl : tl, tR = lane < 63 ? tvr : tr, bL = lane > 0 ? bvl : bl, bR = lane < 63 ? bvr : br;
-  const int32_t lU = lane > 0 ? lvu : tl, lD = lane < 63 ? lvd : bl, rU = lane > 0 ? rvu : tr, rD = lane < 63 ? rvd : br;
+  // (the neighbouring lanes' values by DPP wave shifts, the corners as the fill of lanes 0 / 63)
+  const int32_t tL = from_left(tv, tl), tR = from_right(tv, tr), bL = from_left(bv, bl), bR = from_right(bv, br);
+  const int32_t lU = from_left(lv, tl), lD = from_right(lv, bl), rU = from_left(rv, tr), rD = from_right(rv, br);
   auto reach = [](int32_t a, int32_t b, int32_t c) { const int32_t m = imin(a, imin(b, c)); return m < DINF ? m + 1 : DINF; };
   const int32_t iT = reach(tL, tv, tR), iB = reach(bL, bv, bR), iL = reach(lU, lv, lD), iR = reach(rU, rv, rD);
   int32_t imax_;
