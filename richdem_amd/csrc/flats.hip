@@ -730,15 +730,42 @@ __global__ __launch_bounds__(NTHR) void k_bits_counts(const uint32_t *__restrict
   if (threadIdx.x < 3) out[threadIdx.x] = acc[threadIdx.x];
 }
 
+// inclusive prefix / suffix minimum over the 64 lanes, per lane (DPP row shifts inside the rows of 16; the prefix crosses
+// the rows with row_bcast, the suffix with three v_readlane) -- checked by tools/probes/scan_probe
+__device__ __forceinline__ int32_t wave_prefix_min(int32_t v) {
+  constexpr int32_t I = INT32_MAX;
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
+  constexpr int32_t I = INT32_MAX;
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x101, 0xf, 0xf, false));   // row_shl:1
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x102, 0xf, 0xf, false));   // row_shl:2
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x104, 0xf, 0xf, false));   // row_shl:4
+  v = imin(v, __builtin_amdgcn_update_dpp(I, v, 0x108, 0xf, 0xf, false));   // row_shl:8
+  const int32_t r3 = __builtin_amdgcn_readlane(v, 48), r2 = imin(__builtin_amdgcn_readlane(v, 32), r3),
+                r1 = imin(__builtin_amdgcn_readlane(v, 16), r2);
+  return imin(v, lane < 16 ? r1 : lane < 32 ? r2 : lane < 48 ? r3 : I);
+}
+
 template <int SEED_LEVEL>
 __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
                                                      uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
+  // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
+  // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
+  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
   const uint32_t n = *count;
   for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
   const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wi >= n) return;
   const int lane = threadIdx.x & 63;
+  uint16_t *const orow = open_rows[threadIdx.x >> 6];
   const uint32_t t = tiles[wi];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int x0 = tx * BT, y0 = ty * BT;
@@ -802,6 +829,69 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     if (lane == 0) expanded[t] = 1;
   }
   if (level >= DINF) return;   // nothing new reaches this tile
+  // OPEN WATER: every cell of the tile takes part, so the levels are chessboard distances from the ring (and from what the
+  // tile holds already) and two chamfer sweeps give the fixed point exactly: once the ring has entered through the
+  // levels at which it reaches the edge cells, any shortest king-move path inside the (convex) tile can be ordered into
+  // down/right moves first, up/left moves after.  Lane = column; a row's horizontal pass is a prefix / suffix minimum of
+  // (level -/+ column) over the lanes; the rows wait in LDS between the sweeps.  30 % of S3's tiles (61 % of its NO_FLOW
+  // cells) are open, and they are the tiles of the tail rounds.  (With the 64 rows in registers instead the allocator
+  // spilled both paths of this kernel.)  Levels are kept relative to (level - 1024) in 16 bits, 0xFFFF = not reached; a
+  // consistent open tile spans at most 63 levels, anything below the base falls through to the general search.
+  const int32_t obase = level - 1024;
+  bool open = __all(M == ~0ull);
+  if (open) {
+    // down: from NW, N, NE, then from W along the row
+    int32_t prev = DINF;
+    bool fits = true;
+    for (int r0 = 0; r0 < BT; r0 += 16) {
+      int32_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = D[(size_t)(y0 + r0 + j) * w + x0 + lane];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int y = r0 + j;
+        int32_t d = v[j];
+        fits &= d >= obase;
+        const int32_t l0 = __builtin_amdgcn_readlane(iL, y), e0 = __builtin_amdgcn_readlane(iR, y);
+        d = imin(d, lane == 0 ? l0 : lane == BT - 1 ? e0 : DINF);   // the ring enters through the edge cells' reach levels
+        if (y == 0) d = imin(d, iT);
+        if (y == BT - 1) d = imin(d, iB);
+        if (y > 0) {
+          const int32_t a = __builtin_amdgcn_update_dpp(DINF, prev, 0x138, 0xf, 0xf, false);   // the value of column x - 1
+          const int32_t b = __builtin_amdgcn_update_dpp(DINF, prev, 0x130, 0xf, 0xf, false);   // ... of column x + 1
+          d = imin(d, imin(imin(a, prev), b) + 1);
+        }
+        d = wave_prefix_min(d - lane) + lane;
+        prev = d;
+        const int32_t rel = d - obase;
+        orow[y * BT + lane] = (uint16_t)(d >= DINF || rel > 0xFFFE ? 0xFFFF : rel);
+      }
+    }
+    if (__all(fits)) {
+      // up: from SW, S, SE, then from E along the row; the finished row goes straight to memory
+      int32_t nxt = DINF;
+      for (int y = BT - 1; y >= 0; y--) {
+        const uint16_t rv16 = orow[y * BT + lane];
+        int32_t d = rv16 == 0xFFFF ? DINF : obase + (int32_t)rv16;
+        if (y < BT - 1) {
+          const int32_t a = __builtin_amdgcn_update_dpp(DINF, nxt, 0x138, 0xf, 0xf, false);
+          const int32_t b = __builtin_amdgcn_update_dpp(DINF, nxt, 0x130, 0xf, 0xf, false);
+          d = imin(d, imin(imin(a, nxt), b) + 1);
+        }
+        d = wave_suffix_min(d + lane, lane) - lane;
+        nxt = d;
+        if (d < DINF) D[(size_t)(y0 + y) * w + x0 + lane] = d;
+        const int32_t l0 = __builtin_amdgcn_readlane(d, 0), e0 = __builtin_amdgcn_readlane(d, BT - 1);
+        newL = lane == y ? l0 : newL;   // (the edge columns as one value per lane = row, for the wake test)
+        newR = lane == y ? e0 : newR;
+        if (y == 0) newT = d;
+        if (y == BT - 1) newB = d;
+      }
+    } else {
+      open = false;   // (levels out of the 16-bit window: the general search)
+    }
+  }
+  if (!open) {
   unsigned long long A, F, Rec = 0;
   {
     unsigned long long reached = 0, front = 0;
@@ -915,6 +1005,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   }
   if (__any(Rec != 0)) flush();
   base = level;
+  }
   }
   // Wake a neighbouring tile only if an edge cell that moved here can still lower one of ITS cells (see k_flat_relax).
   // Edge cell (r, c) with new level v against the ring cells next to it, whose levels were read at the start.
