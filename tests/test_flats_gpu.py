@@ -123,6 +123,28 @@ def test_full_pipeline_fill_dirs_accum(rd, orc):
     assert np.array_equal(area, orc.port.d8_flow_accum(edirs, 255, np.float64))
 
 
+def test_open_water_tiles(rd, orc):
+    """Flats that cover whole 64x64 tiles (the bitmap engine's chamfer path for tiles in which every cell takes part):
+    a lake floor with outlets on different sides, with and without islands next to the open tiles, tile-aligned and not,
+    and one deep enough that the levels of a tile straddle several flushes of the general path around it."""
+    rng = np.random.default_rng(5)
+    for (h, w, outlets, islands) in [(300, 400, [(150, 0)], 0), (330, 290, [(0, 100), (329, 200), (100, 289)], 6),
+                                     (200, 700, [(199, 650)], 3), (520, 530, [(260, 0), (0, 265)], 12)]:
+        dem = np.full((h, w), 50, np.int32)
+        dem[3:-3, 3:-3] = 7                                  # the lake floor: NO_FLOW cells only, many full tiles
+        for _ in range(islands):
+            y, x = int(rng.integers(10, h - 20)), int(rng.integers(10, w - 20))
+            dem[y:y + int(rng.integers(1, 9)), x:x + int(rng.integers(1, 9))] = 60
+        for (y, x) in outlets:                               # notches in the rim: the low edges
+            if y in (0, h - 1):
+                dem[0 if y == 0 else h - 3:3 if y == 0 else h, x] = np.arange(3, 0, -1) if y != 0 else np.arange(1, 4)
+            else:
+                dem[y, 0 if x == 0 else w - 3:3 if x == 0 else w] = np.arange(1, 4) if x == 0 else np.arange(3, 0, -1)
+        check(rd, orc, dem, np.int32(-1))
+        got = rd.barnes_flat_resolution_d8(dem, np.int32(-1))
+        assert (got[4:-4, 4:-4][dem[4:-4, 4:-4] == 7] != 0).all()   # the whole floor drains
+
+
 def test_sources_on_tile_edges(rd, orc):
     """Flats whose low/high edges sit exactly on 64x32 tile borders (the relaxation must wake the
     neighbouring tile of a source)."""
