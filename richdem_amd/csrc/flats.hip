@@ -612,8 +612,8 @@ __global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// The same fixed point by breadth-first search on BITMAPS, one wavefront per 64 x 64 tile (single-device path; the
-// row-block shards keep k_flat_relax, whose ghost rows are cells with levels that feed but are not relaxed).
+// The same fixed point by breadth-first search on BITMAPS, one wavefront per 64 x 64 tile (single device and row-block
+// shards alike: see RowWin; k_flat_relax above stays selectable with RDGPU_FLAT_BITS=0).
 // Lane r holds row r of the tile as 64-bit masks: the cells that take part (M), those not yet reached (A), the current
 // front (F).  One BFS level is   N = dilate8(F) & A   =   two DPP row shifts, two bit shifts and a few ORs for the whole
 // tile -- against ~100 VALU instructions per wavefront and stencil step in k_flat_relax, which r02's traces showed to be
@@ -670,6 +670,16 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
 }
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return -wave_min_i32(-v); }   // (values here are > INT32_MIN)
 
+// The rows a search owns.  Single device: [0, h), nothing beyond.  A row-block shard: [lo, hi) inside a buffer of h rows
+// whose rows lo - 1 and hi are GHOST rows -- cells of the neighbouring shard: they are never assigned here, their levels
+// arrive from their owner and act exactly like the ring of a tile (the tile grid starts at row lo, so the upper ghost row
+// IS the ring of the first tile row; the lower one is the ring below the last own row, wherever in its tile that is).
+// gtop / gbot: per tile column, which cells of the ghost row take part (NO_FLOW cells); null: no ghost row.
+struct RowWin {
+  int lo, hi;
+  const unsigned long long *gtop, *gbot;
+};
+
 // Per tile and row: the bitmap of the cells that take part; the start of a field's levels (the seeds hold theirs, all
 // other cells "not reached"), the tiles to visit first, and the edge counts.
 // TOWARDS: seeds = F_NEAR (level 2), D = 1 on the low edges; else seeds = F_HIGH (level 1; with L / fh only those of
@@ -678,7 +688,9 @@ template <bool TOWARDS, bool WRITE_M>
 __global__ __launch_bounds__(NTHR) void k_bits_prepare(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ L,
                                                        const int32_t *__restrict__ fh, int32_t *__restrict__ D,
                                                        unsigned long long *mbits, uint8_t *tile_active, uint32_t *counts,
-                                                       int w, int h, uint32_t tilesX, uint32_t tilesY) {
+                                                       int w, RowWin win, const int32_t *__restrict__ reach, uint32_t tilesX,
+                                                       uint32_t tilesY) {
+  const int h = win.hi;
   const uint32_t t = blockIdx.x;
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -688,15 +700,16 @@ __global__ __launch_bounds__(NTHR) void k_bits_prepare(const uint8_t *__restrict
   uint8_t f[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    const int gy = ty * BT + wv * 16 + j;
+    const int gy = win.lo + ty * BT + wv * 16 + j;
     f[j] = (gx < w && gy < h) ? flags[(size_t)gy * w + gx] : (uint8_t)0;
   }
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    const int gy = ty * BT + wv * 16 + j;
+    const int gy = win.lo + ty * BT + wv * 16 + j;
     const bool in = gx < w && gy < h;
     bool seed = TOWARDS ? (f[j] & F_NEAR) != 0 : (f[j] & F_HIGH) != 0;
     if (!TOWARDS && fh && seed) seed = fh[L[(size_t)gy * w + gx]] >= 0;
+    if (!TOWARDS && reach && seed) seed = reach[(size_t)gy * w + gx] < DINF;   // shards: "the flat has an outlet" through the towards levels
     const unsigned long long mb = __ballot((f[j] & F_NOFLOW) != 0), sb = __ballot(seed);
     if (lane == j) { mrow = mb; srow = sb; }
     if (counts) {
@@ -756,7 +769,7 @@ __device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
 template <int SEED_LEVEL>
 __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
-                                                     uint8_t *next_active, int w, int h, uint32_t tilesX, uint32_t tilesY) {
+                                                     uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
   // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
   // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
   __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
@@ -768,30 +781,33 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   uint16_t *const orow = open_rows[threadIdx.x >> 6];
   const uint32_t t = tiles[wi];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
-  const int x0 = tx * BT, y0 = ty * BT;
+  const int x0 = tx * BT, y0 = win.lo + ty * BT;
+  const int brow = min(BT - 1, win.hi - 1 - y0);   // the tile's last own row (63 except in the last tile row)
   const bool hasL = tx > 0, hasR = tx + 1 < (int)tilesX, hasT = ty > 0, hasB = ty + 1 < (int)tilesY;
+  const bool gT = !hasT && win.gtop != nullptr, gB = !hasB && win.gbot != nullptr;   // a ghost row instead of a tile
   const size_t tb = (size_t)t * BT;
   const unsigned long long M = mbits[tb + lane];
   // which ring cells take part: the facing rows / columns / corners of the eight neighbouring tiles' masks
-  const unsigned long long mT = hasT ? mbits[tb - (size_t)tilesX * BT + (BT - 1)] : 0ull;   // (wave uniform)
-  const unsigned long long mB = hasB ? mbits[tb + (size_t)tilesX * BT] : 0ull;
+  const unsigned long long mT = hasT ? mbits[tb - (size_t)tilesX * BT + (BT - 1)] : gT ? win.gtop[tx] : 0ull;   // (wave uniform)
+  const unsigned long long mB = hasB ? mbits[tb + (size_t)tilesX * BT] : gB ? win.gbot[tx] : 0ull;
   const unsigned long long mL = hasL ? mbits[tb - BT + lane] : 0ull;
   const unsigned long long mR = hasR ? mbits[tb + BT + lane] : 0ull;
-  const bool eTL = hasT && hasL && (mbits[tb - (size_t)tilesX * BT - BT + (BT - 1)] >> 63 & 1ull);
-  const bool eTR = hasT && hasR && (mbits[tb - (size_t)tilesX * BT + BT + (BT - 1)] & 1ull);
-  const bool eBL = hasB && hasL && (mbits[tb + (size_t)tilesX * BT - BT] >> 63 & 1ull);
-  const bool eBR = hasB && hasR && (mbits[tb + (size_t)tilesX * BT + BT] & 1ull);
+  const bool eTL = hasL && ((hasT ? mbits[tb - (size_t)tilesX * BT - BT + (BT - 1)] : gT ? win.gtop[tx - 1] : 0ull) >> 63 & 1ull);
+  const bool eTR = hasR && ((hasT ? mbits[tb - (size_t)tilesX * BT + BT + (BT - 1)] : gT ? win.gtop[tx + 1] : 0ull) & 1ull);
+  const bool eBL = hasL && ((hasB ? mbits[tb + (size_t)tilesX * BT - BT] : gB ? win.gbot[tx - 1] : 0ull) >> 63 & 1ull);
+  const bool eBR = hasR && ((hasB ? mbits[tb + (size_t)tilesX * BT + BT] : gB ? win.gbot[tx + 1] : 0ull) & 1ull);
   // ring levels (clamped addresses, all loads in flight together) and the tile's own edge levels as they are now
   const int cx = min(x0 + lane, w - 1), cy = min(y0 + lane, h - 1);
-  const int yT = max(y0 - 1, 0), yB = min(y0 + BT, h - 1), xL = max(x0 - 1, 0), xR = min(x0 + BT, w - 1);
-  const int yl = min(y0 + BT - 1, h - 1), xl = min(x0 + BT - 1, w - 1);
+  const int yT = max(y0 - 1, 0), yB = min(y0 + brow + 1, h - 1), xL = max(x0 - 1, 0), xR = min(x0 + BT, w - 1);
+  const int yl = min(y0 + brow, h - 1), xl = min(x0 + BT - 1, w - 1);
   int32_t tv = D[(size_t)yT * w + cx], bv = D[(size_t)yB * w + cx], lv = D[(size_t)cy * w + xL], rv = D[(size_t)cy * w + xR];
   int32_t tl = D[(size_t)yT * w + xL], tr = D[(size_t)yT * w + xR], bl = D[(size_t)yB * w + xL], br = D[(size_t)yB * w + xR];
   int32_t oldT = D[(size_t)y0 * w + cx], oldB = D[(size_t)yl * w + cx], oldL = D[(size_t)cy * w + x0], oldR = D[(size_t)cy * w + xl];
   if (!(mT >> lane & 1ull)) tv = DINF;
   if (!(mB >> lane & 1ull)) bv = DINF;
-  if (!(mL >> 63 & 1ull)) lv = DINF;
-  if (!(mR & 1ull)) rv = DINF;
+  // (in a last tile row that ends above row 63 the lane below the last own row holds the ghost row's corner cell)
+  if (!(lane == brow + 1 ? eBL : (bool)(mL >> 63 & 1ull))) lv = DINF;
+  if (!(lane == brow + 1 ? eBR : (bool)(mR & 1ull))) rv = DINF;
   if (!eTL) tl = DINF;
   if (!eTR) tr = DINF;
   if (!eBL) bl = DINF;
@@ -817,7 +833,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   // the stored levels stand.  A tile visited for the first time also has its seeds to expand.  The cells below the
   // start are read back as "reached", those one below it are the front, and the search goes on from there -- a visit
   // that corrects the top of a tile's range costs that part, not the whole tile.
-  const unsigned long long m0 = readlane64(M, 0), m63 = readlane64(M, BT - 1);
+  const unsigned long long m0 = readlane64(M, 0), m63 = readlane64(M, brow);
   int32_t chg = DINF;
   if ((m0 >> lane & 1ull) && iT < oldT) chg = iT;
   if ((m63 >> lane & 1ull) && iB < oldB) chg = imin(chg, iB);
@@ -935,7 +951,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
         const int32_t v = base + (int32_t)val;
         D[(size_t)(y0 + r) * w + x0 + lane] = v;
         if (r == 0) newT = v;
-        if (r == BT - 1) newB = v;
+        if (r == brow) newB = v;
       }
     }
     if (Rec & 1ull) {
@@ -973,7 +989,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     }
     if (level <= imax_) {
       const unsigned long long T = __ballot(iT == level), B = __ballot(iB == level);
-      const unsigned long long tb_ = lane == 0 ? T : lane == BT - 1 ? B : 0ull;
+      const unsigned long long tb_ = (lane == 0 ? T : 0ull) | (lane == brow ? B : 0ull);
       nlo |= (uint32_t)tb_ | (iL == level ? 1u : 0u);
       nhi |= (uint32_t)(tb_ >> 32) | (iR == level ? 0x80000000u : 0u);
     }
@@ -1447,7 +1463,9 @@ static BitsScratch bits_scratch(int w, int h) {
 }
 
 template <int SEED_LEVEL>
-static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s) {
+static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s,
+                                  RowWin win = RowWin{0, -1, nullptr, nullptr}) {
+  if (win.hi < 0) win.hi = h;   // single device: all rows, no ghost rows
   uint32_t *hw = Workspace::get().host_words();
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
   uint32_t rounds = 0, grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
@@ -1457,7 +1475,7 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
       RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
-                b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h,
+                b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
                 b.tilesX, b.tilesY);
     }
     RD_HIP(hipMemcpyAsync(hw, b.ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1485,10 +1503,12 @@ static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m,
   if (cnt) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
   if (write_m)
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
-              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr,
+              b.tilesX, b.tilesY);
   else
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
-              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+              (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr,
+              b.tilesX, b.tilesY);
   if (cnt) {
     unsigned long long *out = reinterpret_cast<unsigned long long *>(cnt + 3 * 256 + 2);
     RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)cnt, out);
@@ -1505,15 +1525,15 @@ static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
   if (write_m)
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
-              b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+              b.tflags, (uint32_t *)nullptr, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   else
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
-              b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+              b.tflags, (uint32_t *)nullptr, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   return relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s);
 }
 
 static bool use_bits_engine() {
-  const char *env = getenv("RDGPU_FLAT_BITS");   // =0: the stencil relaxation (what the row-block shards run): A/B and tests
+  const char *env = getenv("RDGPU_FLAT_BITS");   // =0: the stencil relaxation: A/B and tests
   return !(env && env[0] == '0');
 }
 
@@ -1748,15 +1768,14 @@ static void flat_resolution_alter_host(T *dem, T nodata, int w, int h, uint8_t *
 // towards distances (a NO_FLOW cell is in a drainable flat <=> the towards relaxation reaches it), so the
 // towards field is built first and the away sources are filtered through it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *__restrict__ in, int ghost_row, int own_row,
+__global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *__restrict__ in, int ghost_row, int ty,
                                                     int w, uint8_t *tile_active, uint32_t tilesX) {
   const int x = blockIdx.x * NTHR + threadIdx.x;
   if (x >= w) return;
   const int32_t v = in[x];
   int32_t *g = &D[(size_t)ghost_row * w + x];
   if (v < *g) {
-    *g = v;
-    const int ty = own_row / RCH;
+    *g = v;   // ty: the tile row that holds the own row next to the ghost row
     for (int tx = max(x - 1, 0) / CW; tx <= min(x + 1, w - 1) / CW; tx++) tile_active[(uint32_t)ty * tilesX + (uint32_t)tx] = 1;
   }
 }
@@ -1764,6 +1783,13 @@ __global__ __launch_bounds__(NTHR) void k_fs_inject(int32_t *D, const int32_t *_
 __global__ __launch_bounds__(NTHR) void k_fs_ghost_dirs(uint8_t *dirs, uint32_t n) {
   const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
   if (i < n) dirs[i] = dirs[i] == 0 ? DIR_GHOST_NOFLOW : 1;
+}
+
+// which cells of a ghost row take part (its NO_FLOW cells), one 64-bit mask per tile column
+__global__ __launch_bounds__(64) void k_fs_ghost_mask(const uint8_t *__restrict__ dirs_row, int w, unsigned long long *out) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const unsigned long long m = __ballot(x < w && dirs_row[x] == DIR_GHOST_NOFLOW);
+  if (threadIdx.x == 0) out[blockIdx.x] = m;
 }
 
 struct CutRows { int row[4]; };   // ghost above, first own, last own, ghost below (-1: no such row)
@@ -1870,6 +1896,11 @@ struct rdgpu_flat_shard {
   uint32_t nsrc[2] = {0, 0};
   uint8_t *tflags[2] = {nullptr, nullptr};
   uint32_t *tlist = nullptr, *ctr = nullptr;
+  // the bitmap engine's state (RDGPU_FLAT_BITS=0: the stencil relaxation instead): cells that take part per tile row,
+  // the same for the two ghost rows next to the own rows, "tile visited" per field
+  bool bits = false;
+  unsigned long long *mbits = nullptr, *gmask[2] = {nullptr, nullptr};
+  uint8_t *expanded[2] = {nullptr, nullptr};
   bool seeded[2] = {false, false};
   uint32_t rounds[2] = {0, 0};
   hipStream_t stream = nullptr;
@@ -1902,6 +1933,28 @@ static void fs_relax(rdgpu_flat_shard *f, int phase) {
   const uint32_t tilesX = (w + CW - 1) / CW, tilesY = (h + RCH - 1) / RCH;
   const int row_lo = f->gtop, row_hi = h - f->gbot;   // the own rows: ghost rows feed, they are not relaxed here
   int32_t *D = f->D[phase];
+  if (f->bits) {
+    BitsScratch b;
+    b.tilesX = (w + BT - 1) / BT; b.tilesY = (row_hi - row_lo + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
+    b.mbits = f->mbits; b.tflags = f->tflags[phase]; b.expanded = f->expanded[phase]; b.tlist = f->tlist; b.ctr = f->ctr;
+    b.counts = nullptr;
+    const RowWin win{row_lo, row_hi, f->gtop ? f->gmask[0] : nullptr, f->gbot ? f->gmask[1] : nullptr};
+    if (!f->seeded[phase]) {
+      f->seeded[phase] = true;
+      RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
+      if (phase == 0)
+        RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, (const uint8_t *)f->flags,
+                  (const uint32_t *)nullptr, (const int32_t *)nullptr, D, b.mbits, b.tflags, (uint32_t *)nullptr, w, win,
+                  (const int32_t *)nullptr, b.tilesX, b.tilesY);
+      else   // away sources: the high edges of flats the towards levels reach ("has an outlet")
+        RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, (const uint8_t *)f->flags,
+                  (const uint32_t *)nullptr, (const int32_t *)nullptr, D, b.mbits, b.tflags, (uint32_t *)nullptr, w, win,
+                  (const int32_t *)f->D[0], b.tilesX, b.tilesY);
+    }
+    f->rounds[phase] += phase ? relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s, win)
+                              : relax_rounds_bits<2>(b, D, w, h, "flats.relax_towards", s, win);
+    return;
+  }
   if (!f->seeded[phase]) {
     f->seeded[phase] = true;
     if (phase == 0)
@@ -1962,6 +2015,15 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
     f->tflags[1] = (uint8_t *)alloc(rtiles);
     f->tlist = (uint32_t *)alloc((size_t)rtiles * 4);
     f->ctr = (uint32_t *)alloc(RELAX_BATCH * sizeof(uint32_t));
+    f->bits = use_bits_engine();
+    if (f->bits) {   // (64 x 64 tiles over the own rows: never more than the 64 x 32 tiles over all rows)
+      const uint32_t btiles = tilesX * (uint32_t)((rows - gtop - gbot + BT - 1) / BT);
+      f->mbits = (unsigned long long *)alloc((size_t)btiles * BT * 8);
+      f->gmask[0] = (unsigned long long *)alloc((size_t)tilesX * 8);
+      f->gmask[1] = (unsigned long long *)alloc((size_t)tilesX * 8);
+      f->expanded[0] = (uint8_t *)alloc(btiles);
+      f->expanded[1] = (uint8_t *)alloc(btiles);
+    }
     flowdirs_device<T>(d_z, nodata, w, rows, f->dirs, MODE_D8, s);
     launch_classify<T>(d_z, (const uint8_t *)f->dirs, w, rows, f->flags, s);
     // sources are own cells only; the ghost rows' distances arrive from their owners
@@ -1981,6 +2043,10 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
     // the others are marked as "has a direction"
     if (gtop) RD_LAUNCH("flatshard.ghost_dirs", k_fs_ghost_dirs, dim3(((size_t)gtop * w + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->dirs, (uint32_t)gtop * (uint32_t)w);
     if (gbot) RD_LAUNCH("flatshard.ghost_dirs", k_fs_ghost_dirs, dim3(((size_t)gbot * w + NTHR - 1) / NTHR), dim3(NTHR), 0, s, f->dirs + (size_t)(rows - gbot) * w, (uint32_t)gbot * (uint32_t)w);
+    if (f->bits) {
+      if (gtop) RD_LAUNCH("flatshard.ghost_mask", k_fs_ghost_mask, dim3(tilesX), dim3(64), 0, s, (const uint8_t *)f->dirs + (size_t)(gtop - 1) * w, w, f->gmask[0]);
+      if (gbot) RD_LAUNCH("flatshard.ghost_mask", k_fs_ghost_mask, dim3(tilesX), dim3(64), 0, s, (const uint8_t *)f->dirs + (size_t)(rows - gbot) * w, w, f->gmask[1]);
+    }
     RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles);
     launch_ccl_border<T>(d_z, f->L, w, rows, s);
     RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, f->L, n);
@@ -2014,11 +2080,14 @@ static void fs_inject(rdgpu_flat_shard *f, int phase, const int32_t *d_above, co
   const CutRows cr = cut_rows(f);
   const uint32_t tilesX = (f->w + CW - 1) / CW;
   const dim3 grid((f->w + NTHR - 1) / NTHR), blk(NTHR);
+  // the tile row of the own row next to the ghost row, in the engine's tiling (64-row tiles from the first own row / 32-row
+  // tiles from row 0)
+  auto tile_row = [&](int own_row) { return f->bits ? (own_row - f->gtop) / BT : own_row / RCH; };
   if (d_above && cr.row[0] >= 0)
-    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_above, cr.row[0], cr.row[1], f->w,
+    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_above, cr.row[0], tile_row(cr.row[1]), f->w,
               f->tflags[phase], tilesX);
   if (d_below && cr.row[3] >= 0)
-    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_below, cr.row[3], cr.row[2], f->w,
+    RD_LAUNCH("flatshard.inject", k_fs_inject, grid, blk, 0, f->stream, f->D[phase], d_below, cr.row[3], tile_row(cr.row[2]), f->w,
               f->tflags[phase], tilesX);
 }
 

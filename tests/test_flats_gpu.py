@@ -123,6 +123,25 @@ def test_full_pipeline_fill_dirs_accum(rd, orc):
     assert np.array_equal(area, orc.port.d8_flow_accum(edirs, 255, np.float64))
 
 
+def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
+    """RDGPU_FLAT_BITS=0 selects the stencil relaxation (k_flat_relax) instead of the bitmap search, on a single device
+    and in the row-block shards: same directions, same flat_mask."""
+    import torch
+
+    from richdem_amd.sharded import flat_resolution_blocks
+
+    dem = orc.port.fill(fractal_dem_int(700, 500, 72, 0.02))
+    nd = np.int32(-9999)
+    exp = orc.port.flat_resolution(dem, nd)
+    monkeypatch.setenv("RDGPU_FLAT_BITS", "0")
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), exp)
+    got, _ = flat_resolution_blocks(torch.from_numpy(dem).cuda(), nd, 5)
+    assert np.array_equal(got.cpu().numpy(), exp)
+    monkeypatch.delenv("RDGPU_FLAT_BITS")
+    got, _ = flat_resolution_blocks(torch.from_numpy(dem).cuda(), nd, 5)
+    assert np.array_equal(got.cpu().numpy(), exp)
+
+
 def test_open_water_tiles(rd, orc):
     """Flats that cover whole 64x64 tiles (the bitmap engine's chamfer path for tiles in which every cell takes part):
     a lake floor with outlets on different sides, with and without islands next to the open tiles, tile-aligned and not,
