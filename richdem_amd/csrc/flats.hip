@@ -370,7 +370,8 @@ constexpr int32_t DINF = 0x7F7F7F7F;   // memset-able "not reached"
 constexpr int RCH = 32;                // relaxation tiles are CW x RCH (the labelling tiles CW x CH)
 constexpr int HSTEPS = 8;              // stencil steps per barrier inside a relaxation tile (a step without a move ends them early)
 constexpr int RNT = 256, RBANDS = RNT / 64;   // one wavefront per band of RCH / RBANDS rows
-constexpr int RELAX_BATCH = 8;         // relaxation rounds enqueued per host read-back
+constexpr int RELAX_BATCH = 8;         // relaxation rounds enqueued per host read-back (stencil engine)
+constexpr int BITS_BATCH = 24;         // ... of the bitmap search: its rounds are short, the read-back's bubble is not
 
 __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter) {
   __shared__ uint32_t wcnt[NTHR / 64];
@@ -1425,7 +1426,7 @@ static RelaxScratch relax_scratch(int w, int h) {
   r.tilesX = (w + CW - 1) / CW; r.tilesY = (h + RCH - 1) / RCH; r.ntiles = r.tilesX * r.tilesY;
   r.tflags = ws.buf<uint8_t>("flats.tflags", r.ntiles);
   r.tlist = ws.buf<uint32_t>("flats.tlist", r.ntiles);
-  r.ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
+  r.ctr = ws.buf<uint32_t>("flats.tctr", BITS_BATCH);
   return r;
 }
 
@@ -1457,7 +1458,7 @@ static BitsScratch bits_scratch(int w, int h) {
   b.expanded = ws.buf<uint8_t>("flats.bexp", b.ntiles);
   b.tflags = ws.buf<uint8_t>("flats.btflags", b.ntiles);
   b.tlist = ws.buf<uint32_t>("flats.btlist", b.ntiles);
-  b.ctr = ws.buf<uint32_t>("flats.tctr", RELAX_BATCH);
+  b.ctr = ws.buf<uint32_t>("flats.tctr", BITS_BATCH);
   b.counts = ws.buf<uint32_t>("flats.bcounts", 3 * 256 + 8);
   return b;
 }
@@ -1470,18 +1471,18 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
   uint32_t rounds = 0, grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
   for (;;) {
-    RD_HIP(hipMemsetAsync(b.ctr, 0, RELAX_BATCH * sizeof(uint32_t), s));
-    for (int k = 0; k < RELAX_BATCH; k++) {
+    RD_HIP(hipMemsetAsync(b.ctr, 0, BITS_BATCH * sizeof(uint32_t), s));
+    for (int k = 0; k < BITS_BATCH; k++) {
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
       RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
                 b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
                 b.tilesX, b.tilesY);
     }
-    RD_HIP(hipMemcpyAsync(hw, b.ctr, RELAX_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, b.ctr, BITS_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     uint32_t most = 0;
-    for (int k = 0; k < RELAX_BATCH; k++) {
+    for (int k = 0; k < BITS_BATCH; k++) {
       if (trace) fprintf(stderr, "%s round %u nact %u (grid %u)\n", name, rounds, hw[k], grid);
       if (hw[k] == 0) return rounds;
       most = std::max(most, hw[k]);
@@ -2014,7 +2015,7 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
     f->tflags[0] = (uint8_t *)alloc(rtiles);
     f->tflags[1] = (uint8_t *)alloc(rtiles);
     f->tlist = (uint32_t *)alloc((size_t)rtiles * 4);
-    f->ctr = (uint32_t *)alloc(RELAX_BATCH * sizeof(uint32_t));
+    f->ctr = (uint32_t *)alloc(BITS_BATCH * sizeof(uint32_t));
     f->bits = use_bits_engine();
     if (f->bits) {   // (64 x 64 tiles over the own rows: never more than the 64 x 32 tiles over all rows)
       const uint32_t btiles = tilesX * (uint32_t)((rows - gtop - gbot + BT - 1) / BT);
