@@ -414,3 +414,37 @@ def test_multi_device_entry_on_one_gpu(rd, orc, monkeypatch):
     monkeypatch.delenv("RDGPU_DEVICES")
     arr = (ctypes.c_int * 2)(0, 99)
     assert lib().rdgpu_fill_multi_f32(z.copy().ctypes.data_as(ctypes.c_void_p), 700, 530, 8, arr, 2) != 0
+
+
+def test_two_host_threads_share_the_library(rd, orc):
+    """ctypes (like the pybind module) releases the GIL around every call, so two Python threads can be inside the C-ABI
+    at once; the library serialises them under its process-wide lock (csrc/common.hpp `guarded`) instead of letting them
+    share scratch buffers.  Different rasters, different sizes, different entry points, many times over."""
+    import threading
+
+    from richdem_amd.synth import fractal_dem
+
+    a = fractal_dem(700, 500, seed=301)
+    b = (fractal_dem(333, 610, seed=302) * 3).astype(np.int32)
+    ea, eb = orc.port.fill(a, 8), orc.port.fill(b, 4)
+    da = orc.port.d8_flowdirs(ea, np.float32(-9999))
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(12):
+                if kind == 0:
+                    assert np.array_equal(rd.FillDepressions(a), ea)
+                    assert np.array_equal(rd.d8_flow_directions(ea, np.float32(-9999)), da)
+                else:
+                    assert rd.FillDepressions(b, topology="D4").tobytes() == eb.tobytes()
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
+
