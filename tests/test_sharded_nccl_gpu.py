@@ -51,3 +51,33 @@ def test_sharded_drivers_on_rccl(rd, orc, nccl_world1):
     area = torch.empty(dirs.shape, dtype=torch.float64, device="cuda")
     d8_flow_accum_sharded(dirs.contiguous(), area)
     assert np.array_equal(area.cpu().numpy(), orc.port.d8_flow_accum(exp_dirs, 255, np.float64))
+
+
+def test_bench_line_of_the_sharded_path():
+    """`bench.py --gpus N` for N > 1 goes through richdem_amd.sharded.bench_sharded; RDGPU_BENCH_FORCE_SHARDED=1 runs that
+    path on one rank over RCCL, launched the way the driver launches it.  The JSON line must carry the contract's fields,
+    the stages of BASELINE configs[4] and `exchanges == 1` for the accumulation -- and nothing else on stdout."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RDGPU_BENCH_FORCE_SHARDED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--size", "3000"], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Mcells/s" and d["value"] > 0
+    assert "row-block" in d["config"]["parallelism"]
+    st = d["stages"]
+    assert st["d8_flow_accum"]["exchanges"] == 1 and st["directions_plus_flat_resolution"]["ms"] > 0
+    assert d["roofline"]["bound"] == "hbm"
