@@ -253,3 +253,58 @@ def test_row_split_rejects_more_ranks_than_rows(rd):
         row_split(2, 3)
     with pytest.raises(rd.RdgpuError, match="at least one row"):
         _check_block(np.zeros((0, 5), np.float32), "fill_depressions_sharded")
+
+
+def test_accum_link_solve_random_forests():
+    """Random loop-free link forests (mixed upward and downward crossings, chains over many cuts, several entries landing on
+    one cell) against a plain recursive accumulation."""
+    import sys
+
+    import torch
+
+    from richdem_amd.sharded import accum_link_solve
+
+    sys.setrecursionlimit(20000)
+    rng = np.random.default_rng(9)
+    DOWN = -(1 << 31)
+    for trial in range(25):
+        world, w = int(rng.integers(2, 9)), int(rng.integers(1, 40))
+        boxes = np.zeros((world, 2, w), np.int64)
+        links = np.full((world, 2, w), -1, np.int64)
+        # a potential per node that strictly decreases along every link keeps the graph loop free
+        pot = rng.permutation(world * 2 * w).reshape(world, 2, w)
+        for r in range(world):
+            for k in range(2):
+                for x in range(w):
+                    if rng.random() < 0.6:
+                        down = bool(rng.integers(2))
+                        if (down and r + 1 >= world) or (not down and r == 0):
+                            continue
+                        col = int(rng.integers(w))
+                        dst = (r + 1, 0, col) if down else (r - 1, 1, col)
+                        if pot[dst] < pot[r, k, x]:
+                            links[r, k, x] = (DOWN | col) if down else col
+                    if rng.random() < 0.5:
+                        boxes[r, k, x] = (int(rng.integers(1, 4)) << 56) | int(rng.integers(1, 10 ** 6))
+        low = boxes & ((1 << 56) - 1)
+        i0 = np.zeros_like(low)
+        i0[1:, 0] = low[:-1, 1]
+        i0[:-1, 1] = low[1:, 0]
+        ups = {}
+        for r in range(world):
+            for k in range(2):
+                for x in range(w):
+                    L = int(links[r, k, x])
+                    if L != -1:
+                        dst = (r + 1, 0, L & 0x7FFFFFFF) if L < 0 else (r - 1, 1, L)
+                        ups.setdefault(dst, []).append((r, k, x))
+        memo = {}
+
+        def total(node):
+            if node not in memo:
+                memo[node] = int(i0[node]) + sum(total(u) for u in ups.get(node, []))
+            return memo[node]
+
+        exp = np.array([[[total((r, k, x)) for x in range(w)] for k in range(2)] for r in range(world)], np.int64)
+        got = accum_link_solve(torch.from_numpy(boxes), torch.from_numpy(links.astype(np.int32)), world, w)
+        assert got is not None and np.array_equal(got.numpy(), exp), trial
