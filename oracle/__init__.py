@@ -283,6 +283,16 @@ class _Backend:
         return acc
 
 
+    def fa_d8_lean(self, dem: np.ndarray, nodata, weights: np.ndarray | None = None) -> np.ndarray:
+        """FA_D8 through one receiver byte per cell (oracle port only; see oracle_impl.h orc_fa_d8_lean)."""
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        acc = np.ones((h, w), np.float64) if weights is None else np.ascontiguousarray(weights, dtype=np.float64).copy()
+        self._fn(f"fa_d8_lean_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(acc))
+        return acc
+
+
 port = _Backend(os.path.join(_HERE, "liboracle.so"), "orc")
 ref = _Backend(os.path.join(_HERE, "_ref", "libref.so"), "ref")
 

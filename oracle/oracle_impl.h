@@ -306,6 +306,52 @@ void FN(orc_fa_d8)(const T *dem, T nodata, int w, int h, double *accum) {
   free(props);
 }
 
+/* FA_D8 with one receiver byte per cell instead of the 36 B/cell proportions array -- the same
+ * FM_D8 rule (OCallaghan1984.hpp:37-74) and the same Kahn order (flow_accumulation_generic.hpp:48-97),
+ * written so that a 40000 x 40000 DEM fits a 64 GB host (FA_D8 proper needs ~78 GB there).  Checked
+ * equal to orc_fa_d8 and to the compiled reference's FA_D8 by tests/test_oracle_pinning.py; used for
+ * the S3 digests of tests/golden/make_golden.py --s3-digests. */
+void FN(orc_fa_d8_lean)(const T *dem, T nodata, int w, int h, double *accum) {
+  size_t N = (size_t)w * h;
+  const int nshift[9] = {0, -1, -w - 1, -w, -w + 1, 1, w + 1, w, w - 1};
+  uint8_t *recv = (uint8_t *)calloc(N, 1);                     /* 0 no flow, 1..8, 255 NoData */
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (dem[i] == nodata) { recv[i] = 255; continue; }
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;
+      T e = dem[i], lowest = 0;
+      int lowest_n = 0;
+      for (int n = 1; n <= 8; n++) {
+        T ne = dem[i + nshift[n]];
+        if (ne == nodata || ne >= e) continue;
+        if (!lowest_n || ne < lowest) { lowest = ne; lowest_n = n; }
+      }
+      recv[i] = (uint8_t)lowest_n;
+    }
+  int8_t *deps = (int8_t *)calloc(N, 1);
+  for (int y = 1; y < h - 1; y++)
+    for (int x = 1; x < w - 1; x++) {
+      size_t ci = (size_t)y * w + x;
+      if (recv[ci] >= 1 && recv[ci] <= 8) deps[ci + nshift[recv[ci]]]++;
+    }
+  int32_t *q = (int32_t *)malloc(N * 4);
+  size_t qh = 0, qt = 0;
+  for (size_t i = 0; i < N; i++)
+    if (deps[i] == 0 && recv[i] != 255) q[qt++] = (int32_t)i;
+  while (qh < qt) {
+    size_t ci = (size_t)q[qh++];
+    if (recv[ci] < 1 || recv[ci] > 8) continue;
+    size_t ni = ci + nshift[recv[ci]];
+    if (recv[ni] == 255) continue;
+    accum[ni] += 1.0f * accum[ci];
+    if (--deps[ni] == 0) q[qt++] = (int32_t)ni;
+  }
+  for (size_t i = 0; i < N; i++)
+    if (recv[i] == 255) accum[i] = -1.0;
+  free(recv); free(deps); free(q);
+}
+
 /* ------------------------------------------------------------------------- */
 /* dinf_FlowDir + dinf_flow_directions, flowmet/dinf_flowdirs.hpp:45-115,    */
 /* :128-152 (facet tables :21-27).                                           */

@@ -14,6 +14,8 @@
                         inputs, for the functions the reference has no golden file for
                         (d8_flow_directions, barnes_flat_resolution_d8, FA_D8, fill on float/int DEMs).
                         Inputs are stored too, so the tests do not depend on the generator.
+* ref_s3_digests.npz -- (--s3-digests) per-1000-row-band digests of the compiled reference's outputs on the
+                        40000 x 40000 bench DEM: BASELINE configs[2] / [4] at full size (see s3_digests()).
 /root/reference does not exist on the GPU box; tests read only these .npz files.
 """
 import glob
@@ -133,8 +135,85 @@ def f2():
     print("wrote", len(g), "f2 arrays")
 
 
+def s3_digests(size=40000, seed=3, out=None, keep=None):
+    """BASELINE configs[2] / [4] at FULL size: the compiled reference runs ONCE here on the bench DEM G(seed=3)
+    40000 x 40000 (fill -> barnes_flat_resolution_d8 -> d8_flow_accum<u8,f64>; fill -> ResolveFlatsEpsilon -> FA_D8)
+    and only per-1000-row-band 64-bit digests (tests/golden/digest.py) plus a few counts are committed
+    (ref_s3_digests.npz).  tests/test_s3_digests_gpu.py computes the same digests from the engine's outputs in HBM:
+    seconds on the GPU box, so the driver's own `pytest -m gpu` run proves full-size parity of whatever HEAD is.
+    FA_D8 proper needs ~78 GB of host memory at this size (its 36 B/cell proportions array); its digests come from
+    oracle.port.fa_d8_lean -- the same rule and order on one receiver byte per cell, pinned to the compiled
+    reference's FA_D8 in tests/test_oracle_pinning.py.  ~20 minutes of one host core, ~30 GB."""
+    import time
+    from digest import BAND_ROWS, band_digests_np
+    oracle.build()
+    R = oracle.ref
+    assert R.available
+    n = size
+    g = {"size": np.int64(n), "seed": np.int64(seed), "band_rows": np.int64(BAND_ROWS)}
+    times = {}
+    keep = keep or os.environ.get("S3_KEEP")          # directory for the full arrays (debugging aid, not committed)
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+
+    def stash(name, a):
+        if keep:
+            np.save(os.path.join(keep, name + ".npy"), a)
+
+    z = np.empty((n, n), np.float32)
+    for y0 in range(0, n, 2000):
+        z[y0:y0 + 2000] = fractal_dem(n, min(2000, n - y0), seed, y0=y0)
+    g["dem"] = band_digests_np(z)
+    t0 = time.perf_counter()
+    W = R.fill(z, 8)                                   # PriorityFlood_Zhou2016 = FillDepressions<D8>
+    times["fill"] = time.perf_counter() - t0
+    g["fill"] = band_digests_np(W)
+    g["fill_cells_raised"] = np.int64((W != z).sum())
+    del z
+    stash("fill", W)
+    print("fill", times, int(g["fill_cells_raised"]), flush=True)
+    t0 = time.perf_counter()
+    dirs = R.flat_resolution(W, np.float32(-9999.0))   # barnes_flat_resolution_d8(alter=false)
+    times["flat_resolution"] = time.perf_counter() - t0
+    g["flat_dirs"] = band_digests_np(dirs)
+    g["flat_dirs_noflow_left"] = np.int64((dirs == 0).sum())
+    stash("flat_dirs", dirs)
+    print("flats", times, int(g["flat_dirs_noflow_left"]), flush=True)
+    t0 = time.perf_counter()
+    area = R.d8_flow_accum(dirs, 255, np.float64)      # d8_flow_accum<uint8_t,double>, one thread
+    times["d8_flow_accum"] = time.perf_counter() - t0
+    g["d8_flow_accum"] = band_digests_np(area)
+    g["d8_flow_accum_max"] = np.float64(area.max())
+    stash("d8_flow_accum", area)
+    del area, dirs
+    print("accum", times, float(g["d8_flow_accum_max"]), flush=True)
+    t0 = time.perf_counter()
+    E = R.resolve_flats_epsilon(W, np.float32(-9999.0))   # ResolveFlatsEpsilon
+    times["resolve_flats_epsilon"] = time.perf_counter() - t0
+    g["resolve_flats_epsilon"] = band_digests_np(E)
+    g["resolve_flats_epsilon_cells_changed"] = np.int64((E != W).sum())
+    del W
+    stash("resolve_flats_epsilon", E)
+    print("rfe", times, flush=True)
+    t0 = time.perf_counter()
+    fa = oracle.port.fa_d8_lean(E, np.float32(-9999.0))
+    times["fa_d8_lean_port"] = time.perf_counter() - t0
+    g["fa_d8"] = band_digests_np(fa)
+    g["fa_d8_max"] = np.float64(fa.max())
+    stash("fa_d8", fa)
+    for k, v in times.items():
+        g["ref_seconds/" + k] = np.float64(round(v, 2))
+    out = out or os.path.join(HERE, "ref_s3_digests.npz" if n == 40000 else f"ref_s3_digests_{n}.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, {k: float(v) for k, v in times.items()})
+
+
 if __name__ == "__main__":
-    if "--f2" in sys.argv:
+    if "--s3-digests" in sys.argv:
+        sys.path.insert(0, HERE)
+        size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000
+        s3_digests(size)
+    elif "--f2" in sys.argv:
         f2()
     else:
         main()

@@ -51,6 +51,8 @@ def test_port_matches_generated_reference_outputs(orc, generated):
             assert np.array_equal(fr, generated[f"{name}/{tag}/flat_resolved_dirs"]), (name, tag)
             assert np.array_equal(P.d8_flow_accum(fr, 255, np.float64), generated[f"{name}/{tag}/d8_flow_accum_f64"])
             assert np.array_equal(P.fa_d8(src, nd), generated[f"{name}/{tag}/fa_d8"]), (name, tag)
+            # the one-byte-per-cell form behind the S3 digests (make_golden.py --s3-digests) is the same function
+            assert np.array_equal(P.fa_d8_lean(src, nd), generated[f"{name}/{tag}/fa_d8"]), (name, tag)
 
 
 @pytest.mark.parametrize("seed,scale,dtype", [(21, 1.0, np.float32), (22, 1.0, np.int32), (23, 0.05, np.int32),
@@ -84,6 +86,8 @@ def test_port_matches_live_reference(orc, seed, scale, dtype):
         assert np.array_equal(P.fa_d8(src, nd), R.fa_d8(src, nd))
         wts = np.random.default_rng(seed).random(src.shape)
         assert np.array_equal(P.fa_d8(src, nd, wts), R.fa_d8(src, nd, wts))
+        assert np.array_equal(P.fa_d8_lean(src, nd), R.fa_d8(src, nd))
+        assert np.array_equal(P.fa_d8_lean(src, nd, wts), R.fa_d8(src, nd, wts))
         if dtype not in (np.int64, np.uint64):
             assert np.array_equal(P.resolve_flats_epsilon(src, nd), R.resolve_flats_epsilon(src, nd))
             assert np.array_equal(P.pit_mask(src, nd, 8), R.pit_mask(src, nd, 8))
