@@ -72,10 +72,6 @@ public:
   }
   // pinned host scalar slots for small read-backs
   uint32_t *host_words();
-  // internal streams (non-blocking) and timing-free events of the CURRENT device: stages whose searches are independent
-  // of each other fork onto them from the caller's stream and join back (flats: towards / away levels)
-  hipStream_t side_stream(int i);
-  hipEvent_t side_event(int i);
   void release();
 
 private:
@@ -85,8 +81,6 @@ private:
   };
   std::map<std::string, Slot> slots_;
   uint32_t *host_words_ = nullptr;
-  std::map<int, hipStream_t> streams_;
-  std::map<int, hipEvent_t> events_;
 };
 
 // ------------------------------------------------------------------------------------------

@@ -767,12 +767,20 @@ __device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
   return imin(v, lane < 16 ? r1 : lane < 32 ? r2 : lane < 48 ? r3 : I);
 }
 
-// One visit of tile t by one wavefront (lane = column / row, see above).  orow: (BT - 1) * BT 16-bit words of LDS owned by the
-// wavefront.  Returns, in every lane, the tiles to wake: bit (dy + 1) * 3 + dx + 1 (0: nothing moved that matters).
 template <int SEED_LEVEL>
-__device__ __forceinline__ uint32_t relax_visit(const uint32_t t, const int lane, uint16_t *const orow,
-                                                const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
-                                                int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
+__global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
+                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
+                                                     uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
+  // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
+  // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
+  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
+  const uint32_t n = *count;
+  for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
+  const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n) return;
+  const int lane = threadIdx.x & 63;
+  uint16_t *const orow = open_rows[threadIdx.x >> 6];
+  const uint32_t t = tiles[wi];
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int x0 = tx * BT, y0 = win.lo + ty * BT;
   const int brow = min(BT - 1, win.hi - 1 - y0);   // the tile's last own row (63 except in the last tile row)
@@ -837,7 +845,7 @@ __device__ __forceinline__ uint32_t relax_visit(const uint32_t t, const int lane
     level = imin(level, SEED_LEVEL + 1);
     if (lane == 0) expanded[t] = 1;
   }
-  if (level >= DINF) return 0u;   // nothing new reaches this tile
+  if (level >= DINF) return;   // nothing new reaches this tile
   // OPEN WATER: every cell of the tile takes part, so the levels are chessboard distances from the ring (and from what the
   // tile holds already) and two chamfer sweeps give the fixed point exactly: once the ring has entered through the
   // levels at which it reaches the edge cells, any shortest king-move path inside the (convex) tile can be ordered into
@@ -873,16 +881,15 @@ __device__ __forceinline__ uint32_t relax_visit(const uint32_t t, const int lane
         d = wave_prefix_min(d - lane) + lane;
         prev = d;
         const int32_t rel = d - obase;
-        if (y < BT - 1) orow[y * BT + lane] = (uint16_t)(d >= DINF || rel > 0xFFFE ? 0xFFFF : rel);
-        else prev = (d >= DINF || rel > 0xFFFE) ? DINF : d;   // (the last row stays in its register: 63 rows of LDS)
+        orow[y * BT + lane] = (uint16_t)(d >= DINF || rel > 0xFFFE ? 0xFFFF : rel);
       }
     }
     if (__all(fits)) {
       // up: from SW, S, SE, then from E along the row; the finished row goes straight to memory
       int32_t nxt = DINF;
       for (int y = BT - 1; y >= 0; y--) {
-        const uint16_t rv16 = orow[min(y, BT - 2) * BT + lane];
-        int32_t d = y == BT - 1 ? prev : rv16 == 0xFFFF ? DINF : obase + (int32_t)rv16;
+        const uint16_t rv16 = orow[y * BT + lane];
+        int32_t d = rv16 == 0xFFFF ? DINF : obase + (int32_t)rv16;
         if (y < BT - 1) {
           const int32_t a = __builtin_amdgcn_update_dpp(DINF, nxt, 0x138, 0xf, 0xf, false);
           const int32_t b = __builtin_amdgcn_update_dpp(DINF, nxt, 0x130, 0xf, 0xf, false);
@@ -1055,127 +1062,9 @@ __device__ __forceinline__ uint32_t relax_visit(const uint32_t t, const int lane
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wake |= __shfl_xor(wake, o, 64);
-  return wake & ~(1u << 4);
-}
-
-// Global rounds: the tiles of a compacted list, one wavefront each; the woken tiles are flagged for the next round.
-// (What the row-block shards run, and the A/B reference of the supertile rounds below: RDGPU_FLAT_SUPER=0.)
-template <int SEED_LEVEL>
-__global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
-                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
-                                                     uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
-  // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
-  // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
-  __shared__ uint16_t open_rows[NTHR / 64][(BT - 1) * BT];
-  const uint32_t n = *count;
-  for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
-  const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wi >= n) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t t = tiles[wi];
-  const uint32_t wake = relax_visit<SEED_LEVEL>(t, lane, open_rows[threadIdx.x >> 6], mbits, expanded, D, w, h, win, tilesX, tilesY);
-  const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
-  if (lane < 9 && (wake >> lane & 1u)) {
+  if (lane < 9 && lane != 4 && (wake >> lane & 1u)) {
     const int ntx = tx + lane % 3 - 1, nty = ty + lane / 3 - 1;
     if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Supertile rounds (r03).  The global rounds above advance a front by ONE tile per launch: at S3 the towards field takes
-// ~350 launches of which all but the first few hold 10^2..10^4 tiles -- a round then costs a visit's latency plus the
-// launch, the compaction of the tile flags and the wait for the round's slowest tile.  Here ONE block owns a supertile
-// of SUP x SUP tiles (512 x 512 cells) for the whole launch and iterates it to the fixed point of ITS tiles against the
-// levels the other supertiles held when the launch began: wakes inside the supertile go through a 64-bit mask in LDS
-// (one bit per tile, no list, no compaction), wakes across its border through the NEXT launch's mask of the neighbouring
-// supertile (one 64-bit atomicOr).  The number of launches becomes the geodesic length in SUPERTILES; inside a launch an
-// iteration costs a visit and two barriers.  Correctness is the global rounds' argument unchanged (levels only
-// decrease and stay upper bounds; a tile is visited by one wavefront at a time; every edge cell that moves is tested
-// against the ring levels read at the visit's start, which are never below the neighbour's current ones, so no wake is
-// missed).  Two details: (1) wakes ACROSS supertiles are deferred to the next launch on purpose -- the other
-// supertile's block may sit on another XCD, whose L2 does not see this block's stores before the kernel boundary; a
-// wake consumed earlier could find the old levels and be lost.  Inside the block every wavefront shares the CU's L1,
-// and the barrier waits for the stores.  (2) An iteration cap leaves what is still active to the next launch.
-// ------------------------------------------------------------------------------------------
-constexpr int SUP = 8;
-constexpr int SUPER_BATCH_MAX = 24;
-
-// tile flags (bytes, as k_bits_prepare leaves them) -> one mask per supertile; the flags are cleared
-__global__ __launch_bounds__(NTHR) void k_super_gather(uint8_t *tflags, uint32_t tilesX, uint32_t tilesY, uint32_t superX,
-                                                       uint32_t nsuper, unsigned long long *sact0, unsigned long long *sact1) {
-  const uint32_t st = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6);
-  if (st >= nsuper) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t tx = (st % superX) * SUP + (lane & (SUP - 1)), ty = (st / superX) * SUP + (lane >> 3);
-  bool on = false;
-  if (tx < tilesX && ty < tilesY) {
-    on = tflags[ty * tilesX + tx] != 0;
-    if (on) tflags[ty * tilesX + tx] = 0;
-  }
-  const unsigned long long m = __ballot(on);
-  if (lane == 0) { sact0[st] = m; sact1[st] = 0ull; }
-}
-
-template <int SEED_LEVEL, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void k_relax_super(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
-                                                      unsigned long long *sact_cur, unsigned long long *sact_next, uint32_t *work,
-                                                      int w, int h, uint32_t tilesX, uint32_t tilesY, uint32_t superX,
-                                                      uint32_t nsuper, int maxit) {
-  __shared__ uint16_t open_rows[NW][(BT - 1) * BT];
-  __shared__ unsigned long long act[2];
-  __shared__ uint32_t ticket;
-  const uint32_t st = xcd_tile(blockIdx.x, nsuper);
-  if (st >= nsuper) return;
-  if (threadIdx.x == 0) {
-    const unsigned long long m = sact_cur[st];
-    if (m) sact_cur[st] = 0ull;   // (only this block touches this launch's mask of its supertile)
-    act[0] = m;
-    act[1] = 0ull;
-    ticket = 0;
-  }
-  __syncthreads();
-  if (act[0] == 0ull) return;
-  uint32_t visits = 0;   // (uniform) tile visits of this block, reported with the launch's "had work" word
-  const int lane = threadIdx.x & 63;
-  const int stx = (int)(st % superX) * SUP, sty = (int)(st / superX) * SUP;
-  uint16_t *const orow = open_rows[threadIdx.x >> 6];
-  int cur = 0;
-  for (int it = 0; it < maxit; it++) {
-    const unsigned long long m = act[cur];   // (uniform over the block)
-    if (m == 0ull) break;
-    const uint32_t nact = (uint32_t)__popcll(m);
-    visits += nact;
-    for (;;) {
-      uint32_t k = 0;
-      if (lane == 0) k = atomicAdd(&ticket, 1u);
-      k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-      if (k >= nact) break;
-      unsigned long long mm = m;
-      for (uint32_t i = 0; i < k; i++) mm &= mm - 1ull;   // the k-th active tile of the supertile
-      const int b = __ffsll((long long)mm) - 1;
-      const int ltx = b & (SUP - 1), lty = b >> 3;
-      const uint32_t t = (uint32_t)(sty + lty) * tilesX + (uint32_t)(stx + ltx);
-      const uint32_t wake = relax_visit<SEED_LEVEL>(t, lane, orow, mbits, expanded, D, w, h, RowWin{0, h, nullptr, nullptr}, tilesX, tilesY);
-      if (lane < 9 && (wake >> lane & 1u)) {
-        const int dx = lane % 3 - 1, dy = lane / 3 - 1;
-        const int ntx = stx + ltx + dx, nty = sty + lty + dy;
-        if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) {
-          const int nlx = ltx + dx, nly = lty + dy;
-          if (nlx >= 0 && nlx < SUP && nly >= 0 && nly < SUP)
-            atomicOr(&act[cur ^ 1], 1ull << (nly * SUP + nlx));
-          else
-            atomicOr(&sact_next[(uint32_t)(nty / SUP) * superX + (uint32_t)(ntx / SUP)], 1ull << ((nty % SUP) * SUP + (ntx % SUP)));
-        }
-      }
-    }
-    __syncthreads();   // (waits for the iteration's stores: the next one reads them through the CU's L1)
-    if (threadIdx.x == 0) { act[cur] = 0ull; ticket = 0; }
-    cur ^= 1;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (act[cur] != 0ull) atomicOr(&sact_next[st], act[cur]);   // iteration cap: the rest next launch
-    atomicAdd(work, visits);
   }
 }
 
@@ -1561,16 +1450,15 @@ static uint32_t run_relax_towards(const uint8_t *d_dirs, const uint8_t *flags, i
 }
 
 // ---- the bitmap engine's rounds (same protocol as relax_rounds: batches of rounds, counts read back per batch) ----
-static BitsScratch bits_scratch(int w, int h, int which = 0) {
-  // which: the two searches of one call own their round state (they may run side by side); the bitmaps are shared
+static BitsScratch bits_scratch(int w, int h) {
   Workspace &ws = Workspace::get();
   BitsScratch b;
   b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
   b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT);
-  b.expanded = ws.buf<uint8_t>(which ? "flats.bexp1" : "flats.bexp", b.ntiles);
-  b.tflags = ws.buf<uint8_t>(which ? "flats.btflags1" : "flats.btflags", b.ntiles);
-  b.tlist = ws.buf<uint32_t>(which ? "flats.btlist1" : "flats.btlist", b.ntiles);
-  b.ctr = ws.buf<uint32_t>(which ? "flats.tctr1" : "flats.tctr", BITS_BATCH);
+  b.expanded = ws.buf<uint8_t>("flats.bexp", b.ntiles);
+  b.tflags = ws.buf<uint8_t>("flats.btflags", b.ntiles);
+  b.tlist = ws.buf<uint32_t>("flats.btlist", b.ntiles);
+  b.ctr = ws.buf<uint32_t>("flats.tctr", BITS_BATCH);
   b.counts = ws.buf<uint32_t>("flats.bcounts", 3 * 256 + 8);
   return b;
 }
@@ -1603,192 +1491,6 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
     grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
     if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
   }
-}
-
-// ---- supertile rounds (k_relax_super): launches in batches, one "had work" word per launch read back per batch ----
-static int env_int(const char *name, int def, int lo, int hi) {
-  const char *e = getenv(name);
-  if (!e || !*e) return def;
-  return std::max(lo, std::min(hi, atoi(e)));
-}
-static bool legacy_rounds() {
-  const char *env = getenv("RDGPU_FLAT_LEGACY");   // =1: the r02 driver (one search after the other, global rounds): A/B and tests
-  return env && env[0] == '1';
-}
-static bool use_super_rounds() {
-  const char *env = getenv("RDGPU_FLAT_SUPER");   // =0: one tile per launch (the r02 rounds): A/B and tests
-  return !(env && env[0] == '0');
-}
-
-struct SuperSearch {
-  // One level field: global rounds (every active tile of the raster in parallel, one tile step per launch) while many
-  // tiles are active, supertile launches (k_relax_super) for the long tail of rounds with few.
-  BitsScratch b;
-  unsigned long long *sact[2] = {nullptr, nullptr};
-  uint32_t *work = nullptr, *hw = nullptr;
-  uint32_t superX = 0, nsuper = 0, rounds = 0, grid = 0;
-  int cur = 0, batch = 12, gbatch = 4, maxit = 8, seed_level = 2, nw = 8, sw = 6000, issued = 0;
-  int32_t *D = nullptr;
-  int w = 0, h = 0;
-  const char *name = "";
-  hipStream_t s = nullptr;
-  bool done = false, global_phase = true;
-
-  // b.tflags holds the start flags (k_bits_prepare); which: 0 / 1 = the call's first / second search (own scratch)
-  void begin(const BitsScratch &bs, int which, int seed, int32_t *D_, int w_, int h_, const char *name_, hipStream_t s_) {
-    b = bs; D = D_; w = w_; h = h_; name = name_; s = s_; seed_level = seed;
-    rounds = 0; cur = 0; done = false; global_phase = true;
-    batch = env_int("RDGPU_FLAT_SUPER_BATCH", 12, 1, SUPER_BATCH_MAX);
-    gbatch = env_int("RDGPU_FLAT_GLOBAL_BATCH", 4, 1, SUPER_BATCH_MAX);
-    maxit = env_int("RDGPU_FLAT_SUPER_IT", 8, 1, 4096);
-    nw = env_int("RDGPU_FLAT_SUPER_WAVES", 8, 4, 8) >= 8 ? 8 : 4;
-    sw = use_super_rounds() ? env_int("RDGPU_FLAT_SUPER_SWITCH", 6000, 0, 1 << 30) : -1;   // switch below this many active tiles
-    if (sw < 0) gbatch = BITS_BATCH;
-    grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
-    superX = (b.tilesX + SUP - 1) / SUP;
-    nsuper = superX * ((b.tilesY + SUP - 1) / SUP);
-    Workspace &ws = Workspace::get();
-    sact[0] = ws.buf<unsigned long long>(which ? "flats.sact1a" : "flats.sact0a", nsuper);
-    sact[1] = ws.buf<unsigned long long>(which ? "flats.sact1b" : "flats.sact0b", nsuper);
-    work = ws.buf<uint32_t>(which ? "flats.swork1" : "flats.swork0", SUPER_BATCH_MAX);
-    hw = ws.host_words() + (which ? SUPER_BATCH_MAX : 0);
-  }
-  void enqueue() {
-    if (done) return;
-    RD_HIP(hipMemsetAsync(work, 0, SUPER_BATCH_MAX * sizeof(uint32_t), s));
-    const RowWin win{0, h, nullptr, nullptr};
-    if (global_phase) {
-      issued = gbatch;
-      for (int k = 0; k < issued; k++) {
-        RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
-                  b.tlist, work + k);
-        if (seed_level == 2)
-          RD_LAUNCH(name, (k_relax_bits<2>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, b.expanded, D,
-                    (const uint32_t *)b.tlist, (const uint32_t *)(work + k), b.tflags, w, h, win, b.tilesX, b.tilesY);
-        else
-          RD_LAUNCH(name, (k_relax_bits<1>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, b.expanded, D,
-                    (const uint32_t *)b.tlist, (const uint32_t *)(work + k), b.tflags, w, h, win, b.tilesX, b.tilesY);
-      }
-    } else {
-      issued = batch;
-      const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
-      for (int k = 0; k < issued; k++) {
-        std::string nm = name;
-        if (trace) {   // one profiler entry per launch
-          char buf[96];
-          snprintf(buf, sizeof buf, "%s#%03u", name, rounds + (uint32_t)k);
-          nm = buf;
-        }
-#define RD_SUPER(SEED, NW)                                                                                                       \
-  RD_LAUNCH(nm.c_str(), (k_relax_super<SEED, NW>), dim3(xcd_grid(nsuper)), dim3(NW * 64), 0, s, (const unsigned long long *)b.mbits, \
-            b.expanded, D, sact[cur], sact[cur ^ 1], work + k, w, h, b.tilesX, b.tilesY, superX, nsuper, maxit)
-        if (seed_level == 2) { if (nw == 8) RD_SUPER(2, 8); else RD_SUPER(2, 4); }
-        else { if (nw == 8) RD_SUPER(1, 8); else RD_SUPER(1, 4); }
-#undef RD_SUPER
-        cur ^= 1;
-      }
-    }
-    RD_HIP(hipMemcpyAsync(hw, work, SUPER_BATCH_MAX * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  }
-  void collect() {
-    if (done) return;
-    RD_HIP(hipStreamSynchronize(s));
-    const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
-    uint32_t most = 0;
-    for (int k = 0; k < issued; k++) {
-      if (trace) fprintf(stderr, "%s %s %u %s %u\n", name, global_phase ? "round" : "launch", rounds, global_phase ? "tiles" : "visits", hw[k]);
-      if (hw[k] == 0) { done = true; return; }
-      most = std::max(most, hw[k]);
-      rounds++;
-    }
-    if (rounds > (1u << 17)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
-    if (global_phase) {
-      grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
-      if (sw >= 0 && hw[issued - 1] < (uint32_t)sw) {   // few tiles left: the tail goes supertile by supertile
-        global_phase = false;
-        cur = 0;
-        RD_LAUNCH("flats.super_gather", k_super_gather, dim3((nsuper + NTHR / 64 - 1) / (NTHR / 64)), dim3(NTHR), 0, s, b.tflags,
-                  b.tilesX, b.tilesY, superX, nsuper, sact[0], sact[1]);
-      }
-    }
-  }
-  uint32_t run() {
-    while (!done) { enqueue(); collect(); }
-    return rounds;
-  }
-};
-
-template <bool TOWARDS>
-static void launch_bits_prepare(const BitsScratch &b, const uint8_t *flags, const uint32_t *L, const int32_t *fh, int32_t *D,
-                                bool write_m, uint32_t *cnt, int w, int h, hipStream_t s) {
-  RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
-  RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
-  if (write_m)
-    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<TOWARDS, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
-              b.tflags, cnt, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
-  else
-    RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<TOWARDS, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
-              b.tflags, cnt, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
-}
-
-// The two level fields of one call, side by side.  They are independent searches over the same bitmaps, and after their
-// first few launches both are bound by the latency of a visit, not by the chip: each runs on its own internal stream,
-// forked from the caller's and joined back (RDGPU_FLAT_OVERLAP=0: one after the other on the caller's stream).
-// towards: levels from the low edges into TWd (it also writes the bitmaps and the counts); away: from the high edges
-// into A when there are any (L / fh: only the flats with an outlet).  Returns false when there is no low edge at all.
-static bool run_bits_both(const uint8_t *flags, const uint32_t *L, const int32_t *fh, int32_t *TWd, int32_t *A,
-                          unsigned long long *c3, int w, int h, hipStream_t s) {
-  Workspace &ws = Workspace::get();
-  const char *ov = getenv("RDGPU_FLAT_OVERLAP");
-  const bool overlap = !(ov && ov[0] == '0');
-  hipStream_t sT = s, sA = s;
-  if (overlap) {
-    sT = ws.side_stream(0);
-    sA = ws.side_stream(1);
-    RD_HIP(hipEventRecord(ws.side_event(0), s));
-    RD_HIP(hipStreamWaitEvent(sT, ws.side_event(0), 0));
-    RD_HIP(hipStreamWaitEvent(sA, ws.side_event(0), 0));
-  }
-  auto join = [&]() {
-    if (!overlap) return;
-    RD_HIP(hipEventRecord(ws.side_event(1), sT));
-    RD_HIP(hipEventRecord(ws.side_event(2), sA));
-    RD_HIP(hipStreamWaitEvent(s, ws.side_event(1), 0));
-    RD_HIP(hipStreamWaitEvent(s, ws.side_event(2), 0));
-  };
-  const BitsScratch bT = bits_scratch(w, h, 0), bA = bits_scratch(w, h, 1);
-  uint32_t *cnt = bT.counts;
-  RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), sT));
-  launch_bits_prepare<true>(bT, flags, nullptr, nullptr, TWd, true, cnt, w, h, sT);
-  unsigned long long *out = reinterpret_cast<unsigned long long *>(cnt + 3 * 256 + 2);
-  RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, sT, (const uint32_t *)cnt, out);
-  unsigned long long *hc = reinterpret_cast<unsigned long long *>(ws.host_words() + 2 * SUPER_BATCH_MAX);
-  RD_HIP(hipMemcpyAsync(hc, out, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sT));
-  SuperSearch T, Aw;
-  T.begin(bT, 0, 2, TWd, w, h, "flats.relax_towards", sT);
-  T.enqueue();                              // the first batch is under way while the counts come back
-  RD_HIP(hipEventRecord(ws.side_event(3), sT));
-  RD_HIP(hipStreamSynchronize(sT));
-  c3[0] = hc[0]; c3[1] = hc[1]; c3[2] = hc[2];
-  T.collect();
-  if (c3[0] == 0) { join(); return false; }   // no flats, or none with an outlet (:475-481)
-  const bool away = c3[1] > 0 && A != nullptr;
-  if (away) {
-    launch_bits_prepare<false>(bA, flags, L, fh, A, false, nullptr, w, h, sA);   // (the bitmaps exist: sT was synchronised)
-    Aw.begin(bA, 1, 1, A, w, h, "flats.relax_away", sA);
-  } else {
-    Aw.done = true;
-  }
-  while (!T.done || !Aw.done) {
-    T.enqueue();
-    Aw.enqueue();
-    T.collect();
-    Aw.collect();
-  }
-  g_fstats.towards_levels = T.rounds;
-  g_fstats.away_levels = Aw.rounds;
-  join();
-  return true;
 }
 
 // Towards levels from the low edges, D written in full; write_m: also the bitmap of the cells that take part (shared
@@ -1878,32 +1580,22 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     RD_LAUNCH("flats.mark_low", k_flat_mark_low_flags, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint8_t *)flags, (const uint32_t *)L,
               fh, n);
 
-  // away gradient: sources = high edges whose flat has a low edge; towards gradient from every low edge
+  // away gradient: sources = high edges whose flat has a low edge
   int32_t *A = nullptr;
-  if (use_bits_engine() && !legacy_rounds()) {
-    // the two searches side by side (the towards field does not depend on the flat heights)
-    if (nhigh_all > 0) A = ws.buf<int32_t>("flats.away", n);
-    unsigned long long c3[3] = {0, 0, 0};
-    run_bits_both(flags, L, fh, M, A, c3, w, h, s);
-    if (A)
-      RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
-                n);
-  } else {
-    if (nhigh_all > 0) {
-      A = ws.buf<int32_t>("flats.away", n);
-      if (use_bits_engine()) {
-        g_fstats.away_levels = run_bits_away(flags, L, fh, A, true, w, h, s);
-      } else {
-        RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
-        g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, L, fh, w, h, s);
-      }
-      RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
-                n);
+  if (nhigh_all > 0) {
+    A = ws.buf<int32_t>("flats.away", n);
+    if (use_bits_engine()) {
+      g_fstats.away_levels = run_bits_away(flags, L, fh, A, true, w, h, s);
+    } else {
+      RD_HIP(hipMemsetAsync(A, 0x7F, n * sizeof(int32_t), s));
+      g_fstats.away_levels = run_relax_away(d_dirs, A, highall, nhigh_all, L, fh, w, h, s);
     }
-    // then the combined mask in place
-    g_fstats.towards_levels = use_bits_engine() ? run_bits_towards(flags, M, nhigh_all == 0, nullptr, w, h, s)
-                                                : run_relax_towards(d_dirs, flags, M, w, h, s);
+    RD_LAUNCH("flats.height", k_flat_height, dim3(sgrid(n)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh,
+              n);
   }
+  // towards gradient from every low edge, then the combined mask in place
+  g_fstats.towards_levels = use_bits_engine() ? run_bits_towards(flags, M, nhigh_all == 0, nullptr, w, h, s)
+                                              : run_relax_towards(d_dirs, flags, M, w, h, s);
   if (outA) {   // the caller combines on the fly (k_flat_epsilon): M holds the towards levels
     *outA = A;
     return;
@@ -1934,17 +1626,8 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   int32_t *TWd = ws.buf<int32_t>("flats.mask", n), *A = nullptr;
-  if (use_bits_engine() && !legacy_rounds()) {
-    // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them; both fields at once
-    unsigned long long c3[3] = {0, 0, 0};
-    A = ws.buf<int32_t>("flats.away", n);
-    const bool any = run_bits_both(flags, nullptr, nullptr, TWd, A, c3, w, h, s);
-    g_fstats.low_edges = c3[0];
-    g_fstats.high_edges = c3[1];
-    g_fstats.noflow_cells = c3[2];
-    if (!any) return;   // no flats, or none with an outlet (:475-481)
-    if (c3[1] == 0) A = nullptr;
-  } else if (use_bits_engine()) {
+  if (use_bits_engine()) {
+    // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
     unsigned long long c3[3] = {0, 0, 0};
     g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s);
     g_fstats.low_edges = c3[0];

@@ -56,22 +56,6 @@ uint32_t *Workspace::host_words() {
   return host_words_;
 }
 
-hipStream_t Workspace::side_stream(int i) {
-  int dev = 0;
-  RD_HIP(hipGetDevice(&dev));
-  hipStream_t &st = streams_[dev * 16 + i];
-  if (!st) RD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  return st;
-}
-
-hipEvent_t Workspace::side_event(int i) {
-  int dev = 0;
-  RD_HIP(hipGetDevice(&dev));
-  hipEvent_t &e = events_[dev * 16 + i];
-  if (!e) RD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return e;
-}
-
 void Workspace::release() {
   (void)hipDeviceSynchronize();
   for (auto &kv : slots_)
