@@ -451,14 +451,18 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, 
 template <class A>
 __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
                                                          uint32_t tilesX, uint32_t ntiles,
-                                                         const unsigned long long *__restrict__ nw, A *__restrict__ area) {
+                                                         const unsigned long long *__restrict__ nw, A *__restrict__ area,
+                                                         const uint32_t *__restrict__ tile_list, const uint32_t *__restrict__ tile_count) {
   __shared__ uint8_t sd[LLW * LLW];
   // one word per cell: pending donors (bits 56..63) | in-tile target, 0x1FFF for none (bits 43..55) | total (43 bits)
   __shared__ unsigned long long lw[LT * LT];
   __shared__ unsigned long long ext_in[NTHR];
   __shared__ uint8_t ext_blk[NTHR];
   constexpr unsigned long long TMASK = (1ull << 43) - 1ull, NOTGT = 0x1FFFull;
-  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  // tile_list: only the tiles k_acc_link_final_sums handed over (grid-stride over the list); else every tile once
+  const uint32_t nwork = tile_list ? *tile_count : 1u;
+  for (uint32_t wi = tile_list ? blockIdx.x : 0u; wi < nwork; wi += gridDim.x) {
+  const uint32_t t = tile_list ? tile_list[wi] : xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int tx0 = (int)(t % tilesX), ty0 = (int)(t / tilesX);
   const int x0 = tx0 * LT, y0 = ty0 * LT;
@@ -568,6 +572,136 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
       if (std::is_same<A, unsigned long long>::value) out = (A)(((v >> 56) != 0 ? CNT1 : 0ull) | (v & TMASK));   // a shard's words
     }
     area[(size_t)gy * w + gx] = out;
+  }
+  __syncthreads();   // (the next tile of the list reuses the arrays)
+  }
+}
+
+// The final pass without a walk.  With every donor outside the tile finished (no direction loop upstream) and no loop
+// inside the tile, a cell's total is the sum of the weights of its in-tile SUBTREE (weight = 1, plus what a border cell
+// receives from outside), and subtree sums come out of pointer doubling: S_k(v) = weights of v's descendants closer than
+// 2^k; round k hands S_k(u) to u's 2^k-th ancestor, and S_(k+1)(v) = S_k(v) + what arrives (every descendant at distance
+// [2^k, 2^(k+1)) is counted by exactly one such u).  ceil(log2(longest in-tile path)) rounds of "read own sum, own
+// pointer, the pointer's pointer -- barrier -- one 32-bit LDS add, one pointer store", a cell dropping out as soon as
+// its pointer runs off its path; the last-arriver walk this replaces paid one returning 64-bit LDS atomic per cell of
+// the longest chain per round of sources, at ~10 % lane use (r02: 20.8 of the stage's 37 ms).  Totals are cell counts
+// of a raster below 2^31 cells: 32 bits (24 KB of LDS per tile instead of 38: five blocks per CU).  A tile with a
+// blocked donor, or whose pointers still move after twelve doublings (a direction loop), is appended to slow_tiles and
+// left to k_acc_link_final, which keeps the reference's partial sums there.
+constexpr uint16_t ANC_NONE = 0xFFFFu;
+template <class A>
+__global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                               uint32_t tilesX, uint32_t ntiles,
+                                                               const unsigned long long *__restrict__ nw, A *__restrict__ area,
+                                                               uint32_t *slow_tiles, uint32_t *slow_count) {
+  __shared__ uint8_t sd[LLW * LLW];
+  __shared__ uint32_t S[LT * LT];
+  __shared__ uint16_t anc[LT * LT];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
+  stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
+  __syncthreads();
+  // what the border cells receive from outside, one border cell per thread (all lookups in flight together)
+  unsigned long long inflow = 0;
+  uint32_t blocked = 0;
+  int bcell = -1;
+  {
+    const int slot = (int)threadIdx.x;
+    if (slot < 4 * LT - 4) {
+      const int bx = slot < LT ? slot : slot < 2 * LT ? slot - LT : slot < 3 * LT - 2 ? 0 : LT - 1;
+      const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
+      const int o = (by + 1) * LLW + bx + 1;
+      if (sd[o] != nodata) {
+        bcell = by * LT + bx;
+        unsigned long long wv[8];
+        bool use[8];
+#pragma unroll
+        for (int m = 1; m <= 8; m++) {
+          const int nx = bx + d8dx(m), ny = by + d8dy(m);
+          const uint8_t dn = sd[o + d8dy(m) * LLW + d8dx(m)];
+          use[m - 1] = !(nx >= 0 && nx < LT && ny >= 0 && ny < LT) && dn != nodata && dn == (m <= 4 ? m + 4 : m - 4);
+          wv[m - 1] = 0;
+          if (use[m - 1]) {
+            const int gx = x0 + nx, gy = y0 + ny;
+            wv[m - 1] = nw[((size_t)(gy / LT) * tilesX + (size_t)(gx / LT)) * 256 + (size_t)border_slot(gx % LT, gy % LT)];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          if (!use[m]) continue;
+          const unsigned long long cnt = wv[m] >> 56;
+          if (cnt == 0 || cnt == SRC) inflow += wv[m] & LOWMASK;
+          else blocked++;
+        }
+      }
+    }
+  }
+  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  uint16_t a[LT / 4];      // the 2^k-th ancestor of the thread's cells (ANC_NONE: the path is shorter)
+  uint32_t datamask = 0, act = 0;
+#pragma unroll 4
+  for (int j = 0; j < LT / 4; j++) {   // every cell without branches (see link_stage)
+    const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
+    const uint8_t d = sd[o];
+    const bool data = d != nodata, flows = data && d >= 1 && d <= 8;
+    const int dd = flows ? d : 0;
+    const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
+    const bool in_tile = flows && tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata;
+    a[j] = in_tile ? (uint16_t)(ty * LT + tx) : ANC_NONE;
+    datamask |= (data ? 1u : 0u) << j;
+    act |= (in_tile ? 1u : 0u) << j;
+    S[ly * LT + lx] = data ? 1u : 0u;
+    anc[ly * LT + lx] = a[j];
+  }
+  __syncthreads();
+  if (bcell >= 0 && inflow) S[bcell] += (uint32_t)inflow;   // (one thread per border cell)
+  if (__syncthreads_or(blocked != 0 || inflow >= (1ull << 31))) {
+    if (threadIdx.x == 0) slow_tiles[atomicAdd(slow_count, 1u)] = t;
+    return;
+  }
+  int it = 0;
+  for (; it < 13; it++) {
+    uint32_t sv[LT / 4];
+    uint16_t aa[LT / 4];
+#pragma unroll
+    for (int g = 0; g < LT / 16; g++) {   // groups of four rows: one scalar test skips a group that is done
+      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * g + e;
+        const bool on = act >> j & 1u;
+        sv[j] = S[(ly0 + 4 * j) * LT + lx];
+        aa[j] = anc[on ? a[j] : (ly0 + 4 * j) * LT + lx];   // (a finished cell reads its own slot: no branch around the LDS read)
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < LT / 16; g++) {
+      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * g + e;
+        if (act >> j & 1u) {
+          atomicAdd(&S[a[j]], sv[j]);
+          anc[(ly0 + 4 * j) * LT + lx] = aa[j];
+          a[j] = aa[j];
+          if (aa[j] == ANC_NONE) act &= ~(1u << j);
+        }
+      }
+    }
+    if (!__syncthreads_or(act != 0)) break;
+  }
+  if (it >= 13) {   // 2^12 steps and still on a path: a direction loop inside the tile
+    if (threadIdx.x == 0) slow_tiles[atomicAdd(slow_count, 1u)] = t;
+    return;
+  }
+#pragma unroll 4
+  for (int j = 0; j < LT / 4; j++) {
+    const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const uint32_t v = S[ly * LT + lx];
+    area[(size_t)gy * w + gx] = (datamask >> j & 1u) ? (A)v : (A)-1;   // area.noData() == -1, d8_methods.hpp:64,:72-75
   }
 }
 
@@ -751,8 +885,19 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
       RD_LAUNCH("accum.link_sources", k_acc_link_sources, dim3(ngrid), dim3(NTHR), 0, s, nw, nnodes);
       RD_LAUNCH("accum.link_walk", k_acc_link_walk, dim3((uint32_t)(((nnodes + WALK_CHUNK - 1) / WALK_CHUNK + 3) / 4)), dim3(NTHR),
                 0, s, nw, (const uint32_t *)next, nnodes);
-      RD_LAUNCH("accum.link_final", (k_acc_link_final<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h, tilesX,
-                ntiles, (const unsigned long long *)nw, d_area);
+      const char *sums = getenv("RDGPU_ACCUM_SUMS");   // =0: the last-arriver walk in every tile (r02); A/B and tests
+      if (sums && sums[0] == '0') {
+        RD_LAUNCH("accum.link_final", (k_acc_link_final<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h, tilesX,
+                  ntiles, (const unsigned long long *)nw, d_area, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+        return;
+      }
+      uint32_t *slow = ws.buf<uint32_t>("accum.link_slow", (size_t)ntiles + 1);   // [0]: count, then the tiles
+      RD_HIP(hipMemsetAsync(slow, 0, sizeof(uint32_t), s));
+      RD_LAUNCH("accum.link_final", (k_acc_link_final_sums<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h,
+                tilesX, ntiles, (const unsigned long long *)nw, d_area, slow + 1, slow);
+      RD_LAUNCH("accum.link_final_loops", (k_acc_link_final<A>), dim3(std::min<uint32_t>(ntiles, 2048u)), dim3(NTHR), 0, s, d_dirs,
+                nodata, w, h, tilesX, ntiles, (const unsigned long long *)nw, d_area, (const uint32_t *)(slow + 1),
+                (const uint32_t *)slow);
       return;
     }
   }
