@@ -328,21 +328,35 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   __syncthreads();   // (also: every thread has read what it needs of sd)
 #pragma unroll
   for (int j = 0; j < LT / 4; j++) cnt[(ly0 + 4 * j) * LT + lx] = 0;
+  // (k_descent's loop: two hops per trip, a cell is finished once its pointer names a terminal, and a group of four rows
+  // whose cells are all finished is skipped with one scalar test -- this kernel is bound by instruction issue)
+  uint32_t act = 0;
+#pragma unroll
+  for (int j = 0; j < LT / 4; j++) act |= (keep[j] < LP_TERM ? 1u : 0u) << j;
   for (int it = 0; it < 12; it++) {
-    uint16_t pv[LT / 4], qv[LT / 4];
-#pragma unroll
-    for (int j = 0; j < LT / 4; j++) pv[j] = lp[(ly0 + 4 * j) * LT + lx];
-#pragma unroll
-    for (int j = 0; j < LT / 4; j++) {   // (a terminal code reads its own slot: no branch around the LDS read)
-      const uint16_t q = lp[pv[j] < LP_TERM ? pv[j] : (ly0 + 4 * j) * LT + lx];
-      qv[j] = pv[j] < LP_TERM ? q : pv[j];
-    }
     int still = 0;
 #pragma unroll
-    for (int j = 0; j < LT / 4; j++) {
-      const bool move = pv[j] < LP_TERM && qv[j] < LP_TERM;
-      lp[(ly0 + 4 * j) * LT + lx] = move ? qv[j] : pv[j];   // (rewriting the own slot with its own value is harmless)
-      still |= move;
+    for (int g = 0; g < LT / 16; g++) {
+      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;   // wave uniform
+      uint16_t pv[4], qv[4], rv[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * (4 * g + e)) * LT + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LP_TERM ? pv[e] : (ly0 + 4 * (4 * g + e)) * LT + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LP_TERM ? qv[e] : (ly0 + 4 * (4 * g + e)) * LT + lx];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = 4 * g + e;
+        if (pv[e] < LP_TERM && qv[e] < LP_TERM) {
+          const bool more = rv[e] < LP_TERM;   // q is not the end of the path yet: jump to r and come back
+          lp[(ly0 + 4 * j) * LT + lx] = more ? rv[e] : qv[e];
+          if (more) still = 1;
+          else act &= ~(1u << j);
+        } else {
+          act &= ~(1u << j);
+        }
+      }
     }
     if (!__syncthreads_or(still)) break;
   }
@@ -449,21 +463,14 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, 
 }
 
 template <class A>
-__global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
-                                                         uint32_t tilesX, uint32_t ntiles,
-                                                         const unsigned long long *__restrict__ nw, A *__restrict__ area,
-                                                         const uint32_t *__restrict__ tile_list, const uint32_t *__restrict__ tile_count) {
+__device__ __forceinline__ void link_final_walk_tile(const uint32_t t, const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                     uint32_t tilesX, const unsigned long long *__restrict__ nw, A *__restrict__ area) {
   __shared__ uint8_t sd[LLW * LLW];
   // one word per cell: pending donors (bits 56..63) | in-tile target, 0x1FFF for none (bits 43..55) | total (43 bits)
   __shared__ unsigned long long lw[LT * LT];
   __shared__ unsigned long long ext_in[NTHR];
   __shared__ uint8_t ext_blk[NTHR];
   constexpr unsigned long long TMASK = (1ull << 43) - 1ull, NOTGT = 0x1FFFull;
-  // tile_list: only the tiles k_acc_link_final_sums handed over (grid-stride over the list); else every tile once
-  const uint32_t nwork = tile_list ? *tile_count : 1u;
-  for (uint32_t wi = tile_list ? blockIdx.x : 0u; wi < nwork; wi += gridDim.x) {
-  const uint32_t t = tile_list ? tile_list[wi] : xcd_tile(blockIdx.x, ntiles);
-  if (t >= ntiles) return;
   const int tx0 = (int)(t % tilesX), ty0 = (int)(t / tilesX);
   const int x0 = tx0 * LT, y0 = ty0 * LT;
   stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
@@ -573,7 +580,28 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restri
     }
     area[(size_t)gy * w + gx] = out;
   }
-  __syncthreads();   // (the next tile of the list reuses the arrays)
+}
+
+// every tile once (RDGPU_ACCUM_SUMS=0: the r02 pass)
+template <class A>
+__global__ __launch_bounds__(NTHR) void k_acc_link_final(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                         uint32_t tilesX, uint32_t ntiles,
+                                                         const unsigned long long *__restrict__ nw, A *__restrict__ area) {
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  link_final_walk_tile<A>(t, dirs, nodata, w, h, tilesX, nw, area);
+}
+
+// only the tiles k_acc_link_final_sums handed over: blocked donors, direction loops (grid-stride over the list)
+template <class A>
+__global__ __launch_bounds__(NTHR) void k_acc_link_final_list(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
+                                                              uint32_t tilesX, const unsigned long long *__restrict__ nw,
+                                                              A *__restrict__ area, const uint32_t *__restrict__ tile_list,
+                                                              const uint32_t *__restrict__ tile_count) {
+  const uint32_t n = *tile_count;
+  for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
+    link_final_walk_tile<A>(tile_list[wi], dirs, nodata, w, h, tilesX, nw, area);
+    __syncthreads();   // (the next tile of the list reuses the arrays)
   }
 }
 
@@ -888,15 +916,15 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
       const char *sums = getenv("RDGPU_ACCUM_SUMS");   // =0: the last-arriver walk in every tile (r02); A/B and tests
       if (sums && sums[0] == '0') {
         RD_LAUNCH("accum.link_final", (k_acc_link_final<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h, tilesX,
-                  ntiles, (const unsigned long long *)nw, d_area, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                  ntiles, (const unsigned long long *)nw, d_area);
         return;
       }
       uint32_t *slow = ws.buf<uint32_t>("accum.link_slow", (size_t)ntiles + 1);   // [0]: count, then the tiles
       RD_HIP(hipMemsetAsync(slow, 0, sizeof(uint32_t), s));
       RD_LAUNCH("accum.link_final", (k_acc_link_final_sums<A>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_dirs, nodata, w, h,
                 tilesX, ntiles, (const unsigned long long *)nw, d_area, slow + 1, slow);
-      RD_LAUNCH("accum.link_final_loops", (k_acc_link_final<A>), dim3(std::min<uint32_t>(ntiles, 2048u)), dim3(NTHR), 0, s, d_dirs,
-                nodata, w, h, tilesX, ntiles, (const unsigned long long *)nw, d_area, (const uint32_t *)(slow + 1),
+      RD_LAUNCH("accum.link_final_loops", (k_acc_link_final_list<A>), dim3(std::min<uint32_t>(ntiles, 2048u)), dim3(NTHR), 0, s,
+                d_dirs, nodata, w, h, tilesX, (const unsigned long long *)nw, d_area, (const uint32_t *)(slow + 1),
                 (const uint32_t *)slow);
       return;
     }
