@@ -7,7 +7,7 @@
 
 template <class T>
 struct Flood {
-  static int run(const std::string &in, const std::string &out, uint32_t max_dep_size) {
+  static int run(const std::string &in, const std::string &out, uint64_t max_dep_size) {
     apps::Array2D<T> elevation(in, true);
     if (max_dep_size == 0) rdgpu::PriorityFlood_Zhou2016(elevation);
     else rdgpu::PriorityFlood_Barnes2014_max_dep<apps::Topology::D8>(elevation, max_dep_size);
@@ -26,10 +26,10 @@ static int body(int argc, char **argv) {
   }
   // (round 1 took the element type as the third argument: still accepted)
   std::string type = "f32";
-  uint32_t max_dep_size = 0;
+  uint64_t max_dep_size = 0;   // (the reference takes it as uint64_t: depressions/Barnes2014.hpp:844)
   for (int i = 3; i < argc; i++) {
     const std::string a = argv[i];
-    if (!a.empty() && a.find_first_not_of("0123456789") == std::string::npos) max_dep_size = (uint32_t)std::stoul(a);
+    if (!a.empty() && a.find_first_not_of("0123456789") == std::string::npos) max_dep_size = (uint64_t)std::stoull(a);
     else type = a;
   }
   return apps::route<Flood>(type, std::string(argv[1]), std::string(argv[2]), max_dep_size);

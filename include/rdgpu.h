@@ -134,6 +134,10 @@ typedef struct rdgpu_epsilon_stats {
   uint64_t tile_relaxations; /* tiles relaxed, summed over the rounds                                           */
   uint64_t slack;            /* the slack the successful attempt ran with, in representable steps               */
   uint64_t max_lift;         /* largest lift of a cell above the plain fill, in representable steps             */
+  uint64_t tie_sources;      /* gradient sources (cells at their own elevation next to a raised cell) whose elevation
+                                another source shares: 0 = identical to the reference; otherwise the reference's result
+                                follows std::priority_queue's pop order there and this surface is a cell-wise lower
+                                bound of it (RDGPU_EPS_TIES=0 skips the count)                                      */
 } rdgpu_epsilon_stats;
 int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
 

@@ -89,4 +89,11 @@ __all__ = [
     "profile_collect",
     "profile_reset",
     "profile_totals",
+    "ResolveFlats",
+    "pit_mask",
+    "fill_max_dep",
+    "watersheds",
+    "resolve_flats_epsilon",
+    "fill_epsilon_dev",
+    "epsilon_stats",
 ]

@@ -6,6 +6,7 @@ the same buffer); HBM-resident torch tensors go through ``rdgpu_<op>_dev_<dtype>
 from __future__ import annotations
 
 import ctypes
+import warnings
 
 import numpy as np
 
@@ -72,7 +73,15 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     """Fill all depressions of ``dem`` (reference: ``rd.FillDepressions``,
     wrappers/pyrichdem/richdem/__init__.py:381-422 -> FillDepressions<topo>, depressions.hpp:13-21; ``epsilon=True``
     -> PriorityFloodEpsilon_Barnes2014<topo>, depressions/Barnes2014.hpp:335-420, floating point only, ``nodata`` cells
-    are left alone).  Returns the filled array (or None when ``in_place``)."""
+    are left alone).  Returns the filled array (or None when ``in_place``).
+
+    Ties (``epsilon=True`` only; the plain fill is exact for every input): the reference's result depends on the order
+    in which ``std::priority_queue`` pops cells of EQUAL elevation -- a plateau or lake entered through several cells
+    of one level gets its gradient from whichever pops first.  This engine returns the order-free surface
+    ``E(c) = max(z(c), nextafter(min over neighbours E))``: identical to the reference when no two gradient sources
+    share an elevation, a cell-wise lower bound of it otherwise (quantised / integer-valued DEMs).  The number of such
+    sources is counted on the device (``epsilon_stats()["tie_sources"]``) and a ``RuntimeWarning`` is raised when it is
+    not zero."""
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("FillDepressions: expected a 2-D numpy array")
     out = dem if in_place else dem.copy()
@@ -82,11 +91,19 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
         out = np.ascontiguousarray(out)
     h, w = out.shape
     if epsilon:
+        if shards > 1:
+            raise RdgpuError("FillDepressions(epsilon=True, shards=...): the epsilon fill is not sharded; use shards=1")
         if out.dtype not in (np.float32, np.float64):
             raise RdgpuError("Priority-Flood+Epsilon is only available for floating-point data types!")   # Barnes2014.hpp:424-451
         s = _suffix(out.dtype)
         check(getattr(lib(), f"rdgpu_fill_epsilon_{s}")(out.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
                                                         _topo(topology)), "rdgpu_fill_epsilon")
+        ties = epsilon_stats()["tie_sources"]
+        if ties:
+            warnings.warn(f"FillDepressions(epsilon=True): {ties} gradient sources share their elevation with another one; "
+                          "the reference's Priority-Flood+Epsilon resolves such ties by std::priority_queue's pop order, "
+                          "this engine returns the order-free surface (a cell-wise lower bound of the reference's)",
+                          RuntimeWarning, stacklevel=2)
         return None if in_place else out
     if shards > 1:   # the multi-GPU row-block protocol, shard after shard on one GPU
         if _suffix(out.dtype) in ("f64", "i64", "u64"):
@@ -492,7 +509,7 @@ def fill_epsilon_dev(dem, nodata, topology="D8") -> None:
 
 class _EpsStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_uint32), ("attempts", ctypes.c_uint32), ("tile_relaxations", ctypes.c_uint64),
-                ("slack", ctypes.c_uint64), ("max_lift", ctypes.c_uint64)]
+                ("slack", ctypes.c_uint64), ("max_lift", ctypes.c_uint64), ("tie_sources", ctypes.c_uint64)]
 
 
 def epsilon_stats() -> dict:

@@ -1277,7 +1277,10 @@ static std::vector<bool> &accs_slots() {
 
 static void accs_free(rdgpu_accum_shard *a) {
   if (!a) return;
-  if (a->slot >= 0 && (size_t)a->slot < accs_slots().size()) accs_slots()[a->slot] = false;
+  if (a->slot >= 0 && (size_t)a->slot < accs_slots().size()) {
+    accs_slots()[a->slot] = false;
+    Workspace::get().unpin();
+  }
   delete a;
 }
 
@@ -1295,6 +1298,7 @@ static rdgpu_accum_shard *accs_begin(const uint8_t *d_dirs, uint8_t nodata, int 
     if (k == slots.size()) slots.push_back(false);
     slots[k] = true;
     a->slot = (int)k;
+    Workspace::get().pin();   // (the words live in the workspace: release_workspace() is refused while the shard is alive)
     int nbuf = 0;
     auto alloc = [&](size_t bytes) {
       const std::string name = "accum.shard" + std::to_string(k) + "." + std::to_string(nbuf++);

@@ -72,7 +72,11 @@ public:
   }
   // pinned host scalar slots for small read-backs
   uint32_t *host_words();
+  // Frees every buffer.  Refused (Error) while a shard handle whose tables live in the workspace is alive: the handle
+  // would keep dangling device pointers (rdgpu_*_shard_begin pins, _finish / _free unpins).
   void release();
+  void pin() { pins_++; }
+  void unpin() { if (pins_ > 0) pins_--; }
 
 private:
   struct Slot {
@@ -81,6 +85,7 @@ private:
   };
   std::map<std::string, Slot> slots_;
   uint32_t *host_words_ = nullptr;
+  int pins_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------

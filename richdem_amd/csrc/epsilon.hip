@@ -92,16 +92,30 @@ struct CKey<double> {
 
 // The field a relaxation works on: key type, "not reached", the largest key that still steps, and per cell its floor
 // (the value it can never go below) and whether it is fixed besides the raster border.
+// NoData.  The reference processes a NoData region that touches the raster border first (its border cells are the
+// lowest seeds, their NoData neighbours follow through the pit queue) and pushes the data cells next to it into the heap
+// at their own elevation: such NoData cells are FIXED cells of value NoData here.  An interior NoData hole is only
+// reached when the flood arrives at its ring, and then passes the flood on (Barnes2014.hpp:399-400: it enters the pit
+// queue like a lake cell): here such a cell takes part in the relaxation with floor -infinity -- the level travels
+// through it, one step per cell -- and is never written.  (Fixed at NoData it would drain every lake around a hole.)
+// Which is which: the plain fill W raises an interior hole above NoData and leaves a border-connected region at NoData.
+// What is NOT reproduced: the reference leaves those ring cells of a hole at their own elevation that a hole cell
+// happens to close before the lake's breadth-first front does -- pits inside a filled lake, and an artefact of its
+// queue order; here every ring cell is raised with the lake.
 template <class T>
-struct EpsField {   // the epsilon surface of a float / double DEM: floor = the cell's own elevation, NoData cells fixed
+__device__ __forceinline__ bool nodata_is_fixed(T zz, T nodata, T wv) { return zz == nodata && wv == zz; }
+
+template <class T>
+struct EpsField {   // the epsilon surface of a float / double DEM: floor = the cell's own elevation
   using K = typename CKey<T>::K;
   static constexpr K INF = CKey<T>::INF, POSINF = CKey<T>::POSINF;
   const T *z;
   T nodata;
+  const T *W;
   __device__ __forceinline__ K key(size_t g, bool &fixed) const {
     const T zz = z[g];
-    fixed = zz == nodata;
-    return CKey<T>::to(zz);
+    fixed = nodata_is_fixed(zz, nodata, W[g]);
+    return zz == nodata && !fixed ? (K)0 : CKey<T>::to(zz);   // (an interior hole: floor -infinity)
   }
 };
 template <class T>
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(NT) void k_eps_init(const T *__restrict__ z, const 
     if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
       const size_t g = (size_t)gy * w + gx;
       const T zz = z[g];
-      if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || zz == nodata) v = CKey<T>::to(zz);   // fixed: exact
+      if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || nodata_is_fixed(zz, nodata, W[g])) v = CKey<T>::to(zz);   // fixed: exact
       else {
         const K wk = CKey<T>::to(W[g]);
         v = (wk <= CKey<T>::POSINF && CKey<T>::POSINF - wk > X) ? wk + X : CKey<T>::INF;
@@ -201,9 +215,11 @@ __global__ __launch_bounds__(NT) void k_eps_init(const T *__restrict__ z, const 
     if (gx >= w || gy >= h) continue;
     const size_t g = (size_t)gy * w + gx;
     const T zz = z[g];
-    const K zk = CKey<T>::to(zz);
+    const bool border = gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1;
+    const bool hole = zz == nodata && !border && !nodata_is_fixed(zz, nodata, W[g]);   // interior NoData: floor -infinity
+    const K zk = hole ? (K)0 : CKey<T>::to(zz);
     K d = zk;
-    if (!(gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || zz == nodata)) {
+    if (!(border || (zz == nodata && !hole))) {
       const int o = (ly + 1) * RW + lx + 1;
       K lo = kmin(kmin(sw[o - RW], sw[o + RW]), kmin(sw[o - 1], sw[o + 1]));
       if (TOPO == 8) lo = kmin(lo, kmin(kmin(sw[o - RW - 1], sw[o - RW + 1]), kmin(sw[o + RW - 1], sw[o + RW + 1])));
@@ -242,11 +258,11 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
     if (gx >= w || gy >= h) continue;
     const size_t g = (size_t)gy * w + gx;
     const T zz = z[g];
-    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || zz == nodata) continue;
+    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || nodata_is_fixed(zz, nodata, W[g])) continue;
     const int o = (ly + 1) * RW + lx + 1;
     K lo = kmin(kmin(sd[o - RW], sd[o + RW]), kmin(sd[o - 1], sd[o + 1]));
     if (TOPO == 8) lo = kmin(lo, kmin(kmin(sd[o - RW - 1], sd[o - RW + 1]), kmin(sd[o + RW - 1], sd[o + RW + 1])));
-    const K f = kmax(CKey<T>::to(zz), step_up<EpsField<T>>(lo));
+    const K f = kmax(zz == nodata ? (K)0 : CKey<T>::to(zz), step_up<EpsField<T>>(lo));
     const K d = sd[o];
     if (d != f) nbad++;
     const K wk = CKey<T>::to(W[g]);
@@ -413,9 +429,62 @@ __global__ __launch_bounds__(NT) void k_eps_final(T *z, T nodata, const typename
   }
 }
 
+// ---- tie detector -------------------------------------------------------------------------------------------------
+// The surface above equals the reference's when no two cells of its heap hold the same elevation.  The cells that
+// matter are the SOURCES of a gradient: cells that keep their own elevation (they pass through the heap) and have a
+// raised neighbour (whose value is counted from them).  Two sources of equal elevation = the reference's result there
+// follows std::priority_queue's pop order (a plateau or a lake entered through several cells of one level gets its
+// gradient from whichever of them pops first).  k_eps_sources counts the sources and, in a second call, inserts their
+// keys into an open-addressing set: `ties` = sources whose key was already there.  Conservative (equal sources far apart
+// need not interact), cheap (two stencil passes), and what FillDepressions(epsilon=True) warns with.
+template <class K> struct KeyEmpty { static constexpr K v = (K) ~(K)0; };
+__device__ __forceinline__ uint32_t cas_key(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
+__device__ __forceinline__ uint64_t cas_key(uint64_t *p, uint64_t cmp, uint64_t v) {
+  return (uint64_t)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)cmp, (unsigned long long)v);
+}
+
+template <class T, int TOPO>
+__global__ __launch_bounds__(NT) void k_eps_sources(const T *__restrict__ z, T nodata, const typename CKey<T>::K *__restrict__ D,
+                                                    int w, int h, typename CKey<T>::K *table, unsigned long long mask,
+                                                    unsigned long long *counts /* [0] sources, [1] ties */) {
+  using K = typename CKey<T>::K;
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  unsigned long long nsrc = 0, nties = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const T zc = z[c];
+    if (zc == nodata) continue;
+    const K kc = CKey<T>::to(zc);
+    if (D[c] != kc) continue;   // raised: not a source
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    bool feeds = false;
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        if ((dx == 0 && dy == 0) || (TOPO == 4 && dx != 0 && dy != 0)) continue;
+        const int nx = x + dx, ny = y + dy;
+        if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+        const uint64_t m = (uint64_t)ny * w + nx;
+        const T zn = z[m];
+        if (zn != nodata && D[m] > CKey<T>::to(zn)) feeds = true;
+      }
+    if (!feeds) continue;
+    nsrc++;
+    if (!table) continue;
+    unsigned long long slot = ((unsigned long long)kc * 0x9E3779B97F4A7C15ull >> 20) & mask;
+    for (;;) {
+      K v = table[slot];
+      if (v == KeyEmpty<K>::v) v = cas_key(&table[slot], KeyEmpty<K>::v, kc);
+      if (v == KeyEmpty<K>::v) break;        // inserted
+      if (v == kc) { nties++; break; }       // an equal source exists
+      slot = (slot + 1) & mask;
+    }
+  }
+  if (nsrc) atomicAdd(&counts[0], nsrc);
+  if (nties) atomicAdd(&counts[1], nties);
+}
+
 struct Stats {
   uint32_t rounds = 0, attempts = 0;
-  uint64_t tile_relaxations = 0, slack = 0, max_lift = 0;
+  uint64_t tile_relaxations = 0, slack = 0, max_lift = 0, tie_sources = 0;
 };
 static Stats g_stats;
 
@@ -470,7 +539,7 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     RD_HIP(hipMemsetAsync(ctr + BATCH, 0, 8 * sizeof(uint32_t), s));
     RD_LAUNCH("eps.init", (k_eps_init<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, X, D, tflags,
               w, h, tilesX, ntiles);
-    relax_until_quiet<EpsField<T>, TOPO>(EpsField<T>{d_z, nodata}, D, tflags, tlist, ctr, w, h, "eps.relax", s);
+    relax_until_quiet<EpsField<T>, TOPO>(EpsField<T>{d_z, nodata, d_W}, D, tflags, tlist, ctr, w, h, "eps.relax", s);
     RD_LAUNCH("eps.check", (k_eps_check<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, (const K *)D, w,
               h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2));
     RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -482,6 +551,32 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     // too small: the failed attempt is a lower bound of E, so the true lift is at least `lift`
     const uint64_t next = std::max<uint64_t>((uint64_t)X * 8, lift * 2 + 16);
     X = next >= (uint64_t)CKey<T>::POSINF ? CKey<T>::POSINF : (K)next;   // POSINF: every interior cell starts at +inf
+  }
+  {
+    const char *te = getenv("RDGPU_EPS_TIES");   // =0: skip the tie detector
+    if (!(te && te[0] == '0')) {
+      unsigned long long *tc = ws.buf<unsigned long long>("eps.tiecounts", 2);
+      unsigned long long *htc = reinterpret_cast<unsigned long long *>(hw + 8);
+      const uint32_t tgrid = (uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 32u);
+      RD_HIP(hipMemsetAsync(tc, 0, 2 * sizeof(unsigned long long), s));
+      RD_LAUNCH("eps.sources", (k_eps_sources<T, TOPO>), dim3(tgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const K *)D, w, h,
+                (K *)nullptr, 0ull, tc);
+      RD_HIP(hipMemcpyAsync(htc, tc, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      const unsigned long long nsrc = htc[0];
+      if (nsrc > 1) {
+        unsigned long long slots = 1024;
+        while (slots < 2 * nsrc) slots *= 2;
+        K *table = ws.buf<K>("eps.tietable", slots);
+        RD_HIP(hipMemsetAsync(table, 0xFF, slots * sizeof(K), s));
+        RD_HIP(hipMemsetAsync(tc, 0, 2 * sizeof(unsigned long long), s));
+        RD_LAUNCH("eps.sources", (k_eps_sources<T, TOPO>), dim3(tgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const K *)D, w, h,
+                  table, slots - 1, tc);
+        RD_HIP(hipMemcpyAsync(htc, tc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RD_HIP(hipStreamSynchronize(s));
+        g_stats.tie_sources = htc[1];
+      }
+    }
   }
   RD_LAUNCH("eps.final", (k_eps_final<T>), dim3((uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 32u)), dim3(NT), 0, s, d_z,
             nodata, (const K *)D, n, ctr + BATCH + 4);
@@ -823,6 +918,7 @@ extern "C" int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out) {
   out->tile_relaxations = eps::g_stats.tile_relaxations;
   out->slack = eps::g_stats.slack;
   out->max_lift = eps::g_stats.max_lift;
+  out->tie_sources = eps::g_stats.tie_sources;
   return RDGPU_OK;
 }
 

@@ -1836,7 +1836,10 @@ static void shard_free(rdgpu_fill_shard *sh) {
   if (!sh) return;
   std::lock_guard<std::recursive_mutex> lock(api_mutex());
   for (void *p : sh->owned) (void)hipFree(p);
-  if (sh->cached) g_cached_shard_live[sh->device & 63] = false;
+  if (sh->cached) {
+    g_cached_shard_live[sh->device & 63] = false;
+    Workspace::get().unpin();
+  }
   delete sh;
 }
 
@@ -1898,7 +1901,10 @@ static rdgpu_fill_shard *shard_begin(T *d_dem, int w, int h, int topology, int o
     sh->stream = s;
     RD_HIP(hipGetDevice(&sh->device));
     sh->cached = !g_cached_shard_live[sh->device & 63];
-    if (sh->cached) g_cached_shard_live[sh->device & 63] = true;
+    if (sh->cached) {
+      g_cached_shard_live[sh->device & 63] = true;
+      Workspace::get().pin();   // (its tables live in the workspace: release_workspace() is refused while it is alive)
+    }
     BufAlloc alloc{!sh->cached, &sh->owned, sh->cached};
     if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
     else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);

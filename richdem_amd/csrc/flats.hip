@@ -2172,6 +2172,27 @@ __device__ __forceinline__ T epsilon_steps(T v, uint32_t m) {   // m steps towar
   const long long x = (long long)v, mm = (long long)m;
   return (T)(x > 0 ? (x > mm ? x - mm : 0) : (x < -mm ? x + mm : 0));
 }
+// 64-bit integers: the reference's step is (T)nextafter((double)v, 0.0).  Up to 2^53 in magnitude that is "one towards
+// zero" as above; beyond, (double)v rounds to the double grid and the step is one grid spacing -- reproduced step by
+// step while the value is that large (the conversions are the hardware's round-to-nearest-even, as the host's).
+__device__ __forceinline__ double toward_zero_1(double d) {   // nextafter(d, 0.0) for |d| >= 2^53
+  return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, d) - 1ull);   // (the magnitude sits below the sign bit)
+}
+template <>
+__device__ __forceinline__ int64_t epsilon_steps<int64_t>(int64_t v, uint32_t m) {
+  constexpr long long LIM = 1ll << 53;
+  long long x = v;
+  while (m > 0 && (x > LIM || x < -LIM)) { x = (long long)toward_zero_1((double)x); m--; }
+  const long long mm = (long long)m;
+  return x > 0 ? (x > mm ? x - mm : 0) : (x < -mm ? x + mm : 0);
+}
+template <>
+__device__ __forceinline__ uint64_t epsilon_steps<uint64_t>(uint64_t v, uint32_t m) {
+  constexpr unsigned long long LIM = 1ull << 53;
+  unsigned long long x = v;
+  while (m > 0 && x > LIM) { x = (unsigned long long)toward_zero_1((double)x); m--; }
+  return x > (unsigned long long)m ? x - m : 0ull;
+}
 template <>
 __device__ __forceinline__ float epsilon_steps<float>(float v, uint32_t m) { return next_up_n(v, m); }
 template <>

@@ -57,6 +57,9 @@ uint32_t *Workspace::host_words() {
 }
 
 void Workspace::release() {
+  if (pins_ > 0)
+    throw Error(RDGPU_ERR_ARG, "rdgpu_release_workspace: " + std::to_string(pins_) +
+                                   " shard handle(s) still hold workspace buffers (finish or free them first)");
   (void)hipDeviceSynchronize();
   for (auto &kv : slots_)
     if (kv.second.p) (void)hipFree(kv.second.p);

@@ -106,7 +106,10 @@ def FillDepressions(dem, epsilon: bool = False, in_place: bool = False, topology
     """Fills all depressions in a DEM (reference __init__.py:381-422 -> rdFillDepressionsD8/D4 =
     PriorityFlood_Zhou2016 / PriorityFlood_Barnes2014<D4>, pywrapper.hpp:32-33).
     rdarray in: returns a new rdarray, or None when ``in_place``.  ``epsilon=True`` -> rdPFepsilonD8/D4 =
-    PriorityFloodEpsilon_Barnes2014<topo> (pywrapper.hpp:34-35), floating-point DEMs only."""
+    PriorityFloodEpsilon_Barnes2014<topo> (pywrapper.hpp:34-35), floating-point DEMs only.  With equal elevations among
+    the cells the reference's heap holds, its epsilon surface follows the heap's pop order; this engine returns the
+    order-free surface (a cell-wise lower bound, identical when there are no such ties), warns, and says so in
+    PROCESSING_HISTORY -- see ``richdem_amd.api.FillDepressions``."""
     if type(dem) is not rdarray:
         if isinstance(dem, np.ndarray) and type(dem) is np.ndarray:
             return _api.FillDepressions(dem, epsilon=epsilon, in_place=in_place, topology=topology, shards=shards,
@@ -127,6 +130,11 @@ def FillDepressions(dem, epsilon: bool = False, in_place: bool = False, topology
         work[...] = filled
     else:
         _api.FillDepressions(work, epsilon=epsilon, in_place=True, topology=topology, shards=shards, nodata=nd)
+    if epsilon:
+        ties = _api.epsilon_stats()["tie_sources"]
+        if ties:
+            _add_analysis(dem, f"FillDepressions: {ties} gradient sources of equal elevation -- order-free epsilon surface "
+                               "(lower bound of the reference's heap-order-dependent one)")
     if not in_place:
         return dem
     return None

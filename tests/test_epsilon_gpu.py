@@ -50,6 +50,7 @@ def test_epsilon_equals_reference_on_tie_free_dems(rd, orc, topo):
         if not _unique(z):
             continue
         got = rd.FillDepressions(z, epsilon=True, topology=name_topo, nodata=ND)
+        assert rd.epsilon_stats()["tie_sources"] == 0, name      # no equal elevations: the detector stays silent
         exp = orc.port.fill_epsilon(z, ND, topo)
         assert np.array_equal(got, exp), (name, topo, int((got != exp).sum()))
         if orc.ref.available:
@@ -87,6 +88,72 @@ def test_epsilon_nodata_regions_on_the_border(rd, orc):
             assert (got[m] == ND).all()
 
 
+def _eps_model(z, nd, topo, orc):
+    """numpy restatement of the engine's DEFINITION (csrc/epsilon.hip): E = z on the raster border and on NoData that is
+    connected to it; an interior NoData hole passes the level on (floor -infinity, one step per cell, never written);
+    everything else E(c) = max(z(c), nextafter(min over neighbours E)).  Relaxed from above to the unique fixed point."""
+    h, w = z.shape
+    isnd = z == nd
+    fixed = np.zeros((h, w), bool)
+    fixed[0, :] = fixed[-1, :] = fixed[:, 0] = fixed[:, -1] = True
+    fixed |= isnd & (orc.port.fill(z, topo) == nd)          # the plain fill leaves border-connected NoData at NoData
+    floor = np.where(isnd & ~fixed, -np.inf, z).astype(z.dtype)
+    D = np.full((h, w), np.inf, z.dtype)
+    D[fixed] = z[fixed]
+    inf = z.dtype.type(np.inf)
+    offs = [(dy, dx) for dy in (0, 1, 2) for dx in (0, 1, 2) if (dy, dx) != (1, 1) and (topo == 8 or dy == 1 or dx == 1)]
+    while True:
+        P = np.pad(D, 1, constant_values=np.inf)
+        nb = np.full((h, w), np.inf, z.dtype)
+        for dy, dx in offs:
+            nb = np.minimum(nb, P[dy:dy + h, dx:dx + w])
+        new = np.where(fixed, D, np.minimum(D, np.maximum(floor, np.nextafter(nb, inf))))
+        if np.array_equal(new, D):
+            break
+        D = new
+    out = D.copy()
+    out[isnd] = nd
+    return out, isnd & ~fixed
+
+
+def test_epsilon_interior_nodata_hole_inside_a_lake(rd, orc):
+    """A NoData hole in the middle of a lake.  The reference floods the lake, hands the flood on through the hole, and
+    leaves at their own elevation those ring cells that a hole cell happens to close before the breadth-first front does
+    (queue order).  The engine fills the lake too (the level passes through the hole) and raises every ring cell:
+    bit-exact against the numpy restatement of its definition, equal to the compiled reference everywhere except around
+    the hole, and nowhere near the hole-as-a-drain surface a fixed NoData cell would give."""
+    rng = np.random.default_rng(21)
+    ref = orc.ref if orc.ref.available else orc.port
+    nd = np.float32(ND)
+    for trial in range(8):
+        h, w = 40 + 3 * trial, 46
+        z = (rng.permutation(h * w).reshape(h, w) * 0.01 + 60).astype(np.float32)      # no equal elevations
+        z[6:h - 6, 6:w - 6] -= 45                                                        # a deep lake inside a rim
+        hy, hx, hs = 14 + trial, 18, 2 + trial % 3
+        z[hy:hy + hs, hx:hx + hs] = nd                                                   # the hole
+        if trial % 2:
+            z[:3, 25:] = nd                                                              # and NoData on the border
+        for topo, nm in ((8, "D8"), (4, "D4")):
+            got = rd.FillDepressions(z, epsilon=True, topology=nm, nodata=ND)
+            model, hole = _eps_model(z, nd, topo, orc)
+            assert hole.sum() == hs * hs
+            assert np.array_equal(got, model), (trial, topo, int((got != model).sum()))
+            exp = ref.fill_epsilon(z, nd, topo)
+            diff = got != exp
+            # differences: the ring cells of the hole (raised here, some left at their own elevation by the reference), and
+            # behind those a shadow where the reference's breadth-first front had to walk around them: a few steps apart
+            ring = np.zeros((h, w), bool)
+            ring[hy - 1:hy + hs + 1, hx - 1:hx + hs + 1] = True
+            steps = np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64))
+            near = steps <= 2 * hs + 2
+            assert (near | (ring & (got >= exp)))[diff].all(), (trial, topo)
+            assert diff.sum() <= 0.1 * h * w
+            lake = np.zeros((h, w), bool)
+            lake[6:h - 6, 6:w - 6] = True
+            lake &= z != nd
+            assert (got[lake] > 50).all()                       # the lake is filled (a fixed hole would leave it near 15)
+
+
 def test_epsilon_with_ties_is_a_lower_bound_and_ties_are_detected(rd, orc):
     """Integer-valued and plateau DEMs: the reference depends on its heap's pop order.  Every mismatching case is
     checked to contain equal elevations among the cells that are NOT raised (the cells of the reference's heap), and the
@@ -97,13 +164,19 @@ def test_epsilon_with_ties_is_a_lower_bound_and_ties_are_detected(rd, orc):
     for i in range(30):
         h, w = (int(v) for v in rng.integers(4, 90, 2))
         z = rng.integers(0, 6 + i, (h, w)).astype(np.float32)
-        got = rd.FillDepressions(z, epsilon=True, nodata=ND)
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = rd.FillDepressions(z, epsilon=True, nodata=ND)
+        ties = rd.epsilon_stats()["tie_sources"]
         exp = ref.fill_epsilon(z, ND, 8)
         assert (got <= exp).all() and (got >= z).all()
         if np.array_equal(got, exp):
             n_equal += 1
         else:
             n_diff += 1
+            assert ties > 0, "a mismatch the device-side tie detector did not announce"
+            assert any("gradient sources share their elevation" in str(c.message) for c in caught)
             unraised = z[got == z]
             assert np.unique(unraised).size < unraised.size, "a mismatch without a tie among the heap's cells"
         # whatever the ties, the surface is the fixed point: every interior cell equals max(z, nextafter(min neighbour))

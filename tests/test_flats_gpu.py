@@ -274,6 +274,12 @@ def _epsilon_cases(orc):
     yield "row", np.zeros((1, 9), np.float64), np.float64(-1)
     tiny = np.full((40, 40), -1e-44, np.float32); tiny[0, 0] = -1                # negative denormals: through -0.0 to +denormals
     yield "denormals", tiny, np.float32(-9999)
+    # 64-bit integers beyond 2^53: the reference's step goes through double and moves by the double spacing
+    big = np.full((30, 40), (1 << 60) + 12345, np.int64); big[10:20, 10:30] = (1 << 53) + 3; big[0, 0] = -(1 << 62)
+    yield "i64_beyond_2^53", big, np.int64(-9999)
+    yield "i64_negative_beyond_2^53", -big, np.int64(-9999)
+    ubig = np.full((30, 40), (1 << 63) + (1 << 40) + 77, np.uint64); ubig[5:25, 5:35] = (1 << 53) + 5
+    yield "u64_beyond_2^63", ubig, np.uint64(0)
 
 
 def test_resolve_flats_epsilon(rd, orc):
