@@ -314,12 +314,24 @@ int rdgpu_resolve_flats_i64(const int64_t *dem, int64_t nodata, int width, int h
 int rdgpu_resolve_flats_u64(const uint64_t *dem, uint64_t nodata, int width, int height, uint8_t *dirs, int32_t *mask, int32_t *labels);
 
 /* alter == true (flat_resolution.hpp:597-600 + d8_flats_alter_dem :545-582): the DEM is raised in place by
- * flat_mask increments of nextafterf inside drainable flats, then plain D8 directions are taken on it.
- * float and double DEMs (the reference applies nextafterf, i.e. float steps, to every element type). */
-int rdgpu_flat_resolution_d8_alter_f32(float *dem, float nodata, int width, int height, uint8_t *dirs);
-int rdgpu_flat_resolution_d8_alter_f64(double *dem, double nodata, int width, int height, uint8_t *dirs);
-int rdgpu_flat_resolution_d8_alter_dev_f32(float *d_dem, float nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
-int rdgpu_flat_resolution_d8_alter_dev_f64(double *d_dem, double nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+ * flat_mask increments of nextafterf inside drainable flats, then plain D8 directions are taken on it (the reference
+ * applies nextafterf, i.e. float steps, to every element type). */
+#define RDGPU_DECL_ALTER(SUF, T)                                                                                       \
+  int rdgpu_flat_resolution_d8_alter_##SUF(T *dem, T nodata, int width, int height, uint8_t *dirs);                     \
+  int rdgpu_flat_resolution_d8_alter_dev_##SUF(T *d_dem, T nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+RDGPU_DECL_ALTER(f32, float)
+RDGPU_DECL_ALTER(f64, double)
+/* integer element types: the reference's step is (T)nextafterf((float)e, numeric_limits<T>::infinity() == 0) -- one
+ * towards zero per increment (one float spacing for magnitudes of 2^24 and more) -- reproduced as is */
+RDGPU_DECL_ALTER(u8, uint8_t)
+RDGPU_DECL_ALTER(i8, int8_t)
+RDGPU_DECL_ALTER(i16, int16_t)
+RDGPU_DECL_ALTER(u16, uint16_t)
+RDGPU_DECL_ALTER(i32, int32_t)
+RDGPU_DECL_ALTER(u32, uint32_t)
+RDGPU_DECL_ALTER(i64, int64_t)
+RDGPU_DECL_ALTER(u64, uint64_t)
+#undef RDGPU_DECL_ALTER
 
 typedef struct rdgpu_flat_stats {
   uint64_t low_edges;      /* find_flat_edges: cells with flow next to an equal NO_FLOW cell */

@@ -151,10 +151,12 @@ int c_fill_eps(T *, T, int, int, int) {   // depressions/Barnes2014.hpp:424-451
   throw std::runtime_error("Priority-Flood+Epsilon is only available for floating-point data types!");
 }
 
-inline int c_flatres_alter(float *p, float nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f32(p, nd, w, h, o); }
-inline int c_flatres_alter(double *p, double nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_f64(p, nd, w, h, o); }
-template <class T>
-int c_flatres_alter(T *, T, int, int, uint8_t *) { unsupported("barnes_flat_resolution_d8(alter=true)"); }
+#define RDGPU_SHIM_ALTER(SUF, T) \
+  inline int c_flatres_alter(T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_alter_##SUF(p, nd, w, h, o); }
+RDGPU_SHIM_ALTER(f32, float) RDGPU_SHIM_ALTER(f64, double) RDGPU_SHIM_ALTER(u8, uint8_t) RDGPU_SHIM_ALTER(i8, int8_t)
+RDGPU_SHIM_ALTER(i16, int16_t) RDGPU_SHIM_ALTER(u16, uint16_t) RDGPU_SHIM_ALTER(i32, int32_t) RDGPU_SHIM_ALTER(u32, uint32_t)
+RDGPU_SHIM_ALTER(i64, int64_t) RDGPU_SHIM_ALTER(u64, uint64_t)
+#undef RDGPU_SHIM_ALTER
 
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, int32_t *a) { return rdgpu_d8_flow_accum_i32(d, nd, w, h, a); }
 inline int c_accum(const uint8_t *d, uint8_t nd, int w, int h, float *a) { return rdgpu_d8_flow_accum_f32(d, nd, w, h, a); }

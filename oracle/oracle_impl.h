@@ -249,8 +249,8 @@ void FN(orc_flat_resolution)(const T *dem, T nodata, int w, int h, uint8_t *dirs
 }
 
 /* barnes_flat_resolution_d8(alter=true), flats/flat_resolution.hpp:597-600 with
- * d8_flats_alter_dem :545-582.  The DEM is altered in place.  Meaningful for float / double only
- * (nextafterf towards numeric_limits<U>::infinity(), which is 0 for integer U). */
+ * d8_flats_alter_dem :545-582.  The DEM is altered in place (nextafterf towards numeric_limits<U>::infinity(), which is
+ * 0 for integer U: those walk towards zero, as the reference's do). */
 void FN(orc_flat_resolution_alter)(T *dem, T nodata, int w, int h, uint8_t *dirs) {
   size_t N = (size_t)w * h;
   int32_t *mask = (int32_t *)malloc(N * 4), *labels = (int32_t *)malloc(N * 4);
@@ -260,7 +260,8 @@ void FN(orc_flat_resolution_alter)(T *dem, T nodata, int w, int h, uint8_t *dirs
     for (int x = 1; x < w - 1; x++) {
       size_t i = (size_t)y * w + x;
       if (labels[i] == 0) continue;                                          /* :559-560 */
-      for (int k = 0; k < mask[i]; ++k) dem[i] = (T)nextafterf((float)dem[i], INFINITY);   /* :567-568 */
+      /* :567-568: towards numeric_limits<T>::infinity(), which is 0 for integer T */
+      for (int k = 0; k < mask[i]; ++k) dem[i] = (T)nextafterf((float)dem[i], _Generic((T)0, float: INFINITY, double: INFINITY, default: 0.0f));
     }
   FN(orc_d8_flowdirs)(dem, nodata, w, h, dirs);                             /* :600 */
   free(mask); free(labels);

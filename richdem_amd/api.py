@@ -195,12 +195,10 @@ def barnes_flat_resolution_d8(dem: np.ndarray, nodata, alter: bool = False) -> n
     """Flat-resolved uint8 D8 directions (reference barnes_flat_resolution_d8(elev, flowdirs, alter=false),
     flats/flat_resolution.hpp:587-605)."""
     if alter:
-        if not (isinstance(dem, np.ndarray) and dem.ndim == 2 and dem.dtype in (np.float32, np.float64)
-                and dem.flags["C_CONTIGUOUS"]):
-            raise RdgpuError("barnes_flat_resolution_d8(alter=True): needs a C-contiguous float32/float64 DEM "
-                             "(it is altered in place)")
+        if not (isinstance(dem, np.ndarray) and dem.ndim == 2 and dem.flags["C_CONTIGUOUS"]):
+            raise RdgpuError("barnes_flat_resolution_d8(alter=True): needs a C-contiguous 2-D array (it is altered in place)")
         h, w = dem.shape
-        s = "f32" if dem.dtype == np.float32 else "f64"
+        s = _suffix(dem.dtype)   # integer element types step towards zero, as the reference's nextafterf(e, 0) does
         out = np.empty((h, w), np.uint8)
         fn = getattr(lib(), f"rdgpu_flat_resolution_d8_alter_{s}")
         check(fn(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, out.ctypes.data_as(ctypes.c_void_p)),

@@ -23,6 +23,7 @@
 #include "flowdirs.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <climits>
 #include <cstring>
@@ -1699,9 +1700,9 @@ static void flat_resolution_host(const T *dem, T nodata, int w, int h, uint8_t *
 // ------------------------------------------------------------------------------------------
 // alter == true: d8_flats_alter_dem (flat_resolution.hpp:545-582) raises every cell of a drainable flat by
 // flat_mask increments of nextafterf (in FLOAT precision, whatever the element type -- the reference calls
-// nextafterf on every U), then plain d8_flow_directions runs on the altered DEM (:598-600).  Provided
-// for float and double DEMs; for integer element types the reference's nextafterf(v, 0) walks values
-// towards zero, which is not a meaningful operation to reproduce.
+// nextafterf on every U), then plain d8_flow_directions runs on the altered DEM (:598-600).  Every element type: for
+// integer ones the reference's nextafterf(v, numeric_limits<U>::infinity() == 0) walks values towards zero -- hardly
+// what its author meant, but it is what the function returns, so it is what comes out here (alter_steps below).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float next_up_n(float v, uint32_t m) {   // nextafterf(v, +inf) applied m times
   uint32_t b = __builtin_bit_cast(uint32_t, v);
@@ -1717,6 +1718,32 @@ __device__ __forceinline__ float next_up_n(float v, uint32_t m) {   // nextafter
   return __builtin_bit_cast(float, b);
 }
 
+// m steps of the reference's `e = nextafterf(e, numeric_limits<U>::infinity())` (:567-568) in element type U.  Floating
+// point U: float steps upwards (in FLOAT precision for double too: the reference's TODO).  Integer U: that infinity() is
+// 0, so a step is (U)nextafterf((float)e, 0.0f) -- one towards zero while |e| < 2^24, one float spacing beyond (the
+// conversion to float rounds to nearest even, as the host's) -- reproduced as is.
+template <class T>
+__device__ __forceinline__ T alter_steps(T v, uint32_t m) {
+  constexpr bool sgn = std::is_signed<T>::value;
+  using W = typename std::conditional<sgn, long long, unsigned long long>::type;
+  constexpr long long LIM = 1ll << 24;
+  W x = (W)v;
+  if (sizeof(T) >= 4)
+    while (m > 0 && ((long long)x > LIM || (sgn && (long long)x < -LIM) || (!sgn && x > (W)LIM))) {
+      x = (W)__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)x) - 1u);   // (the magnitude sits below the sign bit)
+      m--;
+    }
+  if (sgn) {
+    const long long xx = (long long)x, mm = (long long)m;
+    return (T)(xx > 0 ? (xx > mm ? xx - mm : 0) : (xx < -mm ? xx + mm : 0));
+  }
+  return (T)(x > (W)m ? x - (W)m : (W)0);
+}
+template <>
+__device__ __forceinline__ float alter_steps<float>(float v, uint32_t m) { return next_up_n(v, m); }
+template <>
+__device__ __forceinline__ double alter_steps<double>(double v, uint32_t m) { return (double)next_up_n((float)v, m); }
+
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_flat_alter(T *z, const int32_t *__restrict__ M, int w, int h) {
   const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
@@ -1725,7 +1752,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_alter(T *z, const int32_t *__rest
     if (m <= 0) continue;   // cells outside drainable flats (labels == 0) and flat cells with mask 0
     const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
     if (x == 0 || y == 0 || x == w - 1 || y == h - 1) continue;    // :556-558 interior only
-    z[c] = (T)next_up_n((float)z[c], (uint32_t)m);                 // :567-568
+    z[c] = alter_steps<T>(z[c], (uint32_t)m);                      // :567-568
   }
 }
 
@@ -2290,6 +2317,14 @@ RD_FLATS_API(u64, uint64_t)
   }
 RD_FLATS_ALTER_API(f32, float)
 RD_FLATS_ALTER_API(f64, double)
+RD_FLATS_ALTER_API(u8, uint8_t)
+RD_FLATS_ALTER_API(i8, int8_t)
+RD_FLATS_ALTER_API(i16, int16_t)
+RD_FLATS_ALTER_API(u16, uint16_t)
+RD_FLATS_ALTER_API(i32, int32_t)
+RD_FLATS_ALTER_API(u32, uint32_t)
+RD_FLATS_ALTER_API(i64, int64_t)
+RD_FLATS_ALTER_API(u64, uint64_t)
 
 
 #define RD_RFE_API(SUF, T)                                                                                     \

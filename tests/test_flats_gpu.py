@@ -191,7 +191,26 @@ def test_alter_true(rd, orc, dtype):
         assert np.array_equal(dirs, edirs), (dtype, shift)
         assert (got != dem).any()
     with pytest.raises(rd.RdgpuError):
-        rd.barnes_flat_resolution_d8(np.zeros((5, 5), np.int32), -1, alter=True)
+        rd.barnes_flat_resolution_d8(np.zeros((5, 5), np.int32)[:, ::2], -1, alter=True)   # not contiguous: cannot alter in place
+
+
+@pytest.mark.parametrize("dtype,offset", [(np.int32, -20), (np.int16, -20), (np.int8, -60), (np.uint8, 0), (np.uint16, 0),
+                                          (np.int64, -20), (np.int32, 1 << 26), (np.uint32, (1 << 31) + 5),
+                                          (np.int64, -(1 << 40)), (np.uint64, 1 << 50)])
+def test_alter_true_integer_dems(rd, orc, dtype, offset):
+    """Integer element types: the reference's step is (T)nextafterf((float)e, numeric_limits<T>::infinity() == 0): one
+    towards zero per flat_mask increment, one FLOAT spacing for magnitudes of 2^24 and more -- bit-exact (the restatement
+    is pinned to the compiled reference on these inputs in test_oracle_pinning.py)."""
+    z = fractal_dem(260, 190, seed=92)
+    dem = (np.floor((z - z.min()) * 0.05).astype(np.int64) + offset).astype(dtype)
+    nd = dtype(0) if np.dtype(dtype).kind == "u" else dtype(-9999)
+    if np.dtype(dtype).itemsize <= 4:
+        dem = orc.port.fill(dem)
+    edem, edirs = orc.port.flat_resolution_alter(dem, nd)
+    got = dem.copy()
+    dirs = rd.barnes_flat_resolution_d8(got, nd, alter=True)
+    assert got.tobytes() == edem.tobytes() and np.array_equal(dirs, edirs)
+    assert (got != dem).any()
 
 
 @pytest.mark.parametrize("n,seed", [(10000, 2), (40000, 3)], ids=["10k", "config4_40k"])

@@ -156,3 +156,20 @@ def test_f2_restatements_equal_the_compiled_reference_outputs(orc, f2):
             assert np.array_equal(filled, orc.port.fill(dem, topo))
             for md in (0, 3, 40, 100000):
                 assert np.array_equal(orc.port.fill_max_dep(dem, md, topo), f2[f"{name}/max_dep{md}_d{topo}"]), (name, topo, md)
+
+
+@pytest.mark.parametrize("dtype,offset", [(np.int32, -20), (np.uint8, 0), (np.int64, -20), (np.int32, 1 << 26),
+                                          (np.uint32, (1 << 31) + 5), (np.int64, -(1 << 40)), (np.uint64, 1 << 50)])
+def test_alter_true_on_integer_dems_port_equals_reference(orc, dtype, offset):
+    """barnes_flat_resolution_d8(alter=true) on integer DEMs (flat_resolution.hpp:545-582: nextafterf towards
+    numeric_limits<int>::infinity() == 0): the restatement and the compiled reference agree bit for bit, beyond 2^24 too."""
+    if not orc.ref.available:
+        pytest.skip("compiled reference not present")
+    from richdem_amd.synth import fractal_dem
+
+    z = fractal_dem(150, 120, 5)
+    dem = (np.floor((z - z.min()) * 0.05).astype(np.int64) + offset).astype(dtype)
+    nd = dtype(0) if np.dtype(dtype).kind == "u" else dtype(-9999)
+    a_dem, a_dirs = orc.port.flat_resolution_alter(dem, nd)
+    b_dem, b_dirs = orc.ref.flat_resolution_alter(dem, nd)
+    assert a_dem.tobytes() == b_dem.tobytes() and np.array_equal(a_dirs, b_dirs) and (a_dem != dem).any()
