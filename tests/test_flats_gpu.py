@@ -203,7 +203,7 @@ def test_alter_true_integer_dems(rd, orc, dtype, offset):
     is pinned to the compiled reference on these inputs in test_oracle_pinning.py)."""
     z = fractal_dem(260, 190, seed=92)
     dem = (np.floor((z - z.min()) * 0.05).astype(np.int64) + offset).astype(dtype)
-    nd = dtype(0) if np.dtype(dtype).kind == "u" else dtype(-9999)
+    nd = dtype(0) if np.dtype(dtype).kind == "u" else dtype(-128 if dtype is np.int8 else -9999)
     if np.dtype(dtype).itemsize <= 4:
         dem = orc.port.fill(dem)
     edem, edirs = orc.port.flat_resolution_alter(dem, nd)
