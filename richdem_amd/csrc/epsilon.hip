@@ -36,6 +36,8 @@
 //     the relaxation is repeated with a larger X (the failed attempt is a lower bound of E, so it tells how large).
 #include "common.hpp"
 
+#include <vector>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -230,26 +232,44 @@ __global__ __launch_bounds__(NT) void k_eps_init(const T *__restrict__ z, const 
   if (__syncthreads_or(anyinf) && threadIdx.x == 0) tile_active[t] = 1;
 }
 
+constexpr uint32_t TIE_STRIPES = 1024;   // counters of the tie detector (source count, tie count per stripe)
+template <class K> struct KeyEmpty { static constexpr K v = (K) ~(K)0; };
+__device__ __forceinline__ uint32_t cas_key(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
+__device__ __forceinline__ uint64_t cas_key(uint64_t *p, uint64_t cmp, uint64_t v) {
+  return (uint64_t)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)cmp, (unsigned long long)v);
+}
+
 // ---- the proof: d == max(z, min_n d(n) + 1) on every relaxed cell -----------------------------------------------------
 // out[0] = number of cells where it fails (0: D is the unique fixed point), out[1..2] = the largest d - key(W) seen
 // (how far the gradient lifted a cell above the plain fill; a lower bound of the true figure when the proof fails).
 template <class T, int TOPO>
 __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const T *__restrict__ W, T nodata,
                                                   const typename CKey<T>::K *__restrict__ D, int w, int h, uint32_t tilesX,
-                                                  uint32_t ntiles, uint32_t *bad, unsigned long long *maxlift) {
+                                                  uint32_t ntiles, uint32_t *bad, unsigned long long *maxlift,
+                                                  typename CKey<T>::K *tie_table, unsigned long long tie_mask,
+                                                  unsigned long long *tie_counts /* [0] sources, [1] ties */) {
   using K = typename CKey<T>::K;
   __shared__ K sd[RH * RW];
+  __shared__ uint8_t sr[RH * RW];   // the cell is raised (a data cell above its own elevation): the tie detector's stencil
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * CW, y0 = (int)(t / tilesX) * RCH;
   for (int i = threadIdx.x; i < RH * RW; i += NT) {
     const int ly = i / RW, lx = i - ly * RW;
     const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-    sd[i] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? D[(size_t)gy * w + gx] : CKey<T>::INF;
+    const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    const K dv = in ? D[(size_t)gy * w + gx] : CKey<T>::INF;
+    sd[i] = dv;
+    uint8_t r = 0;
+    if (tie_table && in) {
+      const T zz = z[(size_t)gy * w + gx];
+      r = (zz != nodata && dv > CKey<T>::to(zz)) ? 1 : 0;
+    }
+    sr[i] = r;
   }
   __syncthreads();
   const int lx = threadIdx.x & (CW - 1), band = threadIdx.x >> 6;
-  uint32_t nbad = 0;
+  uint32_t nbad = 0, nsrc = 0, nties = 0;
   unsigned long long lift = 0;
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
@@ -258,8 +278,35 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
     if (gx >= w || gy >= h) continue;
     const size_t g = (size_t)gy * w + gx;
     const T zz = z[g];
-    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || nodata_is_fixed(zz, nodata, W[g])) continue;
     const int o = (ly + 1) * RW + lx + 1;
+    // Tie detector, on the way: a SOURCE of a gradient is a data cell at its own elevation with a raised neighbour; its
+    // key goes into an open-addressing set, and a key that is already there is a tie (see the comment at Stats below).
+    if (tie_table && zz != nodata && sd[o] == CKey<T>::to(zz)) {
+      int feeds = sr[o - RW] | sr[o + RW] | sr[o - 1] | sr[o + 1];
+      if (TOPO == 8) feeds |= sr[o - RW - 1] | sr[o - RW + 1] | sr[o + RW - 1] | sr[o + RW + 1];
+      if (feeds) {
+        nsrc++;
+        const K kc = sd[o];
+        if (sizeof(K) == 4) {
+          // 32-bit keys: one bit per possible key (512 MB), indexed by the key itself -- the sources of a tile lie within
+          // a few metres of each other, so their bits share cache lines (a scattering hash table cost 39 ms at S3,
+          // a random DRAM access per source; this costs a few)
+          uint32_t *bits = reinterpret_cast<uint32_t *>(tie_table);
+          const uint32_t bit = 1u << ((uint32_t)kc & 31u);
+          if (atomicOr(&bits[(uint32_t)kc >> 5], bit) & bit) nties++;
+        } else {
+          unsigned long long slot = ((unsigned long long)kc * 0x9E3779B97F4A7C15ull >> 20) & tie_mask;
+          for (int probe = 0; probe < 4096; probe++) {   // (bounded: a table that fills up is reported through the source count)
+            K v = tie_table[slot];
+            if (v == KeyEmpty<K>::v) v = cas_key(&tie_table[slot], KeyEmpty<K>::v, kc);
+            if (v == KeyEmpty<K>::v) break;        // inserted
+            if (v == kc) { nties++; break; }       // an equal source exists
+            slot = (slot + 1) & tie_mask;
+          }
+        }
+      }
+    }
+    if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1 || nodata_is_fixed(zz, nodata, W[g])) continue;
     K lo = kmin(kmin(sd[o - RW], sd[o + RW]), kmin(sd[o - 1], sd[o + 1]));
     if (TOPO == 8) lo = kmin(lo, kmin(kmin(sd[o - RW - 1], sd[o - RW + 1]), kmin(sd[o + RW - 1], sd[o + RW + 1])));
     const K f = kmax(zz == nodata ? (K)0 : CKey<T>::to(zz), step_up<EpsField<T>>(lo));
@@ -270,10 +317,16 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
   }
   for (int o = 32; o > 0; o >>= 1) {
     nbad += __shfl_down(nbad, o, 64);
+    nsrc += __shfl_down(nsrc, o, 64);
+    nties += __shfl_down(nties, o, 64);
     const unsigned long long other = __shfl_down(lift, o, 64);
     lift = lift > other ? lift : other;
   }
   if ((threadIdx.x & 63) == 0) {
+    // striped: millions of waves adding to ONE word serialise (~12 ns per same-address atomic: 39 ms at S3)
+    unsigned long long *tcs = tie_counts + 2 * ((t * 4 + (threadIdx.x >> 6)) & (TIE_STRIPES - 1));
+    if (nsrc) atomicAdd(&tcs[0], (unsigned long long)nsrc);
+    if (nties) atomicAdd(&tcs[1], (unsigned long long)nties);
     if (nbad) atomicAdd(bad, nbad);
     if (lift && lift > __hip_atomic_load(maxlift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxlift, lift);
   }
@@ -434,53 +487,9 @@ __global__ __launch_bounds__(NT) void k_eps_final(T *z, T nodata, const typename
 // matter are the SOURCES of a gradient: cells that keep their own elevation (they pass through the heap) and have a
 // raised neighbour (whose value is counted from them).  Two sources of equal elevation = the reference's result there
 // follows std::priority_queue's pop order (a plateau or a lake entered through several cells of one level gets its
-// gradient from whichever of them pops first).  k_eps_sources counts the sources and, in a second call, inserts their
-// keys into an open-addressing set: `ties` = sources whose key was already there.  Conservative (equal sources far apart
-// need not interact), cheap (two stencil passes), and what FillDepressions(epsilon=True) warns with.
-template <class K> struct KeyEmpty { static constexpr K v = (K) ~(K)0; };
-__device__ __forceinline__ uint32_t cas_key(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
-__device__ __forceinline__ uint64_t cas_key(uint64_t *p, uint64_t cmp, uint64_t v) {
-  return (uint64_t)atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)cmp, (unsigned long long)v);
-}
-
-template <class T, int TOPO>
-__global__ __launch_bounds__(NT) void k_eps_sources(const T *__restrict__ z, T nodata, const typename CKey<T>::K *__restrict__ D,
-                                                    int w, int h, typename CKey<T>::K *table, unsigned long long mask,
-                                                    unsigned long long *counts /* [0] sources, [1] ties */) {
-  using K = typename CKey<T>::K;
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
-  unsigned long long nsrc = 0, nties = 0;
-  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
-    const T zc = z[c];
-    if (zc == nodata) continue;
-    const K kc = CKey<T>::to(zc);
-    if (D[c] != kc) continue;   // raised: not a source
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
-    bool feeds = false;
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
-        if ((dx == 0 && dy == 0) || (TOPO == 4 && dx != 0 && dy != 0)) continue;
-        const int nx = x + dx, ny = y + dy;
-        if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
-        const uint64_t m = (uint64_t)ny * w + nx;
-        const T zn = z[m];
-        if (zn != nodata && D[m] > CKey<T>::to(zn)) feeds = true;
-      }
-    if (!feeds) continue;
-    nsrc++;
-    if (!table) continue;
-    unsigned long long slot = ((unsigned long long)kc * 0x9E3779B97F4A7C15ull >> 20) & mask;
-    for (;;) {
-      K v = table[slot];
-      if (v == KeyEmpty<K>::v) v = cas_key(&table[slot], KeyEmpty<K>::v, kc);
-      if (v == KeyEmpty<K>::v) break;        // inserted
-      if (v == kc) { nties++; break; }       // an equal source exists
-      slot = (slot + 1) & mask;
-    }
-  }
-  if (nsrc) atomicAdd(&counts[0], nsrc);
-  if (nties) atomicAdd(&counts[1], nties);
-}
+// gradient from whichever of them pops first).  The proof pass (k_eps_check) has the tile and its ring staged anyway: it
+// inserts the sources' keys into an open-addressing set, `ties` = sources whose key was already there.  Conservative
+// (equal sources far apart need not interact), no extra pass, and what FillDepressions(epsilon=True) warns with.
 
 struct Stats {
   uint32_t rounds = 0, attempts = 0;
@@ -532,18 +541,51 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
   // assumed bound on the lift above the plain fill, in representable steps (RDGPU_EPS_SLACK overrides: tests)
   const char *env = getenv("RDGPU_EPS_SLACK");
   K X = env ? (K)strtoull(env, nullptr, 10) : (K)(1u << 15);
+  // tie detector (RDGPU_EPS_TIES=0 skips it): one slot per four cells, grown if the DEM has more sources than that
+  const char *te = getenv("RDGPU_EPS_TIES");
+  const bool ties_on = !(te && te[0] == '0');
+  unsigned long long tie_slots = 1024;
+  while (ties_on && tie_slots < n / 4) tie_slots *= 2;
+  K *tie_table = nullptr;
+  unsigned long long *tc = ws.buf<unsigned long long>("eps.tiecounts", 2 * TIE_STRIPES);
+  std::vector<unsigned long long> htc_v(2 * TIE_STRIPES);
+  unsigned long long htc[2] = {0, 0};
   for (;;) {
     g_stats.attempts++;
     g_stats.slack = (uint64_t)X;
+    if (ties_on) {
+      if (sizeof(K) == 4) {   // the bitmap over all 2^32 keys
+        tie_slots = (1ull << 32) / 32;
+        tie_table = ws.buf<K>("eps.tiebits", tie_slots);
+        RD_HIP(hipMemsetAsync(tie_table, 0, tie_slots * sizeof(K), s));
+      } else {
+        tie_table = ws.buf<K>("eps.tietable", tie_slots);
+        RD_HIP(hipMemsetAsync(tie_table, 0xFF, tie_slots * sizeof(K), s));
+      }
+      RD_HIP(hipMemsetAsync(tc, 0, 2 * TIE_STRIPES * sizeof(unsigned long long), s));
+    }
     RD_HIP(hipMemsetAsync(tflags, 0, ntiles, s));
     RD_HIP(hipMemsetAsync(ctr + BATCH, 0, 8 * sizeof(uint32_t), s));
     RD_LAUNCH("eps.init", (k_eps_init<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, X, D, tflags,
               w, h, tilesX, ntiles);
     relax_until_quiet<EpsField<T>, TOPO>(EpsField<T>{d_z, nodata, d_W}, D, tflags, tlist, ctr, w, h, "eps.relax", s);
-    RD_LAUNCH("eps.check", (k_eps_check<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, (const K *)D, w,
-              h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2));
-    RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
+    for (;;) {   // (the proof pass; run again only if the tie detector's set turned out too small for this DEM)
+      RD_LAUNCH("eps.check", (k_eps_check<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, (const K *)D, w,
+                h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2), tie_table, tie_slots - 1, tc);
+      RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      if (ties_on) RD_HIP(hipMemcpyAsync(htc_v.data(), tc, 2 * TIE_STRIPES * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      htc[0] = htc[1] = 0;
+      if (ties_on)
+        for (uint32_t i = 0; i < TIE_STRIPES; i++) { htc[0] += htc_v[2 * i]; htc[1] += htc_v[2 * i + 1]; }
+      if (!(ties_on && sizeof(K) == 8 && hw[0] == 0 && htc[0] * 2 > tie_slots)) break;
+      while (tie_slots < 4 * htc[0]) tie_slots *= 2;   // more than half full: a larger set, the same D
+      tie_table = ws.buf<K>("eps.tietable", tie_slots);
+      RD_HIP(hipMemsetAsync(tie_table, 0xFF, tie_slots * sizeof(K), s));
+      RD_HIP(hipMemsetAsync(tc, 0, 2 * TIE_STRIPES * sizeof(unsigned long long), s));
+      RD_HIP(hipMemsetAsync(ctr + BATCH, 0, 8 * sizeof(uint32_t), s));
+    }
+    if (ties_on) g_stats.tie_sources = htc[1];
     const uint64_t lift = (uint64_t)hw[2] | ((uint64_t)hw[3] << 32);
     g_stats.max_lift = lift;
     if (hw[0] == 0) break;   // D = F(D) on every cell: the unique fixed point
@@ -551,32 +593,6 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     // too small: the failed attempt is a lower bound of E, so the true lift is at least `lift`
     const uint64_t next = std::max<uint64_t>((uint64_t)X * 8, lift * 2 + 16);
     X = next >= (uint64_t)CKey<T>::POSINF ? CKey<T>::POSINF : (K)next;   // POSINF: every interior cell starts at +inf
-  }
-  {
-    const char *te = getenv("RDGPU_EPS_TIES");   // =0: skip the tie detector
-    if (!(te && te[0] == '0')) {
-      unsigned long long *tc = ws.buf<unsigned long long>("eps.tiecounts", 2);
-      unsigned long long *htc = reinterpret_cast<unsigned long long *>(hw + 8);
-      const uint32_t tgrid = (uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 32u);
-      RD_HIP(hipMemsetAsync(tc, 0, 2 * sizeof(unsigned long long), s));
-      RD_LAUNCH("eps.sources", (k_eps_sources<T, TOPO>), dim3(tgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const K *)D, w, h,
-                (K *)nullptr, 0ull, tc);
-      RD_HIP(hipMemcpyAsync(htc, tc, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      const unsigned long long nsrc = htc[0];
-      if (nsrc > 1) {
-        unsigned long long slots = 1024;
-        while (slots < 2 * nsrc) slots *= 2;
-        K *table = ws.buf<K>("eps.tietable", slots);
-        RD_HIP(hipMemsetAsync(table, 0xFF, slots * sizeof(K), s));
-        RD_HIP(hipMemsetAsync(tc, 0, 2 * sizeof(unsigned long long), s));
-        RD_LAUNCH("eps.sources", (k_eps_sources<T, TOPO>), dim3(tgrid), dim3(NT), 0, s, (const T *)d_z, nodata, (const K *)D, w, h,
-                  table, slots - 1, tc);
-        RD_HIP(hipMemcpyAsync(htc, tc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        RD_HIP(hipStreamSynchronize(s));
-        g_stats.tie_sources = htc[1];
-      }
-    }
   }
   RD_LAUNCH("eps.final", (k_eps_final<T>), dim3((uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 32u)), dim3(NT), 0, s, d_z,
             nodata, (const K *)D, n, ctr + BATCH + 4);
