@@ -95,6 +95,9 @@ RDGPU_DECL_MAXDEP(i32, int32_t)
 RDGPU_DECL_MAXDEP(u32, uint32_t)
 RDGPU_DECL_MAXDEP(f32, float)
 RDGPU_DECL_MAXDEP(i8, int8_t)
+RDGPU_DECL_MAXDEP(f64, double)    /* the 64-bit element types run on dense value ranks (csrc/fill64.hip), as the fill does */
+RDGPU_DECL_MAXDEP(i64, int64_t)
+RDGPU_DECL_MAXDEP(u64, uint64_t)
 #undef RDGPU_DECL_MAXDEP
 
 /* pit_mask<topology>(const Array2D<T>&, Array2D<uint8_t>&) (depressions/Barnes2014.hpp:593-676,
@@ -110,6 +113,9 @@ RDGPU_DECL_PITMASK(i32, int32_t)
 RDGPU_DECL_PITMASK(u32, uint32_t)
 RDGPU_DECL_PITMASK(f32, float)
 RDGPU_DECL_PITMASK(i8, int8_t)
+RDGPU_DECL_PITMASK(f64, double)
+RDGPU_DECL_PITMASK(i64, int64_t)
+RDGPU_DECL_PITMASK(u64, uint64_t)
 #undef RDGPU_DECL_PITMASK
 
 /* ---- PriorityFloodEpsilon_Barnes2014<topology>(Array2D<T>&) ------------------------------------------------------
@@ -159,6 +165,9 @@ RDGPU_DECL_WS(i32, int32_t)
 RDGPU_DECL_WS(u32, uint32_t)
 RDGPU_DECL_WS(f32, float)
 RDGPU_DECL_WS(i8, int8_t)
+RDGPU_DECL_WS(f64, double)
+RDGPU_DECL_WS(i64, int64_t)
+RDGPU_DECL_WS(u64, uint64_t)
 #undef RDGPU_DECL_WS
 
 /* Environment switches of the fill (read at every call; for tests and A/B timing, results never change):

@@ -114,6 +114,9 @@ RDGPU_SHIM_PITMASK(i32, int32_t)
 RDGPU_SHIM_PITMASK(u32, uint32_t)
 RDGPU_SHIM_PITMASK(f32, float)
 RDGPU_SHIM_PITMASK(i8, int8_t)
+RDGPU_SHIM_PITMASK(f64, double)
+RDGPU_SHIM_PITMASK(i64, int64_t)
+RDGPU_SHIM_PITMASK(u64, uint64_t)
 #undef RDGPU_SHIM_PITMASK
 template <class T>
 int c_pitmask(const T *, T, int, int, int, uint8_t *) { unsupported("pit_mask"); }
@@ -127,6 +130,9 @@ RDGPU_SHIM_MAXDEP(i32, int32_t)
 RDGPU_SHIM_MAXDEP(u32, uint32_t)
 RDGPU_SHIM_MAXDEP(f32, float)
 RDGPU_SHIM_MAXDEP(i8, int8_t)
+RDGPU_SHIM_MAXDEP(f64, double)
+RDGPU_SHIM_MAXDEP(i64, int64_t)
+RDGPU_SHIM_MAXDEP(u64, uint64_t)
 #undef RDGPU_SHIM_MAXDEP
 template <class T>
 int c_fill_maxdep(T *, int, int, int, uint64_t) { unsupported("PriorityFlood_Barnes2014_max_dep"); }
@@ -140,6 +146,9 @@ RDGPU_SHIM_WS(i32, int32_t)
 RDGPU_SHIM_WS(u32, uint32_t)
 RDGPU_SHIM_WS(f32, float)
 RDGPU_SHIM_WS(i8, int8_t)
+RDGPU_SHIM_WS(f64, double)
+RDGPU_SHIM_WS(i64, int64_t)
+RDGPU_SHIM_WS(u64, uint64_t)
 #undef RDGPU_SHIM_WS
 template <class T>
 int c_watersheds(T *, T, int, int, int, int, int32_t *) { unsupported("PriorityFloodWatersheds_Barnes2014"); }

@@ -127,8 +127,6 @@ def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bo
             raise RdgpuError("fill_max_dep(in_place=True) needs a C-contiguous array")
         out = np.ascontiguousarray(out)
     s = _suffix(out.dtype)
-    if s in ("f64", "i64", "u64"):
-        raise RdgpuError("fill_max_dep: 64-bit element types are not provided")
     if int(max_dep_size) < 0:
         raise RdgpuError("fill_max_dep: max_dep_size must not be negative")
     h, w = out.shape
@@ -145,8 +143,6 @@ def watersheds(dem: np.ndarray, nodata=-9999, topology="D8", alter: bool = False
         raise RdgpuError("watersheds: expected a 2-D numpy array")
     work = np.ascontiguousarray(dem).copy()
     s = _suffix(work.dtype)
-    if s in ("f64", "i64", "u64"):
-        raise RdgpuError("watersheds: 64-bit element types are not provided")
     h, w = work.shape
     labels = np.empty((h, w), np.int32)
     check(getattr(lib(), f"rdgpu_watersheds_{s}")(work.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, _topo(topology),
@@ -161,8 +157,6 @@ def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
         raise RdgpuError("pit_mask: expected a 2-D numpy array")
     dem = np.ascontiguousarray(dem)
     s = _suffix(dem.dtype)
-    if s in ("f64", "i64", "u64"):
-        raise RdgpuError("pit_mask: 64-bit element types are not provided")
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)
     check(getattr(lib(), f"rdgpu_pit_mask_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h, _topo(topology),

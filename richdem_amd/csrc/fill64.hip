@@ -13,8 +13,13 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <string>
+
 extern "C" int rdgpu_fill_dev_u32(uint32_t *, int, int, int, void *);
 extern "C" int rdgpu_fill_dev_f32(float *, int, int, int, void *);
+extern "C" int rdgpu_fill_max_dep_dev_u32(uint32_t *, int, int, int, uint64_t, void *);
+extern "C" int rdgpu_pit_mask_dev_u32(const uint32_t *, uint32_t, int, int, int, uint8_t *, void *);
+extern "C" int rdgpu_watersheds_dev_u32(uint32_t *, uint32_t, int, int, int, int, int32_t *, void *);
 
 namespace rdgpu {
 
@@ -108,6 +113,119 @@ __global__ __launch_bounds__(NTHR) void k_ranks_back(T *z, const uint32_t *__res
   }
 }
 
+// Dense value ranks of a 64-bit raster: rk[cell] = number of distinct smaller keys, uniq[rank] = the key.  Any function of
+// the DEM that only compares and copies elevations gives, on the rank raster, the ranks of what it gives on the DEM.
+struct Ranks {
+  uint32_t *rk;
+  uint64_t *uniq;
+  uint32_t *last_rank;   // device word: rank of the largest key (number of distinct keys - 1)
+};
+template <class T>
+static Ranks dense_ranks(const T *d_z, uint64_t n, hipStream_t s) {
+  Workspace &ws = Workspace::get();
+  uint64_t *keys = ws.buf<uint64_t>("fill64.keys", n), *skeys = ws.buf<uint64_t>("fill64.skeys", n);
+  uint32_t *idx = ws.buf<uint32_t>("fill64.idx", n), *sidx = ws.buf<uint32_t>("fill64.sidx", n);
+  RD_LAUNCH("fill64.keys", (k_keys_iota<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, keys, idx, n);
+  size_t tb = 0;
+  RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 64, s));
+  void *tmp = ws.buf("fill64.tmp", tb);
+  RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 64, s));
+  uint32_t *head = idx;                                // idx is dead after the sort
+  uint32_t *rank = reinterpret_cast<uint32_t *>(keys); // so is keys (n * 8 bytes >= n * 4)
+  RD_LAUNCH("fill64.heads", k_heads, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint64_t *)skeys, head, n);
+  size_t tb2 = 0;
+  RD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, head, rank, (int)n, s));
+  void *tmp2 = ws.buf("fill64.tmp2", tb2);
+  RD_HIP(hipcub::DeviceScan::InclusiveSum(tmp2, tb2, head, rank, (int)n, s));
+  uint32_t *rk = ws.buf<uint32_t>("fill64.rk", n);
+  uint64_t *uniq = ws.buf<uint64_t>("fill64.uniq", n);
+  RD_LAUNCH("fill64.scatter_ranks", k_scatter_ranks, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint64_t *)skeys,
+            (const uint32_t *)sidx, (const uint32_t *)rank, (const uint32_t *)head, rk, uniq, n);
+  return Ranks{rk, uniq, rank + (n - 1)};   // (rank[] holds the inclusive scan: its last entry = number of distinct keys)
+}
+
+// rank of `key` among the distinct keys, or 0xFFFFFFFF when the raster does not hold it (binary search, one thread)
+__global__ void k_rank_of(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ ndistinct, uint64_t key, uint32_t *out) {
+  uint32_t lo = 0, hi = *ndistinct;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (uniq[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = (lo < *ndistinct && uniq[lo] == key) ? lo : 0xFFFFFFFFu;
+}
+
+// the NoData value as a rank (what the u32 engines compare cells with); 0xFFFFFFFF = no cell holds it
+template <class T>
+static uint32_t nodata_rank(const Ranks &r, T nodata, hipStream_t s) {
+  Workspace &ws = Workspace::get();
+  uint32_t *d = ws.buf<uint32_t>("fill64.ndrank", 1);
+  hipLaunchKernelGGL(k_rank_of, dim3(1), dim3(1), 0, s, (const uint64_t *)r.uniq, (const uint32_t *)r.last_rank,
+                     Key64<T>::to(nodata), d);
+  RD_HIP(hipGetLastError());
+  uint32_t *hw = ws.host_words();
+  RD_HIP(hipMemcpyAsync(hw, d, 4, hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  return hw[0];
+}
+
+static void check64(const void *p, int w, int h, int topology, const char *who) {
+  if (!p) throw Error(RDGPU_ERR_ARG, std::string(who) + ": null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, std::string(who) + ": width and height must be positive");
+  if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, std::string(who) + ": topology must be 8 or 4");
+  if ((uint64_t)w * h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, std::string(who) + ": raster has more than 2^31-65536 cells");
+}
+
+// ---- the other outputs of the sweep for 64-bit element types, on the rank raster ------------------------
+// PriorityFlood_Barnes2014_max_dep, pit_mask and PriorityFloodWatersheds only compare and copy elevations (and count
+// cells), so they run on the dense ranks with the u32 engine; levels come back through the table of distinct keys.
+template <class T>
+static void fill_max_dep64_device(T *d_z, int w, int h, int topology, uint64_t max_dep, hipStream_t s) {
+  check64(d_z, w, h, topology, "rdgpu_fill_max_dep");
+  const uint64_t n = (uint64_t)w * h;
+  const Ranks r = dense_ranks<T>(d_z, n, s);
+  const int rc = rdgpu_fill_max_dep_dev_u32(r.rk, w, h, topology, max_dep, s);
+  if (rc) throw Error(rc, rdgpu_last_error());
+  RD_LAUNCH("fill64.ranks_back", (k_ranks_back<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint32_t *)r.rk,
+            (const uint64_t *)r.uniq, n);
+}
+
+template <class T>
+static void pit_mask64_device(const T *d_z, T nodata, int w, int h, int topology, uint8_t *d_mask, hipStream_t s) {
+  check64(d_z, w, h, topology, "rdgpu_pit_mask");
+  if (!d_mask) throw Error(RDGPU_ERR_ARG, "rdgpu_pit_mask: null pointer");
+  const uint64_t n = (uint64_t)w * h;
+  const Ranks r = dense_ranks<T>(d_z, n, s);
+  const int rc = rdgpu_pit_mask_dev_u32(r.rk, nodata_rank<T>(r, nodata, s), w, h, topology, d_mask, s);
+  if (rc) throw Error(rc, rdgpu_last_error());
+}
+
+template <class T>
+static void watersheds64_device(T *d_z, T nodata, int w, int h, int topology, int alter, int32_t *d_labels, hipStream_t s) {
+  check64(d_z, w, h, topology, "rdgpu_watersheds");
+  if (!d_labels) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: null pointer");
+  const uint64_t n = (uint64_t)w * h;
+  const Ranks r = dense_ranks<T>(d_z, n, s);
+  const int rc = rdgpu_watersheds_dev_u32(r.rk, nodata_rank<T>(r, nodata, s), w, h, topology, alter, d_labels, s);
+  if (rc) throw Error(rc, rdgpu_last_error());
+  if (alter)
+    RD_LAUNCH("fill64.ranks_back", (k_ranks_back<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint32_t *)r.rk,
+              (const uint64_t *)r.uniq, n);
+}
+
+// host-pointer forms: H2D, the device form, D2H of what the call produces
+template <class T, class F>
+static void with_device_copy(T *dem, int w, int h, bool copy_back, F &&fn) {
+  if (!dem) throw Error(RDGPU_ERR_ARG, "rdgpu: null DEM pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu: width and height must be positive");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem64", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  fn(d);
+  RD_HIP(hipStreamSynchronize(nullptr));
+  if (copy_back) RD_HIP(hipMemcpy(dem, d, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
 template <class T>
 static void fill64_device(T *d_z, int w, int h, int topology, hipStream_t s) {
   if (!d_z) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: null DEM pointer");
@@ -134,24 +252,9 @@ static void fill64_device(T *d_z, int w, int h, int topology, hipStream_t s) {
     }
   }
   // dense ranks
-  uint64_t *keys = ws.buf<uint64_t>("fill64.keys", n), *skeys = ws.buf<uint64_t>("fill64.skeys", n);
-  uint32_t *idx = ws.buf<uint32_t>("fill64.idx", n), *sidx = ws.buf<uint32_t>("fill64.sidx", n);
-  RD_LAUNCH("fill64.keys", (k_keys_iota<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, (const T *)d_z, keys, idx, n);
-  size_t tb = 0;
-  RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 64, s));
-  void *tmp = ws.buf("fill64.tmp", tb);
-  RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 64, s));
-  uint32_t *head = idx;                                // idx is dead after the sort
-  uint32_t *rank = reinterpret_cast<uint32_t *>(keys); // so is keys (n * 8 bytes >= n * 4)
-  RD_LAUNCH("fill64.heads", k_heads, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint64_t *)skeys, head, n);
-  size_t tb2 = 0;
-  RD_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, head, rank, (int)n, s));
-  void *tmp2 = ws.buf("fill64.tmp2", tb2);
-  RD_HIP(hipcub::DeviceScan::InclusiveSum(tmp2, tb2, head, rank, (int)n, s));
-  uint32_t *rk = ws.buf<uint32_t>("fill64.rk", n);
-  uint64_t *uniq = ws.buf<uint64_t>("fill64.uniq", n);
-  RD_LAUNCH("fill64.scatter_ranks", k_scatter_ranks, dim3(sgrid(n)), dim3(NTHR), 0, s, (const uint64_t *)skeys,
-            (const uint32_t *)sidx, (const uint32_t *)rank, (const uint32_t *)head, rk, uniq, n);
+  const Ranks r = dense_ranks<T>(d_z, n, s);
+  uint32_t *rk = r.rk;
+  uint64_t *uniq = r.uniq;
   const int rc = rdgpu_fill_dev_u32(rk, w, h, topology, s);
   if (rc) throw Error(rc, rdgpu_last_error());
   RD_LAUNCH("fill64.ranks_back", (k_ranks_back<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint32_t *)rk,
@@ -184,3 +287,45 @@ using namespace rdgpu;
 RD_FILL64_API(f64, double)
 RD_FILL64_API(i64, int64_t)
 RD_FILL64_API(u64, uint64_t)
+
+#define RD_F2_64_API(SUF, T)                                                                                           \
+  extern "C" int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int w, int h, int topology, uint64_t max_dep_size, void *stream) { \
+    return guarded([&] { fill_max_dep64_device<T>(d_dem, w, h, topology, max_dep_size, (hipStream_t)stream); });       \
+  }                                                                                                                    \
+  extern "C" int rdgpu_fill_max_dep_##SUF(T *dem, int w, int h, int topology, uint64_t max_dep_size) {                 \
+    return guarded([&] {                                                                                               \
+      with_device_copy<T>(dem, w, h, true, [&](T *d) { fill_max_dep64_device<T>(d, w, h, topology, max_dep_size, nullptr); }); \
+    });                                                                                                                \
+  }                                                                                                                    \
+  extern "C" int rdgpu_pit_mask_dev_##SUF(const T *d_dem, T nodata, int w, int h, int topology, uint8_t *d_mask, void *stream) { \
+    return guarded([&] { pit_mask64_device<T>(d_dem, nodata, w, h, topology, d_mask, (hipStream_t)stream); });         \
+  }                                                                                                                    \
+  extern "C" int rdgpu_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topology, uint8_t *mask) {             \
+    return guarded([&] {                                                                                               \
+      if (!mask) throw Error(RDGPU_ERR_ARG, "rdgpu_pit_mask: null pointer");                                           \
+      with_device_copy<T>(const_cast<T *>(dem), w, h, false, [&](T *d) {                                               \
+        uint8_t *dm = Workspace::get().buf<uint8_t>("host.mask64", (size_t)w * h);                                     \
+        pit_mask64_device<T>(d, nodata, w, h, topology, dm, nullptr);                                                  \
+        RD_HIP(hipStreamSynchronize(nullptr));                                                                         \
+        RD_HIP(hipMemcpy(mask, dm, (size_t)w * h, hipMemcpyDeviceToHost));                                             \
+      });                                                                                                              \
+    });                                                                                                                \
+  }                                                                                                                    \
+  extern "C" int rdgpu_watersheds_dev_##SUF(T *d_dem, T nodata, int w, int h, int topology, int alter, int32_t *d_labels, \
+                                            void *stream) {                                                            \
+    return guarded([&] { watersheds64_device<T>(d_dem, nodata, w, h, topology, alter, d_labels, (hipStream_t)stream); }); \
+  }                                                                                                                    \
+  extern "C" int rdgpu_watersheds_##SUF(T *dem, T nodata, int w, int h, int topology, int alter, int32_t *labels) {    \
+    return guarded([&] {                                                                                               \
+      if (!labels) throw Error(RDGPU_ERR_ARG, "rdgpu_watersheds: null pointer");                                       \
+      with_device_copy<T>(dem, w, h, alter != 0, [&](T *d) {                                                           \
+        int32_t *dl = Workspace::get().buf<int32_t>("host.labels64", (size_t)w * h);                                   \
+        watersheds64_device<T>(d, nodata, w, h, topology, alter, dl, nullptr);                                         \
+        RD_HIP(hipStreamSynchronize(nullptr));                                                                         \
+        RD_HIP(hipMemcpy(labels, dl, (size_t)w * h * sizeof(int32_t), hipMemcpyDeviceToHost));                         \
+      });                                                                                                              \
+    });                                                                                                                \
+  }
+RD_F2_64_API(f64, double)
+RD_F2_64_API(i64, int64_t)
+RD_F2_64_API(u64, uint64_t)

@@ -326,8 +326,18 @@ def test_pit_mask(rd, orc):
             assert np.array_equal(got, orc.port.pit_mask(d, nd, topo)), (d.dtype, d.shape, name)
             if d.shape[0] > 2 and d.shape[1] > 2:
                 assert np.array_equal(got == 1, (rd.FillDepressions(d, topology=name) != d) & (d != nd))
-    with pytest.raises(rd.RdgpuError):
-        rd.pit_mask(np.zeros((4, 4), np.float64), -1.0)
+    # 64-bit element types run on dense value ranks (csrc/fill64.hip)
+    rng = np.random.default_rng(8)
+    for dt in (np.float64, np.int64, np.uint64):
+        d = (rng.random((90, 110)) * 1e6).astype(dt)
+        if dt is np.float64:
+            d = d * (1 + 2.0 ** -40) + 1e-7          # values no float32 holds
+        nd = dt(7)
+        d[20:30, 40:55] = nd
+        d[0, :5] = nd
+        for topo, name in ((8, "D8"), (4, "D4")):
+            assert np.array_equal(rd.pit_mask(d, nd, name), orc.port.pit_mask(d, nd, topo)), (dt, name)
+        assert np.array_equal(rd.pit_mask(d, dt(3)), orc.port.pit_mask(d, dt(3), 8))      # a NoData value no cell holds
 
 
 def test_config0_beauford_shaped_dem(rd, orc):

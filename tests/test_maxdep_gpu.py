@@ -87,5 +87,11 @@ def test_max_dep_sizes_and_types(rd, orc):
     for dt in (np.uint8, np.int16, np.uint16, np.uint32):
         q = (rng_dem := np.random.default_rng(3).integers(0, 200, (40, 50))).astype(dt)
         assert np.array_equal(rd.fill_max_dep(q, 10 ** 7), orc.port.fill(q, 8))
-    with pytest.raises(rd.RdgpuError):
-        rd.fill_max_dep(z.astype(np.float64), 3)
+    # 64-bit element types (dense value ranks): values no float32 holds, tie free
+    z64 = zz.astype(np.float64) * (1 + 2.0 ** -40) + 1e-9
+    i64 = (np.random.default_rng(4).permutation(60 * 70).reshape(60, 70).astype(np.int64) << 33) - (1 << 44)
+    for md in (5, 200, 10 ** 7):
+        assert np.array_equal(rd.fill_max_dep(z64, md), orc.port.fill_max_dep(z64, md, 8)), md
+        assert np.array_equal(rd.fill_max_dep(i64, md, "D4"), orc.port.fill_max_dep(i64, md, 4)), md
+        assert np.array_equal(rd.fill_max_dep(i64.astype(np.uint64) + np.uint64(1 << 63), md),
+                              orc.port.fill_max_dep(i64.astype(np.uint64) + np.uint64(1 << 63), md, 8)), md

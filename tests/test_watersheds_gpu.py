@@ -73,3 +73,24 @@ def test_watersheds_larger_and_integer(rd, orc):
         assert np.unique(got).size == got.max()
         differ += not np.array_equal(canon(got), canon(exp))
     print(f"watersheds on integer DEMs: {differ} of 10 partitions differ from the C restatement (ties)")
+
+
+def test_watersheds_64bit_element_types(rd, orc):
+    """f64 / i64 / u64 through the dense value ranks: labels, numbering and the altered DEM equal the C restatement on
+    tie-free DEMs, NoData regions and holes included."""
+    rng = np.random.default_rng(23)
+    for dt in (np.float64, np.int64, np.uint64):
+        h, w = 70, 85
+        if dt is np.float64:
+            z = (rng.permutation(h * w).reshape(h, w) * 1e-3 + 5.0) * (1 + 2.0 ** -40)
+            nd = dt(-9999)
+        else:
+            z = (rng.permutation(h * w).reshape(h, w).astype(np.int64) << 34).astype(dt) + dt(1 << 40)
+            nd = dt(5)
+        z[: h // 3, : w // 4] = nd
+        z[h // 2 : h // 2 + 2, w // 2 : w // 2 + 3] = nd
+        for topo, nm in ((8, "D8"), (4, "D4")):
+            exp, filled = orc.port.watersheds(z, nd, topo, True)
+            got, gfill = rd.watersheds(z, nd, nm, alter=True)
+            assert np.array_equal(got, exp), (dt, topo, int((got != exp).sum()))
+            assert gfill.dtype == z.dtype and np.array_equal(gfill, filled)
