@@ -1,6 +1,7 @@
 """GPU parity tests: D-infinity directions / proportions (FM_Tarboton), FA_Tarboton and the generic
-FlowAccumulation.  Floating point with atan2: compared within north_star's tolerance (<= 1 ULP f32 for
-angles / proportions; accumulation relative 1e-9 in f64 and <= 1 ULP after an f32 cast), not bit for bit."""
+FlowAccumulation.  Floating point with atan2 / pow from the device libm: compared within north_star's tolerance -- <= 1 ULP (f32) for
+angles and proportions, and END TO END (proportions + accumulation) <= 1 ULP after an f32 cast and 1e-12 relative in f64
+(the f64 sums differ from the reference's FIFO order in the last bits only) -- not bit for bit."""
 import numpy as np
 import pytest
 
@@ -58,7 +59,11 @@ def test_fa_tarboton_and_generic_accumulation(rd, orc):
         nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
         exp = orc.port.fa_tarboton(dem, nd)
         got = rd.FlowAccumulation(dem, "Dinf", nodata=nd)
-        assert np.allclose(got, exp, rtol=1e-6, atol=0), name          # proportions may differ by 1 ulp (f32)
+        # END TO END within north_star's bound: <= 1 ULP after an f32 cast (measured r03: 0 ULP on every cell of these
+        # cases, 9e-16 relative in f64 -- the proportions come out bit-identical, only the summation order differs;
+        # tools/probes/mfd_ulps.py, profiles/r03_mfd_ulps.json)
+        assert (ulp_diff_f32(got, exp) <= 1).all(), (name, int(ulp_diff_f32(got, exp).max()))
+        assert np.allclose(got, exp, rtol=1e-12, atol=0), name
         assert np.array_equal(got == -1, exp == -1), name
         # the generic engine on EXACTLY the reference's proportions: only the summation order differs
         props = orc.port.fm_tarboton(dem, nd)
@@ -118,7 +123,9 @@ def test_fa_holmgren_freeman_quinn_d4(rd, orc):
             if method == "D4":
                 assert np.array_equal(got, exp), name
             else:
-                assert np.allclose(got, exp, rtol=2e-6, atol=0), (name, method, x, float(np.abs(got / exp - 1).max()))
+                u = ulp_diff_f32(got, exp)      # north_star: <= 1 ULP on float32 (measured: 0, see above)
+                assert (u <= 1).all(), (name, method, x, int(u.max()))
+                assert np.allclose(got, exp, rtol=1e-12, atol=0), (name, method, x, float(np.abs(got / exp - 1).max()))
         w = np.random.default_rng(3).random(dem.shape)
         got, exp = rd.FlowAccumulation(dem, "Quinn", nodata=nd, weights=w), orc.port.fa_mfd(dem, nd, "Quinn", 1.0, w)
         assert np.allclose(got, exp, rtol=1e-9, atol=0), name

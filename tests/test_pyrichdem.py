@@ -81,7 +81,7 @@ def test_reference_style_session(rd, orc):
             e = orc.port.fa_d8(np.asarray(dem), nd)
         else:
             e = orc.port.fa_mfd(np.asarray(dem), nd, method.replace("OCallaghan", ""), 1.0 if x is None else x)
-        assert np.allclose(a, e, rtol=2e-6, atol=0), method
+        assert np.allclose(a, e, rtol=1e-12, atol=0), method   # (end to end: the f64 sums differ in the last bits only, tests/test_mfd_gpu.py)
 
     props = rd.FlowProportions(dem, method="D8")
     assert type(props) is rd.rd3array and props.no_data == -2 and props.shape == dem.shape + (9,)
