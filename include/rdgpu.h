@@ -239,8 +239,11 @@ int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, const uint3
 int rdgpu_fill_shard_finish_dev(rdgpu_fill_shard *shard, const uint32_t *d_levels);
 /* One process, several devices (the reference's tiled driver, programs/parallel_priority_flood/main.cpp:276-330,
  * :401-547, as a library call): row block s of the host raster goes to devices[s] over that device's own PCIe link,
- * is filled locally there, the cut rows and spillover graphs are joined and solved on the host, every device raises its
- * block and returns it.  Same result as rdgpu_fill_<T>, bit for bit.  A device id may be listed more than once.
+ * is filled locally there (one host thread per device: the devices work side by side), the cut rows and spillover
+ * graphs are joined and solved on devices[0] (RDGPU_MULTI_HOST_SOLVE=1: on the host), every device raises its block and
+ * returns it.  Same result as rdgpu_fill_<T>, bit for bit.  A device id may be listed more than once (its blocks are
+ * then handled in order).  EXPERIMENTAL in one respect: this build's test boxes have one GPU, so the entry is verified
+ * with one physical device listed several times -- threads, staging, the joined solve -- not on several devices.
  * rdgpu_fill_<T> itself takes this path when the environment holds RDGPU_DEVICES=<id>,<id>,... with two or more ids,
  * so rdgpu::FillDepressions(Array2D&) and apps/rd_depressions_flood use several GPUs without a change of signature. */
 int rdgpu_fill_multi_u8(uint8_t *dem, int width, int height, int topology, const int *devices, int ndevices);
@@ -451,6 +454,16 @@ int rdgpu_accum_shard_finish_i32(rdgpu_accum_shard *shard, int32_t *d_area);
 int rdgpu_accum_shard_finish_f32(rdgpu_accum_shard *shard, float *d_area);
 int rdgpu_accum_shard_finish_f64(rdgpu_accum_shard *shard, double *d_area);
 int rdgpu_accum_shard_free(rdgpu_accum_shard *shard);
+
+/* d8_flow_accum of ONE raster over SEVERAL devices of this process (the reference's tiled driver
+ * programs/parallel_d8_accum/main.cpp:373-464 as a library call): row block s on devices[s] (a host thread per device,
+ * its own PCIe link), one exchange of the cut rows' outboxes and links through the host, the same result as
+ * rdgpu_d8_flow_accum_<A> on the whole raster.  Direction loops fall back to devices[0] alone.  A device may be listed
+ * more than once.  rdgpu_d8_flow_accum_<A> takes this path when RDGPU_DEVICES lists two or more ids.
+ * (Verified on one physical device listed several times: this build's test boxes have one GPU.) */
+int rdgpu_d8_flow_accum_multi_i32(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, int32_t *area, const int *devices, int ndevices);
+int rdgpu_d8_flow_accum_multi_f32(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, float *area, const int *devices, int ndevices);
+int rdgpu_d8_flow_accum_multi_f64(const uint8_t *dirs, uint8_t dir_nodata, int width, int height, double *area, const int *devices, int ndevices);
 
 /* ---- FA_D8(const Array2D<T>& elevations, Array2D<double>& accum) ----------------------------
  * Replaces richdem::FA_D8 (include/richdem/methods/flow_accumulation.hpp:27) = FM_D8

@@ -1270,9 +1270,13 @@ namespace rdgpu {
 
 // The per-cell words live in the workspace (a hipMalloc / hipFree of 8 B per cell around every accumulation cost more
 // than the accumulation's own exchange); a live shard owns one numbered set of buffers until finish / free.
-static std::vector<bool> &accs_slots() {
-  static std::vector<bool> v;
-  return v;
+static std::vector<bool> &accs_slots() {   // of the current device (used under that device's API lock)
+  static std::mutex mu;
+  static std::map<int, std::vector<bool>> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  return per_device[dev];
 }
 
 static void accs_free(rdgpu_accum_shard *a) {
@@ -1419,7 +1423,11 @@ namespace rdgpu {
 using namespace rdgpu;
 
 #define RD_ACCUM_API(SUF, A)                                                                                 \
+  extern "C" int rdgpu_d8_flow_accum_multi_##SUF(const uint8_t *, uint8_t, int, int, A *, const int *, int); \
   extern "C" int rdgpu_d8_flow_accum_##SUF(const uint8_t *dirs, uint8_t nodata, int w, int h, A *area) {     \
+    const std::vector<int> devs = env_devices();   /* RDGPU_DEVICES: the node's GPUs, csrc/multi.hip */     \
+    if (devs.size() > 1 && h >= (int)devs.size())                                                            \
+      return rdgpu_d8_flow_accum_multi_##SUF(dirs, nodata, w, h, area, devs.data(), (int)devs.size());       \
     return guarded([&] { d8_flow_accum_host<A>(dirs, nodata, w, h, area); });                                \
   }                                                                                                          \
   extern "C" int rdgpu_d8_flow_accum_dev_##SUF(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A *d_area, \

@@ -5,8 +5,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,12 +36,15 @@ void set_last_error(const std::string &m);
                                               " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
-// Every C-ABI entry point runs under ONE process-wide lock: the grow-only workspace, the statistics and the
-// profiler are process globals, so two host threads (e.g. two Python threads calling the `_richdem` module, which
-// releases the GIL around every call) must not be inside the library at the same time.  Calls from different
-// threads are serialised here; when the calling thread changes, the device is synchronised first so that the
-// previous caller's asynchronous `_dev` work has left the shared scratch buffers.
-std::recursive_mutex &api_mutex();
+// Every C-ABI entry point runs under the lock of the device that is current when it is entered: the grow-only
+// workspace (scratch named per device) must not be used by two host threads at once (e.g. two Python threads calling the
+// `_richdem` module, which releases the GIL around every call).  Calls on ONE device are serialised here, and when the
+// calling thread changes that device is synchronised first, so that the previous caller's asynchronous `_dev` work has
+// left the shared scratch buffers.  Calls on DIFFERENT devices hold different locks and run side by side: one host thread
+// per device is how the single-process multi-device entry points (rdgpu_*_multi_*) drive a node.  What is shared across
+// devices has locks of its own (the workspace's slot map, the profiler) or is per thread (statistics, last error).
+std::recursive_mutex &api_mutex();            // of the current device
+std::recursive_mutex &api_mutex(int device);
 void api_enter();   // call with api_mutex() held
 
 // Runs fn(), maps exceptions to the C-ABI return code convention.
@@ -47,6 +53,22 @@ int guarded(F &&fn) {
   std::lock_guard<std::recursive_mutex> lock(api_mutex());
   try {
     api_enter();
+    fn();
+    return RDGPU_OK;
+  } catch (const Error &e) {
+    set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return RDGPU_ERR_HIP;
+  }
+}
+
+// The same mapping of exceptions to return codes WITHOUT a lock: for entry points that only orchestrate per-device
+// workers, each of which takes its own device's lock (rdgpu_*_multi_*).
+template <class F>
+int unlocked(F &&fn) {
+  try {
     fn();
     return RDGPU_OK;
   } catch (const Error &e) {
@@ -75,18 +97,84 @@ public:
   // Frees every buffer.  Refused (Error) while a shard handle whose tables live in the workspace is alive: the handle
   // would keep dangling device pointers (rdgpu_*_shard_begin pins, _finish / _free unpins).
   void release();
-  void pin() { pins_++; }
-  void unpin() { if (pins_ > 0) pins_--; }
+  void pin() { std::lock_guard<std::mutex> g(mu_); pins_++; }
+  void unpin() { std::lock_guard<std::mutex> g(mu_); if (pins_ > 0) pins_--; }
 
 private:
   struct Slot {
     void *p = nullptr;
     size_t cap = 0;
   };
+  std::mutex mu_;   // the maps below are shared by the threads of different devices
   std::map<std::string, Slot> slots_;
-  uint32_t *host_words_ = nullptr;
+  std::map<int, uint32_t *> host_words_;   // per device: a read-back of one device must not land in another's words
   int pins_ = 0;
 };
+
+// ------------------------------------------------------------------------------------------
+// one host thread per device (the single-process multi-device entry points)
+// ------------------------------------------------------------------------------------------
+struct DeviceGuard {   // the worker's device: current + locked for the scope
+  int prev = 0;
+  std::unique_lock<std::recursive_mutex> lock;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    RD_HIP(hipSetDevice(dev));
+    lock = std::unique_lock<std::recursive_mutex>(api_mutex(dev));
+    api_enter();
+  }
+  ~DeviceGuard() {
+    lock.unlock();
+    (void)hipSetDevice(prev);
+  }
+};
+
+// runs job(device, its shard indices) for every distinct device, each in a thread of its own; rethrows the first failure
+template <class Job>
+inline void per_device(const int *devices, int ndev, Job job) {
+  std::vector<int> order;                       // distinct devices in order of first appearance
+  std::map<int, std::vector<int>> shards;
+  for (int s = 0; s < ndev; s++) {
+    if (!shards.count(devices[s])) order.push_back(devices[s]);
+    shards[devices[s]].push_back(s);
+  }
+  std::vector<std::exception_ptr> err(order.size());
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < order.size(); k++)
+    th.emplace_back([&, k] {
+      try {
+        DeviceGuard g(order[k]);
+        job(order[k], shards[order[k]]);
+      } catch (...) {
+        err[k] = std::current_exception();
+      }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+}
+
+// RDGPU_DEVICES=0,1,2,...: the host-pointer entry points (what rdgpu::FillDepressions(Array2D&), rdgpu::d8_flow_accum and
+// the apps call) spread their row blocks over these devices (rdgpu_*_multi_*); unset or one id: the current device.
+// A multi-device driver that falls back to one device switches the routing off for its own thread meanwhile.
+inline bool &multi_route_off() {
+  static thread_local bool off = false;
+  return off;
+}
+inline std::vector<int> env_devices() {
+  std::vector<int> v;
+  const char *e = getenv("RDGPU_DEVICES");
+  if (!e || multi_route_off()) return v;
+  for (const char *p = e; *p;) {
+    char *end = nullptr;
+    const long id = strtol(p, &end, 10);
+    if (end == p) break;
+    v.push_back((int)id);
+    p = *end == ',' ? end + 1 : end;
+    if (*end != ',') break;
+  }
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------
 // per-kernel timing with HIP events on the launch stream
@@ -110,10 +198,12 @@ private:
   struct Pending {
     std::string name;
     hipEvent_t a, b;
+    int device;
   };
+  std::mutex mu_;
   std::vector<Pending> pending_;
-  std::vector<hipEvent_t> pool_;
-  hipEvent_t take();
+  std::map<int, std::vector<hipEvent_t>> pool_;   // events belong to the device they were created on
+  hipEvent_t take(int device);
 };
 
 // Launch a kernel, bracketed by events when profiling is on.

@@ -495,7 +495,7 @@ struct Stats {
   uint32_t rounds = 0, attempts = 0;
   uint64_t tile_relaxations = 0, slack = 0, max_lift = 0, tie_sources = 0;
 };
-static Stats g_stats;
+static thread_local Stats g_stats;
 
 // Rounds until no tile is active: compact the active-tile flags into a list + count on the device, relax that list;
 // BATCH rounds are enqueued per host read-back, the rounds enqueued past the fixed point see an empty list.

@@ -47,7 +47,7 @@ constexpr uint32_t OUTP = 0xFFFFFFFFu;  // descent pointer of a border cell: dra
 constexpr uint32_t CLOSED = 0x80000000u;
 constexpr uint32_t NO_TID = 0xFFFFFFFFu;   // tid[b]: basin b is not a cut-row terminal
 
-static rdgpu_fill_stats g_stats;
+static thread_local rdgpu_fill_stats g_stats;   // (per host thread: one thread per device may be inside the library)
 
 // ------------------------------------------------------------------------------------------
 // 1. descent pointers, path-compressed inside the tile
@@ -2121,23 +2121,6 @@ static void shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels2w) {
 }  // namespace rdgpu
 
 using namespace rdgpu;
-
-// RDGPU_DEVICES=0,1,2,...: the host-pointer fill (what rdgpu::FillDepressions(Array2D&) and rd_depressions_flood call)
-// spreads its row blocks over these devices (rdgpu_fill_multi_*); unset or one id: the current device
-static std::vector<int> env_devices() {
-  std::vector<int> v;
-  const char *e = getenv("RDGPU_DEVICES");
-  if (!e) return v;
-  for (const char *p = e; *p;) {
-    char *end = nullptr;
-    const long id = strtol(p, &end, 10);
-    if (end == p) break;
-    v.push_back((int)id);
-    p = *end == ',' ? end + 1 : end;
-    if (*end != ',' ) break;
-  }
-  return v;
-}
 
 #define RD_FILL_API(SUF, T)                                                                       \
   extern "C" int rdgpu_fill_multi_##SUF(T *, int, int, int, const int *, int);                    \

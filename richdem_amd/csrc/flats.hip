@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(NTHR) void k_flat_labels_out(const uint32_t *__rest
 // ------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------
-static rdgpu_flat_stats g_fstats;
+static thread_local rdgpu_flat_stats g_fstats;
 static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + NTHR - 1) / NTHR, 256u * 32u); }
 
 template <class T>

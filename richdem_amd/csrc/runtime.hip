@@ -9,22 +9,42 @@ namespace rdgpu {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &m) { g_last_error = m; }
 
+std::recursive_mutex &api_mutex(int device) {
+  static std::mutex mu;
+  static std::map<int, std::recursive_mutex *> locks;   // (never freed: a lock may be held at exit)
+  std::lock_guard<std::mutex> g(mu);
+  std::recursive_mutex *&m = locks[device];
+  if (!m) m = new std::recursive_mutex();
+  return *m;
+}
+
 std::recursive_mutex &api_mutex() {
-  static std::recursive_mutex m;
-  return m;
+  int dev = 0;
+  (void)hipGetDevice(&dev);   // (no device at all: everything shares lock 0 and fails later with a proper error)
+  return api_mutex(dev);
 }
 
 void api_enter() {
-  static std::thread::id last{};
-  static int depth_guard = 0;
+  // per device: which host thread used it last (held under that device's lock)
+  static std::mutex mu;
+  static std::map<int, std::thread::id> last;
+  static thread_local int depth_guard = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   const std::thread::id me = std::this_thread::get_id();
-  if (last != std::thread::id{} && last != me && depth_guard == 0) {
-    // another host thread used the library last: its asynchronous work may still read the shared scratch
+  bool sync = false;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = last.find(dev);
+    sync = it != last.end() && it->second != me && depth_guard == 0;
+    last[dev] = me;
+  }
+  if (sync) {
+    // another host thread used this device last: its asynchronous work may still read the shared scratch
     depth_guard = 1;
     (void)hipDeviceSynchronize();
     depth_guard = 0;
   }
-  last = me;
 }
 
 // ---- Workspace ----------------------------------------------------------------------------
@@ -38,7 +58,12 @@ void *Workspace::buf(const char *name, size_t bytes) {
   // device 1 against scratch that lives in device 0's HBM
   int dev = 0;
   RD_HIP(hipGetDevice(&dev));
-  Slot &s = slots_[std::to_string(dev) + ":" + name];
+  Slot *sp;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    sp = &slots_[std::to_string(dev) + ":" + name];   // (map nodes are stable; a slot is only used under its device's API lock)
+  }
+  Slot &s = *sp;
   if (bytes > s.cap) {
     if (s.p) RD_HIP(hipFree(s.p));
     s.p = nullptr;
@@ -52,20 +77,33 @@ void *Workspace::buf(const char *name, size_t bytes) {
 }
 
 uint32_t *Workspace::host_words() {
-  if (!host_words_) RD_HIP(hipHostMalloc((void **)&host_words_, 64 * sizeof(uint32_t), hipHostMallocDefault));
-  return host_words_;
+  int dev = 0;
+  RD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu_);
+  uint32_t *&p = host_words_[dev];
+  if (!p) RD_HIP(hipHostMalloc((void **)&p, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  return p;
 }
 
 void Workspace::release() {
+  std::lock_guard<std::mutex> g(mu_);
   if (pins_ > 0)
     throw Error(RDGPU_ERR_ARG, "rdgpu_release_workspace: " + std::to_string(pins_) +
                                    " shard handle(s) still hold workspace buffers (finish or free them first)");
-  (void)hipDeviceSynchronize();
+  int home = 0, ndev = 0;
+  (void)hipGetDevice(&home);
+  (void)hipGetDeviceCount(&ndev);
+  for (int d = 0; d < ndev; d++) {   // buffers of every device this process touched
+    (void)hipSetDevice(d);
+    (void)hipDeviceSynchronize();
+  }
+  (void)hipSetDevice(home);
   for (auto &kv : slots_)
     if (kv.second.p) (void)hipFree(kv.second.p);
   slots_.clear();
-  if (host_words_) (void)hipHostFree(host_words_);
-  host_words_ = nullptr;
+  for (auto &kv : host_words_)
+    if (kv.second) (void)hipHostFree(kv.second);
+  host_words_.clear();
 }
 
 // ---- Profiler -----------------------------------------------------------------------------
@@ -74,10 +112,11 @@ Profiler &Profiler::get() {
   return p;
 }
 
-hipEvent_t Profiler::take() {
-  if (!pool_.empty()) {
-    hipEvent_t e = pool_.back();
-    pool_.pop_back();
+hipEvent_t Profiler::take(int device) {
+  std::vector<hipEvent_t> &pool = pool_[device];
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
     return e;
   }
   hipEvent_t e;
@@ -86,32 +125,48 @@ hipEvent_t Profiler::take() {
 }
 
 void Profiler::begin(const char *name, hipStream_t s) {
+  int dev = 0;
+  RD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu_);
   Pending p;
   p.name = name;
-  p.a = take();
-  p.b = take();
+  p.device = dev;
+  p.a = take(dev);
+  p.b = take(dev);
   RD_HIP(hipEventRecord(p.a, s));
   pending_.push_back(p);
 }
 
-void Profiler::end(hipStream_t s) { RD_HIP(hipEventRecord(pending_.back().b, s)); }
+void Profiler::end(hipStream_t s) {
+  int dev = 0;
+  RD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu_);
+  for (size_t i = pending_.size(); i-- > 0;)   // the calling thread's open entry: the latest one of its device
+    if (pending_[i].device == dev) { RD_HIP(hipEventRecord(pending_[i].b, s)); return; }
+}
 
 void Profiler::collect() {
+  std::lock_guard<std::mutex> g(mu_);
+  int home = 0;
+  (void)hipGetDevice(&home);
   for (auto &p : pending_) {
+    (void)hipSetDevice(p.device);
     RD_HIP(hipEventSynchronize(p.b));
     float ms = 0;
     RD_HIP(hipEventElapsedTime(&ms, p.a, p.b));
     Tot &t = totals[p.name];
     t.ms += ms;
     t.n += 1;
-    pool_.push_back(p.a);
-    pool_.push_back(p.b);
+    pool_[p.device].push_back(p.a);
+    pool_[p.device].push_back(p.b);
   }
+  (void)hipSetDevice(home);
   pending_.clear();
 }
 
 void Profiler::reset() {
   collect();
+  std::lock_guard<std::mutex> g(mu_);
   totals.clear();
 }
 

@@ -12,7 +12,10 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <exception>
+#include <map>
 #include <queue>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -22,6 +25,8 @@ int rdgpu_fill_shard_edge_count(rdgpu_fill_shard *sh, uint32_t *n_edges);
 int rdgpu_fill_shard_export(rdgpu_fill_shard *sh, uint32_t *top_keys, uint32_t *bottom_keys, uint32_t *edges);
 int rdgpu_fill_shard_finish(rdgpu_fill_shard *sh, const uint32_t *levels);
 int rdgpu_fill_shard_free(rdgpu_fill_shard *sh);
+int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, const uint32_t *d_keys_all, const uint32_t *d_edges_all,
+                               const uint32_t *d_counts, uint32_t cap, uint32_t *d_levels_all, void *stream);
 }
 
 namespace rdgpu {
@@ -157,17 +162,23 @@ static void fill_sharded_host(T *dem, int w, int h, int topology, int nshards, B
 }
 
 // The same protocol over SEVERAL devices driven by this one process (the role of the reference's
-// programs/parallel_priority_flood producer + consumers, main.cpp:276-330, :401-547): row block s lives on devices[s],
-// is uploaded over that device's own PCIe link, filled locally there, the cut rows and spillover graphs meet on the
-// host, the solved levels go back, and every device raises and returns its block.  A device may be listed more than
-// once (its blocks are then handled one after the other: what the one-GPU tests do).
+// programs/parallel_priority_flood producer + consumers, main.cpp:276-330, :401-547): row block s lives on devices[s], is
+// uploaded over that device's own PCIe link and filled locally there, the cut rows and spillover graphs meet in the
+// middle, the solved levels go back, and every device raises and returns its block.
+// One HOST THREAD PER DEVICE: the local phase synchronises with its device several times per Boruvka round, so issuing
+// the blocks from one thread would run them one after another (r02).  A worker holds its device's API lock for its
+// phase (common.hpp: locks are per device), so the devices run side by side and a second caller on one of them waits.
+// A device may be listed more than once: its blocks are then handled in order by that device's worker (what the
+// one-GPU tests do -- they exercise the threads, the staging and the joined solve, not the concurrency).
+// The joined graph is solved on devices[0] with the raster's own Boruvka kernels (rdgpu_fill_graph_solve_dev, 0.7 ms at
+// S3 / 8 blocks; RDGPU_MULTI_HOST_SOLVE=1: the host Priority-Flood above, 106 ms -- kept for A/B and the tests).
 template <class T, class Begin>
 static void fill_multi_host(T *dem, int w, int h, int topology, const int *devices, int ndev, Begin begin) {
   if (!dem || w <= 0 || h <= 0 || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: bad arguments");
   if (ndev < 1 || (ndev > 1 && h / ndev < 2)) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: need >= 2 rows per device");
-  int ndevices = 0, home = 0;
+  if (topology != 8 && topology != 4) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: topology must be 8 or 4");
+  int ndevices = 0;
   RD_HIP(hipGetDeviceCount(&ndevices));
-  RD_HIP(hipGetDevice(&home));
   for (int s = 0; s < ndev; s++)
     if (devices[s] < 0 || devices[s] >= ndevices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: no such device");
   std::vector<rdgpu_fill_shard *> sh(ndev, nullptr);
@@ -175,53 +186,87 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
   std::vector<hipStream_t> st(ndev, nullptr);
   std::vector<int> r0(ndev + 1);
   for (int s = 0; s <= ndev; s++) r0[s] = (int)((int64_t)h * s / ndev);
-  auto cleanup = [&]() {
+  const size_t per = (size_t)2 * w;
+  std::vector<uint32_t> keys((size_t)ndev * per, 0), levels((size_t)ndev * per, 0);
+  std::vector<std::vector<uint32_t>> edges(ndev);
+  auto cleanup = [&]() noexcept {   // error path only: best effort
     for (int s = 0; s < ndev; s++) {
-      (void)hipSetDevice(devices[s]);
+      if (hipSetDevice(devices[s]) != hipSuccess) continue;
       if (sh[s]) rdgpu_fill_shard_free(sh[s]);
       if (st[s]) { (void)hipStreamSynchronize(st[s]); (void)hipStreamDestroy(st[s]); }
     }
-    (void)hipSetDevice(home);
   };
+  int home = 0;
+  RD_HIP(hipGetDevice(&home));
   try {
-    const size_t per = (size_t)2 * w;
-    std::vector<uint32_t> keys((size_t)ndev * per, 0), levels((size_t)ndev * per, 0), edges;
-    std::vector<uint64_t> offs(ndev + 1, 0);
-    // uploads first, every block on its device's own stream (they overlap when the caller's buffer is pinned) ...
-    for (int s = 0; s < ndev; s++) {
-      RD_HIP(hipSetDevice(devices[s]));
-      const size_t cells = (size_t)(r0[s + 1] - r0[s]) * w;
-      blk[s] = Workspace::get().buf<T>(("multi.block." + std::to_string(s)).c_str(), cells);
-      RD_HIP(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
-      RD_HIP(hipMemcpyAsync(blk[s], dem + (size_t)r0[s] * w, cells * sizeof(T), hipMemcpyHostToDevice, st[s]));
-    }
-    // ... then the local phases
-    for (int s = 0; s < ndev; s++) {
-      RD_HIP(hipSetDevice(devices[s]));
-      const int rc = begin(blk[s], w, r0[s + 1] - r0[s], topology, s > 0, s + 1 < ndev, st[s], &sh[s]);
+    // 1. every device: upload its blocks (own PCIe link, own stream), local phase, cut rows + spillover graph back
+    per_device(devices, ndev, [&](int, const std::vector<int> &mine) {
+      for (int s : mine) {
+        const size_t cells = (size_t)(r0[s + 1] - r0[s]) * w;
+        blk[s] = Workspace::get().buf<T>(("multi.block." + std::to_string(s)).c_str(), cells);
+        RD_HIP(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
+        RD_HIP(hipMemcpyAsync(blk[s], dem + (size_t)r0[s] * w, cells * sizeof(T), hipMemcpyHostToDevice, st[s]));
+      }
+      for (int s : mine) {
+        const int rc = begin(blk[s], w, r0[s + 1] - r0[s], topology, s > 0, s + 1 < ndev, st[s], &sh[s]);
+        if (rc) throw Error(rc, rdgpu_last_error());
+        uint32_t ne = 0;
+        rdgpu_fill_shard_edge_count(sh[s], &ne);
+        edges[s].resize((size_t)ne * 3);
+        const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
+                                                ne ? edges[s].data() : nullptr);
+        if (rc2) throw Error(rc2, rdgpu_last_error());
+      }
+    });
+    // 2. the joined graph
+    const char *hs = getenv("RDGPU_MULTI_HOST_SOLVE");
+    if (ndev > 1 && !(hs && hs[0] == '1')) {
+      DeviceGuard g(devices[0]);
+      uint32_t cap = 1;
+      std::vector<uint32_t> counts(ndev);
+      for (int s = 0; s < ndev; s++) { counts[s] = (uint32_t)(edges[s].size() / 3); cap = std::max(cap, counts[s]); }
+      std::vector<uint32_t> padded((size_t)ndev * cap * 3, 0);
+      for (int s = 0; s < ndev; s++) std::copy(edges[s].begin(), edges[s].end(), padded.begin() + (size_t)s * cap * 3);
+      Workspace &ws = Workspace::get();
+      uint32_t *d_keys = ws.buf<uint32_t>("multi.keys", keys.size()), *d_edges = ws.buf<uint32_t>("multi.edges", padded.size());
+      uint32_t *d_counts = ws.buf<uint32_t>("multi.counts", ndev), *d_levels = ws.buf<uint32_t>("multi.levels", levels.size());
+      RD_HIP(hipMemcpy(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+      RD_HIP(hipMemcpy(d_edges, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+      RD_HIP(hipMemcpy(d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice));
+      const int rc = rdgpu_fill_graph_solve_dev(ndev, w, topology, d_keys, d_edges, d_counts, cap, d_levels, nullptr);
       if (rc) throw Error(rc, rdgpu_last_error());
-      uint32_t ne = 0;
-      rdgpu_fill_shard_edge_count(sh[s], &ne);
-      offs[s + 1] = offs[s] + ne;
-      edges.resize((size_t)offs[s + 1] * 3);
-      const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
-                                              ne ? &edges[(size_t)offs[s] * 3] : nullptr);
-      if (rc2) throw Error(rc2, rdgpu_last_error());
+      RD_HIP(hipStreamSynchronize(nullptr));
+      RD_HIP(hipMemcpy(levels.data(), d_levels, levels.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<uint64_t> offs(ndev + 1, 0);
+      std::vector<uint32_t> flat;
+      for (int s = 0; s < ndev; s++) {
+        offs[s + 1] = offs[s] + edges[s].size() / 3;
+        flat.insert(flat.end(), edges[s].begin(), edges[s].end());
+      }
+      graph_solve(ndev, w, topology, keys.data(), flat.data(), offs.data(), levels.data());
     }
-    graph_solve(ndev, w, topology, keys.data(), edges.data(), offs.data(), levels.data());
-    for (int s = 0; s < ndev; s++) {
-      RD_HIP(hipSetDevice(devices[s]));
-      rdgpu_fill_shard *p = sh[s];
-      sh[s] = nullptr;
-      const int rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);   // synchronises the block's stream
-      if (rc) throw Error(rc, rdgpu_last_error());
-      RD_HIP(hipMemcpyAsync(dem + (size_t)r0[s] * w, blk[s], (size_t)(r0[s + 1] - r0[s]) * w * sizeof(T), hipMemcpyDeviceToHost, st[s]));
-    }
+    // 3. every device: raise its blocks, copy them back, and only then report success
+    per_device(devices, ndev, [&](int, const std::vector<int> &mine) {
+      for (int s : mine) {
+        rdgpu_fill_shard *p = sh[s];
+        sh[s] = nullptr;
+        const int rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);   // synchronises the block's stream
+        if (rc) throw Error(rc, rdgpu_last_error());
+        RD_HIP(hipMemcpyAsync(dem + (size_t)r0[s] * w, blk[s], (size_t)(r0[s + 1] - r0[s]) * w * sizeof(T), hipMemcpyDeviceToHost, st[s]));
+      }
+      for (int s : mine) {
+        RD_HIP(hipStreamSynchronize(st[s]));   // a failed copy must not return RDGPU_OK with a partly updated DEM
+        RD_HIP(hipStreamDestroy(st[s]));
+        st[s] = nullptr;
+      }
+    });
   } catch (...) {
     cleanup();
+    (void)hipSetDevice(home);
     throw;
   }
-  cleanup();
+  (void)hipSetDevice(home);
 }
 
 }  // namespace rdgpu
@@ -242,20 +287,9 @@ extern "C" int rdgpu_fill_graph_solve(int nshards, int width, int topology, cons
                              return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, nullptr, o);         \
                            });                                                                              \
     });                                                                                                     \
-  }
-#undef RD_SHARDED_API
-#define RD_SHARDED_API(SUF, T)                                                                              \
-  extern "C" int rdgpu_fill_shard_begin_##SUF(T *, int, int, int, int, int, void *, rdgpu_fill_shard **);   \
-  extern "C" int rdgpu_fill_sharded_##SUF(T *dem, int w, int h, int topology, int nshards) {                \
-    return guarded([&] {                                                                                    \
-      fill_sharded_host<T>(dem, w, h, topology, nshards,                                                    \
-                           [](T *d, int w_, int h_, int t, int ot, int ob, rdgpu_fill_shard **o) {          \
-                             return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, nullptr, o);         \
-                           });                                                                              \
-    });                                                                                                     \
   }                                                                                                         \
   extern "C" int rdgpu_fill_multi_##SUF(T *dem, int w, int h, int topology, const int *devices, int ndev) { \
-    return guarded([&] {                                                                                    \
+    return unlocked([&] {                                                                                   \
       fill_multi_host<T>(dem, w, h, topology, devices, ndev,                                                \
                          [](T *d, int w_, int h_, int t, int ot, int ob, hipStream_t st, rdgpu_fill_shard **o) { \
                            return rdgpu_fill_shard_begin_##SUF(d, w_, h_, t, ot, ob, (void *)st, o);        \

@@ -419,6 +419,12 @@ def test_multi_device_entry_on_one_gpu(rd, orc, monkeypatch):
     arr = (ctypes.c_int * 3)(0, 0, 0)
     check(lib().rdgpu_fill_multi_i16(a.ctypes.data_as(ctypes.c_void_p), 700, 530, 4, arr, 3), "rdgpu_fill_multi_i16")
     assert a.tobytes() == orc.port.fill(q, 4).tobytes()
+    monkeypatch.setenv("RDGPU_MULTI_HOST_SOLVE", "1")        # the joined graph on the host instead of on devices[0]
+    a = z.copy()
+    arr = (ctypes.c_int * 4)(0, 0, 0, 0)
+    check(lib().rdgpu_fill_multi_f32(a.ctypes.data_as(ctypes.c_void_p), 700, 530, 8, arr, 4), "rdgpu_fill_multi_f32")
+    assert np.array_equal(a, exp)
+    monkeypatch.delenv("RDGPU_MULTI_HOST_SOLVE")
     monkeypatch.setenv("RDGPU_DEVICES", "0,0,0")
     assert np.array_equal(rd.FillDepressions(z), exp)
     monkeypatch.delenv("RDGPU_DEVICES")

@@ -298,3 +298,44 @@ def test_sharded_directions_halo(rd, orc):
             rd.d8_flow_directions_dev(halo, -9999.0, d)
             outs.append(d[a - lo : a - lo + (b - a)])
         assert np.array_equal(torch.cat(outs, 0).cpu().numpy(), exp), world
+
+
+def test_multi_device_accumulation_entry_on_one_gpu(rd, orc, monkeypatch):
+    """rdgpu_d8_flow_accum_multi_<A> (one process, a list of devices: the reference's parallel_d8_accum driver as a library
+    call).  With device 0 listed several times the row blocks go through exactly the multi-device code -- a worker thread
+    per device, ghost rows, the one exchange through the host's link solve, add_paths, per-block finish -- and the result
+    equals the single-device call on every cell; direction loops fall back to one device and keep the reference's partial
+    sums; RDGPU_DEVICES routes the plain host entry the same way."""
+    import ctypes
+
+    from richdem_amd._lib import check, lib
+    from richdem_amd.synth import fractal_dem
+
+    z = orc.port.fill(fractal_dem(530, 410, seed=77))
+    dirs = orc.port.flat_resolution(z, np.float32(-9999))
+    dirs[100:104, 200:230] = 255                                   # a NoData hole
+    h, w = dirs.shape
+    for dt, suf in ((np.float64, "f64"), (np.int32, "i32"), (np.float32, "f32")):
+        exp = orc.port.d8_flow_accum(dirs, 255, dt)
+        for devs in ([0], [0, 0], [0] * 7, [0] * 64):
+            out = np.empty((h, w), dt)
+            arr = (ctypes.c_int * len(devs))(*devs)
+            check(getattr(lib(), f"rdgpu_d8_flow_accum_multi_{suf}")(dirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), w, h,
+                                                                      out.ctypes.data_as(ctypes.c_void_p), arr, len(devs)), "multi")
+            assert np.array_equal(out, exp), (suf, len(devs))
+    # raw directions with loops: reported by the blocks / the link solve, then one device
+    rng = np.random.default_rng(5)
+    loops = rng.integers(0, 9, (260, 300)).astype(np.uint8)
+    exp = orc.port.d8_flow_accum(loops, 255, np.float64)
+    out = np.empty(loops.shape, np.float64)
+    arr = (ctypes.c_int * 5)(0, 0, 0, 0, 0)
+    check(lib().rdgpu_d8_flow_accum_multi_f64(loops.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), 300, 260,
+                                              out.ctypes.data_as(ctypes.c_void_p), arr, 5), "multi")
+    assert np.array_equal(out, exp)
+    monkeypatch.setenv("RDGPU_DEVICES", "0,0,0")
+    assert np.array_equal(rd.d8_flow_accum(dirs, 255, np.float64), orc.port.d8_flow_accum(dirs, 255, np.float64))
+    assert np.array_equal(rd.d8_flow_accum(loops, 255, np.float64), exp)
+    monkeypatch.delenv("RDGPU_DEVICES")
+    arr = (ctypes.c_int * 2)(0, 99)
+    assert lib().rdgpu_d8_flow_accum_multi_f64(dirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), w, h,
+                                               out.ctypes.data_as(ctypes.c_void_p), arr, 2) != 0
