@@ -403,6 +403,25 @@ int rdgpu_flat_shard_finish(rdgpu_flat_shard *shard, const int32_t *d_heights_4w
 int rdgpu_flat_shard_rounds(const rdgpu_flat_shard *shard, int phase);
 void rdgpu_flat_shard_free(rdgpu_flat_shard *shard);
 
+/* barnes_flat_resolution_d8(alter = false) of ONE raster over SEVERAL devices of this process: row block s (+ two ghost
+ * rows per cut) on devices[s], a host thread per device, the cut rows of the two level fields exchanged through the host
+ * until none changes, the flat heights agreed on devices[0]; the result equals rdgpu_flat_resolution_d8_<T> on the whole
+ * raster.  A device may be listed more than once.  rdgpu_flat_resolution_d8_<T> takes this path when RDGPU_DEVICES
+ * lists two or more ids.  (Verified on one physical device listed several times.) */
+#define RDGPU_DECL_FLATS_MULTI(SUF, T) \
+  int rdgpu_flat_resolution_d8_multi_##SUF(const T *dem, T nodata, int width, int height, uint8_t *dirs, const int *devices, int ndevices);
+RDGPU_DECL_FLATS_MULTI(u8, uint8_t)
+RDGPU_DECL_FLATS_MULTI(i8, int8_t)
+RDGPU_DECL_FLATS_MULTI(i16, int16_t)
+RDGPU_DECL_FLATS_MULTI(u16, uint16_t)
+RDGPU_DECL_FLATS_MULTI(i32, int32_t)
+RDGPU_DECL_FLATS_MULTI(u32, uint32_t)
+RDGPU_DECL_FLATS_MULTI(f32, float)
+RDGPU_DECL_FLATS_MULTI(f64, double)
+RDGPU_DECL_FLATS_MULTI(i64, int64_t)
+RDGPU_DECL_FLATS_MULTI(u64, uint64_t)
+#undef RDGPU_DECL_FLATS_MULTI
+
 /* ---- d8_flow_accum(const Array2D<uint8_t>& flowdirs, Array2D<A>& area) ----------------------
  * Replaces richdem::d8_flow_accum (include/richdem/methods/d8_methods.hpp:47-139): area = number of
  * cells draining through each cell (itself included); cells whose direction equals dir_nodata get

@@ -243,6 +243,16 @@ class _Backend:
         self._fn(f"fill_max_dep_{s}")(_ptr(out), w, h, int(topo), ctypes.c_uint64(int(max_dep_size)))
         return out
 
+    def pf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
+        """PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555): uint8 D8 directions, every cell flows
+        to the cell that closed it; NoData cells 0."""
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        s = _suf(dem)
+        out = np.empty((h, w), np.uint8)
+        self._fn(f"pf_flowdirs_{s}")(_ptr(dem), _CT[s](nodata), w, h, _ptr(out))
+        return out
+
     def dinf_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)
         h, w = dem.shape

@@ -584,6 +584,66 @@ void FN(orc_pit_mask)(const T *dem, T nodata, int w, int h, int topo, uint8_t *m
 
 
 /* ------------------------------------------------------------------------- */
+/* PriorityFloodFlowdirs_Barnes2014, depressions/Barnes2014.hpp:483-555.      */
+/* A Priority-Flood that raises nothing: cells leave a STABLE queue -- lowest  */
+/* elevation first, equal elevations in insertion order (GridCellZk_low_pq,    */
+/* common/grid_cell.hpp:75-81,:114-122) -- and every cell flows to the cell    */
+/* that closed it (neighbours are visited cardinals first, :524).  Because the */
+/* order is total, the output does not depend on the heap implementation.      */
+/* ------------------------------------------------------------------------- */
+typedef struct { T z; int32_t k, x, y; } FN(kcell);
+static int FN(kcell_gt)(const FN(kcell) *a, const FN(kcell) *b) { return a->z > b->z || (a->z == b->z && a->k > b->k); }
+void FN(orc_pf_flowdirs)(const T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  static const int order[9] = {0, 1, 3, 5, 7, 2, 4, 6, 8}, inverse[9] = {0, 5, 6, 7, 8, 1, 2, 3, 4};
+  size_t N = (size_t)w * h, hn = 0, hcap = 2 * ((size_t)w + h) + 16;
+  FN(kcell) *heap = (FN(kcell) *)malloc(hcap * sizeof(FN(kcell)));
+  int8_t *closed = (int8_t *)calloc(N, 1);
+  int32_t count = 0;
+  memset(dirs, 0, N);                                                        /* flowdirs.setNoData(NO_FLOW = 0) */
+#define ORC_PUSH(X, Y, Z) do { FN(kcell) c_ = {(Z), ++count, (X), (Y)}; size_t i_ = hn++;                      \
+    if (hn > hcap) { hcap *= 2; heap = (FN(kcell) *)realloc(heap, hcap * sizeof(FN(kcell))); }                 \
+    while (i_ > 0) { size_t p_ = (i_ - 1) / 2; if (!FN(kcell_gt)(&heap[p_], &c_)) break; heap[i_] = heap[p_]; i_ = p_; } \
+    heap[i_] = c_; } while (0)
+  for (int x = 0; x < w; x++) {                                              /* :508-515 */
+    ORC_PUSH(x, 0, dem[x]);
+    ORC_PUSH(x, h - 1, dem[(size_t)(h - 1) * w + x]);
+    dirs[x] = 3; dirs[(size_t)(h - 1) * w + x] = 7;
+    closed[x] = 1; closed[(size_t)(h - 1) * w + x] = 1;
+  }
+  for (int y = 1; y < h - 1; y++) {                                          /* :516-523 */
+    ORC_PUSH(0, y, dem[(size_t)y * w]);
+    ORC_PUSH(w - 1, y, dem[(size_t)y * w + w - 1]);
+    dirs[(size_t)y * w] = 1; dirs[(size_t)y * w + w - 1] = 5;
+    closed[(size_t)y * w] = 1; closed[(size_t)y * w + w - 1] = 1;
+  }
+  dirs[0] = 2; dirs[w - 1] = 4; dirs[(size_t)(h - 1) * w] = 8; dirs[(size_t)(h - 1) * w + w - 1] = 6;   /* :525-528 */
+  while (hn > 0) {                                                           /* :533-553 */
+    FN(kcell) c = heap[0], last = heap[--hn];
+    size_t i = 0;
+    for (;;) {
+      size_t l = 2 * i + 1, r = l + 1, m;
+      if (l >= hn) break;
+      m = (r < hn && FN(kcell_gt)(&heap[l], &heap[r])) ? r : l;
+      if (!FN(kcell_gt)(&last, &heap[m])) break;
+      heap[i] = heap[m];
+      i = m;
+    }
+    if (hn) heap[i] = last;
+    for (int no = 1; no <= 8; no++) {
+      int n = order[no], nx = c.x + D8X[n], ny = c.y + D8Y[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      closed[ni] = 1;
+      dirs[ni] = dem[ni] == nodata ? 0 : (uint8_t)inverse[n];               /* :545-548 */
+      ORC_PUSH(nx, ny, dem[ni]);
+    }
+  }
+#undef ORC_PUSH
+  free(heap); free(closed);
+}
+
+/* ------------------------------------------------------------------------- */
 /* the other outputs of the Priority-Flood sweep.               */
 /* Ties: the reference pops equal elevations in the order libstdc++'s         */
 /* std::priority_queue happens to hold them; this heap has its own order.  On */

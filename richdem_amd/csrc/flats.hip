@@ -2285,7 +2285,11 @@ RD_INST(int8_t) RD_INST(int64_t) RD_INST(uint64_t)
 using namespace rdgpu;
 
 #define RD_FLATS_API(SUF, T)                                                                                   \
+  extern "C" int rdgpu_flat_resolution_d8_multi_##SUF(const T *, T, int, int, uint8_t *, const int *, int);    \
   extern "C" int rdgpu_flat_resolution_d8_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs) {         \
+    const std::vector<int> devs = env_devices();   /* RDGPU_DEVICES: the node's GPUs, csrc/multi.hip */       \
+    if (devs.size() > 1 && h >= 2 * (int)devs.size())                                                          \
+      return rdgpu_flat_resolution_d8_multi_##SUF(dem, nodata, w, h, dirs, devs.data(), (int)devs.size());     \
     return guarded([&] { flat_resolution_host<T>(dem, nodata, w, h, dirs, nullptr, nullptr); });               \
   }                                                                                                            \
   extern "C" int rdgpu_resolve_flats_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs, int32_t *mask, \

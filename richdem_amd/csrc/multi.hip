@@ -179,9 +179,144 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// barnes_flat_resolution_d8(alter = false) of one raster over several devices.  The reference resolves flats on one
+// node only; the row-block protocol is this engine's own (flats.hip, "Row-block shards"): a block
+// holds its rows plus TWO ghost rows per cut, relaxes each level field to its local fixed point, the cut rows are
+// exchanged and the ghost rows lowered until no cut row changes any more (towards field first, then away), the deepest
+// away level per flat is agreed on through one small union-find over the cut rows (on devices[0]), and every block
+// writes the directions of its own rows.  Driver = richdem_amd/sharded.py::flat_exchange, here for the devices of one
+// process: the relaxations synchronise with their device per batch of rounds, hence a host thread per device.
+// ------------------------------------------------------------------------------------------------------------------
+#define RD_FS_BEGIN(SUF, T)                                                                                        \
+  static int fs_begin_typed(const T *d, T nd, int w, int rows, int gt, int gb, hipStream_t st, rdgpu_flat_shard **o) { \
+    return rdgpu_flat_shard_begin_##SUF(d, nd, w, rows, gt, gb, (void *)st, o);                                      \
+  }
+RD_FS_BEGIN(u8, uint8_t) RD_FS_BEGIN(i8, int8_t) RD_FS_BEGIN(i16, int16_t) RD_FS_BEGIN(u16, uint16_t) RD_FS_BEGIN(i32, int32_t)
+RD_FS_BEGIN(u32, uint32_t) RD_FS_BEGIN(f32, float) RD_FS_BEGIN(f64, double) RD_FS_BEGIN(i64, int64_t) RD_FS_BEGIN(u64, uint64_t)
+#undef RD_FS_BEGIN
+
+template <class T>
+static void flat_resolution_multi_host(const T *dem, T nodata, int w, int h, uint8_t *dirs, const int *devices, int ndev) {
+  if (!dem || !dirs || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_multi: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_multi: width and height must be positive");
+  if (ndev < 1 || (ndev > 1 && h / ndev < 2)) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_multi: need >= 2 rows per device");
+  int ndevices = 0;
+  RD_HIP(hipGetDeviceCount(&ndevices));
+  for (int s = 0; s < ndev; s++)
+    if (devices[s] < 0 || devices[s] >= ndevices) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8_multi: no such device");
+  const int S = ndev;
+  std::vector<int> r0(S + 1);
+  for (int s = 0; s <= S; s++) r0[s] = (int)((int64_t)h * s / S);
+  std::vector<rdgpu_flat_shard *> sh(S, nullptr);
+  std::vector<T *> d_ext(S, nullptr);
+  std::vector<int32_t> cut((size_t)S * 2 * w), prev, heights((size_t)S * 8 * w), solved((size_t)S * 4 * w);
+  int home = 0;
+  RD_HIP(hipGetDevice(&home));
+  auto cleanup = [&]() noexcept {
+    for (int s = 0; s < S; s++) {
+      if (!sh[s] || hipSetDevice(devices[s]) != hipSuccess) continue;
+      rdgpu_flat_shard_free(sh[s]);
+      sh[s] = nullptr;
+    }
+    (void)hipSetDevice(home);
+  };
+  auto name = [](const char *what, int s) { return std::string("multi.") + what + "." + std::to_string(s); };
+  try {
+    per_device(devices, S, [&](int, const std::vector<int> &mine) {
+      Workspace &ws = Workspace::get();
+      for (int s : mine) {   // own rows + two ghost rows per cut: contiguous in the caller's raster
+        const int gt = s > 0 ? 2 : 0, gb = s + 1 < S ? 2 : 0, rows = r0[s + 1] - r0[s] + gt + gb;
+        d_ext[s] = ws.buf<T>(name("dem", s).c_str(), (size_t)rows * w);
+        RD_HIP(hipMemcpy(d_ext[s], dem + (size_t)(r0[s] - gt) * w, (size_t)rows * w * sizeof(T), hipMemcpyHostToDevice));
+        const int rc = fs_begin_typed(d_ext[s], nodata, w, rows, gt, gb, nullptr, &sh[s]);
+        if (rc) throw Error(rc, rdgpu_last_error());
+      }
+    });
+    for (int phase = 0; phase < 2; phase++) {   // towards the low edges first: it also tells which flats have an outlet
+      prev.clear();
+      for (;;) {
+        per_device(devices, S, [&](int, const std::vector<int> &mine) {
+          Workspace &ws = Workspace::get();
+          for (int s : mine) {
+            int rc = rdgpu_flat_shard_relax(sh[s], phase);
+            if (rc) throw Error(rc, rdgpu_last_error());
+            int32_t *d_b = ws.buf<int32_t>(name("cut", s).c_str(), (size_t)2 * w);
+            rc = rdgpu_flat_shard_boundary(sh[s], phase, d_b);
+            if (rc) throw Error(rc, rdgpu_last_error());
+            RD_HIP(hipStreamSynchronize(nullptr));
+            RD_HIP(hipMemcpy(&cut[(size_t)s * 2 * w], d_b, (size_t)2 * w * 4, hipMemcpyDeviceToHost));
+          }
+        });
+        if (!prev.empty() && prev == cut) break;   // no cut row changed anywhere: the field is final
+        per_device(devices, S, [&](int, const std::vector<int> &mine) {
+          Workspace &ws = Workspace::get();
+          for (int s : mine) {
+            int32_t *d_in = ws.buf<int32_t>(name("cutin", s).c_str(), (size_t)2 * w);
+            // the last own row of the block above, the first own row of the block below
+            if (s > 0) RD_HIP(hipMemcpy(d_in, &cut[((size_t)(s - 1) * 2 + 1) * w], (size_t)w * 4, hipMemcpyHostToDevice));
+            if (s + 1 < S) RD_HIP(hipMemcpy(d_in + w, &cut[((size_t)(s + 1) * 2) * w], (size_t)w * 4, hipMemcpyHostToDevice));
+            const int rc = rdgpu_flat_shard_inject(sh[s], phase, s > 0 ? d_in : nullptr, s + 1 < S ? d_in + w : nullptr);
+            if (rc) throw Error(rc, rdgpu_last_error());
+          }
+        });
+        prev = cut;
+      }
+    }
+    per_device(devices, S, [&](int, const std::vector<int> &mine) {
+      Workspace &ws = Workspace::get();
+      for (int s : mine) {
+        int32_t *d_h = ws.buf<int32_t>(name("heights", s).c_str(), (size_t)8 * w);
+        const int rc = rdgpu_flat_shard_heights(sh[s], d_h);
+        if (rc) throw Error(rc, rdgpu_last_error());
+        RD_HIP(hipStreamSynchronize(nullptr));
+        RD_HIP(hipMemcpy(&heights[(size_t)s * 8 * w], d_h, (size_t)8 * w * 4, hipMemcpyDeviceToHost));
+      }
+    });
+    {
+      DeviceGuard g(devices[0]);
+      Workspace &ws = Workspace::get();
+      int32_t *d_g = ws.buf<int32_t>("multi.heights_all", heights.size()), *d_o = ws.buf<int32_t>("multi.solved_all", solved.size());
+      RD_HIP(hipMemcpy(d_g, heights.data(), heights.size() * 4, hipMemcpyHostToDevice));
+      const int rc = rdgpu_flat_graph_solve_dev(d_g, S, w, d_o, nullptr);
+      if (rc) throw Error(rc, rdgpu_last_error());
+      RD_HIP(hipStreamSynchronize(nullptr));
+      RD_HIP(hipMemcpy(solved.data(), d_o, solved.size() * 4, hipMemcpyDeviceToHost));
+    }
+    per_device(devices, S, [&](int, const std::vector<int> &mine) {
+      Workspace &ws = Workspace::get();
+      for (int s : mine) {
+        const int rows = r0[s + 1] - r0[s];
+        int32_t *d_s = ws.buf<int32_t>(name("solved", s).c_str(), (size_t)4 * w);
+        uint8_t *d_d = ws.buf<uint8_t>(name("dirs", s).c_str(), (size_t)rows * w);
+        RD_HIP(hipMemcpy(d_s, &solved[(size_t)s * 4 * w], (size_t)4 * w * 4, hipMemcpyHostToDevice));
+        const int rc = rdgpu_flat_shard_finish(sh[s], d_s, d_d);   // (does not release the handle)
+        if (rc) throw Error(rc, rdgpu_last_error());
+        RD_HIP(hipStreamSynchronize(nullptr));
+        RD_HIP(hipMemcpy(dirs + (size_t)r0[s] * w, d_d, (size_t)rows * w, hipMemcpyDeviceToHost));
+        rdgpu_flat_shard_free(sh[s]);
+        sh[s] = nullptr;
+      }
+    });
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
 }  // namespace rdgpu
 
 using namespace rdgpu;
+
+#define RD_FLATS_MULTI_API(SUF, T)                                                                              \
+  extern "C" int rdgpu_flat_resolution_d8_multi_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs,      \
+                                                      const int *devices, int ndev) {                           \
+    return unlocked([&] { flat_resolution_multi_host<T>(dem, nodata, w, h, dirs, devices, ndev); });            \
+  }
+RD_FLATS_MULTI_API(u8, uint8_t) RD_FLATS_MULTI_API(i8, int8_t) RD_FLATS_MULTI_API(i16, int16_t) RD_FLATS_MULTI_API(u16, uint16_t)
+RD_FLATS_MULTI_API(i32, int32_t) RD_FLATS_MULTI_API(u32, uint32_t) RD_FLATS_MULTI_API(f32, float) RD_FLATS_MULTI_API(f64, double)
+RD_FLATS_MULTI_API(i64, int64_t) RD_FLATS_MULTI_API(u64, uint64_t)
 
 #define RD_ACCUM_MULTI_API(SUF, A)                                                                              \
   extern "C" int rdgpu_d8_flow_accum_multi_##SUF(const uint8_t *dirs, uint8_t nodata, int w, int h, A *area,    \

@@ -107,3 +107,36 @@ def test_errors(rd):
         sh.begin(torch.zeros((4, 8), dtype=torch.float32, device="cuda"), -1.0, 1, 0)
     with pytest.raises(rd.RdgpuError):
         sh.begin(torch.zeros((4, 8), dtype=torch.float32, device="cuda"), -1.0, 2, 2)
+
+
+def test_multi_device_flat_resolution_entry_on_one_gpu(rd, orc, monkeypatch):
+    """rdgpu_flat_resolution_d8_multi_<T> (one process, a list of devices): with device 0 listed several times the row
+    blocks go through exactly the multi-device code -- a worker thread per device, two ghost rows per cut, the cut-row
+    exchanges through the host, the flat-height solve on devices[0] -- and the directions equal the single-device call
+    (and the oracle) on every cell; RDGPU_DEVICES routes the plain host entry the same way."""
+    import ctypes
+
+    from richdem_amd._lib import check, lib
+    from richdem_amd.synth import fractal_dem_int
+
+    z = orc.port.fill(fractal_dem_int(420, 380, 55, 0.05).astype(np.float32))      # big flats that cross every cut
+    exp = orc.port.flat_resolution(z, np.float32(-9999))
+    h, w = z.shape
+    for devs in ([0], [0, 0], [0] * 5, [0] * 16):
+        out = np.empty((h, w), np.uint8)
+        arr = (ctypes.c_int * len(devs))(*devs)
+        check(lib().rdgpu_flat_resolution_d8_multi_f32(z.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(-9999), w, h,
+                                                       out.ctypes.data_as(ctypes.c_void_p), arr, len(devs)), "multi")
+        assert np.array_equal(out, exp), len(devs)
+    q = z.astype(np.int32)
+    out = np.empty((h, w), np.uint8)
+    arr = (ctypes.c_int * 3)(0, 0, 0)
+    check(lib().rdgpu_flat_resolution_d8_multi_i32(q.ctypes.data_as(ctypes.c_void_p), ctypes.c_int32(-9999), w, h,
+                                                   out.ctypes.data_as(ctypes.c_void_p), arr, 3), "multi")
+    assert np.array_equal(out, orc.port.flat_resolution(q, np.int32(-9999)))
+    monkeypatch.setenv("RDGPU_DEVICES", "0,0,0,0")
+    assert np.array_equal(rd.barnes_flat_resolution_d8(z, np.float32(-9999)), exp)
+    monkeypatch.delenv("RDGPU_DEVICES")
+    arr = (ctypes.c_int * 2)(0, 99)
+    assert lib().rdgpu_flat_resolution_d8_multi_f32(z.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(-9999), w, h,
+                                                    out.ctypes.data_as(ctypes.c_void_p), arr, 2) != 0
