@@ -768,7 +768,11 @@ __device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
   return imin(v, lane < 16 ? r1 : lane < 32 ? r2 : lane < 48 ? r3 : I);
 }
 
-template <int SEED_LEVEL>
+// visit statistics of the STATS instantiation (RDGPU_FLAT_TRACE): [0] visits, [1] left at once (nothing new reaches the
+// tile), [2] open-water visits, [3] general visits, [4] BFS levels stepped, [5] flushes, [6] rows flushed
+__device__ unsigned long long g_relax_stats[8];
+
+template <int SEED_LEVEL, bool STATS = false>
 __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
                                                      uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
@@ -846,6 +850,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     level = imin(level, SEED_LEVEL + 1);
     if (lane == 0) expanded[t] = 1;
   }
+  if (STATS && lane == 0) { atomicAdd(&g_relax_stats[0], 1ull); if (level >= DINF) atomicAdd(&g_relax_stats[1], 1ull); }
   if (level >= DINF) return;   // nothing new reaches this tile
   // OPEN WATER: every cell of the tile takes part, so the levels are chessboard distances from the ring (and from what the
   // tile holds already) and two chamfer sweeps give the fixed point exactly: once the ring has entered through the
@@ -885,6 +890,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
         orow[y * BT + lane] = (uint16_t)(d >= DINF || rel > 0xFFFE ? 0xFFFF : rel);
       }
     }
+    if (STATS && lane == 0 && __all(fits)) atomicAdd(&g_relax_stats[2], 1ull);
     if (__all(fits)) {
       // up: from SW, S, SE, then from E along the row; the finished row goes straight to memory
       int32_t nxt = DINF;
@@ -910,6 +916,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     }
   }
   if (!open) {
+  if (STATS && lane == 0) atomicAdd(&g_relax_stats[3], 1ull);
   unsigned long long A, F, Rec = 0;
   {
     unsigned long long reached = 0, front = 0;
@@ -937,6 +944,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   auto flush = [&]() {
     const int np = 32 - __clz(relmax | 1);
     unsigned long long rows = __ballot(Rec != 0);
+    if (STATS && lane == 0) { atomicAdd(&g_relax_stats[5], 1ull); atomicAdd(&g_relax_stats[6], (unsigned long long)__popcll(rows)); }
     while (rows) {
       const int r = __ffsll((long long)rows) - 1;
       rows &= rows - 1;
@@ -997,6 +1005,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     }
     nlo &= (uint32_t)A; nhi &= (uint32_t)(A >> 32);
     const unsigned long long N = ((unsigned long long)nhi << 32) | nlo;
+    if (STATS && lane == 0) atomicAdd(&g_relax_stats[4], 1ull);
     if (__any(N != 0)) {
       const int32_t rel = level - base;
       relmax = rel;
@@ -1476,15 +1485,26 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
     for (int k = 0; k < BITS_BATCH; k++) {
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
-      RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
-                b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
-                b.tilesX, b.tilesY);
+      if (trace)
+        RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL, true>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
+                  b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
+                  b.tilesX, b.tilesY);
+      else
+        RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
+                  b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
+                  b.tilesX, b.tilesY);
     }
     RD_HIP(hipMemcpyAsync(hw, b.ctr, BITS_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     uint32_t most = 0;
     for (int k = 0; k < BITS_BATCH; k++) {
       if (trace) fprintf(stderr, "%s round %u nact %u (grid %u)\n", name, rounds, hw[k], grid);
+      if (hw[k] == 0 && trace) {
+        unsigned long long st[8];
+        RD_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_relax_stats), sizeof st));
+        fprintf(stderr, "%s stats (cumulative): visits %llu, left at once %llu, open-water %llu, general %llu, levels stepped %llu, "
+                        "flushes %llu, rows flushed %llu\n", name, st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+      }
       if (hw[k] == 0) return rounds;
       most = std::max(most, hw[k]);
       rounds++;

@@ -266,11 +266,23 @@ int main() {
     bool threw = false;
     try { rdgpu::PriorityFloodEpsilon_Barnes2014<Topo::D8>(d); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
-    Arr<int64_t> e(8, 8, 1);
+    // 64-bit element types run on dense value ranks (csrc/fill64.hip): pit_mask, max_dep, watersheds as well as the fill
+    Arr<int64_t> e(8, 8, (int64_t)1 << 40);
+    e(3, 3) = -((int64_t)1 << 41);
+    e(3, 4) = 5;
     Arr<uint8_t> m;
-    threw = false;
-    try { rdgpu::pit_mask<Topo::D8>(e, m); } catch (const std::runtime_error &) { threw = true; }
-    EXPECT(threw);
+    rdgpu::pit_mask<Topo::D8>(e, m);
+    EXPECT(m(3, 3) == 1 && m(3, 4) == 1 && m(0, 0) == 0 && m(2, 2) == 0);
+    rdgpu::PriorityFlood_Barnes2014_max_dep<Topo::D8>(e, 1);      // the pit has two cells: left alone
+    EXPECT(e(3, 3) == -((int64_t)1 << 41));
+    rdgpu::PriorityFlood_Barnes2014_max_dep<Topo::D8>(e, 2);
+    EXPECT(e(3, 3) == ((int64_t)1 << 40) && e(3, 4) == ((int64_t)1 << 40));
+    // barnes_flat_resolution_d8(alter = true) on an integer DEM: the reference's towards-zero steps (flat_resolution.hpp:567)
+    Arr<int32_t> fl(9, 9, 50);
+    for (int x = 0; x < 9; x++) fl(x, 8) = 10;                    // the flat drains over its lower edge
+    Arr<uint8_t> fd;
+    rdgpu::barnes_flat_resolution_d8(fl, fd, true);
+    EXPECT(fl(4, 4) < 50 && fl(4, 1) < 50 && fd(4, 4) != 0);
   }
   // the other outputs of the sweep through the shim: epsilon fill, bounded depressions, watershed labels
   {
