@@ -550,12 +550,15 @@ __device__ __forceinline__ void pair_spill(const EdgeOut &eo, unsigned long long
   }
 }
 
-template <class T, int TOPO, bool FIRST, bool VEC, bool EMIT>
+// L16 (the compact-label fill below): `lab` holds 16-bit slots (the cell's root within its 64 x 64 descent tile), a cell's
+// component is cur[tile_base[its tile] + slot] -- cur is then the node table curN --, and FIRST is not used.
+template <class T, int TOPO, bool FIRST, bool VEC, bool EMIT, bool L16 = false>
 __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                const uint32_t *__restrict__ cur, unsigned long long *best,
                                                int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
                                                const uint32_t *__restrict__ tiles_in, uint32_t nwork,
-                                               uint8_t *alive_out, EdgeOut eo) {
+                                               uint8_t *alive_out, EdgeOut eo,
+                                               const uint32_t *__restrict__ tile_base = nullptr, uint32_t dtx = 0) {
   __shared__ __attribute__((aligned(8))) uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   // The component table: in the pair pass it is only needed AFTER the pairs are reduced, when the keys are dead, so it
@@ -593,7 +596,23 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     constexpr int QPT = (NQ + NTHR - 1) / NTHR;       // per thread
     Quad<T> zq[QPT];   // four cells per load: 16 / 8 / 4 bytes for 4- / 2- / 1-byte elevations
     Quad<uint32_t> lq[QPT];
+    uint32_t tb[L16 ? QPT : 1];   // L16: node base of the descent tile the quad lies in
     bool ok[QPT];
+    const uint16_t *lab16 = reinterpret_cast<const uint16_t *>(lab);
+    uint32_t tbU = 0, tbC = 0, tbD = 0, tbL[3] = {0, 0, 0}, tbR[3] = {0, 0, 0};
+    if (L16) {
+      static_assert(TW == DW && DH % TH == 0, "a scan tile lies inside one descent tile");
+      const int dcol = x0 / DW, rU = max(y0 - 1, 0) / DH, rC = y0 / DH, rD = min(y0 + TH, h - 1) / DH;
+      const int rows3[3] = {rU, rC, rD};
+      tbU = tile_base[(uint32_t)rU * dtx + (uint32_t)dcol];
+      tbC = tile_base[(uint32_t)rC * dtx + (uint32_t)dcol];
+      tbD = tile_base[(uint32_t)rD * dtx + (uint32_t)dcol];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        tbL[k] = tile_base[(uint32_t)rows3[k] * dtx + (uint32_t)max(dcol - 1, 0)];
+        tbR[k] = tile_base[(uint32_t)rows3[k] * dtx + min((uint32_t)dcol + 1u, dtx - 1u)];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
       const int i = threadIdx.x + r * NTHR;
@@ -602,8 +621,19 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
       ok[r] = i < NQ && gy >= 0 && gy < h && gx < w;
       if (ok[r]) {
         const size_t g = (size_t)gy * w + gx;
-        zq[r] = load_quad<T, VEC>(z + (g - gx), gx, w, T());
-        lq[r] = load_quad<uint32_t, VEC>(lab + (g - gx), gx, w, B);   // past the row end: the outside's label
+        if (L16) {
+          // (the labels first, the elevations in a loop of their own below: loads return in order, and the component
+          // gathers only wait for the labels -- the elevation loads are still in flight behind them)
+          const Quad<uint16_t> sq = load_quad<uint16_t, VEC>(lab16 + (g - gx), gx, w, (uint16_t)0);
+#pragma unroll
+          for (int e = 0; e < 4; e++) lq[r].v[e] = sq.v[e];
+          // node base of the quad's descent tile: the scan tile lies inside ONE descent tile (TW == DW, TH divides DH),
+          // only its halo rows may belong to the tile above / below -- three block-uniform (scalar) loads
+          tb[r] = ly == 0 ? tbU : ly == LH - 1 ? tbD : tbC;
+        } else {
+          zq[r] = load_quad<T, VEC>(z + (g - gx), gx, w, T());
+          lq[r] = load_quad<uint32_t, VEC>(lab + (g - gx), gx, w, B);   // past the row end: the outside's label
+        }
       }
     }
     // halo columns: one cell per thread for the first 2 * LH threads
@@ -611,23 +641,53 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
     const int hly = threadIdx.x >> 1, hlx = (threadIdx.x & 1) ? LW - 1 : 0;
     bool hok = false;
     T hz = T();
-    uint32_t hl = 0;
+    uint32_t hl = 0, htb = 0;
     if (hcell) {
       const int gx = x0 - 1 + hlx, gy = y0 - 1 + hly;
       hok = gx >= 0 && gx < w && gy >= 0 && gy < h;
-      if (hok) { hz = z[(size_t)gy * w + gx]; hl = lab[(size_t)gy * w + gx]; }
+      if (hok) {
+        if (L16) {
+          hl = lab16[(size_t)gy * w + gx];
+          const int k = hly == 0 ? 0 : hly == LH - 1 ? 2 : 1;
+          htb = (threadIdx.x & 1) ? (k == 0 ? tbR[0] : k == 1 ? tbR[1] : tbR[2]) : (k == 0 ? tbL[0] : k == 1 ? tbL[1] : tbL[2]);
+        } else {
+          hl = lab[(size_t)gy * w + gx];
+        }
+        hz = z[(size_t)gy * w + gx];
+      }
+    }
+    if (L16) {
+#pragma unroll
+      for (int r = 0; r < QPT; r++) {
+        const int i = threadIdx.x + r * NTHR;
+        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+        const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
+        if (ok[r]) zq[r] = load_quad<T, VEC>(z + (size_t)gy * w, gx, w, T());
+      }
     }
     uint32_t cq[QPT][4];
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
       // branch-free: an absent quad reads the outside's entry (label B: cur[B] == B | CLOSED), so all gathers of
       // the thread are in flight together
-      const uint32_t l[4] = {ok[r] ? lq[r].v[0] : B, ok[r] ? lq[r].v[1] : B, ok[r] ? lq[r].v[2] : B, ok[r] ? lq[r].v[3] : B};
+      if (L16) {
+        const int q4 = 4 * ((threadIdx.x + r * NTHR) % (TW / 4));
 #pragma unroll
-      for (int e = 0; e < 4; e++) cq[r][e] = RD_COMP(l[e]);
+        for (int e = 0; e < 4; e++) {   // (absent cells and cells past the row end: node 0 is read, the outside is taken)
+          const bool in = ok[r] && x0 + q4 + e < w;
+          const uint32_t c = cur[in ? tb[r] + lq[r].v[e] : 0u];
+          cq[r][e] = in ? c : (B | CLOSED);
+        }
+      } else {
+        const uint32_t l[4] = {ok[r] ? lq[r].v[0] : B, ok[r] ? lq[r].v[1] : B, ok[r] ? lq[r].v[2] : B, ok[r] ? lq[r].v[3] : B};
+#pragma unroll
+        for (int e = 0; e < 4; e++) cq[r][e] = RD_COMP(l[e]);
+      }
     }
     const uint32_t hlsafe = hok ? hl : B;
-    const uint32_t hc = RD_COMP(hlsafe);
+    uint32_t hc;
+    if (L16) { const uint32_t c = cur[hok ? htb + hl : 0u]; hc = hok ? c : (B | CLOSED); }
+    else hc = RD_COMP(hlsafe);
 #pragma unroll
     for (int r = 0; r < QPT; r++) {
       const int i = threadIdx.x + r * NTHR;
@@ -1428,7 +1488,8 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
             h, B, tilesX, ntiles, (const uint32_t *)(LIST), (uint32_t)(NWORK), alive, eo)
 #define RD_SCAN_V(FIRST_, EMIT_, LIST, NWORK)                                                                    \
   { if (vec) RD_SCAN(FIRST_, true, EMIT_, LIST, NWORK); else RD_SCAN(FIRST_, false, EMIT_, LIST, NWORK); }
-      if (first && !sharded) { if (emit) RD_SCAN_V(true, true, nullptr, ntiles) else RD_SCAN_V(true, false, nullptr, ntiles) }
+      const char *env_first = getenv("RDGPU_FILL_FIRST");   // =0: the pair pass gathers cur[label] like a shard's (A/B probe)
+      if (first && !sharded && !(env_first && env_first[0] == '0')) { if (emit) RD_SCAN_V(true, true, nullptr, ntiles) else RD_SCAN_V(true, false, nullptr, ntiles) }
       else if (first) { if (emit) RD_SCAN_V(false, true, nullptr, ntiles) else RD_SCAN_V(false, false, nullptr, ntiles) }
       else RD_SCAN_V(false, false, tlist, nlive)
 #undef RD_SCAN_V
@@ -1774,9 +1835,442 @@ static void fill_max_dep_host(T *dem, int w, int h, int topology, uint64_t max_d
   RD_HIP(hipMemcpy(dem, d, bytes, hipMemcpyDeviceToHost));
 }
 
+// ==========================================================================================================
+// The compact-label fill (r03): 16-bit labels, no label pass over the raster.
+//
+// The classic path above reads the raster four times (descent, labels, pair pass, finalize: 4.8 x the algorithmic bytes
+// at S3) and moves a 32-bit label per cell through three of them.  Here
+//   k_descent16      descent pointers and in-tile path compression as k_descent; then every ROOT of the tile -- a pit, a
+//                    cell draining off the raster, a cell whose descent neighbour lies outside the tile -- becomes a
+//                    NODE: local slot 0.., global id tile_base + slot, G[node] = basin id | PEND | first cell outside
+//                    the tile | OUTP.  A cell's label is the SLOT of its root: 2 bytes per cell (lab16).
+//   k_resolve_nodes  node -> basin (curN): a pending node follows lab16 / G from tile to tile.  A table pass over ~2 % of
+//                    the cell count replaces k_tile_label's raster pass (10.7 GB at S3).
+//   k_scan<L16>      the one pair pass, reading z + lab16 (6 B / cell) and gathering the components from curN.
+//   rounds           unchanged (pair list).
+//   k_finalize16     z <- max(z, level of the cell's node): z + lab16 and the tile's node levels from LDS.
+// (Tried first and dropped: the pairs in the descent kernel itself, on slots, with the pairs across tile edges from edge
+// strips -- correct, but slot boundaries are several times as many as basin boundaries, since every exit of a tile is a
+// slot of its own until it is resolved: 22 ms for the kernel, 80 M records; profiles/r03h_fill_fused_ab.json.)
+// Anything the scheme cannot hold (more nodes or records than the buffers) raises a flag and the classic path runs.
+// Row-block shards, pit_mask, max_dep and the watershed code keep the classic path (they consume 32-bit labels).
+// ==========================================================================================================
+struct FusedBuf {
+  uint16_t *lab16;                 // [cells] slot of the cell's root within its descent tile
+  uint32_t *G;                     // [gcap] node table
+  uint32_t *tile_base, *tile_count;   // [descent tiles]
+  unsigned long long *counters;    // [0] (nodes << 32) | pits
+  uint32_t gcap;
+  uint32_t *overflow;
+};
+
+template <class T, int TOPO, bool VEC>
+__global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
+                                                    uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint32_t sk[DLH * DLW];
+  __shared__ uint16_t lp[DH * DW];
+  __shared__ uint32_t wtot[NTHR / 64];
+  __shared__ uint32_t pbase, rbase, nroots_s;
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
+  {
+    constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
+    Quad<T> zq[QPT];
+    bool okq[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
+      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+      const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
+      okq[r] = i < NQ && gy >= 0 && gy < h && gx < w;
+      if (okq[r]) zq[r] = load_quad<T, VEC>(z + (size_t)gy * w, gx, w, T());
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = threadIdx.x + r * NTHR;
+      if (i >= NQ) continue;
+      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+      const int o = ly * DLW + 1 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; e++) sk[o + e] = (okq[r] && x0 + 4 * q + e < w) ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
+    }
+    for (int i = threadIdx.x; i < 2 * DLH; i += NTHR) {   // halo columns
+      const int ly = i >> 1, lxh = (i & 1) ? DLW - 1 : 0;
+      const int gx = x0 - 1 + lxh, gy = y0 - 1 + ly;
+      uint32_t kk = 0xFFFFFFFFu;
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) kk = Key32<T>::to(z[(size_t)gy * w + gx]);
+      sk[ly * DLW + lxh] = kk;
+    }
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (DW - 1), ly0 = (threadIdx.x >> 6) * (DH / 4);
+  const int gx = x0 + lx;
+  {   // descent pointers: k_descent's loop (no cut rows here)
+    uint32_t k0[3], k1[3], k2[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) { k0[e] = sk[ly0 * DLW + lx + e]; k1[e] = sk[(ly0 + 1) * DLW + lx + e]; }
+#pragma unroll 4
+    for (int j = 0; j < DH / 4; j++) {
+      const int ly = ly0 + j, gy = y0 + ly;
+#pragma unroll
+      for (int e = 0; e < 3; e++) k2[e] = sk[(ly + 2) * DLW + lx + e];
+#define RD_Q(n) ((n) | (((n) / 3) << 4) | (((n) % 3) << 6))
+      const uint32_t kc = k1[1];
+      uint32_t bk, q;
+      if (TOPO == 8) {
+        bk = k0[0]; q = RD_Q(0);
+        { const bool t_ = k0[1] < bk; bk = t_ ? k0[1] : bk; q = t_ ? RD_Q(1) : q; }
+        { const bool t_ = k0[2] < bk; bk = t_ ? k0[2] : bk; q = t_ ? RD_Q(2) : q; }
+        { const bool t_ = k1[0] < bk; bk = t_ ? k1[0] : bk; q = t_ ? RD_Q(3) : q; }
+        { const bool t_ = k1[2] < bk; bk = t_ ? k1[2] : bk; q = t_ ? RD_Q(5) : q; }
+        { const bool t_ = k2[0] < bk; bk = t_ ? k2[0] : bk; q = t_ ? RD_Q(6) : q; }
+        { const bool t_ = k2[1] < bk; bk = t_ ? k2[1] : bk; q = t_ ? RD_Q(7) : q; }
+        { const bool t_ = k2[2] < bk; bk = t_ ? k2[2] : bk; q = t_ ? RD_Q(8) : q; }
+      } else {
+        bk = k0[1]; q = RD_Q(1);
+        { const bool t_ = k1[0] < bk; bk = t_ ? k1[0] : bk; q = t_ ? RD_Q(3) : q; }
+        { const bool t_ = k1[2] < bk; bk = t_ ? k1[2] : bk; q = t_ ? RD_Q(5) : q; }
+        { const bool t_ = k2[1] < bk; bk = t_ ? k2[1] : bk; q = t_ ? RD_Q(7) : q; }
+      }
+#undef RD_Q
+      const int n = (int)(q & 15u);
+      const bool drains = (bk < kc) | ((bk == kc) & (n < 4));
+      const int tx = lx + (int)(q >> 6 & 3u) - 1, ty = ly + (int)(q >> 4 & 3u) - 1;
+      const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
+      const uint16_t ldrain = inside ? (uint16_t)(ty * DW + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
+      const bool incell = (gx < w) & (gy < h);
+      const bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
+      const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : !drains ? LTERM_BASE : ldrain;
+      lp[ly * DW + lx] = l;
+#pragma unroll
+      for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
+    }
+  }
+  __syncthreads();
+  {   // pointer jumping inside the tile (k_descent's loop)
+    uint32_t act = 0;
+#pragma unroll
+    for (int j = 0; j < DH / 4; j++) act |= (lp[(ly0 + j) * DW + lx] < LTERM_BASE ? 1u : 0u) << j;
+    for (int it = 0; it < 12; it++) {
+      int still = 0;
+#pragma unroll
+      for (int g = 0; g < DH / 16; g++) {
+        if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
+        uint16_t pv[4], qv[4], rv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+        for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LTERM_BASE ? pv[e] : (ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+        for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LTERM_BASE ? qv[e] : (ly0 + 4 * g + e) * DW + lx];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int j = 4 * g + e;
+          if (pv[e] < LTERM_BASE && qv[e] < LTERM_BASE) {
+            const bool more = rv[e] < LTERM_BASE;
+            lp[(ly0 + j) * DW + lx] = more ? rv[e] : qv[e];
+            if (more) still = 1;
+            else act &= ~(1u << j);
+          } else {
+            act &= ~(1u << j);
+          }
+        }
+      }
+      if (!__syncthreads_or(still)) break;
+    }
+  }
+  __syncthreads();
+  // ---- nodes: every root of the tile gets a local slot; pits a dense basin id --------------------------------------
+  uint32_t rootmask = 0, pitmask = 0;
+#pragma unroll
+  for (int j = 0; j < DH / 4; j++) {
+    const int gy = y0 + ly0 + j;
+    const uint16_t v = lp[(ly0 + j) * DW + lx];
+    const bool root = (gx < w) & (gy < h) & (v >= LTERM_BASE);
+    rootmask |= (root ? 1u : 0u) << j;
+    pitmask |= ((root & ((v & 15u) == 0u)) ? 1u : 0u) << j;
+  }
+  const uint32_t mine = ((uint32_t)__popc(rootmask) << 16) | (uint32_t)__popc(pitmask);   // (<= 1024 each per wavefront)
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if ((threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t nr = (wtot[0] >> 16) + (wtot[1] >> 16) + (wtot[2] >> 16) + (wtot[3] >> 16);
+    const uint32_t np = (wtot[0] & 0xFFFFu) + (wtot[1] & 0xFFFFu) + (wtot[2] & 0xFFFFu) + (wtot[3] & 0xFFFFu);
+    const unsigned long long old = atomicAdd(fo.counters, ((unsigned long long)nr << 32) | np);
+    pbase = (uint32_t)old;
+    rbase = (uint32_t)(old >> 32);
+    nroots_s = nr;
+    fo.tile_base[t] = rbase;
+    fo.tile_count[t] = nr;
+    if ((unsigned long long)rbase + nr > fo.gcap) *fo.overflow = 1;
+  }
+  __syncthreads();
+  const uint32_t nodes0 = rbase;
+  const bool gfits = (unsigned long long)nodes0 + nroots_s <= fo.gcap;
+  constexpr uint16_t ROOT_TAG = 0xC000u;   // a numbered root's entry: ROOT_TAG | slot (pointers are < 4096, codes >= LTERM_BASE)
+  {
+    uint32_t pre = incl - mine;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) pre += wtot[k];
+    uint32_t slot = pre >> 16, pit = pbase + (pre & 0xFFFFu);
+    for (uint32_t m = rootmask; m; m &= m - 1) {
+      const int j = __ffs((int)m) - 1;
+      const int ly = ly0 + j;
+      const int code = lp[ly * DW + lx] & 15;
+      const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour (codes 1..8)
+      const int nr = n >= 6 ? 2 : n >= 3 ? 1 : 0, nc = n - 3 * nr;
+      const uint32_t pend = LAB_PEND | ((uint32_t)(y0 + ly + nr - 1) * (uint32_t)w + (uint32_t)(x0 + lx + nc - 1));
+      const uint32_t word = code == 0 ? pit++ : code == 9 ? OUTP : pend;
+      if (gfits) fo.G[nodes0 + slot] = word;
+      lp[ly * DW + lx] = (uint16_t)(ROOT_TAG | slot);
+      slot++;
+    }
+  }
+  __syncthreads();
+  // a cell's label: the slot of its root (its own when it is one)
+#pragma unroll 4
+  for (int j = 0; j < DH / 4; j++) {
+    const int ly = ly0 + j, gy = y0 + ly;
+    const uint16_t v = lp[ly * DW + lx];
+    const uint16_t rv = lp[v < (uint16_t)(DW * DH) ? v : ly * DW + lx];
+    if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = (uint16_t)(rv & 0x0FFFu);
+  }
+}
+
+// node -> its basin as a component id: curN[n] = basin, or B | CLOSED for the outside.  A pending node names the first
+// cell outside its tile on the path: that cell's node is looked up through lab16 and the tile bases, and so on from
+// tile to tile.  Resolved words are written back into G (any value ever stored there is valid: concurrent chasers and
+// stale reads are harmless), so long chains are shared.
+__global__ __launch_bounds__(NTHR) void k_resolve_nodes(uint32_t *G, uint32_t nnodes, const uint16_t *__restrict__ lab16,
+                                                        const uint32_t *__restrict__ tile_base, int w, uint32_t tilesX,
+                                                        uint32_t B, uint32_t *curN, uint32_t *flag) {
+  const uint32_t n = blockIdx.x * NTHR + threadIdx.x;
+  if (n >= nnodes) return;
+  uint32_t v = G[n];
+  int hops = 0;
+  while ((v & LAB_PEND) && v != OUTP) {
+    const uint32_t cell = v & ~LAB_PEND;
+    const uint32_t cx = cell % (uint32_t)w, cy = cell / (uint32_t)w;
+    const uint32_t node = tile_base[(cy / DH) * tilesX + cx / DW] + lab16[cell];
+    v = __hip_atomic_load(&G[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++hops > (1 << 22)) { *flag = 1; break; }   // (cannot happen: descent paths are loop free)
+  }
+  if (hops) __hip_atomic_store(&G[n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  curN[n] = v == OUTP ? (B | CLOSED) : v;
+}
+
+// level of every node: the final level of its basin (0 for the outside: never above a key that matters)
+__global__ __launch_bounds__(NTHR) void k_node_levels(const uint32_t *__restrict__ curN, const uint32_t *__restrict__ acc,
+                                                      uint32_t nnodes, uint32_t *lvl) {
+  const uint32_t n = blockIdx.x * NTHR + threadIdx.x;
+  if (n < nnodes) lvl[n] = acc[curN[n] & ~CLOSED];
+}
+
+// z <- max(z, level of the cell's node).  One block per descent tile: its node levels (<= 4096) in LDS, then z and the
+// 16-bit labels in quads; a quad is written back only when one of its cells is raised.
+template <class T, bool VEC>
+__global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__restrict__ lab16, const uint32_t *__restrict__ lvl,
+                                                     const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_count,
+                                                     int w, int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint32_t sl[DH * DW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
+  const int qx = threadIdx.x & 15, ry = threadIdx.x >> 4;   // 16 quads per row, rows ry, ry + 16, ry + 32, ry + 48
+  const int gx = x0 + 4 * qx;
+  // the thread's quads first (in flight while the node levels arrive), then the tile's levels into LDS
+  Quad<T> zqs[DH / 16];
+  Quad<uint16_t> lqs[DH / 16];
+#pragma unroll
+  for (int r = 0; r < DH / 16; r++) {
+    const int gy = y0 + ry + 16 * r;
+    const bool in = gx < w && gy < h;
+    const size_t g = in ? (size_t)gy * w + gx : 0;
+    zqs[r] = load_quad<T, VEC>(z + (g - (in ? gx : 0)), in ? gx : 0, w, T());
+    lqs[r] = load_quad<uint16_t, VEC>(lab16 + (g - (in ? gx : 0)), in ? gx : 0, w, (uint16_t)0);
+  }
+  const uint32_t base = tile_base[t], cnt = tile_count[t];
+  for (uint32_t i = threadIdx.x; i < cnt; i += NTHR) sl[i] = lvl[base + i];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < DH / 16; r++) {
+    const int gy = y0 + ry + 16 * r;
+    if (gx >= w || gy >= h) continue;
+    const size_t g = (size_t)gy * w + gx;
+    Quad<T> zq = zqs[r];
+    const Quad<uint16_t> lq = lqs[r];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (gx + e >= w) continue;
+      const uint32_t L = sl[lq.v[e] & (uint16_t)(DW * DH - 1)];
+      if (L > Key32<T>::to(zq.v[e])) { zq.v[e] = Key32<T>::from(L); any = true; }
+    }
+    if (any) {
+      if (VEC) {
+        struct alignas(4 * sizeof(T)) AQ { T v[4]; };
+        AQ a;
+#pragma unroll
+        for (int e = 0; e < 4; e++) a.v[e] = zq.v[e];
+        *reinterpret_cast<AQ *>(z + g) = a;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (gx + e < w) z[g + e] = zq.v[e];
+      }
+    }
+  }
+}
+
+// The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
+// provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
+template <class T, int TOPO>
+static bool fill_fused(T *d_z, int w, int h, hipStream_t s) {
+  const char *fe = getenv("RDGPU_FILL_FUSED");   // =0: the classic four-pass fill (A/B and tests)
+  if (fe && fe[0] == '0') return false;
+  const char *env_edges = getenv("RDGPU_FILL_EDGES");
+  if (env_edges && env_edges[0] == '0') return false;   // (the raster-round fallback lives in the classic path)
+  const uint64_t n64 = (uint64_t)w * (uint64_t)h;
+  if (n64 > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: raster (or shard) has more than 2^31-65536 cells");
+  const uint32_t n = (uint32_t)n64;
+  if (w <= 2 || h <= 2) return false;   // every cell is a border cell: the classic path's trivial case
+  g_stats = rdgpu_fill_stats{n64, 0, 0, 0, 0, (uint32_t)(TW * TH), 0};
+  Workspace &ws = Workspace::get();
+  uint32_t *hw = ws.host_words();
+  const uint32_t dtx = cdiv(w, DW), dty = cdiv(h, DH), dnt = dtx * dty;
+  const uint32_t tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), ntiles = tilesX * tilesY;
+  const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
+  FusedBuf fo;
+  fo.gcap = n / 4 + 4096;
+  fo.lab16 = ws.buf<uint16_t>("fused.lab16", n);
+  fo.G = ws.buf<uint32_t>("fused.G", fo.gcap);
+  fo.tile_base = ws.buf<uint32_t>("fused.tile_base", dnt);
+  fo.tile_count = ws.buf<uint32_t>("fused.tile_count", dnt);
+  uint32_t *dflags = ws.buf<uint32_t>("fused.flags", 16);   // [0] chase flag, [2] roots, [3] alive tiles, [4] records, [5] overflow, [8..9] counters
+  fo.counters = reinterpret_cast<unsigned long long *>(dflags + 8);
+  fo.overflow = dflags + 5;
+  uint32_t *curN = ws.buf<uint32_t>("fused.curN", fo.gcap);
+  RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
+  if (vec)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt);
+  else
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt);
+  RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  if (hw[1] != 0) return false;   // more nodes than the table holds: nothing was written to the DEM
+  const uint32_t B = hw[4], NN = hw[5];   // counters: low word pits, high word nodes
+  g_stats.basins = B;
+  if (B == 0) return true;        // no pits: nothing to raise
+  RD_LAUNCH("fill.resolve_nodes", k_resolve_nodes, dim3(cdiv(NN, NTHR)), dim3(NTHR), 0, s, fo.G, NN, (const uint16_t *)fo.lab16,
+            (const uint32_t *)fo.tile_base, w, dtx, B, curN, dflags);
+  g_stats.jump_passes = 1;
+  uint32_t *cur = ws.buf<uint32_t>("fill.cur", (size_t)B + 1);
+  uint32_t *acc = ws.buf<uint32_t>("fill.acc", (size_t)B + 1);
+  unsigned long long *best = ws.buf<unsigned long long>("fill.best", (size_t)B + 1);
+  unsigned long long *link = ws.buf<unsigned long long>("fill.link", (size_t)B + 1);
+  uint32_t *rootsA = ws.buf<uint32_t>("fill.rootsA", B);
+  uint32_t *rootsB = ws.buf<uint32_t>("fill.rootsB", B);
+  RD_LAUNCH("fill.init_tables", k_init_tables, dim3(cdiv((uint64_t)B + 1, NTHR)), dim3(NTHR), 0, s, cur, acc, link, rootsA,
+            dflags + 2, (const uint32_t *)nullptr, B);
+  // the pair list of the one raster pass: capacity as in the classic path
+  uint32_t nseg = 1;
+  while (nseg < ESEG && (uint64_t)nseg * 128 <= ntiles) nseg *= 2;
+  const char *env_cap = getenv("RDGPU_FILL_EDGE_CAP");
+  const uint64_t cap = env_cap ? strtoull(env_cap, nullptr, 10) : std::min<uint64_t>(12ull * B, n / 2) + 2048;
+  const uint32_t segcap = cdiv(cdiv(cap, nseg), NTHR * EPT) * (NTHR * EPT);
+  const size_t ecap = (size_t)nseg * segcap;
+  uint32_t *elist[2] = {ws.buf<uint32_t>("fill.edges0", 3 * ecap), nullptr};
+  size_t pcap[2] = {ecap, 0};
+  uint32_t *segcount = ws.buf<uint32_t>("fill.segcount", nseg);
+  RD_HIP(hipMemsetAsync(segcount, 0, nseg * sizeof(uint32_t), s));
+  EdgeOut eo{elist[0], elist[0] + ecap, elist[0] + 2 * ecap, segcount, segcap, nseg - 1, dflags + 5};
+  uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
+  uint32_t nroots = B, nedges = 0;
+  int ein = 0;
+  bool first = true, eseg = true;
+  const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
+  const bool dedup = !(env_dedup && env_dedup[0] == '0');
+  while (nroots > 0) {
+    const uint32_t rgrid = cdiv(nroots, NTHR);
+    RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
+    if (first) {   // round 1: the one raster pass (components gathered from the node table)
+      if (vec)
+        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
+                  reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
+                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx);
+      else
+        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, false, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
+                  reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
+                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx);
+      RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, dflags + 4);
+      g_stats.scan_tiles += ntiles;
+    } else {
+      const int eout = ein ^ 1;
+      RD_HIP(hipMemsetAsync(dflags + 4, 0, sizeof(uint32_t), s));
+      const uint32_t *ia = elist[ein], *ib = elist[ein] + pcap[ein], *ik = elist[ein] + 2 * pcap[ein];
+      uint32_t *oa = elist[eout], *ob = elist[eout] + pcap[eout], *ok = elist[eout] + 2 * pcap[eout];
+      if (eseg)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<true, false>), dim3(cdiv(ecap, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
+                  (uint32_t)ecap, (const uint32_t *)segcount, segcap, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
+      else if (nedges > 0 && dedup)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, true>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik, nedges,
+                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
+      else if (nedges > 0)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, false>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik, nedges,
+                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
+      eseg = false;
+      ein = eout;
+    }
+    RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
+    for (;;) {
+      RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
+      RD_LAUNCH("fill.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 32, dflags);
+      RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (hw[0] == 0) break;
+    }
+    RD_LAUNCH("fill.update_basins", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
+    RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
+    RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
+              dflags + 2);
+    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    const uint32_t next = hw[0];
+    if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
+    if (first && hw[3] != 0) return false;   // the pair list overflowed: the DEM is untouched, the classic path takes over
+    nroots = next;
+    nedges = hw[2];
+    if (first) {
+      g_stats.edge_records = nedges;
+      pcap[1] = std::max<size_t>(nedges, 1);
+      elist[1] = ws.buf<uint32_t>("fill.edges1", 3 * pcap[1]);
+    }
+    first = false;
+    std::swap(rootsA, rootsB);
+    g_stats.rounds++;
+  }
+  uint32_t *lvl = fo.G;   // (the node table is dead: its storage holds the nodes' levels)
+  RD_LAUNCH("fill.node_levels", k_node_levels, dim3(cdiv(NN, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc, NN,
+            lvl);
+  if (vec)
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
+              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt);
+  else
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
+              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt);
+  return true;
+}
+
 template <class T>
 static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
   check_fill_args(d_z, w, h, topology);
+  if (topology == 8 ? fill_fused<T, 8>(d_z, w, h, s) : fill_fused<T, 4>(d_z, w, h, s)) return;
   FillBuffers fb;
   BufAlloc ws_alloc{false, nullptr};
   if (topology == 8) fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s);
