@@ -263,7 +263,15 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
 constexpr int LT = 64, LLW = LT + 2;
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 constexpr uint16_t LP_TERM = 0xF000u, LP_EXIT = 0xF001u;
-constexpr unsigned long long NOT_A_NODE = 0xFEull;   // count field of a slot that is not an exit
+// The words of the link forest's nodes (exits): pending in-links in bits 40..63, total in bits 0..39.  The per-cell words
+// of the raster-wide walk keep their count in 8 bits (a cell has at most 8 donors), but an EXIT can be handed flow by
+// every exit of the neighbouring tiles whose path ends at it -- several hundred when a tile funnels everything it
+// receives through one cell (r03: the S3 digest test found 1899 cells of FA_D8 wrong where an 8-bit field had wrapped).
+// Totals are cell counts of a raster below 2^31 cells: 40 bits are plenty.
+constexpr int LK_SHIFT = 40;
+constexpr unsigned long long LK_CNT1 = 1ull << LK_SHIFT, LK_LOW = LK_CNT1 - 1ull;
+constexpr unsigned long long LK_SRC = 0xFFFFFFull;      // count-field marker: an exit nobody hands anything to
+constexpr unsigned long long NOT_A_NODE = 0xFFFFFEull;  // count field of a slot that is not an exit
 
 __device__ __forceinline__ int border_slot(int lx, int ly) {
   if (ly == 0) return lx;
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   // what the border cells publish (252 of the tile's 256 slots; the four spare ones are marked unused)
   if (threadIdx.x < 4) {
     const size_t node = (size_t)t * 256 + 252 + threadIdx.x;
-    nw[node] = NOT_A_NODE << 56; next[node] = NO_NODE; rootslot[node] = 255;
+    nw[node] = NOT_A_NODE << LK_SHIFT; next[node] = NO_NODE; rootslot[node] = 255;
   }
   for (int j = 0; j < LT / 4; j++) {
     const int ly = ly0 + 4 * j;
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
       }
     }
     rootslot[node] = rs;
-    unsigned long long word = NOT_A_NODE << 56;
+    unsigned long long word = NOT_A_NODE << LK_SHIFT;
     uint32_t tn = NO_NODE;
     if (is_exit) {
       word = (unsigned long long)cnt[c];   // complete by construction: every cell counted has a path to it
@@ -417,14 +425,14 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_edges(unsigned long long *nw,
   const uint8_t r = rootslot[tn];
   const uint32_t nx = r == 255 ? NO_NODE : ((tn & ~255u) | r);
   next[i] = nx;
-  if (nx != NO_NODE) atomicAdd(&nw[nx], CNT1);
+  if (nx != NO_NODE) atomicAdd(&nw[nx], LK_CNT1);
 }
 
 __global__ __launch_bounds__(NTHR) void k_acc_link_sources(unsigned long long *nw, uint64_t nnodes) {
   const uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x;
   if (i >= nnodes) return;
   const unsigned long long v = nw[i];
-  if ((v >> 56) == 0) nw[i] = v | (SRC << 56);   // an exit nobody hands anything to: a source of the link forest
+  if ((v >> LK_SHIFT) == 0) nw[i] = v | (LK_SRC << LK_SHIFT);   // an exit nobody hands anything to: a source of the link forest
 }
 
 __global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, const uint32_t *__restrict__ next,
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, 
       const uint64_t my = nxt + (uint64_t)__popcll(idle & ((1ull << lane) - 1ull));
       if (!active && my < end) {
         const unsigned long long wd = nw[my];   // a source's word is never modified: plain read
-        if ((wd >> 56) == SRC) { active = true; c = (uint32_t)my; v = wd & LOWMASK; }
+        if ((wd >> LK_SHIFT) == LK_SRC) { active = true; c = (uint32_t)my; v = wd & LK_LOW; }
       }
       nxt += (uint64_t)__popcll(idle);
     } else if (idle == ~0ull) {
@@ -454,9 +462,9 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_walk(unsigned long long *nw, 
       const uint32_t t = next[c];
       if (t == NO_NODE) active = false;
       else {
-        const unsigned long long old = atomicAdd(&nw[t], v - CNT1);
-        if ((old >> 56) != 1) active = false;
-        else { v = (old & LOWMASK) + v; c = t; }
+        const unsigned long long old = atomicAdd(&nw[t], v - LK_CNT1);
+        if ((old >> LK_SHIFT) != 1) active = false;
+        else { v = (old & LK_LOW) + v; c = t; }
       }
     }
   }
@@ -502,8 +510,8 @@ __device__ __forceinline__ void link_final_walk_tile(const uint32_t t, const uin
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           if (!use[m]) continue;
-          const unsigned long long cnt = wv[m] >> 56;
-          if (cnt == 0 || cnt == SRC) inflow += wv[m] & LOWMASK;
+          const unsigned long long cnt = wv[m] >> LK_SHIFT;
+          if (cnt == 0 || cnt == LK_SRC) inflow += wv[m] & LK_LOW;
           else blocked++;
         }
       }
@@ -658,8 +666,8 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           if (!use[m]) continue;
-          const unsigned long long cnt = wv[m] >> 56;
-          if (cnt == 0 || cnt == SRC) inflow += wv[m] & LOWMASK;
+          const unsigned long long cnt = wv[m] >> LK_SHIFT;
+          if (cnt == 0 || cnt == LK_SRC) inflow += wv[m] & LK_LOW;
           else blocked++;
         }
       }

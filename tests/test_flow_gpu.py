@@ -339,3 +339,27 @@ def test_multi_device_accumulation_entry_on_one_gpu(rd, orc, monkeypatch):
     arr = (ctypes.c_int * 2)(0, 99)
     assert lib().rdgpu_d8_flow_accum_multi_f64(dirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), w, h,
                                                out.ctypes.data_as(ctypes.c_void_p), arr, 2) != 0
+
+
+def test_an_exit_with_more_than_255_in_links(rd, orc):
+    """Tile links: an exit cell can be handed flow by every exit of the neighbouring tiles whose path ends at it.  Here
+    the centre tile of a 3 x 3 arrangement receives flow through all 256 cells of its four edges and funnels it through
+    one corner: 256+ in-links on one node of the link forest (an 8-bit pending count wrapped there until r03 -- found by
+    the full-size digest test on FA_D8, 1899 cells of 1.6e9)."""
+    T = 64
+    d = np.zeros((3 * T, 3 * T), np.uint8)
+    d[:, :] = 5                                   # default: east
+    d[0:T, T:2 * T] = 7                           # top tile: south, into the centre
+    d[2 * T:, T:2 * T] = 3                        # bottom tile: north, into the centre
+    d[T:2 * T, 2 * T:] = 1                        # right tile: west, into the centre
+    d[0:T, 2 * T:] = 1                            # top-right corner tile: west, into the top tile
+    d[2 * T:, 0:T] = 5                            # bottom-left: east, into the bottom tile
+    c = d[T:2 * T, T:2 * T]                       # the centre tile: east along the rows, south down the last column
+    c[:, :] = 5
+    c[:, T - 1] = 7
+    c[T - 1, T - 1] = 6                           # ... and out through the corner, south-east
+    d[2 * T:, 2 * T:] = 5                         # the tile it leaves into drains off the raster
+    for dt in (np.float64, np.int32):
+        exp = orc.port.d8_flow_accum(d, 255, dt)
+        assert np.array_equal(rd.d8_flow_accum(d, 255, dt), exp), dt
+    assert exp[2 * T - 1, 2 * T - 1] > 3 * T * T  # everything the four side tiles and the centre hold goes through that corner
