@@ -61,7 +61,7 @@ def test_fa_tarboton_and_generic_accumulation(rd, orc):
         got = rd.FlowAccumulation(dem, "Dinf", nodata=nd)
         # END TO END within north_star's bound: <= 1 ULP after an f32 cast (measured r03: 0 ULP on every cell of these
         # cases, 9e-16 relative in f64 -- the proportions come out bit-identical, only the summation order differs;
-        # tools/probes/mfd_ulps.py, profiles/r03_mfd_ulps.json)
+        # tests/tools/mfd_ulps.py, profiles/r03_mfd_ulps.json)
         assert (ulp_diff_f32(got, exp) <= 1).all(), (name, int(ulp_diff_f32(got, exp).max()))
         assert np.allclose(got, exp, rtol=1e-12, atol=0), name
         assert np.array_equal(got == -1, exp == -1), name

@@ -47,6 +47,16 @@ def counters(directory, name):
     return per
 
 
+def kernel_shas():
+    """sha1 (first 12 hex digits) of every kernel source: the evidence names the engine state it was taken on"""
+    import hashlib
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "richdem_amd", "csrc", "*.hip"))):
+        with open(f, "rb") as fh:
+            out.append(os.path.basename(f) + ":" + hashlib.sha1(fh.read()).hexdigest()[:12])
+    return " ".join(out)
+
+
 def main():
     tag = sys.argv[1]
     steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
@@ -82,13 +92,15 @@ def main():
         rows.append((k, n, fg, wg, fg + wg))
     with open(os.path.join(OUT, f"{tag}_{what}_pmc_summary.csv"), "w") as f:
         f.write(f"# {tag} PMC summary: fill, 40000x40000 f32, 1 step (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)\n")
+        f.write(f"# git {os.environ.get('RDGPU_GIT_SHA')}  kernel sources sha1: {kernel_shas()}\n")
         f.write("# counters are KiB; WRITE_SIZE x1, FETCH_SIZE x2 (gfx950 half-count; calibration: k_synth writes 6.4e9 B, k_count_pits reads 6.4e9 B)\n")
         f.write("kernel,launches,fetch_GB_per_launch(x2),write_GB_per_launch,total_GB_per_launch\n")
         for r in rows:
             f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f}\n")
     # per-launch HBM traffic of the fill's kernels, under the names the library's profiler (and bench.py) uses
-    names = {"k_scan": "fill.scan", "k_descent": "fill.descent", "k_tile_label": "fill.tile_label",
-             "k_finalize": "fill.finalize", "k_finalize_tiled": "fill.finalize", "k_edge_round": "fill.edge_round"}
+    names = {"k_scan": "fill.scan", "k_descent": "fill.descent", "k_descent16": "fill.descent", "k_tile_label": "fill.tile_label",
+             "k_finalize": "fill.finalize", "k_finalize_tiled": "fill.finalize", "k_finalize16": "fill.finalize",
+             "k_edge_round": "fill.edge_round", "k_resolve_nodes": "fill.resolve_nodes"}
     per = {}
     for kern, prof_name in names.items():
         sel = [r for r in rows if r[0].split("<")[0] == "rdgpu::" + kern]
@@ -100,13 +112,15 @@ def main():
             sys.path.insert(0, ROOT)
             from richdem_amd.roofline import engine_sha
 
-            fill_kernels = ("k_descent", "k_tile_label", "k_scan", "k_edge_round", "k_finalize", "k_finalize_tiled", "k_hook",
+            fill_kernels = ("k_descent", "k_descent16", "k_resolve_nodes", "k_node_levels", "k_finalize16", "k_tile_label", "k_scan",
+                            "k_edge_round", "k_finalize", "k_finalize_tiled", "k_hook",
                             "k_chase_links", "k_update_basins", "k_compact_roots", "k_best_reset", "k_init_tables",
                             "k_compact_alive", "k_sum_segments", "k_chase", "k_label_cells")
             # launches counted by the profiling command's fills (1 timed + the instrumented pass of bench.py)
-            nfill = max(1, sum(r[1] for r in rows if r[0].split("<")[0] == "rdgpu::k_descent"))
+            nfill = max(1, sum(r[1] for r in rows if r[0].split("<")[0] in ("rdgpu::k_descent", "rdgpu::k_descent16")))
             per_fill = sum(r[4] * r[1] for r in rows if r[0].split("<")[0].replace("rdgpu::", "") in fill_kernels) / nfill
             json.dump({"size": 40000, "GB_per_launch": per, "GB_per_fill": round(per_fill, 2), "engine_sha": engine_sha(),
+                       "git_sha": os.environ.get("RDGPU_GIT_SHA"),
                        "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
         # the bench line above was printed before these passes ran: give it this round's traffic figure
         d = json.loads(line)
