@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 #: SURVEY.md section 8d, algorithmic bytes per cell
 STAGE_BYTES = {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
-               "resolve_flats_epsilon": 8, "fa_d8": 20}
+               "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8}
 
 
 def cpu_baseline(Z, sample: int):
@@ -99,8 +99,9 @@ def stage_entry(seconds: float, cells: int, bytes_per_cell: int, n_gpus: int = 1
             "alg_GBps": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_GBS * n_gpus), 4)}
 
 
-def run_stages(rd, torch, W, nodata: float, reps: int = 2) -> dict:
-    """The path after the fill on one GPU, HBM-resident, through the C-ABI `_dev_` entry points.  W = the filled DEM."""
+def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None) -> dict:
+    """The path after the fill on one GPU, HBM-resident, through the C-ABI `_dev_` entry points.  W = the filled DEM,
+    Z = the unfilled one (for PriorityFloodEpsilon, the other fill of depressions.hpp)."""
     n_cells = W.numel()
     sync = torch.cuda.synchronize
     out = {}
@@ -135,6 +136,17 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2) -> dict:
     out["fa_d8"] = stage_entry(t_fa, n_cells, 20)
     out["fa_d8"]["input"] = "fill -> ResolveFlatsEpsilon output, unit weights"
     out["fa_d8"]["max_accum"] = float(area.max().item())
+    del area
+    if Z is not None:
+        rd.fill_epsilon_dev(E.copy_(Z), nodata)
+        t_eps = 1e30
+        for _ in range(reps):
+            E.copy_(Z)
+            t_eps = min(t_eps, _best(lambda: rd.fill_epsilon_dev(E, nodata), 1, sync))
+        out["priority_flood_epsilon"] = stage_entry(t_eps, n_cells, STAGE_BYTES["priority_flood_epsilon"])
+        es = rd.epsilon_stats()
+        out["priority_flood_epsilon"].update({"input": "the unfilled bench DEM (PriorityFloodEpsilon_Original semantics)",
+                                              **{k: es[k] for k in ("rounds", "tie_sources") if k in es}})
     return out
 
 
@@ -273,7 +285,7 @@ def main():
     }
     if not args.no_stages:
         out["stages"] = {"fill": stage_entry(dt / args.steps, cells, 8)}
-        out["stages"].update(run_stages(rd, torch, W, -9999.0))
+        out["stages"].update(run_stages(rd, torch, W, -9999.0, Z=Z))
     if not args.no_host:
         del W
         bufs.clear()

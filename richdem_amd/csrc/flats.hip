@@ -770,22 +770,35 @@ __device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
 
 // visit statistics of the STATS instantiation (RDGPU_FLAT_TRACE): [0] visits, [1] left at once (nothing new reaches the
 // tile), [2] open-water visits, [3] general visits, [4] BFS levels stepped, [5] flushes, [6] rows flushed
-__device__ unsigned long long g_relax_stats[8];
+// [8..15] (tail launches, < 8000 tiles): visits timed, 10 ns ticks of: setup (ring loads, start level), open-water visit,
+// general rows read, level loop incl. flushes, flushes alone, wake test, whole visit; [15] longest visit
+__device__ unsigned long long g_relax_stats[16];
 
-template <int SEED_LEVEL, bool STATS = false>
-__global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
-                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
-                                                     uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
-  // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
-  // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
-  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
-  const uint32_t n = *count;
-  for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
-  const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wi >= n) return;
+// D accesses of a visit.  CO (the asynchronous search, k_relax_bits_async): other wavefronts of the SAME launch write the
+// ring cells this visit reads and read the cells it writes, across CUs and XCDs whose L1 / L2 are not coherent with each
+// other -- relaxed agent-scope atomics (sc1 loads and write-through stores) on both sides, MI355X_MICROARCH.md's
+// "sc1 payload -> vmcnt(0) -> flag" hand-off.  Otherwise (one launch per round): plain loads and stores.
+template <bool CO>
+__device__ __forceinline__ int32_t ldD(const int32_t *p) {
+  if (CO) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool CO>
+__device__ __forceinline__ void stD(int32_t *p, int32_t v) {
+  if (CO) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// One visit of tile t by one wavefront; returns the 9-bit mask of the neighbouring tiles to wake (bit (dy + 1) * 3 + dx + 1,
+// the same in every lane).
+template <int SEED_LEVEL, bool STATS, bool CO>
+__device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
+                                                const uint32_t t, uint16_t *const orow, const bool timed, int w, int h, RowWin win,
+                                                uint32_t tilesX, uint32_t tilesY) {
   const int lane = threadIdx.x & 63;
-  uint16_t *const orow = open_rows[threadIdx.x >> 6];
-  const uint32_t t = tiles[wi];
+  constexpr int RB = CO ? 32 : 16;   // rows read per batch (the coherent loads come from beyond the L2: fewer, longer batches)
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tkf = 0;
+  if (STATS) tk0 = wall_clock64();
   const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
   const int x0 = tx * BT, y0 = win.lo + ty * BT;
   const int brow = min(BT - 1, win.hi - 1 - y0);   // the tile's last own row (63 except in the last tile row)
@@ -806,9 +819,9 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   const int cx = min(x0 + lane, w - 1), cy = min(y0 + lane, h - 1);
   const int yT = max(y0 - 1, 0), yB = min(y0 + brow + 1, h - 1), xL = max(x0 - 1, 0), xR = min(x0 + BT, w - 1);
   const int yl = min(y0 + brow, h - 1), xl = min(x0 + BT - 1, w - 1);
-  int32_t tv = D[(size_t)yT * w + cx], bv = D[(size_t)yB * w + cx], lv = D[(size_t)cy * w + xL], rv = D[(size_t)cy * w + xR];
-  int32_t tl = D[(size_t)yT * w + xL], tr = D[(size_t)yT * w + xR], bl = D[(size_t)yB * w + xL], br = D[(size_t)yB * w + xR];
-  int32_t oldT = D[(size_t)y0 * w + cx], oldB = D[(size_t)yl * w + cx], oldL = D[(size_t)cy * w + x0], oldR = D[(size_t)cy * w + xl];
+  int32_t tv = ldD<CO>(&D[(size_t)yT * w + cx]), bv = ldD<CO>(&D[(size_t)yB * w + cx]), lv = ldD<CO>(&D[(size_t)cy * w + xL]), rv = ldD<CO>(&D[(size_t)cy * w + xR]);
+  int32_t tl = ldD<CO>(&D[(size_t)yT * w + xL]), tr = ldD<CO>(&D[(size_t)yT * w + xR]), bl = ldD<CO>(&D[(size_t)yB * w + xL]), br = ldD<CO>(&D[(size_t)yB * w + xR]);
+  int32_t oldT = ldD<CO>(&D[(size_t)y0 * w + cx]), oldB = ldD<CO>(&D[(size_t)yl * w + cx]), oldL = ldD<CO>(&D[(size_t)cy * w + x0]), oldR = ldD<CO>(&D[(size_t)cy * w + xl]);
   if (!(mT >> lane & 1ull)) tv = DINF;
   if (!(mB >> lane & 1ull)) bv = DINF;
   // (in a last tile row that ends above row 63 the lane below the last own row holds the ghost row's corner cell)
@@ -846,12 +859,13 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   if ((M & 1ull) && iL < oldL) chg = imin(chg, iL);
   if ((M >> 63 & 1ull) && iR < oldR) chg = imin(chg, iR);
   int32_t level = __builtin_amdgcn_readfirstlane(wave_min_i32(chg));   // the level being assigned
-  if (!__builtin_amdgcn_readfirstlane((int)expanded[t])) {
+  if (!CO && !__builtin_amdgcn_readfirstlane((int)expanded[t])) {   // (CO: every tile with seeds has been visited before)
     level = imin(level, SEED_LEVEL + 1);
     if (lane == 0) expanded[t] = 1;
   }
   if (STATS && lane == 0) { atomicAdd(&g_relax_stats[0], 1ull); if (level >= DINF) atomicAdd(&g_relax_stats[1], 1ull); }
-  if (level >= DINF) return;   // nothing new reaches this tile
+  if (level >= DINF) return 0u;   // nothing new reaches this tile
+  if (STATS) tk1 = wall_clock64();
   // OPEN WATER: every cell of the tile takes part, so the levels are chessboard distances from the ring (and from what the
   // tile holds already) and two chamfer sweeps give the fixed point exactly: once the ring has entered through the
   // levels at which it reaches the edge cells, any shortest king-move path inside the (convex) tile can be ordered into
@@ -866,12 +880,12 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     // down: from NW, N, NE, then from W along the row
     int32_t prev = DINF;
     bool fits = true;
-    for (int r0 = 0; r0 < BT; r0 += 16) {
-      int32_t v[16];
+    for (int r0 = 0; r0 < BT; r0 += RB) {
+      int32_t v[RB];
 #pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = D[(size_t)(y0 + r0 + j) * w + x0 + lane];
+      for (int j = 0; j < RB; j++) v[j] = ldD<CO>(&D[(size_t)(y0 + r0 + j) * w + x0 + lane]);
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < RB; j++) {
         const int y = r0 + j;
         int32_t d = v[j];
         fits &= d >= obase;
@@ -904,7 +918,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
         }
         d = wave_suffix_min(d + lane, lane) - lane;
         nxt = d;
-        if (d < DINF) D[(size_t)(y0 + y) * w + x0 + lane] = d;
+        if (d < DINF) stD<CO>(&D[(size_t)(y0 + y) * w + x0 + lane], d);
         const int32_t l0 = __builtin_amdgcn_readlane(d, 0), e0 = __builtin_amdgcn_readlane(d, BT - 1);
         newL = lane == y ? l0 : newL;   // (the edge columns as one value per lane = row, for the wake test)
         newR = lane == y ? e0 : newR;
@@ -915,18 +929,20 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
       open = false;   // (levels out of the 16-bit window: the general search)
     }
   }
+  if (STATS) tk2 = wall_clock64();
+  if (timed && open && lane == 0) atomicAdd(&g_relax_stats[9], tk2 - tk1);
   if (!open) {
   if (STATS && lane == 0) atomicAdd(&g_relax_stats[3], 1ull);
   unsigned long long A, F, Rec = 0;
   {
     unsigned long long reached = 0, front = 0;
 #pragma unroll
-    for (int r0 = 0; r0 < BT; r0 += 16) {
-      int32_t v[16];
+    for (int r0 = 0; r0 < BT; r0 += RB) {
+      int32_t v[RB];
 #pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = D[(size_t)min(y0 + r0 + j, h - 1) * w + cx];
+      for (int j = 0; j < RB; j++) v[j] = ldD<CO>(&D[(size_t)min(y0 + r0 + j, h - 1) * w + cx]);
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < RB; j++) {
         const unsigned long long rb = __ballot(v[j] < level), fb = __ballot(v[j] == level - 1);
         if (lane == r0 + j) { reached = rb; front = fb; }
       }
@@ -934,6 +950,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
     A = M & ~reached;
     F = M & front;
   }
+  if (STATS) { tk3 = wall_clock64(); if (timed && lane == 0) atomicAdd(&g_relax_stats[10], tk3 - tk2); }
   uint32_t Plo[BPLANES], Phi[BPLANES];
 #pragma unroll
   for (int j = 0; j < BPLANES; j++) Plo[j] = Phi[j] = 0;
@@ -942,6 +959,8 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
 
   // store the cells recorded since the last flush; keeps the new edge levels for the wake test
   auto flush = [&]() {
+    unsigned long long tf0 = 0;
+    if (STATS) tf0 = wall_clock64();
     const int np = 32 - __clz(relmax | 1);
     unsigned long long rows = __ballot(Rec != 0);
     if (STATS && lane == 0) { atomicAdd(&g_relax_stats[5], 1ull); atomicAdd(&g_relax_stats[6], (unsigned long long)__popcll(rows)); }
@@ -959,7 +978,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
         }
       if (lanes_of(rec, 1u)) {
         const int32_t v = base + (int32_t)val;
-        D[(size_t)(y0 + r) * w + x0 + lane] = v;
+        stD<CO>(&D[(size_t)(y0 + r) * w + x0 + lane], v);
         if (r == 0) newT = v;
         if (r == brow) newB = v;
       }
@@ -980,6 +999,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
 #pragma unroll
     for (int j = 0; j < BPLANES; j++) Plo[j] = Phi[j] = 0;
     relmax = 0;
+    if (STATS) tkf += wall_clock64() - tf0;
   };
 
   // Segments of at most 256 levels: the inner loop leaves when the planes are full (or the search is over), the flush
@@ -1033,7 +1053,10 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   if (__any(Rec != 0)) flush();
   base = level;
   }
+  if (timed && lane == 0) { atomicAdd(&g_relax_stats[11], wall_clock64() - tk3); atomicAdd(&g_relax_stats[12], tkf); }
   }
+  unsigned long long tk4 = 0;
+  if (STATS) tk4 = wall_clock64();
   // Wake a neighbouring tile only if an edge cell that moved here can still lower one of ITS cells (see k_flat_relax).
   // Edge cell (r, c) with new level v against the ring cells next to it, whose levels were read at the start.
   uint32_t wake = 0;   // bit (dy + 1) * 3 + dx + 1
@@ -1072,9 +1095,197 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wake |= __shfl_xor(wake, o, 64);
+  if (timed && lane == 0) {
+    const unsigned long long te = wall_clock64();
+    atomicAdd(&g_relax_stats[7], 1ull);
+    atomicAdd(&g_relax_stats[8], tk1 - tk0);
+    atomicAdd(&g_relax_stats[13], te - tk4);
+    atomicAdd(&g_relax_stats[14], te - tk0);
+    atomicMax(&g_relax_stats[15], te - tk0);
+  }
+  return wake;
+}
+
+template <int SEED_LEVEL, bool STATS = false>
+__global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
+                                                     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
+                                                     uint8_t *next_active, int w, int h, RowWin win, uint32_t tilesX, uint32_t tilesY) {
+  // open-water tiles keep their rows here between the two chamfer sweeps, as 16-bit levels relative to a base (8 KB per
+  // wavefront: five blocks per CU, the occupancy the kernel's registers allow anyway)
+  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
+  const uint32_t n = *count;
+  for (uint32_t i = gridDim.x * 4 + blockIdx.x * NTHR + threadIdx.x; i < n; i += gridDim.x * NTHR) next_active[tiles[i]] = 1;
+  const uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = tiles[wi];
+  const uint32_t wake = relax_visit<SEED_LEVEL, STATS, false>(mbits, expanded, D, t, open_rows[threadIdx.x >> 6], STATS && n < 8000u, w,
+                                                              h, win, tilesX, tilesY);
   if (lane < 9 && lane != 4 && (wake >> lane & 1u)) {
+    const int tx = (int)(t % tilesX), ty = (int)(t / tilesX);
     const int ntx = tx + lane % 3 - 1, nty = ty + lane / 3 - 1;
     if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) next_active[nty * tilesX + ntx] = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The asynchronous tail of the search.  A launch per round costs the round's SLOWEST visit plus the launch: at S3 the
+// towards field needs ~350 rounds, the last 320 of them over fewer than 8000 tiles whose working visits average 15 us --
+// and the rounds take 36-66 us each (profiles/r03c_flat_phases.txt).  The fixed point does not depend on the order of
+// the visits (levels only ever decrease and stay upper bounds), so once the front is thin the rounds are dropped: ONE
+// launch of resident wavefronts that pull tiles from a queue, visit them and push the neighbours they wake, until the
+// queue runs dry.  The critical path is then the chain of dependent visits, each at its own length.
+//   tile state   AQ_WAKE: queued, or woken while running;  AQ_RUN: a wavefront is visiting it.  A tile is in the queue
+//                at most once and visited by at most one wavefront at a time (two visits of one tile at once could
+//                store an older, higher level over a newer one).
+//   queue        a ring of tile numbers (AQ_EMPTY = free slot); tickets from tail / head counters; a pusher waits for
+//                its slot to be free, a popper for its slot to be filled
+//   pending      tiles with a state other than 0; the search is over when it reaches 0
+//   data         every D access of these visits is a relaxed agent-scope atomic (ldD / stD), the stores are drained
+//                (s_waitcnt vmcnt(0)) before the state words of the neighbours are touched
+// A wavefront that finds no work sleeps and polls; a launch that exceeds its tick budget raises the abort word and
+// every wavefront leaves (the host reports it: this must not happen, and a hang would cost the whole GPU).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t AQ_WAKE = 1u, AQ_RUN = 2u, AQ_EMPTY = 0xFFFFFFFFu, AQ_NONE = 0xFFFFFFFEu, AQ_DONE = 0xFFFFFFFDu;
+// One word saturates at ~90 atomics per microsecond on this part (MI355X_MICROARCH.md, "dequeue"), a tail of 600 000 visits
+// and 4 000 polling wavefronts on one head / tail / pending word took SECONDS.  So: AQ_NQ queues, tile t in queue
+// t % AQ_NQ, wavefront i serving queue i % AQ_NQ, and the termination test on sharded MONOTONE counters: enq[] (tiles
+// that left the idle state) and done[] (visits that ended idle).  Reading every done[] first and every enq[] after, equal
+// sums mean the search was over when the done[] reads ended -- each enq[] read is at least its value then, and
+// enq >= done at all times.  Any idle wavefront may run the test (wavefront 0 often, the others rarely) and raises the
+// per-queue finished words that every idle wavefront polls together with its queue's head / tail.
+constexpr int AQ_NQ = 64, AQ_STRIDE = 64;   // control words per queue: [0] head [1] tail [2] finished | [32] enq [33] done
+constexpr int AQ_G_ABORT = AQ_NQ * AQ_STRIDE, AQ_G_VISITS = AQ_G_ABORT + 32, AQ_G_BUSY = AQ_G_ABORT + 34 /* 64-bit: ticks in visits */,
+              AQ_G_SPAN = AQ_G_ABORT + 36 /* longest wavefront lifetime, ticks */, AQ_WORDS = AQ_G_ABORT + 64;
+struct AsyncQ {
+  uint32_t *q, *state, *ctl;
+  uint32_t qmask;   // slots per queue - 1
+};
+
+__device__ __forceinline__ uint32_t aq_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr uint32_t AQ_SPIN_CAP = 1u << 22;   // polls of one slot before the launch is given up (never reached unless the protocol is broken)
+__device__ __forceinline__ void aq_push(const AsyncQ &Q, uint32_t tile) {
+  const uint32_t qi = tile % AQ_NQ;
+  const uint32_t slot = atomicAdd(&Q.ctl[qi * AQ_STRIDE + 1], 1u) & Q.qmask;
+  uint32_t *const cell = &Q.q[(size_t)qi * (Q.qmask + 1u) + slot];
+  for (uint32_t spin = 0; atomicCAS(cell, AQ_EMPTY, tile) != AQ_EMPTY; spin++) {
+    if (spin > AQ_SPIN_CAP) { atomicExch(&Q.ctl[AQ_G_ABORT], 2u); return; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// the queues' first content: the list the last compaction made (one thread per entry)
+__global__ __launch_bounds__(NTHR) void k_async_init(const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count, AsyncQ Q) {
+  const uint32_t n = *count, i = blockIdx.x * NTHR + threadIdx.x;
+  if (i < n) {
+    const uint32_t t = tiles[i], qi = t % AQ_NQ;
+    const uint32_t slot = atomicAdd(&Q.ctl[qi * AQ_STRIDE + 1], 1u) & Q.qmask;
+    Q.q[(size_t)qi * (Q.qmask + 1u) + slot] = t;
+    Q.state[t] = AQ_WAKE;
+    atomicAdd(&Q.ctl[qi * AQ_STRIDE + 32], 1u);
+  }
+}
+
+// all lanes: is the search over?  (see above; lane = queue)
+__device__ __forceinline__ bool aq_terminated(const AsyncQ &Q, int lane) {
+  uint32_t d = aq_load(&Q.ctl[lane * AQ_STRIDE + 33]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+  // (the shuffles consumed every done[] value: those loads have returned before the enq[] loads are issued)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t e = aq_load(&Q.ctl[lane * AQ_STRIDE + 32]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) e += __shfl_xor(e, o, 64);
+  return e == d;
+}
+
+template <int SEED_LEVEL>
+__global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned long long *__restrict__ mbits, int32_t *D, AsyncQ Q, int w,
+                                                           int h, RowWin win, uint32_t tilesX, uint32_t tilesY,
+                                                           unsigned long long tick_budget, int nap) {
+  static_assert(AQ_NQ == 64, "one lane per queue in the termination test");
+  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
+  const int lane = threadIdx.x & 63;
+  uint16_t *const orow = open_rows[threadIdx.x >> 6];
+  const uint32_t me = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6);
+  uint32_t *const myctl = Q.ctl + (size_t)(me % AQ_NQ) * AQ_STRIDE;
+  uint32_t *const myq = Q.q + (size_t)(me % AQ_NQ) * (Q.qmask + 1u);
+  const unsigned long long t_start = wall_clock64();
+  uint32_t idle_polls = 0, visits = 0;
+  unsigned long long busy = 0;
+  for (;;) {
+    uint32_t tile = AQ_NONE;
+    if (lane == 0) {
+      unsigned long long ht = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(myctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t hd = (uint32_t)ht;
+      bool got = false;
+      while ((int32_t)((uint32_t)(ht >> 32) - hd) > 0) {
+        const uint32_t seen = atomicCAS(&myctl[0], hd, hd + 1u);
+        if (seen == hd) { got = true; break; }
+        hd = seen;
+        ht = (ht & 0xFFFFFFFF00000000ull) | hd;
+      }
+      if (got) {
+        uint32_t *const cell = &myq[hd & Q.qmask];
+        uint32_t v, spin = 0;
+        while ((v = atomicExch(cell, AQ_EMPTY)) == AQ_EMPTY && ++spin <= AQ_SPIN_CAP) __builtin_amdgcn_s_sleep(1);   // its pusher has the ticket, the store is on its way
+        if (v == AQ_EMPTY) { atomicExch(&Q.ctl[AQ_G_ABORT], 3u); tile = AQ_DONE; }
+        else { tile = v; atomicExch(&Q.state[tile], AQ_RUN); }   // (queued: AQ_WAKE alone)
+      } else if (aq_load(&myctl[2]) != 0u) {
+        tile = AQ_DONE;
+      }
+    }
+    // The state word must BE "running" before the ring is read: a neighbour that stores, drains and then finds the tile
+    // still "queued" relies on the coming visit to see its stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile == AQ_DONE) break;
+    if (tile == AQ_NONE) {
+      idle_polls++;
+      if (me == 0u ? (idle_polls & 3u) == 0u : (idle_polls & 255u) == 0u) {
+        const bool late = wall_clock64() - t_start > tick_budget;
+        if (late && lane == 0) atomicExch(&Q.ctl[AQ_G_ABORT], 1u);
+        const bool stop = late || aq_load(&Q.ctl[AQ_G_ABORT]) != 0u || aq_terminated(Q, lane);
+        if (stop) { __hip_atomic_store(&Q.ctl[lane * AQ_STRIDE + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      // back off: a wavefront that has been idle for a while polls less often (the polls share the memory channels with the work)
+      for (int k = 0, n = idle_polls < 8u ? 1 : idle_polls < 32u ? 2 * nap : 4 * nap; k < n; k++) __builtin_amdgcn_s_sleep(32);
+      continue;
+    }
+    idle_polls = 0;
+    visits++;
+    const unsigned long long tv0 = wall_clock64();
+    const uint32_t wake = relax_visit<SEED_LEVEL, false, true>(mbits, nullptr, D, tile, orow, false, w, h, win, tilesX, tilesY);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the visit's write-through stores have landed
+    busy += wall_clock64() - tv0;
+    // Wake the neighbours: an idle one goes into its queue (a queued one will see the stores when it is visited, a running
+    // one is queued again by its own wavefront).  Measured and dropped (r03c): the waking wavefront visiting one of the
+    // woken tiles itself, without the trip through the queue -- 40.6 vs 39.8 ms at S3: the tail is bound by the number
+    // of visits (0.75-1.0 M of 18-26 us for 7500 tiles at the switch), not by the hops of its longest chain.
+    if (lane < 9 && lane != 4 && (wake >> lane & 1u)) {
+      const int tx = (int)(tile % tilesX), ty = (int)(tile / tilesX);
+      const int ntx = tx + lane % 3 - 1, nty = ty + lane / 3 - 1;
+      if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) {
+        const uint32_t nt = (uint32_t)nty * tilesX + (uint32_t)ntx;
+        if (atomicOr(&Q.state[nt], AQ_WAKE) == 0u) {
+          atomicAdd(&myctl[32], 1u);
+          aq_push(Q, nt);
+        }
+      }
+    }
+    if (lane == 0) {
+      const uint32_t old = atomicAnd(&Q.state[tile], ~AQ_RUN);
+      if (old & AQ_WAKE) aq_push(Q, tile);   // woken while it ran: once more (it never was idle)
+      else atomicAdd(&myctl[33], 1u);
+    }
+  }
+  if (lane == 0) {
+    if (visits) {
+      atomicAdd(&Q.ctl[AQ_G_VISITS], visits);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&Q.ctl[AQ_G_BUSY]), busy);
+    }
+    atomicMax(&Q.ctl[AQ_G_SPAN], (uint32_t)(wall_clock64() - t_start));
   }
 }
 
@@ -1473,16 +1684,80 @@ static BitsScratch bits_scratch(int w, int h) {
   return b;
 }
 
+// RDGPU_FLAT_ASYNC = n: the rounds end and the asynchronous tail (k_relax_bits_async) takes over once a round visits
+// fewer than n tiles (default 8000; 0: rounds to the end).
+static uint32_t async_threshold() {
+  const char *env = getenv("RDGPU_FLAT_ASYNC");
+  return env ? (uint32_t)strtoul(env, nullptr, 10) : 8000u;
+}
+
+struct AsyncInfo { uint32_t visits, launches; };
+static thread_local AsyncInfo g_async_info = {0, 0};
+
+template <int SEED_LEVEL>
+static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s, RowWin win) {
+  Workspace &ws = Workspace::get();
+  uint32_t per_q = 64;   // slots per queue: every tile of a queue at once
+  while (per_q < (b.ntiles + AQ_NQ - 1) / AQ_NQ) per_q <<= 1;
+  AsyncQ Q;
+  Q.q = ws.buf<uint32_t>("flats.aq", (size_t)per_q * AQ_NQ);
+  Q.state = ws.buf<uint32_t>("flats.aqstate", b.ntiles);
+  Q.ctl = ws.buf<uint32_t>("flats.aqctl", AQ_WORDS);
+  Q.qmask = per_q - 1;
+  int dev = 0, cus = 0, rate_khz = 0;
+  RD_HIP(hipGetDevice(&dev));
+  RD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  RD_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev));
+  const unsigned long long budget = (unsigned long long)std::max(rate_khz, 1000) * 1000ull * 10ull;   // ten seconds of wall_clock64 ticks
+  RD_HIP(hipMemsetAsync(b.ctr, 0, sizeof(uint32_t), s));
+  RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
+            b.ctr);
+  RD_HIP(hipMemsetAsync(Q.q, 0xFF, (size_t)per_q * AQ_NQ * sizeof(uint32_t), s));
+  RD_HIP(hipMemsetAsync(Q.state, 0, (size_t)b.ntiles * sizeof(uint32_t), s));
+  RD_HIP(hipMemsetAsync(Q.ctl, 0, AQ_WORDS * sizeof(uint32_t), s));
+  RD_LAUNCH("flats.async_init", k_async_init, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)b.tlist,
+            (const uint32_t *)b.ctr, Q);
+  uint32_t blocks = (uint32_t)cus * 2u;   // (measured at S3: 2 per CU 40.6 ms, 1: 45.5, 3: 40.9, 4: 42.7 -- idle wavefronts poll)
+  int nap = 1;
+  if (const char *e = getenv("RDGPU_FLAT_ASYNC_BLOCKS")) blocks = std::max(1, atoi(e));
+  if (const char *e = getenv("RDGPU_FLAT_ASYNC_NAP")) nap = std::min(255, std::max(1, atoi(e)));
+  RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
+            h, win, b.tilesX, b.tilesY, budget, nap);
+  // the end state, checked on the host: no abort, every counter pair equal, every queue drained
+  std::vector<uint32_t> all(AQ_WORDS);
+  RD_HIP(hipMemcpyAsync(all.data(), Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  uint64_t enq = 0, done = 0, queued = 0, pushes = 0;
+  for (int qi = 0; qi < AQ_NQ; qi++) {
+    enq += all[qi * AQ_STRIDE + 32]; done += all[qi * AQ_STRIDE + 33];
+    queued += all[qi * AQ_STRIDE + 1] - all[qi * AQ_STRIDE + 0];
+    pushes += all[qi * AQ_STRIDE + 1];
+  }
+  if (all[AQ_G_ABORT] != 0 || enq != done || queued != 0)
+    throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: the asynchronous search did not finish (abort " + std::to_string(all[AQ_G_ABORT]) +
+                                   ", " + std::to_string(enq - done) + " tiles pending, " + std::to_string(queued) +
+                                   " queued); RDGPU_FLAT_ASYNC=0 runs the rounds to the end");
+  g_async_info.visits += all[AQ_G_VISITS];
+  g_async_info.launches++;
+  if (getenv("RDGPU_FLAT_TRACE"))
+    fprintf(stderr, "%s asynchronous tail: %u visits, %llu pushes, %u wavefronts on %d CUs, ticks (%d kHz): in visits %llu, longest wavefront %u\n",
+            name, all[AQ_G_VISITS], (unsigned long long)pushes, blocks * 4u, cus, rate_khz,
+            (unsigned long long)all[AQ_G_BUSY] | ((unsigned long long)all[AQ_G_BUSY + 1] << 32), all[AQ_G_SPAN]);
+}
+
 template <int SEED_LEVEL>
 static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s,
                                   RowWin win = RowWin{0, -1, nullptr, nullptr}) {
   if (win.hi < 0) win.hi = h;   // single device: all rows, no ghost rows
   uint32_t *hw = Workspace::get().host_words();
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
+  const uint32_t async_below = async_threshold();
   uint32_t rounds = 0, grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
   for (;;) {
+    // with the asynchronous tail ahead the batches are short (the switch is decided on the host, from the counts)
+    const int batch = async_below ? (rounds == 0 ? 6 : 3) : BITS_BATCH;
     RD_HIP(hipMemsetAsync(b.ctr, 0, BITS_BATCH * sizeof(uint32_t), s));
-    for (int k = 0; k < BITS_BATCH; k++) {
+    for (int k = 0; k < batch; k++) {
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
       if (trace)
@@ -1494,20 +1769,27 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
                   b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
                   b.tilesX, b.tilesY);
     }
-    RD_HIP(hipMemcpyAsync(hw, b.ctr, BITS_BATCH * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, b.ctr, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     uint32_t most = 0;
-    for (int k = 0; k < BITS_BATCH; k++) {
+    for (int k = 0; k < batch; k++) {
       if (trace) fprintf(stderr, "%s round %u nact %u (grid %u)\n", name, rounds, hw[k], grid);
       if (hw[k] == 0 && trace) {
-        unsigned long long st[8];
+        unsigned long long st[16];
         RD_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_relax_stats), sizeof st));
         fprintf(stderr, "%s stats (cumulative): visits %llu, left at once %llu, open-water %llu, general %llu, levels stepped %llu, "
                         "flushes %llu, rows flushed %llu\n", name, st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+        fprintf(stderr, "%s tail launches (< 8000 tiles), working visits %llu, 10 ns ticks: setup %llu, open-water %llu, rows read %llu, "
+                        "level loop + flushes %llu, flushes %llu, wake %llu, whole %llu, longest %llu\n", name, st[7], st[8], st[9],
+                st[10], st[11], st[12], st[13], st[14], st[15]);
       }
       if (hw[k] == 0) return rounds;
       most = std::max(most, hw[k]);
       rounds++;
+    }
+    if (async_below && hw[batch - 1] < async_below) {
+      relax_async_tail<SEED_LEVEL>(b, D, w, h, name, s, win);
+      return rounds + 1;
     }
     grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
     if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");

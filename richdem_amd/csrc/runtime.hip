@@ -81,7 +81,7 @@ uint32_t *Workspace::host_words() {
   RD_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> g(mu_);
   uint32_t *&p = host_words_[dev];
-  if (!p) RD_HIP(hipHostMalloc((void **)&p, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  if (!p) RD_HIP(hipHostMalloc((void **)&p, 256 * sizeof(uint32_t), hipHostMallocDefault));
   return p;
 }
 
