@@ -1130,11 +1130,11 @@ __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long
 
 // ------------------------------------------------------------------------------------------
 // The asynchronous tail of the search.  A launch per round costs the round's SLOWEST visit plus the launch: at S3 the
-// towards field needs ~350 rounds, the last 320 of them over fewer than 8000 tiles whose working visits average 15 us --
-// and the rounds take 36-66 us each (profiles/r03c_flat_phases.txt).  The fixed point does not depend on the order of
-// the visits (levels only ever decrease and stay upper bounds), so once the front is thin the rounds are dropped: ONE
-// launch of resident wavefronts that pull tiles from a queue, visit them and push the neighbours they wake, until the
-// queue runs dry.  The critical path is then the chain of dependent visits, each at its own length.
+// towards field needs ~350 rounds, the last 335 of them over fewer than 8000 tiles, at 36-66 us a round (rocprofv3 kernel
+// trace, r03c) -- while a visit averages 18 us (this kernel's own clock: 744 000 visits, 13.3 wavefront-seconds).
+// The fixed point does not depend on the order of the visits (levels only ever decrease and stay upper bounds), so once
+// the front is thin the rounds are dropped: ONE launch of resident wavefronts that pull tiles from queues, visit them and
+// push the neighbours they wake, until the queues run dry.  S3: 26.1 -> 17.0 ms for the towards field.
 //   tile state   AQ_WAKE: queued, or woken while running;  AQ_RUN: a wavefront is visiting it.  A tile is in the queue
 //                at most once and visited by at most one wavefront at a time (two visits of one tile at once could
 //                store an older, higher level over a newer one).
