@@ -94,6 +94,14 @@ public:
   }
   // pinned host scalar slots for small read-backs
   uint32_t *host_words();
+  // A second stream of the current device (non-blocking, created on first use, kept for the life of the process) with a
+  // fork and a join event: work that does not depend on what the caller's stream is doing runs beside it --
+  // record fork on the caller's stream, let side wait for it, enqueue, record join on side, let the caller's stream wait.
+  struct SideLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+  };
+  SideLane &side_lane();
   // Frees every buffer.  Refused (Error) while a shard handle whose tables live in the workspace is alive: the handle
   // would keep dangling device pointers (rdgpu_*_shard_begin pins, _finish / _free unpins).
   void release();
@@ -108,6 +116,7 @@ private:
   std::mutex mu_;   // the maps below are shared by the threads of different devices
   std::map<std::string, Slot> slots_;
   std::map<int, uint32_t *> host_words_;   // per device: a read-back of one device must not land in another's words
+  std::map<int, SideLane> side_;
   int pins_ = 0;
 };
 

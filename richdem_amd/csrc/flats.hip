@@ -23,6 +23,7 @@
 #include "flowdirs.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <type_traits>
 #include <cstdlib>
 #include <climits>
@@ -210,9 +211,13 @@ __global__ __launch_bounds__(NTHR) void k_flag_fill(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------
 constexpr int CW = 64, CH = 32;
 
+// colZ / colL (optional): the tile's left and right columns (elevation, tile-level label), 2 * CH entries per tile, for
+// k_ccl_border2 -- read back from the raster those columns cost a 128-byte line per row and array (25.6 GB at S3).
+// A row outside the raster holds the label CCL_NOCELL.
+constexpr uint32_t CCL_NOCELL = 0xFFFFFFFFu;
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint32_t *__restrict__ L, int w, int h,
-                                                   uint32_t tilesX, uint32_t ntiles) {
+                                                   uint32_t tilesX, uint32_t ntiles, T *__restrict__ colZ, uint32_t *__restrict__ colL) {
   __shared__ T sz[CH * CW];
   __shared__ uint16_t lab[CH * CW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
@@ -231,6 +236,24 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
     lab[ly * CW + lx] = (uint16_t)(ly * CW + lx);
   }
   __syncthreads();
+  // A tile of ONE elevation (open water: 30 % of S3's tiles, 61 % of its NO_FLOW cells) is one component.
+  {
+    const bool inside = x0 + CW <= w && y0 + CH <= h;
+    const T z00 = sz[0];
+    bool same = inside;
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) same &= sz[(band * ROWS + j) * CW + lx] == z00;
+    if (__syncthreads_and(same)) {
+      const uint32_t root = (uint32_t)y0 * (uint32_t)w + (uint32_t)x0;
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) L[(size_t)(y0 + band * ROWS + j) * w + gx] = root;
+      if (colZ && threadIdx.x < 2 * CH) {
+        colZ[(size_t)t * (2 * CH) + threadIdx.x] = z00;
+        colL[(size_t)t * (2 * CH) + threadIdx.x] = root;
+      }
+      return;
+    }
+  }
   // 8-bit mask of in-tile, in-raster neighbours of equal elevation (bit k-1 for neighbour k)
   uint32_t msk[ROWS];
   int any = 0;
@@ -282,6 +305,13 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
     const int r = lab[ly * CW + lx];
     L[(size_t)gy * w + gx] = (uint32_t)(y0 + (r >> 6)) * (uint32_t)w + (uint32_t)(x0 + (r & (CW - 1)));
   }
+  if (colZ && threadIdx.x < 2 * CH) {
+    const int side = threadIdx.x / CH, ly = threadIdx.x % CH, cx = side ? CW - 1 : 0;
+    const bool in = x0 + cx < w && y0 + ly < h;
+    const int r = lab[ly * CW + cx];
+    colZ[(size_t)t * (2 * CH) + threadIdx.x] = sz[ly * CW + cx];
+    colL[(size_t)t * (2 * CH) + threadIdx.x] = in ? (uint32_t)(y0 + (r >> 6)) * (uint32_t)w + (uint32_t)(x0 + (r & (CW - 1))) : CCL_NOCELL;
+  }
 }
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *L, uint32_t x) {
@@ -328,6 +358,110 @@ __global__ __launch_bounds__(NTHR) void k_ccl_border(const T *__restrict__ z, ui
       if (x < w - 1 && (ty == 0 || tx == CW - 1) && z[c - w + 1] == e) uf_unite(L, c, c - (uint32_t)w + 1u);
     }
     if (x > 0 && tx == 0 && z[c - 1] == e) uf_unite(L, c, c - 1u);
+  }
+}
+
+// The same unions from the compact column records and with the repeats left out.  Along a lake's tile border every cell
+// asks for the SAME union (its tile's component with the neighbouring tile's): a pair of tile-level labels a lane has
+// asked for already, or that the lane before it asks for, is skipped -- the lane that keeps it is the first of the run.
+//   part A  one thread per cell of a tile's top row: NW, N, NE (the row above, other tiles; coalesced raster reads)
+//   part B  one thread per row of a tile's left column: NW, W, SW in the right column of the tile to the left
+//           (the NE of a right-column cell is the SW of the left-column cell one row up; the first / last row's
+//           NW / SW belong to another tile row: part A of the cell concerned has them as its NW / NE)
+__device__ __forceinline__ bool ccl_repeat(unsigned long long key, bool valid, const unsigned long long (&mine)[3], const bool (&mv)[3],
+                                           int upto, const unsigned long long (&prev)[3], const bool (&pv)[3], bool has_prev) {
+  if (!valid) return true;
+  for (int j = 0; j < upto; j++)
+    if (mv[j] && mine[j] == key) return true;
+  if (has_prev)
+    for (int j = 0; j < 3; j++)
+      if (pv[j] && prev[j] == key) return true;
+  return false;
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_ccl_border2(const T *__restrict__ z, uint32_t *L, const T *__restrict__ colZ,
+                                                      const uint32_t *__restrict__ colL, int w, int h, uint32_t tilesX, uint32_t ntiles) {
+  const uint64_t nA = (uint64_t)ntiles * CW, total = nA + (uint64_t)ntiles * CH;
+  const uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  unsigned long long key[3] = {0, 0, 0};
+  bool kv[3] = {false, false, false};
+  uint32_t a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+  if (i < nA) {
+    const uint32_t t = (uint32_t)(i / CW);
+    const int tx = (int)(i % CW);
+    const int x = (int)(t % tilesX) * CW + tx, y = (int)(t / tilesX) * CH;
+    if (x < w && y > 0 && y < h) {
+      const uint32_t c = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+      const T e = z[c];
+      const uint32_t lc = L[c];   // (a member of c's set whatever the unions under way have done to it)
+      for (int d = 0; d < 3; d++) {
+        const int nx = x + d - 1;
+        if (nx < 0 || nx >= w) continue;
+        const uint32_t n = c - (uint32_t)w + (uint32_t)(d - 1);
+        if (!(z[n] == e)) continue;
+        a[d] = lc; b[d] = L[n];
+        key[d] = ((unsigned long long)a[d] << 32) | b[d];
+        kv[d] = true;
+      }
+    }
+  } else if (i < total) {
+    const uint64_t k = i - nA;
+    const uint32_t t = (uint32_t)(k / CH);
+    const int ly = (int)(k % CH);
+    if (t % tilesX != 0) {
+      const size_t me = (size_t)t * (2 * CH) + ly, nb = (size_t)(t - 1) * (2 * CH) + CH;   // my left column, its right column
+      const uint32_t lc = colL[me];
+      if (lc != CCL_NOCELL) {
+        const T e = colZ[me];
+        for (int d = 0; d < 3; d++) {
+          const int ny = ly + d - 1;
+          if (ny < 0 || ny >= CH) continue;
+          const uint32_t ln = colL[nb + ny];
+          if (ln == CCL_NOCELL || !(colZ[nb + ny] == e)) continue;
+          a[d] = lc; b[d] = ln;
+          key[d] = ((unsigned long long)lc << 32) | ln;
+          kv[d] = true;
+        }
+      }
+    }
+  }
+  unsigned long long pk[3];
+  bool pv[3];
+  for (int d = 0; d < 3; d++) {
+    pk[d] = __shfl_up(key[d], 1, 64);
+    pv[d] = __shfl_up((int)kv[d], 1, 64) != 0;
+  }
+  for (int d = 0; d < 3; d++)
+    if (!ccl_repeat(key[d], kv[d], key, kv, d, pk, pv, lane > 0)) uf_unite(L, a[d], b[d]);
+}
+
+// k_ccl_flatten four cells a thread, and flat_height's start: a component's deepest away level is collected at its root
+// (fh[root] = 0; the other entries of fh are never read by the lean path)
+__global__ __launch_bounds__(NTHR) void k_ccl_flatten4(uint32_t *L, int32_t *fh, uint64_t n) {
+  const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t q = (uint64_t)blockIdx.x * NTHR + threadIdx.x; q < n4 + (n & 3); q += stride) {
+    if (q < n4) {
+      uint4 v = reinterpret_cast<const uint4 *>(L)[q];
+      uint32_t p[4] = {v.x, v.y, v.z, v.w};
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t c = (uint32_t)(4 * q) + e;
+        if (p[e] == c) { fh[c] = 0; continue; }
+        const uint32_t r = uf_find(L, p[e]);
+        any |= r != p[e];
+        p[e] = r;
+      }
+      if (any) reinterpret_cast<uint4 *>(L)[q] = make_uint4(p[0], p[1], p[2], p[3]);
+    } else {
+      const uint64_t c = 4 * n4 + (q - n4);
+      const uint32_t p = L[c];
+      if (p == (uint32_t)c) { fh[c] = 0; continue; }
+      const uint32_t r = uf_find(L, p);
+      if (r != p) L[c] = r;
+    }
   }
 }
 
@@ -1301,6 +1435,29 @@ __global__ __launch_bounds__(NTHR) void k_flat_height(const int32_t *__restrict_
   }
 }
 
+// the same, four cells a thread
+__global__ __launch_bounds__(NTHR) void k_flat_height4(const int32_t *__restrict__ A, const uint32_t *__restrict__ L, int32_t *fh,
+                                                       uint64_t n) {
+  const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * NTHR;
+  auto one = [&](int32_t a, uint32_t r) {
+    if (__hip_atomic_load(&fh[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a) atomicMax(&fh[r], a);
+  };
+  for (uint64_t q = (uint64_t)blockIdx.x * NTHR + threadIdx.x; q < n4 + (n & 3); q += stride) {
+    if (q < n4) {
+      const int4 a = reinterpret_cast<const int4 *>(A)[q];
+      if (a.x >= DINF && a.y >= DINF && a.z >= DINF && a.w >= DINF) continue;
+      const uint4 l = reinterpret_cast<const uint4 *>(L)[q];
+      if (a.x < DINF) one(a.x, l.x);
+      if (a.y < DINF) one(a.y, l.y);
+      if (a.z < DINF) one(a.z, l.z);
+      if (a.w < DINF) one(a.w, l.w);
+    } else {
+      const uint64_t c = 4 * n4 + (q - n4);
+      if (A[c] < DINF) one(A[c], L[c]);
+    }
+  }
+}
+
 // flat_mask from the two distance fields, in place over the towards distances (:279-284):
 //   low edge -> 2;  NO_FLOW cell at towards level t, away level a: (a reached ? flat_height - a : 0) + 2t
 __global__ __launch_bounds__(NTHR) void k_flat_combine(int32_t *M /* in: towards level */, const int32_t *__restrict__ A,
@@ -1695,7 +1852,8 @@ struct AsyncInfo { uint32_t visits, launches; };
 static thread_local AsyncInfo g_async_info = {0, 0};
 
 template <int SEED_LEVEL>
-static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s, RowWin win) {
+static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s, RowWin win,
+                             const std::function<void()> *beside) {
   Workspace &ws = Workspace::get();
   uint32_t per_q = 64;   // slots per queue: every tile of a queue at once
   while (per_q < (b.ntiles + AQ_NQ - 1) / AQ_NQ) per_q <<= 1;
@@ -1723,6 +1881,7 @@ static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, con
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_NAP")) nap = std::min(255, std::max(1, atoi(e)));
   RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
             h, win, b.tilesX, b.tilesY, budget, nap);
+  if (beside) (*beside)();   // (the resident wavefronts have their places: now the work that is to run beside them)
   // the end state, checked on the host: no abort, every counter pair equal, every queue drained
   std::vector<uint32_t> all(AQ_WORDS);
   RD_HIP(hipMemcpyAsync(all.data(), Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1747,7 +1906,9 @@ static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, con
 
 template <int SEED_LEVEL>
 static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s,
-                                  RowWin win = RowWin{0, -1, nullptr, nullptr}) {
+                                  RowWin win = RowWin{0, -1, nullptr, nullptr}, const std::function<void()> *beside = nullptr) {
+  // beside: called once, when the search has come down to its latency-bound tail (or is over): the moment to enqueue
+  // independent work on another stream
   if (win.hi < 0) win.hi = h;   // single device: all rows, no ghost rows
   uint32_t *hw = Workspace::get().host_words();
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
@@ -1783,12 +1944,15 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
                         "level loop + flushes %llu, flushes %llu, wake %llu, whole %llu, longest %llu\n", name, st[7], st[8], st[9],
                 st[10], st[11], st[12], st[13], st[14], st[15]);
       }
-      if (hw[k] == 0) return rounds;
+      if (hw[k] == 0) {
+        if (beside) (*beside)();
+        return rounds;
+      }
       most = std::max(most, hw[k]);
       rounds++;
     }
     if (async_below && hw[batch - 1] < async_below) {
-      relax_async_tail<SEED_LEVEL>(b, D, w, h, name, s, win);
+      relax_async_tail<SEED_LEVEL>(b, D, w, h, name, s, win, beside);
       return rounds + 1;
     }
     grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
@@ -1799,7 +1963,7 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
 // Towards levels from the low edges, D written in full; write_m: also the bitmap of the cells that take part (shared
 // with the away field); counts3 (optional, host): low edges, high edges, NO_FLOW cells.
 static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m, unsigned long long *counts3, int w, int h,
-                                 hipStream_t s) {
+                                 hipStream_t s, const std::function<void()> *beside = nullptr) {
   const BitsScratch b = bits_scratch(w, h);
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
@@ -1818,7 +1982,7 @@ static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m,
     RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)cnt, out);
     RD_HIP(hipMemcpyAsync(counts3, out, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // (read after the rounds' sync)
   }
-  return relax_rounds_bits<2>(b, D, w, h, "flats.relax_towards", s);
+  return relax_rounds_bits<2>(b, D, w, h, "flats.relax_towards", s, RowWin{0, -1, nullptr, nullptr}, beside);
 }
 
 // Away levels from the high edges (with L / fh: only those of flats that have an outlet), D written in full.
@@ -1834,6 +1998,11 @@ static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
               b.tflags, (uint32_t *)nullptr, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   return relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s);
+}
+
+static bool lean_labels() {
+  const char *env = getenv("RDGPU_RFE_LEAN");   // =0: labels, outlet marks and flat heights as the flat_mask path makes them: A/B and tests
+  return !(env && env[0] == '0');
 }
 
 static bool use_bits_engine() {
@@ -1869,9 +2038,52 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   int32_t *fh = ws.buf<int32_t>("flats.fh", n);
   *outL = L;
   *outFh = fh;
+  if (outA && use_bits_engine() && lean_labels()) {
+    // The caller wants the levels, the labels and the flat heights (ResolveFlatsEpsilon), nothing per flat beyond that: the
+    // labels do not depend on the searches here.  "The flat has an outlet" (:491-500) is what the towards levels say anyway
+    // (a flat without a low edge is never reached: its cells keep DINF and k_flat_epsilon4 skips them), so the away field
+    // starts from EVERY high edge and fh needs no "-1 = no outlet" marks: no k_flat_mark_low pass, no fill of fh.
+    const uint32_t tilesX = (w + CW - 1) / CW, ntiles = tilesX * ((h + CH - 1) / CH);
+    T *colZ = ws.buf<T>("flats.colz", (size_t)ntiles * 2 * CH);
+    uint32_t *colL = ws.buf<uint32_t>("flats.coll", (size_t)ntiles * 2 * CH);
+    // ... and so they are made BESIDE the tail of the towards search (and the away search after it), on the device's side
+    // stream: the tail keeps two resident blocks per CU busy with dependent visits and leaves the memory system idle, the
+    // labelling is three streaming passes.  (Started with the search's first rounds, which are throughput-bound
+    // themselves, the labels only took their turn: 64.4 -> 63.0 ms at S3.)  RDGPU_RFE_OVERLAP=0: one stream.
+    const char *env = getenv("RDGPU_RFE_OVERLAP");
+    const bool beside = !(env && env[0] == '0');
+    hipStream_t ls = s;
+    Workspace::SideLane *lane = nullptr;
+    if (beside) {
+      lane = &ws.side_lane();
+      ls = lane->stream;
+      RD_HIP(hipEventRecord(lane->fork, s));   // (the DEM and the workspace are as the caller's stream left them)
+    }
+    const std::function<void()> labels = [&]() {
+      if (beside) RD_HIP(hipStreamWaitEvent(ls, lane->fork, 0));
+      RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, ls, d_z, L, w, h, tilesX, ntiles, colZ, colL);
+      const uint64_t nthreads = (uint64_t)ntiles * (CW + CH);
+      RD_LAUNCH("flats.ccl_border", (k_ccl_border2<T>), dim3((uint32_t)((nthreads + NTHR - 1) / NTHR)), dim3(NTHR), 0, ls, d_z, L,
+                (const T *)colZ, (const uint32_t *)colL, w, h, tilesX, ntiles);
+      RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten4, dim3(sgrid(n / 4 + 3)), dim3(NTHR), 0, ls, L, fh, n);
+      if (beside) RD_HIP(hipEventRecord(lane->join, ls));
+    };
+    if (!beside) labels();
+    g_fstats.towards_levels = run_bits_towards(flags, M, true, nullptr, w, h, s, beside ? &labels : nullptr);
+    int32_t *A = nullptr;
+    if (nhigh_all > 0) {
+      A = ws.buf<int32_t>("flats.away", n);
+      g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
+    }
+    if (beside) RD_HIP(hipStreamWaitEvent(s, lane->join, 0));
+    if (A) RD_LAUNCH("flats.height", k_flat_height4, dim3(sgrid(n / 4 + 3)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh, n);
+    *outA = A;
+    return;
+  }
   {
     const uint32_t tilesX = (w + CW - 1) / CW, ntiles = tilesX * ((h + CH - 1) / CH);
-    RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, L, w, h, tilesX, ntiles);
+    RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, L, w, h, tilesX, ntiles, (T *)nullptr,
+              (uint32_t *)nullptr);
   }
   launch_ccl_border<T>(d_z, L, w, h, s);
   RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, L, n);
@@ -2377,7 +2589,8 @@ static rdgpu_flat_shard *fs_begin(const T *d_z, T nodata, int w, int rows, int g
       if (gtop) RD_LAUNCH("flatshard.ghost_mask", k_fs_ghost_mask, dim3(tilesX), dim3(64), 0, s, (const uint8_t *)f->dirs + (size_t)(gtop - 1) * w, w, f->gmask[0]);
       if (gbot) RD_LAUNCH("flatshard.ghost_mask", k_fs_ghost_mask, dim3(tilesX), dim3(64), 0, s, (const uint8_t *)f->dirs + (size_t)(rows - gbot) * w, w, f->gmask[1]);
     }
-    RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles);
+    RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, f->L, w, rows, tilesX, ntiles, (T *)nullptr,
+              (uint32_t *)nullptr);
     launch_ccl_border<T>(d_z, f->L, w, rows, s);
     RD_LAUNCH("flats.ccl_flatten", k_ccl_flatten, dim3(sgrid(n)), dim3(NTHR), 0, s, f->L, n);
     RD_HIP(hipMemsetAsync(f->fh, 0, n * 4, s));
@@ -2544,6 +2757,49 @@ __global__ __launch_bounds__(NTHR) void k_flat_epsilon(T *z, const int32_t *__re
   }
 }
 
+// the same, four cells a thread (16-byte loads of the level fields; a vector of elevations is stored only when one of
+// its cells moved)
+template <class T>
+struct alignas(sizeof(T) * 4 > 16 ? 16 : sizeof(T) * 4) ElevQuad { T v[4]; };
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_flat_epsilon4(T *z, const int32_t *__restrict__ TW, const int32_t *__restrict__ A,
+                                                        const uint32_t *__restrict__ L, const int32_t *__restrict__ fh, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, n4 = n / 4, stride = (uint64_t)gridDim.x * NTHR;
+  auto mask_of = [&](int32_t t, int32_t a, uint32_t l, uint64_t c) -> uint32_t {
+    if (t >= DINF) return 0u;
+    const int32_t m = (a < DINF ? fh[l] - a : 0) + 2 * t;
+    if (m <= 0) return 0u;
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) return 0u;
+    return (uint32_t)m;
+  };
+  for (uint64_t q = (uint64_t)blockIdx.x * NTHR + threadIdx.x; q < n4 + (n & 3); q += stride) {
+    if (q < n4) {
+      const int4 t = reinterpret_cast<const int4 *>(TW)[q];
+      if (t.x >= DINF && t.y >= DINF && t.z >= DINF && t.w >= DINF) continue;
+      int4 a = make_int4(DINF, DINF, DINF, DINF);
+      uint4 l = make_uint4(0, 0, 0, 0);
+      if (A) {
+        a = reinterpret_cast<const int4 *>(A)[q];
+        if (a.x < DINF || a.y < DINF || a.z < DINF || a.w < DINF) l = reinterpret_cast<const uint4 *>(L)[q];
+      }
+      const uint32_t m[4] = {mask_of(t.x, a.x, l.x, 4 * q), mask_of(t.y, a.y, l.y, 4 * q + 1), mask_of(t.z, a.z, l.z, 4 * q + 2),
+                             mask_of(t.w, a.w, l.w, 4 * q + 3)};
+      if (!(m[0] | m[1] | m[2] | m[3])) continue;
+      ElevQuad<T> e = reinterpret_cast<const ElevQuad<T> *>(z)[q];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (m[k]) e.v[k] = epsilon_steps<T>(e.v[k], m[k]);
+      reinterpret_cast<ElevQuad<T> *>(z)[q] = e;
+    } else {
+      const uint64_t c = 4 * n4 + (q - n4);
+      const int32_t a = A ? A[c] : DINF;
+      const uint32_t m = mask_of(TW[c], a, a < DINF ? L[c] : 0u, c);
+      if (m) z[c] = epsilon_steps<T>(z[c], m);
+    }
+  }
+}
+
 template <class T>
 void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s) {
   if (!d_z) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: null pointer");
@@ -2560,9 +2816,14 @@ void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s)
   uint32_t *L;
   const int32_t *A = nullptr;
   resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s, &A);
-  if (L)
-    RD_LAUNCH("flats.epsilon", (k_flat_epsilon<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, A,
-              (const uint32_t *)L, (const int32_t *)fh, w, h);
+  if (L) {
+    if (reinterpret_cast<uintptr_t>(d_z) % 16 == 0)
+      RD_LAUNCH("flats.epsilon", (k_flat_epsilon4<T>), dim3(sgrid((uint64_t)w * h / 4 + 3)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, A,
+                (const uint32_t *)L, (const int32_t *)fh, w, h);
+    else   // (a DEM pointer that is not 16-byte aligned: one cell a thread)
+      RD_LAUNCH("flats.epsilon", (k_flat_epsilon<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, A,
+                (const uint32_t *)L, (const int32_t *)fh, w, h);
+  }
 }
 
 template <class T>

@@ -85,6 +85,19 @@ uint32_t *Workspace::host_words() {
   return p;
 }
 
+Workspace::SideLane &Workspace::side_lane() {
+  int dev = 0;
+  RD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu_);
+  SideLane &l = side_[dev];
+  if (!l.stream) {
+    RD_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    RD_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+    RD_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+  }
+  return l;
+}
+
 void Workspace::release() {
   std::lock_guard<std::mutex> g(mu_);
   if (pins_ > 0)
