@@ -334,13 +334,23 @@ void ref_fill_max_dep(T *dem, int w, int h, int topo, uint64_t max_dep_size) {
   if (topo == 8) PriorityFlood_Barnes2014_max_dep<Topology::D8>(a, max_dep_size);
   else PriorityFlood_Barnes2014_max_dep<Topology::D4>(a, max_dep_size);
 }
+// PriorityFloodFlowdirs_Barnes2014(elevations, flowdirs) (:483-555)
+template <class T>
+void ref_pf_flowdirs(T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  Array2D<d8_flowdir_t> fd;
+  PriorityFloodFlowdirs_Barnes2014(a, fd);
+  std::memcpy(dirs, fd.data(), (size_t)w * h);
+}
 #define REF_F2_API(SUF, T)                                                                                                    \
   extern "C" void ref_watersheds_##SUF(T *dem, T nodata, int w, int h, int topo, int alter, int32_t *labels) {                \
     ref_watersheds<T>(dem, nodata, w, h, topo, alter, labels);                                                                \
   }                                                                                                                           \
   extern "C" void ref_fill_max_dep_##SUF(T *dem, int w, int h, int topo, uint64_t max_dep_size) {                             \
     ref_fill_max_dep<T>(dem, w, h, topo, max_dep_size);                                                                       \
-  }
+  }                                                                                                                           \
+  extern "C" void ref_pf_flowdirs_##SUF(T *dem, T nodata, int w, int h, uint8_t *dirs) { ref_pf_flowdirs<T>(dem, nodata, w, h, dirs); }
 REF_F2_API(u8, uint8_t)
 REF_F2_API(i8, int8_t)
 REF_F2_API(i16, int16_t)

@@ -158,6 +158,28 @@ def test_f2_restatements_equal_the_compiled_reference_outputs(orc, f2):
                 assert np.array_equal(orc.port.fill_max_dep(dem, md, topo), f2[f"{name}/max_dep{md}_d{topo}"]), (name, topo, md)
 
 
+def test_pf_flowdirs_restatement_equals_the_compiled_reference(orc, f2):
+    """PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555): its queue orders equal elevations by
+    insertion, so the output is defined with ties too -- committed outputs of the compiled reference on tie-free and on
+    tie-heavy DEMs, and the live reference on random ones.  (Oracle only: the engine does not provide this entry point,
+    DESIGN.md section 3b.)"""
+    names = sorted(k.split("/")[0] for k in f2.files if k.endswith("/pf_flowdirs"))
+    assert len(names) >= 6
+    for name in names:
+        assert np.array_equal(orc.port.pf_flowdirs(f2[f"{name}/dem"], -9999.0), f2[f"{name}/pf_flowdirs"]), name
+    ties = sorted(k.split("/")[0] for k in f2.files if k.endswith("/pf_flowdirs_ties"))
+    assert len(ties) >= 2
+    for name in ties:
+        dem = f2[f"{name}/dem_ties"]
+        assert np.array_equal(orc.port.pf_flowdirs(dem, dem.dtype.type(-9999)), f2[f"{name}/pf_flowdirs_ties"]), name
+    if orc.ref.available:
+        rng = np.random.default_rng(11)
+        for t in range(30):
+            h, w = rng.integers(3, 70, 2)
+            dem = rng.integers(0, 8, (h, w)).astype(np.int32) if t % 2 else rng.random((h, w)).astype(np.float32)
+            assert np.array_equal(orc.port.pf_flowdirs(dem, -9999), orc.ref.pf_flowdirs(dem, -9999)), t
+
+
 @pytest.mark.parametrize("dtype,offset", [(np.int32, -20), (np.uint8, 0), (np.int64, -20), (np.int32, 1 << 26),
                                           (np.uint32, (1 << 31) + 5), (np.int64, -(1 << 40)), (np.uint64, 1 << 50)])
 def test_alter_true_on_integer_dems_port_equals_reference(orc, dtype, offset):
