@@ -132,12 +132,14 @@ def f2():
             for md in (0, 3, 40, 100000):
                 g[f"{name}/max_dep{md}_d{topo}"] = R.fill_max_dep(dem, md, topo)
         g[f"{name}/pf_flowdirs"] = R.pf_flowdirs(dem, -9999.0)
+    ties = {}
     # PriorityFloodFlowdirs breaks ties by insertion order (a total order): its output is a function of the DEM even
     # with equal elevations, so tie-heavy integer DEMs are pinned too
     for name, dem in {"ties_i32": rng.integers(0, 6, (47, 61)).astype(np.int32),
                       "ties_nodata_f32": np.where(rng.random((40, 53)) < 0.06, -9999.0, rng.integers(0, 40, (40, 53))).astype(np.float32)}.items():
-        g[f"{name}/dem_ties"] = dem
-        g[f"{name}/pf_flowdirs_ties"] = R.pf_flowdirs(dem, dem.dtype.type(-9999))
+        ties[f"{name}/dem"] = dem
+        ties[f"{name}/pf_flowdirs"] = R.pf_flowdirs(dem, dem.dtype.type(-9999))
+    np.savez_compressed(os.path.join(HERE, "ref_pf_flowdirs_ties.npz"), **ties)
     np.savez_compressed(os.path.join(HERE, "ref_f2.npz"), **g)
     print("wrote", len(g), "f2 arrays")
 

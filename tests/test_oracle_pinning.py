@@ -167,11 +167,14 @@ def test_pf_flowdirs_restatement_equals_the_compiled_reference(orc, f2):
     assert len(names) >= 6
     for name in names:
         assert np.array_equal(orc.port.pf_flowdirs(f2[f"{name}/dem"], -9999.0), f2[f"{name}/pf_flowdirs"]), name
-    ties = sorted(k.split("/")[0] for k in f2.files if k.endswith("/pf_flowdirs_ties"))
+    import os
+
+    tg = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_pf_flowdirs_ties.npz"))
+    ties = sorted(k.split("/")[0] for k in tg.files if k.endswith("/pf_flowdirs"))
     assert len(ties) >= 2
     for name in ties:
-        dem = f2[f"{name}/dem_ties"]
-        assert np.array_equal(orc.port.pf_flowdirs(dem, dem.dtype.type(-9999)), f2[f"{name}/pf_flowdirs_ties"]), name
+        dem = tg[f"{name}/dem"]
+        assert np.array_equal(orc.port.pf_flowdirs(dem, dem.dtype.type(-9999)), tg[f"{name}/pf_flowdirs"]), name
     if orc.ref.available:
         rng = np.random.default_rng(11)
         for t in range(30):
