@@ -101,7 +101,7 @@ public:
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
   };
-  SideLane &side_lane();
+  SideLane &side_lane(int k = 0);   // k = 0, 1: two lanes per device
   // Frees every buffer.  Refused (Error) while a shard handle whose tables live in the workspace is alive: the handle
   // would keep dangling device pointers (rdgpu_*_shard_begin pins, _finish / _free unpins).
   void release();
@@ -116,7 +116,7 @@ private:
   std::mutex mu_;   // the maps below are shared by the threads of different devices
   std::map<std::string, Slot> slots_;
   std::map<int, uint32_t *> host_words_;   // per device: a read-back of one device must not land in another's words
-  std::map<int, SideLane> side_;
+  std::map<std::pair<int, int>, SideLane> side_;
   int pins_ = 0;
 };
 

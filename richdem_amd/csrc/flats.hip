@@ -1828,15 +1828,16 @@ static uint32_t run_relax_towards(const uint8_t *d_dirs, const uint8_t *flags, i
 }
 
 // ---- the bitmap engine's rounds (same protocol as relax_rounds: batches of rounds, counts read back per batch) ----
-static BitsScratch bits_scratch(int w, int h) {
+// second = true: the tile flags, lists and counters of a search that runs BESIDE another one (the bitmaps are shared)
+static BitsScratch bits_scratch(int w, int h, bool second = false) {
   Workspace &ws = Workspace::get();
   BitsScratch b;
   b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
   b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT);
-  b.expanded = ws.buf<uint8_t>("flats.bexp", b.ntiles);
-  b.tflags = ws.buf<uint8_t>("flats.btflags", b.ntiles);
-  b.tlist = ws.buf<uint32_t>("flats.btlist", b.ntiles);
-  b.ctr = ws.buf<uint32_t>("flats.tctr", BITS_BATCH);
+  b.expanded = ws.buf<uint8_t>(second ? "flats.bexp2" : "flats.bexp", b.ntiles);
+  b.tflags = ws.buf<uint8_t>(second ? "flats.btflags2" : "flats.btflags", b.ntiles);
+  b.tlist = ws.buf<uint32_t>(second ? "flats.btlist2" : "flats.btlist", b.ntiles);
+  b.ctr = ws.buf<uint32_t>(second ? "flats.tctr2" : "flats.tctr", BITS_BATCH);
   b.counts = ws.buf<uint32_t>("flats.bcounts", 3 * 256 + 8);
   return b;
 }
@@ -1851,40 +1852,62 @@ static uint32_t async_threshold() {
 struct AsyncInfo { uint32_t visits, launches; };
 static thread_local AsyncInfo g_async_info = {0, 0};
 
+// What relax_rounds_bits / the static search hand to the code around them when the search reaches its tail: mark() before
+// the resident launch is enqueued (the place for an event the side work waits on), go() after it (the resident
+// wavefronts have their places: now the work that is to run beside them).  Both are called exactly once, also when the
+// search ends in its rounds.
+struct Beside {
+  std::function<void()> mark, go;
+};
+
+struct AsyncRun {
+  AsyncQ Q;
+  uint32_t blocks = 0;
+  int cus = 0, rate_khz = 0;
+};
+
+// compaction of the flags the last round left + the queues' first content + the resident launch, all on s, no host step
 template <int SEED_LEVEL>
-static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s, RowWin win,
-                             const std::function<void()> *beside) {
+static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s, RowWin win, bool second,
+                              const Beside *beside) {
   Workspace &ws = Workspace::get();
   uint32_t per_q = 64;   // slots per queue: every tile of a queue at once
   while (per_q < (b.ntiles + AQ_NQ - 1) / AQ_NQ) per_q <<= 1;
-  AsyncQ Q;
-  Q.q = ws.buf<uint32_t>("flats.aq", (size_t)per_q * AQ_NQ);
-  Q.state = ws.buf<uint32_t>("flats.aqstate", b.ntiles);
-  Q.ctl = ws.buf<uint32_t>("flats.aqctl", AQ_WORDS);
+  AsyncRun r;
+  AsyncQ &Q = r.Q;
+  Q.q = ws.buf<uint32_t>(second ? "flats.aq2" : "flats.aq", (size_t)per_q * AQ_NQ);
+  Q.state = ws.buf<uint32_t>(second ? "flats.aqstate2" : "flats.aqstate", b.ntiles);
+  Q.ctl = ws.buf<uint32_t>(second ? "flats.aqctl2" : "flats.aqctl", AQ_WORDS);
   Q.qmask = per_q - 1;
-  int dev = 0, cus = 0, rate_khz = 0;
+  int dev = 0;
   RD_HIP(hipGetDevice(&dev));
-  RD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  RD_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev));
-  const unsigned long long budget = (unsigned long long)std::max(rate_khz, 1000) * 1000ull * 10ull;   // ten seconds of wall_clock64 ticks
-  RD_HIP(hipMemsetAsync(b.ctr, 0, sizeof(uint32_t), s));
+  RD_HIP(hipDeviceGetAttribute(&r.cus, hipDeviceAttributeMultiprocessorCount, dev));
+  RD_HIP(hipDeviceGetAttribute(&r.rate_khz, hipDeviceAttributeWallClockRate, dev));
+  const unsigned long long budget = (unsigned long long)std::max(r.rate_khz, 1000) * 1000ull * 10ull;   // ten seconds of wall_clock64 ticks
+  uint32_t *last = b.ctr + (BITS_BATCH - 1);   // (its own counter word: the rounds' words may not have been read back yet)
+  RD_HIP(hipMemsetAsync(last, 0, sizeof(uint32_t), s));
   RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
-            b.ctr);
+            last);
   RD_HIP(hipMemsetAsync(Q.q, 0xFF, (size_t)per_q * AQ_NQ * sizeof(uint32_t), s));
   RD_HIP(hipMemsetAsync(Q.state, 0, (size_t)b.ntiles * sizeof(uint32_t), s));
   RD_HIP(hipMemsetAsync(Q.ctl, 0, AQ_WORDS * sizeof(uint32_t), s));
   RD_LAUNCH("flats.async_init", k_async_init, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)b.tlist,
-            (const uint32_t *)b.ctr, Q);
-  uint32_t blocks = (uint32_t)cus * 2u;   // (measured at S3: 2 per CU 40.6 ms, 1: 45.5, 3: 40.9, 4: 42.7 -- idle wavefronts poll)
+            (const uint32_t *)last, Q);
+  r.blocks = (uint32_t)r.cus * 2u;   // (measured at S3: 2 per CU 40.6 ms, 1: 45.5, 3: 40.9, 4: 42.7 -- idle wavefronts poll)
   int nap = 1;
-  if (const char *e = getenv("RDGPU_FLAT_ASYNC_BLOCKS")) blocks = std::max(1, atoi(e));
+  if (const char *e = getenv("RDGPU_FLAT_ASYNC_BLOCKS")) r.blocks = std::max(1, atoi(e));
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_NAP")) nap = std::min(255, std::max(1, atoi(e)));
-  RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
+  if (beside && beside->mark) beside->mark();
+  RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(r.blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
             h, win, b.tilesX, b.tilesY, budget, nap);
-  if (beside) (*beside)();   // (the resident wavefronts have their places: now the work that is to run beside them)
-  // the end state, checked on the host: no abort, every counter pair equal, every queue drained
+  if (beside && beside->go) beside->go();
+  return r;
+}
+
+// the end state, checked on the host (s is synchronised here): no abort, every counter pair equal, every queue drained
+static void async_check(const AsyncRun &r, const char *name, hipStream_t s) {
   std::vector<uint32_t> all(AQ_WORDS);
-  RD_HIP(hipMemcpyAsync(all.data(), Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  RD_HIP(hipMemcpyAsync(all.data(), r.Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   uint64_t enq = 0, done = 0, queued = 0, pushes = 0;
   for (int qi = 0; qi < AQ_NQ; qi++) {
@@ -1900,15 +1923,13 @@ static void relax_async_tail(const BitsScratch &b, int32_t *D, int w, int h, con
   g_async_info.launches++;
   if (getenv("RDGPU_FLAT_TRACE"))
     fprintf(stderr, "%s asynchronous tail: %u visits, %llu pushes, %u wavefronts on %d CUs, ticks (%d kHz): in visits %llu, longest wavefront %u\n",
-            name, all[AQ_G_VISITS], (unsigned long long)pushes, blocks * 4u, cus, rate_khz,
+            name, all[AQ_G_VISITS], (unsigned long long)pushes, r.blocks * 4u, r.cus, r.rate_khz,
             (unsigned long long)all[AQ_G_BUSY] | ((unsigned long long)all[AQ_G_BUSY + 1] << 32), all[AQ_G_SPAN]);
 }
 
 template <int SEED_LEVEL>
 static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s,
-                                  RowWin win = RowWin{0, -1, nullptr, nullptr}, const std::function<void()> *beside = nullptr) {
-  // beside: called once, when the search has come down to its latency-bound tail (or is over): the moment to enqueue
-  // independent work on another stream
+                                  RowWin win = RowWin{0, -1, nullptr, nullptr}, const Beside *beside = nullptr) {
   if (win.hi < 0) win.hi = h;   // single device: all rows, no ghost rows
   uint32_t *hw = Workspace::get().host_words();
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
@@ -1945,14 +1966,16 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
                 st[10], st[11], st[12], st[13], st[14], st[15]);
       }
       if (hw[k] == 0) {
-        if (beside) (*beside)();
+        if (beside && beside->mark) beside->mark();
+        if (beside && beside->go) beside->go();
         return rounds;
       }
       most = std::max(most, hw[k]);
       rounds++;
     }
     if (async_below && hw[batch - 1] < async_below) {
-      relax_async_tail<SEED_LEVEL>(b, D, w, h, name, s, win, beside);
+      const AsyncRun run = async_enqueue<SEED_LEVEL>(b, D, w, h, name, s, win, false, beside);
+      async_check(run, name, s);
       return rounds + 1;
     }
     grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
@@ -1963,7 +1986,7 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
 // Towards levels from the low edges, D written in full; write_m: also the bitmap of the cells that take part (shared
 // with the away field); counts3 (optional, host): low edges, high edges, NO_FLOW cells.
 static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m, unsigned long long *counts3, int w, int h,
-                                 hipStream_t s, const std::function<void()> *beside = nullptr) {
+                                 hipStream_t s, const Beside *beside = nullptr) {
   const BitsScratch b = bits_scratch(w, h);
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
@@ -1998,6 +2021,49 @@ static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
               b.tflags, (uint32_t *)nullptr, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   return relax_rounds_bits<1>(b, D, w, h, "flats.relax_away", s);
+}
+
+// The away search as ONE enqueue, without a host decision: start levels, AWAY_STATIC_ROUNDS rounds over a full grid, the
+// asynchronous tail for whatever is left (any number of rounds before the tail gives the same levels).  It runs on a side
+// stream beside the TAIL of the towards search: that tail keeps two resident blocks per CU on dependent visits, the
+// away search's rounds are throughput-bound.  RDGPU_FLAT_AWAY_BESIDE=0: after the towards search, on its stream.
+constexpr int AWAY_STATIC_ROUNDS = 8;
+struct StaticAway {
+  BitsScratch b;
+  AsyncRun run;
+};
+static bool away_beside() {
+  const char *env = getenv("RDGPU_FLAT_AWAY_BESIDE");
+  return !(env && env[0] == '0') && async_threshold() > 0 && getenv("RDGPU_FLAT_TRACE") == nullptr;
+}
+static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, int h, hipStream_t s) {
+  static_assert(AWAY_STATIC_ROUNDS < BITS_BATCH - 1, "the tail's own counter word is the last one");
+  StaticAway sa;
+  sa.b = bits_scratch(w, h, true);
+  const BitsScratch &b = sa.b;
+  const RowWin win{0, h, nullptr, nullptr};
+  RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
+  RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
+            (const int32_t *)nullptr, A, b.mbits, b.tflags, (uint32_t *)nullptr, w, win, (const int32_t *)nullptr, b.tilesX, b.tilesY);
+  RD_HIP(hipMemsetAsync(b.ctr, 0, BITS_BATCH * sizeof(uint32_t), s));
+  for (int k = 0; k < AWAY_STATIC_ROUNDS; k++) {
+    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
+              b.ctr + k);
+    RD_LAUNCH("flats.relax_away", (k_relax_bits<1>), dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
+              b.expanded, A, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win, b.tilesX, b.tilesY);
+  }
+  sa.run = async_enqueue<1>(b, A, w, h, "flats.relax_away", s, win, true, nullptr);
+  return sa;
+}
+// on a stream that has waited for the side stream: the end state of the tail, and the number of rounds that had work
+static uint32_t finish_away_static(const StaticAway &sa, hipStream_t s) {
+  uint32_t counts[AWAY_STATIC_ROUNDS];
+  RD_HIP(hipMemcpyAsync(counts, sa.b.ctr, sizeof counts, hipMemcpyDeviceToHost, s));
+  async_check(sa.run, "flats.relax_away", s);   // (synchronises s)
+  uint32_t rounds = 1;
+  for (int k = 0; k < AWAY_STATIC_ROUNDS; k++) rounds += counts[k] != 0;
+  return rounds;
 }
 
 static bool lean_labels() {
@@ -2053,13 +2119,13 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     const char *env = getenv("RDGPU_RFE_OVERLAP");
     const bool beside = !(env && env[0] == '0');
     hipStream_t ls = s;
-    Workspace::SideLane *lane = nullptr;
+    Workspace::SideLane *lane = nullptr;   // (lane 0: the labels; lane 1: the away search)
     if (beside) {
-      lane = &ws.side_lane();
+      lane = &ws.side_lane(0);
       ls = lane->stream;
       RD_HIP(hipEventRecord(lane->fork, s));   // (the DEM and the workspace are as the caller's stream left them)
     }
-    const std::function<void()> labels = [&]() {
+    const auto labels = [&]() {
       if (beside) RD_HIP(hipStreamWaitEvent(ls, lane->fork, 0));
       RD_LAUNCH("flats.ccl_tile", (k_ccl_tile<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, ls, d_z, L, w, h, tilesX, ntiles, colZ, colL);
       const uint64_t nthreads = (uint64_t)ntiles * (CW + CH);
@@ -2069,9 +2135,31 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
       if (beside) RD_HIP(hipEventRecord(lane->join, ls));
     };
     if (!beside) labels();
-    g_fstats.towards_levels = run_bits_towards(flags, M, true, nullptr, w, h, s, beside ? &labels : nullptr);
+    // ... the away search too, on a second side stream (see enqueue_away_static), only on request: with the labels already
+    // beside the tail a third stream gains nothing (S3: 58.7 ms without, 59.5 with; RDGPU_RFE_AWAY_BESIDE=1)
+    const char *env3 = getenv("RDGPU_RFE_AWAY_BESIDE");
+    const bool away_too = beside && env3 && env3[0] == '1' && away_beside() && nhigh_all > 0;
+    Workspace::SideLane *alane = away_too ? &ws.side_lane(1) : nullptr;
+    StaticAway sa;
     int32_t *A = nullptr;
-    if (nhigh_all > 0) {
+    Beside bs;
+    bs.mark = [&]() {
+      if (away_too) RD_HIP(hipEventRecord(alane->fork, s));
+    };
+    bs.go = [&]() {
+      if (beside) labels();
+      if (away_too) {
+        RD_HIP(hipStreamWaitEvent(alane->stream, alane->fork, 0));
+        A = ws.buf<int32_t>("flats.away", n);
+        sa = enqueue_away_static(flags, A, w, h, alane->stream);
+        RD_HIP(hipEventRecord(alane->join, alane->stream));
+      }
+    };
+    g_fstats.towards_levels = run_bits_towards(flags, M, true, nullptr, w, h, s, &bs);
+    if (away_too) {
+      RD_HIP(hipStreamWaitEvent(s, alane->join, 0));
+      g_fstats.away_levels = finish_away_static(sa, s);
+    } else if (nhigh_all > 0) {
       A = ws.buf<int32_t>("flats.away", n);
       g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
     }
@@ -2144,14 +2232,39 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   if (use_bits_engine()) {
     // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
     unsigned long long c3[3] = {0, 0, 0};
-    g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s);
+    // the away search starts when the towards search enters its tail (the counts have arrived by then), on a side stream
+    const bool beside = away_beside();
+    Workspace::SideLane *lane = beside ? &ws.side_lane(1) : nullptr;
+    StaticAway sa;
+    bool started = false;
+    Beside bs;
+    bs.mark = [&]() {
+      if (beside) RD_HIP(hipEventRecord(lane->fork, s));   // (the bitmaps are made, the flags and the DEM as the caller left them)
+    };
+    bs.go = [&]() {
+      if (!beside || c3[0] == 0 || c3[1] == 0) return;
+      RD_HIP(hipStreamWaitEvent(lane->stream, lane->fork, 0));
+      A = ws.buf<int32_t>("flats.away", n);
+      sa = enqueue_away_static(flags, A, w, h, lane->stream);
+      RD_HIP(hipEventRecord(lane->join, lane->stream));
+      started = true;
+    };
+    g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s, &bs);
+    if (started) RD_HIP(hipStreamWaitEvent(s, lane->join, 0));
     g_fstats.low_edges = c3[0];
     g_fstats.high_edges = c3[1];
     g_fstats.noflow_cells = c3[2];
     if (c3[0] == 0) return;   // no flats, or none with an outlet (:475-481)
-    if (c3[1] > 0) {
+    if (c3[1] > 0 && !started) {
       A = ws.buf<int32_t>("flats.away", n);
       g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
+    }
+    if (started) {
+      const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
+      RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
+                (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
+      g_fstats.away_levels = finish_away_static(sa, s);   // (checked while the directions are being written)
+      return;
     }
   } else {
     uint32_t *low = nullptr, *highall = nullptr;

@@ -85,11 +85,11 @@ uint32_t *Workspace::host_words() {
   return p;
 }
 
-Workspace::SideLane &Workspace::side_lane() {
+Workspace::SideLane &Workspace::side_lane(int k) {
   int dev = 0;
   RD_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> g(mu_);
-  SideLane &l = side_[dev];
+  SideLane &l = side_[std::make_pair(dev, k)];
   if (!l.stream) {
     RD_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     RD_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
