@@ -1342,14 +1342,18 @@ __global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned lon
   __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
   const int lane = threadIdx.x & 63;
   uint16_t *const orow = open_rows[threadIdx.x >> 6];
-  const uint32_t me = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6);
-  uint32_t *const myctl = Q.ctl + (size_t)(me % AQ_NQ) * AQ_STRIDE;
-  uint32_t *const myq = Q.q + (size_t)(me % AQ_NQ) * (Q.qmask + 1u);
+  const uint32_t me = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6), nworkers = gridDim.x * (NTHR / 64);
+  uint32_t *const homectl = Q.ctl + (size_t)(me % AQ_NQ) * AQ_STRIDE;   // the shard of the counters this wavefront adds to
+  // the queue it serves: its own, and -- when the launch has fewer wavefronts than a multiple of AQ_NQ covers -- the
+  // next one after every poll that found nothing, so that no queue is left without a wavefront
+  uint32_t serve = me % AQ_NQ;
   const unsigned long long t_start = wall_clock64();
   uint32_t idle_polls = 0, visits = 0;
   unsigned long long busy = 0;
   for (;;) {
     uint32_t tile = AQ_NONE;
+    uint32_t *const myctl = Q.ctl + (size_t)serve * AQ_STRIDE;
+    uint32_t *const myq = Q.q + (size_t)serve * (Q.qmask + 1u);
     if (lane == 0) {
       unsigned long long ht = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(myctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t hd = (uint32_t)ht;
@@ -1377,6 +1381,7 @@ __global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned lon
     if (tile == AQ_DONE) break;
     if (tile == AQ_NONE) {
       idle_polls++;
+      serve = (serve + nworkers) % AQ_NQ;   // (unchanged when the wavefronts cover the queues evenly; else the residues mod gcd(nworkers, 64) are covered by consecutive wavefronts)
       if (me == 0u ? (idle_polls & 3u) == 0u : (idle_polls & 255u) == 0u) {
         const bool late = wall_clock64() - t_start > tick_budget;
         if (late && lane == 0) atomicExch(&Q.ctl[AQ_G_ABORT], 1u);
@@ -1403,7 +1408,7 @@ __global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned lon
       if (ntx >= 0 && nty >= 0 && ntx < (int)tilesX && nty < (int)tilesY) {
         const uint32_t nt = (uint32_t)nty * tilesX + (uint32_t)ntx;
         if (atomicOr(&Q.state[nt], AQ_WAKE) == 0u) {
-          atomicAdd(&myctl[32], 1u);
+          atomicAdd(&homectl[32], 1u);
           aq_push(Q, nt);
         }
       }
@@ -1411,7 +1416,7 @@ __global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned lon
     if (lane == 0) {
       const uint32_t old = atomicAnd(&Q.state[tile], ~AQ_RUN);
       if (old & AQ_WAKE) aq_push(Q, tile);   // woken while it ran: once more (it never was idle)
-      else atomicAdd(&myctl[33], 1u);
+      else atomicAdd(&homectl[33], 1u);
     }
   }
   if (lane == 0) {
