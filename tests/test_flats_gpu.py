@@ -142,6 +142,28 @@ def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
     assert np.array_equal(got.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("switch", ["RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000", "RDGPU_FLAT_AWAY_BESIDE=0", "RDGPU_FLAT_ASYNC_BLOCKS=3",
+                                    "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1"])
+def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
+    """The bitmap search in rounds to the end, with its asynchronous tail from the first batch on (k_relax_bits_async),
+    with the away search after instead of beside the towards tail, on three resident blocks; ResolveFlatsEpsilon with the
+    older label path, on one stream, on three: the fixed point does not depend on the schedule -- directions and
+    epsilon-resolved elevations equal the oracle's under every switch, on lakes that span many 64 x 64 tiles."""
+    k, v = switch.split("=")
+    dem = orc.port.fill(fractal_dem_int(1300, 900, 73, 0.01))
+    nd = np.int32(-9999)
+    edirs = orc.port.flat_resolution(dem, nd)
+    femp = orc.port.fill(fractal_dem(1100, 700, seed=74) * np.float32(0.02)).astype(np.float32)
+    ffl = np.floor(femp).astype(np.float32)            # float DEM with wide lakes
+    eeps = orc.port.resolve_flats_epsilon(ffl, np.float32(-9999))
+    monkeypatch.setenv(k, v)
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
+    assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
+    monkeypatch.delenv(k)
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
+    assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
+
+
 def test_open_water_tiles(rd, orc):
     """Flats that cover whole 64x64 tiles (the bitmap engine's chamfer path for tiles in which every cell takes part):
     a lake floor with outlets on different sides, with and without islands next to the open tiles, tile-aligned and not,
