@@ -283,6 +283,11 @@ __device__ __forceinline__ int border_slot(int lx, int ly) {
 
 // stage the tile's directions (+ ring; cells outside the raster read as NoData) and, per cell, its in-tile donors
 // and its in-tile target / LP_EXIT / LP_TERM
+// The pointer tables of the tile passes are gathered at random by all 64 lanes; with rows of 64 two-byte entries every row
+// starts on the same LDS bank, so lanes that point at neighbouring columns of DIFFERENT rows -- the usual case: flow
+// converges -- collide.  Rows of LPS = 66 entries shift the banks by one per row (r03e: SQ_LDS_BANK_CONFLICT was 57 % of
+// k_acc_link_tile's LDS cycles, 44 % of k_acc_link_final_sums').  A cell's table index is ly * LPS + lx.
+constexpr int LPS = LT + 2;
 __device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h, int x0, int y0,
                                            uint8_t *sd, uint16_t *lp) {
   stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
@@ -299,7 +304,7 @@ __device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uin
     const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
     const bool into_data = sd[(ty + 1) * LLW + tx + 1] != nodata;   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
     const bool inside = tx >= 0 && tx < LT && ty >= 0 && ty < LT;
-    lp[ly * LT + lx] = !(flows && into_data) ? LP_TERM : inside ? (uint16_t)(ty * LT + tx) : LP_EXIT;
+    lp[ly * LPS + lx] = !(flows && into_data) ? LP_TERM : inside ? (uint16_t)(ty * LPS + tx) : LP_EXIT;
   }
 }
 
@@ -312,10 +317,10 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   // needed here at all (r02c ran the full last-arriver walk in this pass too: 20 of the stage's 47 ms).  Cells that
   // drain into a direction loop inside the tile have no root and are counted nowhere, as in the reference.
   // The staged directions are only needed until every cell knows its target; their 4.3 KB then hold the counters.
-  __shared__ uint32_t cnt[LT * LT];
-  __shared__ uint16_t lp[LT * LT];
+  __shared__ uint32_t cnt[LT * LPS];
+  __shared__ uint16_t lp[LT * LPS];
   uint8_t *const sd = reinterpret_cast<uint8_t *>(cnt);
-  static_assert(LLW * LLW <= LT * LT * 4, "the staged directions fit into the counters' storage");
+  static_assert(LLW * LLW <= LT * LPS * 4, "the staged directions fit into the counters' storage");
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
@@ -332,10 +337,10 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   // twelve doublings cover any loop-free path of a 4096-cell tile, what still points at a non-terminal then runs into a loop
   uint16_t keep[LT / 4];
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) keep[j] = lp[(ly0 + 4 * j) * LT + lx];   // own entries before they are compressed
+  for (int j = 0; j < LT / 4; j++) keep[j] = lp[(ly0 + 4 * j) * LPS + lx];   // own entries before they are compressed
   __syncthreads();   // (also: every thread has read what it needs of sd)
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) cnt[(ly0 + 4 * j) * LT + lx] = 0;
+  for (int j = 0; j < LT / 4; j++) cnt[(ly0 + 4 * j) * LPS + lx] = 0;
   // (k_descent's loop: two hops per trip, a cell is finished once its pointer names a terminal, and a group of four rows
   // whose cells are all finished is skipped with one scalar test -- this kernel is bound by instruction issue)
   uint32_t act = 0;
@@ -348,17 +353,17 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
       if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;   // wave uniform
       uint16_t pv[4], qv[4], rv[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * (4 * g + e)) * LT + lx];
+      for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * (4 * g + e)) * LPS + lx];
 #pragma unroll
-      for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LP_TERM ? pv[e] : (ly0 + 4 * (4 * g + e)) * LT + lx];
+      for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LP_TERM ? pv[e] : (ly0 + 4 * (4 * g + e)) * LPS + lx];
 #pragma unroll
-      for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LP_TERM ? qv[e] : (ly0 + 4 * (4 * g + e)) * LT + lx];
+      for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LP_TERM ? qv[e] : (ly0 + 4 * (4 * g + e)) * LPS + lx];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int j = 4 * g + e;
         if (pv[e] < LP_TERM && qv[e] < LP_TERM) {
           const bool more = rv[e] < LP_TERM;   // q is not the end of the path yet: jump to r and come back
-          lp[(ly0 + 4 * j) * LT + lx] = more ? rv[e] : qv[e];
+          lp[(ly0 + 4 * j) * LPS + lx] = more ? rv[e] : qv[e];
           if (more) still = 1;
           else act &= ~(1u << j);
         } else {
@@ -372,11 +377,22 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   // every cell adds itself to the exit its path ends at (an exit to itself); anything else adds 0 to its own counter
 #pragma unroll 4
   for (int j = 0; j < LT / 4; j++) {
-    const int c = (ly0 + 4 * j) * LT + lx;
+    const int c = (ly0 + 4 * j) * LPS + lx;
     const uint16_t p = lp[c];
     const uint16_t code = lp[p < LP_TERM ? p : c];   // p is terminal iff its own (uncompressed == compressed) entry is a code
     const bool self_exit = keep[j] == LP_EXIT, via = keep[j] < LP_TERM && p < LP_TERM && code == LP_EXIT;
-    atomicAdd(&cnt[via ? p : c], (self_exit || via) ? 1u : 0u);
+    // Neighbouring cells of a row mostly leave through the same exit: a run of lanes with the same target adds its
+    // LENGTH once, from its first lane (same-address LDS atomics serialise: SQ_LDS_ADDR_CONFLICT was 26 % of this
+    // kernel's LDS cycles).  Lanes that add nothing target their own counter: runs of length one.
+    const bool adds = self_exit || via;
+    const uint32_t tgt = adds ? (uint32_t)(via ? p : c) : 0x10000u + (uint32_t)lx;
+    const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)tgt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const unsigned long long heads = __ballot(tgt != left);                  // (lane 0 is a head: its "left" is the fill)
+    if (adds && tgt != left) {
+      const unsigned long long above = heads & ~((2ull << lx) - 1ull);       // the heads after this lane
+      const int end = above ? __ffsll((long long)above) - 1 : 64;            // first lane of the next run
+      atomicAdd(&cnt[tgt], (uint32_t)(end - lx));
+    }
   }
   __syncthreads();
   // what the border cells publish (252 of the tile's 256 slots; the four spare ones are marked unused)
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
     const int slot = border_slot(lx, ly);
     if (slot < 0) continue;
     const size_t node = (size_t)t * 256 + slot;
-    const int c = ly * LT + lx;
+    const int c = ly * LPS + lx;
     const bool is_exit = keep[j] == LP_EXIT;
     // root: the cell itself when it is terminal, else the terminal its compressed pointer names
     uint8_t rs = 255;
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
       const uint16_t p = lp[c];
       if (p < LP_TERM) {
         const uint16_t code = lp[p];
-        if (code == LP_EXIT) rs = (uint8_t)border_slot(p & (LT - 1), p >> 6);
+        if (code == LP_EXIT) rs = (uint8_t)border_slot(p % LPS, p / LPS);
       }
     }
     rootslot[node] = rs;
@@ -631,8 +647,8 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
                                                                const unsigned long long *__restrict__ nw, A *__restrict__ area,
                                                                uint32_t *slow_tiles, uint32_t *slow_count) {
   __shared__ uint8_t sd[LLW * LLW];
-  __shared__ uint32_t S[LT * LT];
-  __shared__ uint16_t anc[LT * LT];
+  __shared__ uint32_t S[LT * LPS];      // (rows of LPS entries: see link_stage)
+  __shared__ uint16_t anc[LT * LPS];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
       const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
       const int o = (by + 1) * LLW + bx + 1;
       if (sd[o] != nodata) {
-        bcell = by * LT + bx;
+        bcell = by * LPS + bx;
         unsigned long long wv[8];
         bool use[8];
 #pragma unroll
@@ -684,11 +700,11 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
     const int dd = flows ? d : 0;
     const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
     const bool in_tile = flows && tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata;
-    a[j] = in_tile ? (uint16_t)(ty * LT + tx) : ANC_NONE;
+    a[j] = in_tile ? (uint16_t)(ty * LPS + tx) : ANC_NONE;
     datamask |= (data ? 1u : 0u) << j;
     act |= (in_tile ? 1u : 0u) << j;
-    S[ly * LT + lx] = data ? 1u : 0u;
-    anc[ly * LT + lx] = a[j];
+    S[ly * LPS + lx] = data ? 1u : 0u;
+    anc[ly * LPS + lx] = a[j];
   }
   __syncthreads();
   if (bcell >= 0 && inflow) S[bcell] += (uint32_t)inflow;   // (one thread per border cell)
@@ -707,8 +723,8 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
       for (int e = 0; e < 4; e++) {
         const int j = 4 * g + e;
         const bool on = act >> j & 1u;
-        sv[j] = S[(ly0 + 4 * j) * LT + lx];
-        aa[j] = anc[on ? a[j] : (ly0 + 4 * j) * LT + lx];   // (a finished cell reads its own slot: no branch around the LDS read)
+        sv[j] = S[(ly0 + 4 * j) * LPS + lx];
+        aa[j] = anc[on ? a[j] : (ly0 + 4 * j) * LPS + lx];   // (a finished cell reads its own slot: no branch around the LDS read)
       }
     }
     __syncthreads();
@@ -720,7 +736,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
         const int j = 4 * g + e;
         if (act >> j & 1u) {
           atomicAdd(&S[a[j]], sv[j]);
-          anc[(ly0 + 4 * j) * LT + lx] = aa[j];
+          anc[(ly0 + 4 * j) * LPS + lx] = aa[j];
           a[j] = aa[j];
           if (aa[j] == ANC_NONE) act &= ~(1u << j);
         }
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
   for (int j = 0; j < LT / 4; j++) {
     const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
     if (gx >= w || gy >= h) continue;
-    const uint32_t v = S[ly * LT + lx];
+    const uint32_t v = S[ly * LPS + lx];
     area[(size_t)gy * w + gx] = (datamask >> j & 1u) ? (A)v : (A)-1;   // area.noData() == -1, d8_methods.hpp:64,:72-75
   }
 }
