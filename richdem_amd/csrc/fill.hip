@@ -1868,7 +1868,10 @@ template <class T, int TOPO, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
                                                     uint32_t tilesX, uint32_t ntiles) {
   __shared__ uint32_t sk[DLH * DLW];
-  __shared__ uint16_t lp[DH * DW];
+  // rows of LPD = 66 entries: with 64 two-byte entries every row starts on the same LDS bank and the jumps' gathers --
+  // neighbouring columns of different rows -- collide (29 % of the kernel's LDS cycles, r03e)
+  constexpr int LPD = DW + 2;
+  __shared__ uint16_t lp[DH * LPD];
   __shared__ uint32_t wtot[NTHR / 64];
   __shared__ uint32_t pbase, rbase, nroots_s;
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
@@ -1938,11 +1941,11 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
       const bool drains = (bk < kc) | ((bk == kc) & (n < 4));
       const int tx = lx + (int)(q >> 6 & 3u) - 1, ty = ly + (int)(q >> 4 & 3u) - 1;
       const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
-      const uint16_t ldrain = inside ? (uint16_t)(ty * DW + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
+      const uint16_t ldrain = inside ? (uint16_t)(ty * LPD + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
       const bool incell = (gx < w) & (gy < h);
       const bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
       const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : !drains ? LTERM_BASE : ldrain;
-      lp[ly * DW + lx] = l;
+      lp[ly * LPD + lx] = l;
 #pragma unroll
       for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
     }
@@ -1951,7 +1954,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   {   // pointer jumping inside the tile (k_descent's loop)
     uint32_t act = 0;
 #pragma unroll
-    for (int j = 0; j < DH / 4; j++) act |= (lp[(ly0 + j) * DW + lx] < LTERM_BASE ? 1u : 0u) << j;
+    for (int j = 0; j < DH / 4; j++) act |= (lp[(ly0 + j) * LPD + lx] < LTERM_BASE ? 1u : 0u) << j;
     for (int it = 0; it < 12; it++) {
       int still = 0;
 #pragma unroll
@@ -1959,17 +1962,17 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
         if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
         uint16_t pv[4], qv[4], rv[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * g + e) * DW + lx];
+        for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * g + e) * LPD + lx];
 #pragma unroll
-        for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LTERM_BASE ? pv[e] : (ly0 + 4 * g + e) * DW + lx];
+        for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LTERM_BASE ? pv[e] : (ly0 + 4 * g + e) * LPD + lx];
 #pragma unroll
-        for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LTERM_BASE ? qv[e] : (ly0 + 4 * g + e) * DW + lx];
+        for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LTERM_BASE ? qv[e] : (ly0 + 4 * g + e) * LPD + lx];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int j = 4 * g + e;
           if (pv[e] < LTERM_BASE && qv[e] < LTERM_BASE) {
             const bool more = rv[e] < LTERM_BASE;
-            lp[(ly0 + j) * DW + lx] = more ? rv[e] : qv[e];
+            lp[(ly0 + j) * LPD + lx] = more ? rv[e] : qv[e];
             if (more) still = 1;
             else act &= ~(1u << j);
           } else {
@@ -1986,7 +1989,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
 #pragma unroll
   for (int j = 0; j < DH / 4; j++) {
     const int gy = y0 + ly0 + j;
-    const uint16_t v = lp[(ly0 + j) * DW + lx];
+    const uint16_t v = lp[(ly0 + j) * LPD + lx];
     const bool root = (gx < w) & (gy < h) & (v >= LTERM_BASE);
     rootmask |= (root ? 1u : 0u) << j;
     pitmask |= ((root & ((v & 15u) == 0u)) ? 1u : 0u) << j;
@@ -2022,13 +2025,13 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
     for (uint32_t m = rootmask; m; m &= m - 1) {
       const int j = __ffs((int)m) - 1;
       const int ly = ly0 + j;
-      const int code = lp[ly * DW + lx] & 15;
+      const int code = lp[ly * LPD + lx] & 15;
       const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour (codes 1..8)
       const int nr = n >= 6 ? 2 : n >= 3 ? 1 : 0, nc = n - 3 * nr;
       const uint32_t pend = LAB_PEND | ((uint32_t)(y0 + ly + nr - 1) * (uint32_t)w + (uint32_t)(x0 + lx + nc - 1));
       const uint32_t word = code == 0 ? pit++ : code == 9 ? OUTP : pend;
       if (gfits) fo.G[nodes0 + slot] = word;
-      lp[ly * DW + lx] = (uint16_t)(ROOT_TAG | slot);
+      lp[ly * LPD + lx] = (uint16_t)(ROOT_TAG | slot);
       slot++;
     }
   }
@@ -2037,8 +2040,8 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
 #pragma unroll 4
   for (int j = 0; j < DH / 4; j++) {
     const int ly = ly0 + j, gy = y0 + ly;
-    const uint16_t v = lp[ly * DW + lx];
-    const uint16_t rv = lp[v < (uint16_t)(DW * DH) ? v : ly * DW + lx];
+    const uint16_t v = lp[ly * LPD + lx];
+    const uint16_t rv = lp[v < (uint16_t)(LPD * DH) ? v : ly * LPD + lx];
     if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = (uint16_t)(rv & 0x0FFFu);
   }
 }
