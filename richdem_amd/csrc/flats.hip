@@ -2232,24 +2232,29 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   *outM = M;
   *outL = nullptr;
   *outFh = nullptr;
-  RD_HIP(hipMemsetAsync(M, 0, n * sizeof(int32_t), s));            // flat_mask.setAll(0), :469
+  const bool lean = outA && use_bits_engine() && lean_labels();
+  if (!lean) RD_HIP(hipMemsetAsync(M, 0, n * sizeof(int32_t), s));  // flat_mask.setAll(0), :469 (lean: the towards search writes every cell)
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
 
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   uint32_t *low = nullptr, *highall = nullptr;
   uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
-  compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s, !use_bits_engine());
-  g_fstats.low_edges = nlow;
-  g_fstats.noflow_cells = nnoflow;
-  g_fstats.high_edges = nhigh_all;
-  if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
+  if (!lean) {
+    compact_edges(flags, n, &low, &nlow, &highall, &nhigh_all, &nnoflow, s, !use_bits_engine());
+    g_fstats.low_edges = nlow;
+    g_fstats.noflow_cells = nnoflow;
+    g_fstats.high_edges = nhigh_all;
+    if (nlow == 0) return;   // no flats, or none with an outlet (:475-481)
+  }
 
   uint32_t *L = ws.buf<uint32_t>("flats.L", n);
   int32_t *fh = ws.buf<int32_t>("flats.fh", n);
-  *outL = L;
-  *outFh = fh;
-  if (outA && use_bits_engine() && lean_labels()) {
+  if (!lean) {
+    *outL = L;
+    *outFh = fh;
+  }
+  if (lean) {
     // The caller wants the levels, the labels and the flat heights (ResolveFlatsEpsilon), nothing per flat beyond that: the
     // labels do not depend on the searches here.  "The flat has an outlet" (:491-500) is what the towards levels say anyway
     // (a flat without a low edge is never reached: its cells keep DINF and k_flat_epsilon4 skips them), so the away field
@@ -2283,7 +2288,9 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     // ... the away search too, on a second side stream (see enqueue_away_static), only on request: with the labels already
     // beside the tail a third stream gains nothing (S3: 58.7 ms without, 59.5 with; RDGPU_RFE_AWAY_BESIDE=1)
     const char *env3 = getenv("RDGPU_RFE_AWAY_BESIDE");
-    const bool away_too = beside && env3 && env3[0] == '1' && away_beside() && nhigh_all > 0;
+    // (the edge counts come with the towards search's start levels, as on the directions path: no counting pass)
+    unsigned long long c3[3] = {0, 0, 0};
+    const bool away_too = beside && env3 && env3[0] == '1' && away_beside();
     Workspace::SideLane *alane = away_too ? &ws.side_lane(1) : nullptr;
     StaticAway sa;
     int32_t *A = nullptr;
@@ -2291,24 +2298,32 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     bs.mark = [&]() {
       if (away_too) RD_HIP(hipEventRecord(alane->fork, s));
     };
+    bool away_started = false;
     bs.go = [&]() {
       if (beside) labels();
-      if (away_too) {
+      if (away_too && c3[0] > 0 && c3[1] > 0) {
+        away_started = true;
         RD_HIP(hipStreamWaitEvent(alane->stream, alane->fork, 0));
         A = ws.buf<int32_t>("flats.away", n);
         sa = enqueue_away_static(flags, A, w, h, alane->stream);
         RD_HIP(hipEventRecord(alane->join, alane->stream));
       }
     };
-    g_fstats.towards_levels = run_bits_towards(flags, M, true, nullptr, w, h, s, &bs);
-    if (away_too) {
+    g_fstats.towards_levels = run_bits_towards(flags, M, true, c3, w, h, s, &bs);
+    g_fstats.low_edges = c3[0];
+    g_fstats.high_edges = c3[1];
+    g_fstats.noflow_cells = c3[2];
+    if (away_started) {
       RD_HIP(hipStreamWaitEvent(s, alane->join, 0));
       g_fstats.away_levels = finish_away_static(sa, s);
-    } else if (nhigh_all > 0) {
+    } else if (c3[0] > 0 && c3[1] > 0) {
       A = ws.buf<int32_t>("flats.away", n);
       g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
     }
     if (beside) RD_HIP(hipStreamWaitEvent(s, lane->join, 0));
+    if (c3[0] == 0) return;   // no flats, or none with an outlet (:475-481): *outL stays null, nothing is altered
+    *outL = L;
+    *outFh = fh;
     if (A) RD_LAUNCH("flats.height", k_flat_height4, dim3(sgrid(n / 4 + 3)), dim3(NTHR), 0, s, (const int32_t *)A, (const uint32_t *)L, fh, n);
     *outA = A;
     return;
