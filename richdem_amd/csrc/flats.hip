@@ -1988,10 +1988,10 @@ static BitsScratch bits_scratch(int w, int h, bool second = false) {
 }
 
 // RDGPU_FLAT_ASYNC = n: the rounds end and the asynchronous tail (k_relax_bits_async) takes over once a round visits
-// fewer than n tiles (default 8000; 0: rounds to the end).
+// fewer than n tiles (default 20000; 0: rounds to the end).
 static uint32_t async_threshold() {
   const char *env = getenv("RDGPU_FLAT_ASYNC");
-  return env ? (uint32_t)strtoul(env, nullptr, 10) : 8000u;
+  return env ? (uint32_t)strtoul(env, nullptr, 10) : 20000u;
 }
 
 struct AsyncInfo { uint32_t visits, launches; };
@@ -2038,7 +2038,11 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
   RD_HIP(hipMemsetAsync(Q.ctl, 0, AQ_WORDS * sizeof(uint32_t), s));
   RD_LAUNCH("flats.async_init", k_async_init, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, (const uint32_t *)b.tlist,
             (const uint32_t *)last, Q);
-  r.blocks = (uint32_t)r.cus * 2u;   // (measured at S3: 2 per CU 40.6 ms, 1: 45.5, 3: 40.9, 4: 42.7 -- idle wavefronts poll)
+  // Resident blocks: alone, two per CU were the optimum (S3: 1 / 2 / 3 / 4 per CU 45.5 / 40.6 / 40.9 / 42.7 ms: idle
+  // wavefronts poll); with the away search or the labels running BESIDE the tail, fewer leave them room:
+  // 256 / 320 / 384 / 448 / 512 / 640 blocks 33.8 / 33.9 / 34.4 / 35.5 / 36.6 / 38.7 ms for the stage, 53.8 ms (320) against
+  // 56.4 (512) for ResolveFlatsEpsilon.
+  r.blocks = (uint32_t)r.cus * 5u / 4u;
   int nap = 1;
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_BLOCKS")) r.blocks = std::max(1, atoi(e));
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_NAP")) nap = std::min(255, std::max(1, atoi(e)));
