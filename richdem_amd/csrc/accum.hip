@@ -981,21 +981,38 @@ void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A
 // integers, exact in a double; that goes through the tile links (56 ms instead of 85 at S3).  One read of the weights
 // decides.  Anything else: tile prewalk + raster-wide walk on doubles.  (Tile links on doubles were measured too: three
 // LDS arrays per tile leave 2-3 blocks per CU, 112 ms at S3 -- not kept.)
-void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, hipStream_t s) {
+static bool unit_check_enabled() {
+  const char *unit = getenv("RDGPU_ACCUM_UNIT");   // =0: always the weighted path (A/B and tests)
+  return !(unit && unit[0] == '0');
+}
+
+// "are all weights 1": enqueued on `on` (which has been made to wait for the caller's stream), answered by unit_check_end
+static void unit_check_begin(const double *d_acc, uint64_t n, hipStream_t on) {
+  uint32_t *flag = Workspace::get().buf<uint32_t>("accum.unit_flag", 1);
+  RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), on));
+  RD_LAUNCH("accum.unit_check", k_acc_not_all_ones, dim3(sgrid(n)), dim3(NTHR), 0, on, d_acc, n, flag);
+}
+static bool unit_check_end(hipStream_t on) {
+  uint32_t *flag = Workspace::get().buf<uint32_t>("accum.unit_flag", 1);
+  uint32_t other = 1;
+  RD_HIP(hipMemcpyAsync(&other, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, on));
+  RD_HIP(hipStreamSynchronize(on));
+  return other == 0;
+}
+
+// unit_known: -1 = find out here; 0 / 1 = the caller has checked the weights already (fa_d8_device does, beside its
+// direction pass)
+void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, hipStream_t s, int unit_known = -1) {
   {
     const uint64_t n = (uint64_t)w * h;
-    const char *unit = getenv("RDGPU_ACCUM_UNIT");   // =0: always the weighted path (A/B and tests)
-    if (!(unit && unit[0] == '0')) {
-      uint32_t *flag = Workspace::get().buf<uint32_t>("accum.unit_flag", 1);
-      RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
-      RD_LAUNCH("accum.unit_check", k_acc_not_all_ones, dim3(sgrid(n)), dim3(NTHR), 0, s, (const double *)d_acc, n, flag);
-      uint32_t other = 1;
-      RD_HIP(hipMemcpyAsync(&other, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      if (!other) {
-        d8_flow_accum_device<double>(d_dirs, (uint8_t)255, w, h, d_acc, s);
-        return;
-      }
+    bool unit = unit_known == 1;
+    if (unit_known < 0 && unit_check_enabled()) {
+      unit_check_begin(d_acc, n, s);
+      unit = unit_check_end(s);
+    }
+    if (unit) {
+      d8_flow_accum_device<double>(d_dirs, (uint8_t)255, w, h, d_acc, s);
+      return;
     }
   }
   const uint64_t n = (uint64_t)w * h;
@@ -1014,9 +1031,21 @@ template <class T>
 void fa_d8_device(const T *d_z, T nodata, int w, int h, double *d_acc, hipStream_t s) {
   if (!d_z || !d_acc) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_d8: null pointer");
   check_dims(w, h, "rdgpu_fa_d8");
-  uint8_t *dirs = Workspace::get().buf<uint8_t>("accum.fmdirs", (size_t)w * h);
-  flowdirs_device<T>(d_z, nodata, w, h, dirs, MODE_FM, s);
-  flow_accum_f64_device(dirs, w, h, d_acc, s);
+  Workspace &ws = Workspace::get();
+  uint8_t *dirs = ws.buf<uint8_t>("accum.fmdirs", (size_t)w * h);
+  // the one read of the weights runs on the side stream while the directions are made on the caller's
+  int unit = -1;
+  if (unit_check_enabled()) {
+    Workspace::SideLane &lane = ws.side_lane(0);
+    RD_HIP(hipEventRecord(lane.fork, s));
+    RD_HIP(hipStreamWaitEvent(lane.stream, lane.fork, 0));
+    unit_check_begin(d_acc, (uint64_t)w * h, lane.stream);
+    flowdirs_device<T>(d_z, nodata, w, h, dirs, MODE_FM, s);
+    unit = unit_check_end(lane.stream) ? 1 : 0;
+  } else {
+    flowdirs_device<T>(d_z, nodata, w, h, dirs, MODE_FM, s);
+  }
+  flow_accum_f64_device(dirs, w, h, d_acc, s, unit);
 }
 
 template <class A>
