@@ -155,6 +155,32 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
  * alter != 0: the DEM is filled as by PriorityFlood_Barnes2014 (:793-794).  Identical to the reference, numbering
  * included, on DEMs without equal elevations among the cells of its heap; with ties the reference's partition follows
  * std::priority_queue's pop order. */
+/* PriorityFloodFlowdirs_Barnes2014(elevations, flowdirs) -- depressions/Barnes2014.hpp:483-555: D8 directions of the flood
+ * that does not raise the DEM; every cell points at the neighbour that was flooded first (border cells off the raster, NoData
+ * cells 0).  Identical to the reference on DEMs WITHOUT equal elevations (its queue breaks ties by insertion order, which only
+ * the serial sweep defines); cells whose direction stays ambiguous because of ties are counted in the stats and get their
+ * lowest-numbered candidate.  One whole-raster fill per nesting level of the depressions: provided, not tuned.
+ * The highest value of the element type (+inf for float) must not occur in the DEM.  8 / 16 / 32-bit element types. */
+typedef struct rdgpu_pf_flowdirs_stats {
+  uint32_t levels;      /* fills run */
+  uint32_t reserved;
+  uint64_t unresolved;  /* cells with more than one candidate left */
+} rdgpu_pf_flowdirs_stats;
+int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);
+#define RDGPU_DECL_PFD(SUF, T)                                                                              \
+  int rdgpu_pf_flowdirs_##SUF(const T *dem, T nodata, int width, int height, uint8_t *dirs);                \
+  int rdgpu_pf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int width, int height, uint8_t *d_dirs, void *hip_stream); \
+  /* building block: the D8 fill with interior outlets (cells flagged in d_outlet drain like border cells) */ \
+  int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int width, int height, void *hip_stream);
+RDGPU_DECL_PFD(u8, uint8_t)
+RDGPU_DECL_PFD(i8, int8_t)
+RDGPU_DECL_PFD(i16, int16_t)
+RDGPU_DECL_PFD(u16, uint16_t)
+RDGPU_DECL_PFD(i32, int32_t)
+RDGPU_DECL_PFD(u32, uint32_t)
+RDGPU_DECL_PFD(f32, float)
+#undef RDGPU_DECL_PFD
+
 #define RDGPU_DECL_WS(SUF, T)                                                                                          \
   int rdgpu_watersheds_##SUF(T *dem, T nodata, int width, int height, int topology, int alter, int32_t *labels);      \
   int rdgpu_watersheds_dev_##SUF(T *d_dem, T nodata, int width, int height, int topology, int alter, int32_t *d_labels, void *hip_stream);

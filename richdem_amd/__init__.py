@@ -37,6 +37,8 @@ from .pyrichdem import (  # noqa: F401
     SaveNative,
 )
 from .api import (  # noqa: F401
+    pf_flowdirs,
+    pf_flowdirs_stats,
     pit_mask,
     fill_max_dep,
     watersheds,
@@ -90,6 +92,8 @@ __all__ = [
     "profile_reset",
     "profile_totals",
     "ResolveFlats",
+    "pf_flowdirs",
+    "pf_flowdirs_stats",
     "pit_mask",
     "fill_max_dep",
     "watersheds",

@@ -150,6 +150,40 @@ def watersheds(dem: np.ndarray, nodata=-9999, topology="D8", alter: bool = False
     return (labels, work) if alter else labels
 
 
+class _PfdStats(ctypes.Structure):
+    _fields_ = [("levels", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("unresolved", ctypes.c_uint64)]
+
+
+def pf_flowdirs_stats() -> dict:
+    st = _PfdStats()
+    check(lib().rdgpu_pf_flowdirs_get_stats(ctypes.byref(st)), "rdgpu_pf_flowdirs_get_stats")
+    return {"levels": st.levels, "unresolved": st.unresolved}
+
+
+def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
+    """PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555): uint8 D8 directions in which every cell
+    points at the neighbour the (non-raising) flood reached first; NoData cells 0.  Equal to the reference on DEMs without
+    equal elevations; with ties the reference follows its queue's insertion order -- a RuntimeWarning reports cells
+    whose direction stayed ambiguous (pf_flowdirs_stats()["unresolved"])."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("pf_flowdirs: expected a 2-D numpy array")
+    dem = np.ascontiguousarray(dem)
+    s = _suffix(dem.dtype)
+    if s not in ("u8", "i8", "i16", "u16", "i32", "u32", "f32"):
+        raise RdgpuError("pf_flowdirs: 8 / 16 / 32-bit element types only")
+    h, w = dem.shape
+    out = np.empty((h, w), np.uint8)
+    check(getattr(lib(), f"rdgpu_pf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
+                                                   out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_pf_flowdirs")
+    st = pf_flowdirs_stats()
+    if st["unresolved"]:
+        import warnings
+
+        warnings.warn(f"pf_flowdirs: {st['unresolved']} cells have equal-elevation candidates; the reference breaks such ties "
+                      "by the insertion order of its queue, this result by neighbour number", RuntimeWarning)
+    return out
+
+
 def pit_mask(dem: np.ndarray, nodata, topology="D8") -> np.ndarray:
     """uint8 mask of the cells lying in depressions: 1 = the fill would raise the cell, 0 = not, 3 = NoData
     (reference pit_mask<topo>, depressions/Barnes2014.hpp:593-676; apps/rd_depressions_mask.cpp)."""

@@ -88,7 +88,8 @@ template <class T, int TOPO, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint32_t *__restrict__ lab,
                                                   uint32_t *pit_counter,
                                                   int w, int h, uint32_t tilesX, uint32_t ntiles, int open_top,
-                                                  int open_bottom) {
+                                                  int open_bottom, const uint8_t *__restrict__ outlet) {
+  // outlet (optional): cells that drain like border cells (rdgpu_fill_outlets_dev_*, pfdirs.hip)
   __shared__ uint32_t sk[DLH * DLW];
   __shared__ uint16_t lp[DH * DW];
   __shared__ uint32_t wtot[NTHR / 64];
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(NTHR) void k_descent(const T *__restrict__ z, uint3
       const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
       const uint16_t ldrain = inside ? (uint16_t)(ty * DW + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
       const bool incell = (gx < w) & (gy < h);
-      const bool border = (gx == 0) | (gx == w - 1) | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);   // true border
+      bool border = (gx == 0) | (gx == w - 1) | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);   // true border
+      if (outlet) border |= incell && outlet[(size_t)gy * w + gx] != 0;
       const bool cutrow = (gy == 0) | (gy == h - 1);   // (not a border: the cut row of a row-block shard, a frozen terminal)
       const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : (cutrow | !drains) ? LTERM_BASE : ldrain;
       lp[ly * DW + lx] = l;
@@ -1351,7 +1353,7 @@ struct BufAlloc {   // where persistent buffers come from: the shared workspace,
 // a cut row of a row-block shard whose cells are frozen terminals.
 template <class T, int TOPO>
 static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_bottom, BufAlloc alloc, FillBuffers &fb,
-                             hipStream_t s) {
+                             hipStream_t s, const uint8_t *outlet = nullptr) {
   const uint64_t n64 = (uint64_t)w * (uint64_t)h;
   if (n64 > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: raster (or shard) has more than 2^31-65536 cells");
   const uint32_t n = (uint32_t)n64;
@@ -1376,10 +1378,10 @@ static void fill_local_phase(const T *d_z, int w, int h, int open_top, int open_
   const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
   if (vec)
     RD_LAUNCH("fill.descent", (k_descent<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, lab, dflags + 1, w,
-              h, dtx, dnt, open_top, open_bottom);
+              h, dtx, dnt, open_top, open_bottom, outlet);
   else
     RD_LAUNCH("fill.descent", (k_descent<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, lab, dflags + 1, w,
-              h, dtx, dnt, open_top, open_bottom);
+              h, dtx, dnt, open_top, open_bottom, outlet);
   RD_HIP(hipMemcpyAsync(hw, dflags + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   const uint32_t B = hw[0];
@@ -1864,9 +1866,11 @@ struct FusedBuf {
   uint32_t *overflow;
 };
 
-template <class T, int TOPO, bool VEC>
+// OUTLETS: cells flagged in `outlet` drain like the raster's border cells (interior outlets: the restricted fills of
+// pfdirs.hip); the instantiation of the plain fill does not look at the pointer.
+template <class T, int TOPO, bool VEC, bool OUTLETS = false>
 __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
-                                                    uint32_t tilesX, uint32_t ntiles) {
+                                                    uint32_t tilesX, uint32_t ntiles, const uint8_t *__restrict__ outlet = nullptr) {
   __shared__ uint32_t sk[DLH * DLW];
   // rows of LPD = 66 entries: with 64 two-byte entries every row starts on the same LDS bank and the jumps' gathers --
   // neighbouring columns of different rows -- collide (29 % of the kernel's LDS cycles, r03e)
@@ -1943,7 +1947,8 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
       const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
       const uint16_t ldrain = inside ? (uint16_t)(ty * LPD + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
       const bool incell = (gx < w) & (gy < h);
-      const bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
+      bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
+      if (OUTLETS) border |= incell && outlet[(size_t)gy * w + gx] != 0;
       const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : !drains ? LTERM_BASE : ldrain;
       lp[ly * LPD + lx] = l;
 #pragma unroll
@@ -2134,7 +2139,7 @@ __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__res
 // The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
 // provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
 template <class T, int TOPO>
-static bool fill_fused(T *d_z, int w, int h, hipStream_t s) {
+static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr) {
   const char *fe = getenv("RDGPU_FILL_FUSED");   // =0: the classic four-pass fill (A/B and tests)
   if (fe && fe[0] == '0') return false;
   const char *env_edges = getenv("RDGPU_FILL_EDGES");
@@ -2160,10 +2165,18 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s) {
   fo.overflow = dflags + 5;
   uint32_t *curN = ws.buf<uint32_t>("fused.curN", fo.gcap);
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
-  if (vec)
-    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt);
+  if (outlet && vec)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
+              outlet);
+  else if (outlet)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
+              outlet);
+  else if (vec)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
+              (const uint8_t *)nullptr);
   else
-    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt);
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
+              (const uint8_t *)nullptr);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   if (hw[1] != 0) return false;   // more nodes than the table holds: nothing was written to the DEM
@@ -2278,6 +2291,19 @@ static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
   BufAlloc ws_alloc{false, nullptr};
   if (topology == 8) fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s);
   else fill_local_phase<T, 4>(d_z, w, h, 0, 0, ws_alloc, fb, s);
+  fill_finalize<T>(d_z, w, h, fb, s);
+}
+
+// The D8 fill with interior outlets (cells flagged in d_outlet drain like border cells).
+template <class T>
+static void fill_outlets_device(T *d_z, const uint8_t *d_outlet, int w, int h, hipStream_t s) {
+  check_fill_args(d_z, w, h, 8);
+  if (!d_outlet) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_outlets: null outlet mask");
+  if (w <= 2 || h <= 2) return;   // every cell is a border cell
+  if (fill_fused<T, 8>(d_z, w, h, s, d_outlet)) return;
+  FillBuffers fb;   // (the compact labels ran out of table space, or are switched off: the classic path)
+  BufAlloc ws_alloc{false, nullptr};
+  fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s, d_outlet);
   fill_finalize<T>(d_z, w, h, fb, s);
 }
 
@@ -2627,6 +2653,9 @@ using namespace rdgpu;
       return rdgpu_fill_multi_##SUF(dem, w, h, topology, devs.data(), (int)devs.size());          \
     return guarded([&] { fill_host<T>(dem, w, h, topology); });                                   \
   }                                                                                               \
+  extern "C" int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int w, int h, void *stream) { \
+    return rdgpu::guarded([&] { rdgpu::fill_outlets_device<T>(d_dem, d_outlet, w, h, (hipStream_t)stream); });    \
+  }                                                                                                \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
     return guarded([&] { fill_device<T>(d_dem, w, h, topology, (hipStream_t)stream); });          \
   }                                                                                               \

@@ -1,0 +1,259 @@
+// pfdirs.hip -- PriorityFloodFlowdirs_Barnes2014 (reference include/richdem/depressions/Barnes2014.hpp:483-555) without a
+// priority queue, for DEMs WITHOUT equal elevations.
+//
+// The reference floods the DEM without raising it on a queue ordered by (elevation, insertion counter); a cell's
+// direction points at the neighbour that was popped first.  With distinct elevations the pop order is the
+// lexicographic order of the sequences
+//     key(c) = (F_0(c), F_1(c), ..., F_k(c) = z(c))
+// where F_0 is the plain fill (the minimax level from the raster border) and, for a cell that is still below its level
+// (F_{j-1}(c) > z(c): "wet"), F_j(c) is the minimax level from the cells through which the flood ENTERS its pocket --
+// the wet cells next to THE cell of elevation F_{j-1}(c) -- inside the pocket; a sequence that is a prefix of another one
+// comes first (it is that pocket's entry phase).  Proof sketch: every cell below level w is popped before any cell of
+// elevation >= w; after the one cell of elevation w the flood runs through the pocket(s) behind it before anything
+// higher, and inside them the same argument holds with the pocket's entry cells as sources.
+// So: one fill per nesting level -- the compact-label fill of fill.hip with walls (the highest value of the type)
+// everywhere outside the wet cells and OUTLETS at the entry cells (rdgpu_fill_outlets_dev_*) -- and per cell a shrinking
+// set of candidate neighbours: those with the lowest F_0, among them those with the lowest F_1, ...; a candidate whose
+// sequence has ended (its elevation IS the level) is the phase cell itself and wins.
+// The number of levels is the longest run of successive descents of the flood inside a depression (35 on a 200 x 200
+// fractal DEM, more on larger ones): this entry point is provided for completeness, not tuned -- every level is a
+// whole-raster fill.  With equal elevations the reference's order depends on its insertion counters; cells whose
+// candidates cannot be separated are counted (rdgpu_pf_flowdirs_get_stats) and given their lowest-numbered candidate.
+// tests/tools/proto_pf_flowdirs.py is the same algorithm in numpy, checked against the oracle.
+#include "common.hpp"
+
+#include <limits>
+
+#define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_dev_##SUF(T *, const uint8_t *, int, int, void *); \
+                           extern "C" int rdgpu_fill_dev_##SUF(T *, int, int, int, void *);
+RD_OUTLETS(u8, uint8_t) RD_OUTLETS(i8, int8_t) RD_OUTLETS(i16, int16_t) RD_OUTLETS(u16, uint16_t) RD_OUTLETS(i32, int32_t)
+RD_OUTLETS(u32, uint32_t) RD_OUTLETS(f32, float)
+#undef RD_OUTLETS
+extern "C" const char *rdgpu_last_error(void);
+
+namespace rdgpu {
+namespace pfd {
+
+constexpr int NT = 256;
+__device__ __forceinline__ int ndx(int n) { return (n == 1 || n == 2 || n == 8) ? -1 : (n >= 4 && n <= 6) ? 1 : 0; }
+__device__ __forceinline__ int ndy(int n) { return (n >= 2 && n <= 4) ? -1 : (n >= 6 && n <= 8) ? 1 : 0; }
+
+template <class T>
+__host__ __device__ constexpr T wall_value() {
+  return std::numeric_limits<T>::has_infinity ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::max();
+}
+
+static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((n + NT - 1) / NT, 256u * 64u); }
+
+// One level of the comparison.  F holds this level's fill.  A cell with more than one candidate keeps those of the lowest
+// level; one of them whose own elevation IS that level ends the comparison.  counters[0]: cells still undecided.
+template <class T>
+__global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T *__restrict__ F, uint8_t *cand, int w, int h,
+                                               unsigned long long *counters, unsigned long long *ambiguous) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  uint32_t open = 0, amb = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t m = cand[c];
+    if ((m & (m - 1u)) == 0u) continue;   // decided (or a border cell: 0)
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    T fv[8], zv[8];
+#pragma unroll
+    for (int k = 1; k <= 8; k++) {   // (an interior cell: all eight neighbours exist)
+      const size_t g = (size_t)(y + ndy(k)) * w + (x + ndx(k));
+      fv[k - 1] = F[g];
+      zv[k - 1] = z[g];
+    }
+    T lo = wall_value<T>();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if ((m >> k & 1u) && fv[k] < lo) lo = fv[k];
+    uint32_t keep = 0, ended = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const bool on = (m >> k & 1u) && fv[k] == lo;
+      keep |= (on ? 1u : 0u) << k;
+      ended |= ((on && zv[k] == lo) ? 1u : 0u) << k;
+    }
+    if (keep == 0u) keep = m;                                // (every candidate behind a wall: cannot happen without ties)
+    const uint32_t out = ended ? (ended & (0u - ended)) : keep;   // the phase cell (one without ties: the lowest bit)
+    if (ended & (ended - 1u)) amb++;                              // several cells of that elevation: a tie decided by number
+    cand[c] = (uint8_t)out;
+    if (out & (out - 1u)) open++;
+  }
+  for (int o = 32; o > 0; o >>= 1) { open += __shfl_down(open, o, 64); amb += __shfl_down(amb, o, 64); }
+  if ((threadIdx.x & 63) == 0 && open) atomicAdd(&counters[(blockIdx.x & 63) * 2], (unsigned long long)open);   // striped
+  if ((threadIdx.x & 63) == 0 && amb) atomicAdd(ambiguous, (unsigned long long)amb);
+}
+
+// The next level's problem, in place over this level's fill: a wet cell (below its level) keeps its elevation, everything
+// else becomes a wall; outlet = wet cell next to THE cell whose elevation is its level.  counters[1]: wet cells.
+template <class T>
+__global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, int w, int h,
+                                                   unsigned long long *counters) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  uint32_t nwet = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const T f = F[c], e = z[c];
+    const bool wet = f > e && f < wall_value<T>();
+    uint8_t o = 0;
+    if (wet) {
+      nwet++;
+      const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);   // (a wet cell is never on the raster's border)
+#pragma unroll
+      for (int k = 1; k <= 8; k++) o |= z[(size_t)(y + ndy(k)) * w + (x + ndx(k))] == f ? 1 : 0;
+    }
+    outlet[c] = o;
+    F[c] = wet ? e : wall_value<T>();
+  }
+  for (int o = 32; o > 0; o >>= 1) nwet += __shfl_down(nwet, o, 64);
+  if ((threadIdx.x & 63) == 0 && nwet) atomicAdd(&counters[(blockIdx.x & 63) * 2 + 1], (unsigned long long)nwet);
+}
+
+__global__ __launch_bounds__(128) void k_sum_counters(unsigned long long *counters, unsigned long long *out) {
+  __shared__ unsigned long long acc[2];
+  if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+  __syncthreads();
+  atomicAdd(&acc[threadIdx.x & 1], counters[threadIdx.x]);
+  __syncthreads();
+  if (threadIdx.x < 2) out[threadIdx.x] = acc[threadIdx.x];
+  counters[threadIdx.x] = 0;
+}
+
+// candidates of every cell at the start: all eight neighbours of an interior cell, none for a border cell
+__global__ __launch_bounds__(NT) void k_init_cand(uint8_t *cand, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    cand[c] = (x == 0 || y == 0 || x == w - 1 || y == h - 1) ? 0 : 0xFF;
+  }
+}
+
+// the directions: the border cells' fixed ones (:508-528), 0 for NoData cells (:545-548), else the one candidate left
+template <class T>
+__global__ __launch_bounds__(NT) void k_finish(const T *__restrict__ z, T nodata, const uint8_t *__restrict__ cand, uint8_t *dirs, int w,
+                                               int h, unsigned long long *unresolved) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  uint32_t bad = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    int d;
+    if (y == 0 || y == h - 1 || x == 0 || x == w - 1) {
+      // the reference's writes in their order (:508-528; a later one wins where a raster is a single row or column):
+      // top row 3, bottom row 7, the side columns of the rows between 1 / 5, the four corners 2, 4, 8, 6
+      d = 0;
+      if (y == 0) d = 3;
+      if (y == h - 1) d = 7;
+      if (y >= 1 && y <= h - 2) {
+        if (x == 0) d = 1;
+        if (x == w - 1) d = 5;
+      }
+      if (x == 0 && y == 0) d = 2;
+      if (x == w - 1 && y == 0) d = 4;
+      if (x == 0 && y == h - 1) d = 8;
+      if (x == w - 1 && y == h - 1) d = 6;
+    } else if (z[c] == nodata) {
+      d = 0;
+    } else {
+      const uint32_t m = cand[c];
+      if (m & (m - 1u)) bad++;
+      d = m ? __ffs((int)m) : 0;
+    }
+    dirs[c] = (uint8_t)d;
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, (unsigned long long)bad);
+}
+
+static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0};
+
+template <class T>
+struct Calls;
+#define RD_CALLS(SUF, T)                                                                                             \
+  template <>                                                                                                        \
+  struct Calls<T> {                                                                                                  \
+    static int fill(T *d, int w, int h, void *s) { return rdgpu_fill_dev_##SUF(d, w, h, 8, s); }                     \
+    static int fill_outlets(T *d, const uint8_t *o, int w, int h, void *s) { return rdgpu_fill_outlets_dev_##SUF(d, o, w, h, s); } \
+  };
+RD_CALLS(u8, uint8_t) RD_CALLS(i8, int8_t) RD_CALLS(i16, int16_t) RD_CALLS(u16, uint16_t) RD_CALLS(i32, int32_t)
+RD_CALLS(u32, uint32_t) RD_CALLS(f32, float)
+#undef RD_CALLS
+
+static void check_rc(int rc) {
+  if (rc != 0) throw Error(rc, std::string("rdgpu_pf_flowdirs: ") + rdgpu_last_error());
+}
+
+template <class T>
+void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, hipStream_t s) {
+  if (!d_z || !d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: width and height must be positive");
+  if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: raster too large");
+  const uint64_t n = (uint64_t)w * h;
+  Workspace &ws = Workspace::get();
+  g_stats = rdgpu_pf_flowdirs_stats{0, 0, 0};
+  uint8_t *cand = ws.buf<uint8_t>("pfd.cand", n);
+  unsigned long long *counters = ws.buf<unsigned long long>("pfd.counters", 128 + 4);
+  unsigned long long *sums = counters + 128;   // [0] undecided, [1] wet, [2] unresolved
+  RD_HIP(hipMemsetAsync(counters, 0, (128 + 4) * sizeof(unsigned long long), s));
+  RD_LAUNCH("pfd.init", k_init_cand, dim3(sgrid(n)), dim3(NT), 0, s, cand, w, h);
+  if (w > 2 && h > 2) {
+    T *F = ws.buf<T>("pfd.level", n);
+    uint8_t *outlet = ws.buf<uint8_t>("pfd.outlet", n);
+    RD_HIP(hipMemcpyAsync(F, d_z, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    check_rc(Calls<T>::fill(F, w, h, (void *)s));
+    unsigned long long host[2] = {0, 0}, last_open = ~0ull, last_wet = ~0ull;
+    for (;;) {
+      g_stats.levels++;
+      RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2);
+      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, F, outlet, w, h, counters);
+      RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
+      RD_HIP(hipMemcpyAsync(host, sums, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (host[0] == 0 || host[1] == 0) break;                       // every cell decided / nothing wet any more
+      if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
+      last_open = host[0];
+      last_wet = host[1];
+      check_rc(Calls<T>::fill_outlets(F, outlet, w, h, (void *)s));
+    }
+  }
+  RD_LAUNCH("pfd.finish", (k_finish<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, (const uint8_t *)cand, d_dirs, w, h, sums + 2);
+  unsigned long long unres = 0;
+  RD_HIP(hipMemcpyAsync(&unres, sums + 2, sizeof unres, hipMemcpyDeviceToHost, s));
+  RD_HIP(hipStreamSynchronize(s));
+  g_stats.unresolved = unres;
+}
+
+template <class T>
+static void pf_flowdirs_host(const T *dem, T nodata, int w, int h, uint8_t *dirs) {
+  if (!dem || !dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: null pointer");
+  if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: width and height must be positive");
+  const size_t n = (size_t)w * h;
+  T *d = Workspace::get().buf<T>("host.dem", n);
+  uint8_t *dd = Workspace::get().buf<uint8_t>("host.dirs", n);
+  RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
+  pf_flowdirs_device<T>(d, nodata, w, h, dd, nullptr);
+  RD_HIP(hipMemcpy(dirs, dd, n, hipMemcpyDeviceToHost));
+}
+
+}  // namespace pfd
+}  // namespace rdgpu
+
+#define RD_PFD_API(SUF, T)                                                                                                  \
+  extern "C" int rdgpu_pf_flowdirs_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs) {                             \
+    return rdgpu::guarded([&] { rdgpu::pfd::pf_flowdirs_host<T>(dem, nodata, w, h, dirs); });                              \
+  }                                                                                                                         \
+  extern "C" int rdgpu_pf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int w, int h, uint8_t *d_dirs, void *stream) {       \
+    return rdgpu::guarded([&] { rdgpu::pfd::pf_flowdirs_device<T>(d_dem, nodata, w, h, d_dirs, (hipStream_t)stream); });   \
+  }
+RD_PFD_API(u8, uint8_t)
+RD_PFD_API(i8, int8_t)
+RD_PFD_API(i16, int16_t)
+RD_PFD_API(u16, uint16_t)
+RD_PFD_API(i32, int32_t)
+RD_PFD_API(u32, uint32_t)
+RD_PFD_API(f32, float)
+
+extern "C" int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out) {
+  if (!out) return RDGPU_ERR_ARG;
+  *out = rdgpu::pfd::g_stats;
+  return 0;
+}

@@ -1,0 +1,88 @@
+"""PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555) on the GPU: one fill per nesting level of the
+depressions (csrc/pfdirs.hip) against the oracle's restatement of the reference's stable-queue sweep, which is pinned to
+the compiled reference (tests/test_oracle_pinning.py).  Equal on DEMs without equal elevations; with ties the cells that
+stay ambiguous are counted."""
+import warnings
+
+import numpy as np
+import pytest
+
+from richdem_amd.synth import fractal_dem
+
+pytestmark = pytest.mark.gpu
+
+
+def _distinct(dem, rng):
+    out = dem.astype(np.float32).copy()
+    flat = out.ravel()
+    for _ in range(60):
+        _, first = np.unique(flat, return_index=True)
+        dup = np.setdiff1d(np.arange(flat.size), first)
+        if dup.size == 0:
+            return out
+        flat[dup] = np.nextafter(flat[dup], np.float32(np.inf)) + rng.random(dup.size).astype(np.float32) * np.float32(1e-3)
+    raise AssertionError("could not make the DEM tie free")
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (4, 7), (9, 9), (33, 65), (64, 64), (130, 97), (257, 300)])
+def test_random_permutations(rd, orc, shape):
+    """every elevation distinct, no structure at all: deep nesting on small rasters"""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    dem = rng.permutation(h * w).reshape(h, w).astype(np.int32)
+    got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
+    assert np.array_equal(got, orc.port.pf_flowdirs(dem, np.int32(-9999)))
+    assert rd.pf_flowdirs_stats()["unresolved"] == 0
+
+
+@pytest.mark.parametrize("seed,shape", [(1, (200, 260)), (2, (333, 190)), (3, (512, 512))])
+def test_fractal_terrain_without_ties(rd, orc, seed, shape):
+    rng = np.random.default_rng(seed)
+    dem = _distinct(fractal_dem(shape[1], shape[0], seed=40 + seed), rng)
+    got = rd.pf_flowdirs(dem, nodata=np.float32(-9999))
+    exp = orc.port.pf_flowdirs(dem, np.float32(-9999))
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    st = rd.pf_flowdirs_stats()
+    assert st["unresolved"] == 0 and st["levels"] >= 3
+
+
+def test_nodata_cells_and_other_dtypes(rd, orc):
+    rng = np.random.default_rng(7)
+    dem = rng.permutation(90 * 70).reshape(70, 90).astype(np.float32)
+    dem[rng.random(dem.shape) < 0.03] = -9999.0          # NoData cells flood like any cell and get direction 0 (:545-548)
+    nd = np.float32(-9999)
+    holes = dem == nd
+    dem[holes] = -9999.0 - np.arange(holes.sum(), dtype=np.float32)   # (distinct values below the data ...)
+    exp = orc.port.pf_flowdirs(dem, np.float32(-9999))
+    assert np.array_equal(rd.pf_flowdirs(dem, nodata=nd), exp)
+    for dt in (np.uint16, np.int16, np.uint32):
+        d = rng.permutation(60 * 50).reshape(50, 60).astype(dt)
+        assert np.array_equal(rd.pf_flowdirs(d, nodata=dt(0)), orc.port.pf_flowdirs(d, dt(0))), dt
+    small = rng.permutation(200).reshape(10, 20).astype(np.uint8)
+    assert np.array_equal(rd.pf_flowdirs(small, nodata=np.uint8(255)), orc.port.pf_flowdirs(small, np.uint8(255)))
+
+
+def test_ties_are_counted_not_hidden(rd, orc):
+    """Equal elevations: the reference's answer follows its insertion counters.  The engine still returns a direction for
+    every cell (towards a neighbour that IS flooded no later than any other candidate it could separate), warns, and
+    says how many cells it could not separate; where it reports none the result equals the reference."""
+    rng = np.random.default_rng(9)
+    dem = rng.integers(0, 6, (80, 100)).astype(np.int32)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
+    st = rd.pf_flowdirs_stats()
+    assert st["unresolved"] > 0 and any("equal-elevation" in str(x.message) for x in wlist)
+    exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
+    warnings.warn(f"pf_flowdirs with ties (6 elevations, 80 x 100): {float((got != exp).mean()):.3f} of the cells differ from the "
+                  f"reference's, {st['unresolved']} cells reported as ambiguous")
+    assert got.shape == dem.shape and got[1:-1, 1:-1].min() >= 1 and got.max() <= 8
+    assert got[0, 1] == 3 and got[-1, 1] == 7 and got[1, 0] == 1 and got[1, -1] == 5 and got[0, 0] == 2
+
+
+def test_border_only_rasters_and_errors(rd, orc):
+    for shape in [(1, 1), (1, 5), (2, 2), (2, 9)]:
+        dem = np.arange(shape[0] * shape[1], dtype=np.float32).reshape(shape)
+        assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.float32(-1)), orc.port.pf_flowdirs(dem, np.float32(-1))), shape
+    with pytest.raises(rd.RdgpuError):
+        rd.pf_flowdirs(np.zeros((4, 4), np.float64))
