@@ -153,6 +153,14 @@ RDGPU_SHIM_WS(u64, uint64_t)
 template <class T>
 int c_watersheds(T *, T, int, int, int, int, int32_t *) { unsupported("PriorityFloodWatersheds_Barnes2014"); }
 
+#define RDGPU_SHIM_PFD(SUF, T) \
+  inline int c_pf_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_pf_flowdirs_##SUF(p, nd, w, h, o); }
+RDGPU_SHIM_PFD(u8, uint8_t) RDGPU_SHIM_PFD(i8, int8_t) RDGPU_SHIM_PFD(i16, int16_t) RDGPU_SHIM_PFD(u16, uint16_t)
+RDGPU_SHIM_PFD(i32, int32_t) RDGPU_SHIM_PFD(u32, uint32_t) RDGPU_SHIM_PFD(f32, float)
+#undef RDGPU_SHIM_PFD
+template <class T>
+int c_pf_flowdirs(const T *, T, int, int, uint8_t *) { unsupported("PriorityFloodFlowdirs_Barnes2014"); }
+
 inline int c_fill_eps(float *p, float nd, int w, int h, int t) { return rdgpu_fill_epsilon_f32(p, nd, w, h, t); }
 inline int c_fill_eps(double *p, double nd, int w, int h, int t) { return rdgpu_fill_epsilon_f64(p, nd, w, h, t); }
 template <class T>
@@ -261,6 +269,20 @@ void dirs_into(const E &elevations, F &flowdirs, Fn fn, const char *who) {
   }
 }
 }  // namespace detail
+
+// richdem::PriorityFloodFlowdirs_Barnes2014(const Array2D<T>&, Array2D<d8_flowdir_t>&)   depressions/Barnes2014.hpp:483-555
+// flowdirs resized to the DEM, NoData = NO_FLOW (0) (:495-496).  Identical to the reference on DEMs without equal
+// elevations (rdgpu.h; rdgpu_pf_flowdirs_get_stats counts the cells that ties left ambiguous).
+template <class E, class F>
+void PriorityFloodFlowdirs_Barnes2014(const E &elevations, F &flowdirs) {
+  using T = detail::elem_t<E>;
+  static_assert(std::is_same<detail::elem_t<F>, uint8_t>::value, "PriorityFloodFlowdirs_Barnes2014: flowdirs must be Array2D<d8_flowdir_t>");
+  flowdirs.resize(elevations.width(), elevations.height());
+  flowdirs.setNoData((uint8_t)0);
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::check(detail::c_pf_flowdirs(elevations.data(), elevations.noData(), elevations.width(), elevations.height(), flowdirs.data()),
+                "PriorityFloodFlowdirs_Barnes2014");
+}
 
 // richdem::d8_flow_directions(const Array2D<T>&, Array2D<U>&)   flowmet/d8_flowdirs.hpp:96-123
 template <class E, class F>

@@ -35,6 +35,7 @@ void orc_fill_f64(double *, int, int, int);
 void orc_flat_resolution_f32(const float *, float, int, int, uint8_t *);
 void orc_flat_resolution_alter_f32(float *, float, int, int, uint8_t *);
 void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
+void orc_pf_flowdirs_f32(const float *, float, int, int, uint8_t *);
 void orc_d8_flow_accum_f64(const uint8_t *, uint8_t, int, int, double *);
 void orc_d8_flow_accum_i32(const uint8_t *, uint8_t, int, int, int32_t *);
 void orc_fa_mfd_f32(const float *dem, float nodata, int w, int h, int method, double xparam, double *accum);
@@ -95,6 +96,20 @@ int main() {
     EXPECT(wrapped.data() == buf.data());
     EXPECT(std::memcmp(buf.data(), e.data(), e.size() * 4) == 0);
   }
+  // PriorityFloodFlowdirs_Barnes2014 on a DEM without equal elevations (a permutation of 0 .. w*h-1 scattered by a prime)
+  {
+    Arr<float> p(w, h, 0.0f);
+    p.setNoData(-9999.0f);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) p(x, y) = (float)(((uint64_t)(y * w + x) * 2654435761ull) % 1000003ull);
+    Arr<uint8_t> fd;
+    rdgpu::PriorityFloodFlowdirs_Barnes2014(p, fd);
+    EXPECT(fd.width() == w && fd.height() == h && fd.noData() == 0);
+    std::vector<uint8_t> ef((size_t)w * h);
+    orc_pf_flowdirs_f32(p.data(), -9999.0f, w, h, ef.data());
+    EXPECT(std::memcmp(fd.data(), ef.data(), ef.size()) == 0);
+  }
+
   // rd_d8_flowdirs chain: fill -> barnes_flat_resolution_d8 -> d8_flow_accum
   {
     Arr<float> a = dem;
