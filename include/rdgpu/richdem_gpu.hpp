@@ -275,7 +275,6 @@ void dirs_into(const E &elevations, F &flowdirs, Fn fn, const char *who) {
 // elevations (rdgpu.h; rdgpu_pf_flowdirs_get_stats counts the cells that ties left ambiguous).
 template <class E, class F>
 void PriorityFloodFlowdirs_Barnes2014(const E &elevations, F &flowdirs) {
-  using T = detail::elem_t<E>;
   static_assert(std::is_same<detail::elem_t<F>, uint8_t>::value, "PriorityFloodFlowdirs_Barnes2014: flowdirs must be Array2D<d8_flowdir_t>");
   flowdirs.resize(elevations.width(), elevations.height());
   flowdirs.setNoData((uint8_t)0);
