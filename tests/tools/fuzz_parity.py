@@ -146,6 +146,12 @@ def main():
             chk(f"fa_{m}", np.array_equal(ga == -1, ea == -1) and np.allclose(ga, ea, rtol=2e-6, atol=0))
             ga, ea = rd.FlowAccumulation(src, "Dinf", nodata=nd), P.fa_tarboton(src, nd)
             chk("fa_dinf", np.array_equal(ga == -1, ea == -1) and np.allclose(ga, ea, rtol=2e-6, atol=0))
+            # PriorityFloodFlowdirs on the same shape with every elevation distinct (a permutation ranked by the terrain)
+            order = np.argsort(dem.astype(np.float64).ravel() + rng.random(h * w) * 0.5, kind="stable")
+            perm = np.empty(h * w, np.int32)
+            perm[order] = np.arange(h * w, dtype=np.int32)
+            pd = perm.reshape(h, w)
+            chk("pf_flowdirs", np.array_equal(rd.pf_flowdirs(pd, nodata=np.int32(-9999)), P.pf_flowdirs(pd, np.int32(-9999))))
         except Exception as e:   # noqa: BLE001
             bad.append(f"EXC {tag}: {type(e).__name__}: {e}")
     kinds = {}
