@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 #: SURVEY.md section 8d, algorithmic bytes per cell
 STAGE_BYTES = {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
-               "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8}
+               "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8, "priority_flood_flowdirs": 5}
 
 
 def cpu_baseline(Z, sample: int):
@@ -147,6 +147,14 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None) -> dict:
         es = rd.epsilon_stats()
         out["priority_flood_epsilon"].update({"input": "the unfilled bench DEM (PriorityFloodEpsilon_Original semantics)",
                                               **{k: es[k] for k in ("rounds", "tie_sources") if k in es}})
+        # PriorityFloodFlowdirs_Barnes2014: one fill per nesting level of the depressions (seconds, not milliseconds: once)
+        del E
+        pdirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
+        t_pf = _best(lambda: rd.pf_flowdirs_dev(Z, nodata, pdirs), 1, sync)
+        out["priority_flood_flowdirs"] = stage_entry(t_pf, n_cells, STAGE_BYTES["priority_flood_flowdirs"])
+        ps = rd.pf_flowdirs_stats()
+        out["priority_flood_flowdirs"].update({"input": "the unfilled bench DEM", "levels": ps["levels"],
+                                               "cells_ambiguous_by_ties": ps["unresolved"]})
     return out
 
 

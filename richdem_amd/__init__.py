@@ -38,6 +38,7 @@ from .pyrichdem import (  # noqa: F401
 )
 from .api import (  # noqa: F401
     pf_flowdirs,
+    pf_flowdirs_dev,
     pf_flowdirs_stats,
     pit_mask,
     fill_max_dep,
@@ -93,6 +94,7 @@ __all__ = [
     "profile_totals",
     "ResolveFlats",
     "pf_flowdirs",
+    "pf_flowdirs_dev",
     "pf_flowdirs_stats",
     "pit_mask",
     "fill_max_dep",

@@ -150,6 +150,21 @@ def watersheds(dem: np.ndarray, nodata=-9999, topology="D8", alter: bool = False
     return (labels, work) if alter else labels
 
 
+def pf_flowdirs_dev(dem, nodata, dirs) -> None:
+    """PriorityFloodFlowdirs_Barnes2014 of a contiguous 2-D CUDA tensor (8 / 16 / 32-bit element type) into a uint8 CUDA
+    tensor of the same shape, on torch's current stream (the call synchronises: one read-back per nesting level)."""
+    import torch
+
+    h, w = _dev2d(dem, "pf_flowdirs_dev")
+    if dirs.dtype != torch.uint8 or tuple(dirs.shape) != (h, w) or not dirs.is_contiguous() or not dirs.is_cuda:
+        raise RdgpuError("pf_flowdirs_dev: dirs must be a contiguous uint8 CUDA tensor of the DEM's shape")
+    s = _torch_elev_suffix(dem)
+    if s not in ("u8", "i8", "i16", "u16", "i32", "u32", "f32"):
+        raise RdgpuError("pf_flowdirs_dev: 8 / 16 / 32-bit element types only")
+    check(getattr(lib(), f"rdgpu_pf_flowdirs_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+                                                       ctypes.c_void_p(dirs.data_ptr()), _stream_ptr()), "rdgpu_pf_flowdirs_dev")
+
+
 class _PfdStats(ctypes.Structure):
     _fields_ = [("levels", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("unresolved", ctypes.c_uint64)]
 
