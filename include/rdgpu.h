@@ -160,7 +160,7 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
  * cells 0).  Identical to the reference on DEMs WITHOUT equal elevations (its queue breaks ties by insertion order, which only
  * the serial sweep defines); cells whose direction stays ambiguous because of ties are counted in the stats and get their
  * lowest-numbered candidate.  One whole-raster fill per nesting level of the depressions: provided, not tuned.
- * The highest value of the element type (+inf for float) must not occur in the DEM.  8 / 16 / 32-bit element types. */
+ * The highest value of an 8 / 16 / 32-bit element type (+inf for float) must not occur in the DEM. */
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
   uint32_t reserved;
@@ -180,6 +180,14 @@ RDGPU_DECL_PFD(i32, int32_t)
 RDGPU_DECL_PFD(u32, uint32_t)
 RDGPU_DECL_PFD(f32, float)
 #undef RDGPU_DECL_PFD
+/* f64 / i64 / u64: on the dense value ranks of the DEM (fill64.hip), no restriction on the values */
+#define RDGPU_DECL_PFD64(SUF, T)                                                                            \
+  int rdgpu_pf_flowdirs_##SUF(const T *dem, T nodata, int width, int height, uint8_t *dirs);                \
+  int rdgpu_pf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int width, int height, uint8_t *d_dirs, void *hip_stream);
+RDGPU_DECL_PFD64(f64, double)
+RDGPU_DECL_PFD64(i64, int64_t)
+RDGPU_DECL_PFD64(u64, uint64_t)
+#undef RDGPU_DECL_PFD64
 
 #define RDGPU_DECL_WS(SUF, T)                                                                                          \
   int rdgpu_watersheds_##SUF(T *dem, T nodata, int width, int height, int topology, int alter, int32_t *labels);      \

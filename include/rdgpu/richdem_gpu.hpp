@@ -157,6 +157,7 @@ int c_watersheds(T *, T, int, int, int, int, int32_t *) { unsupported("PriorityF
   inline int c_pf_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_pf_flowdirs_##SUF(p, nd, w, h, o); }
 RDGPU_SHIM_PFD(u8, uint8_t) RDGPU_SHIM_PFD(i8, int8_t) RDGPU_SHIM_PFD(i16, int16_t) RDGPU_SHIM_PFD(u16, uint16_t)
 RDGPU_SHIM_PFD(i32, int32_t) RDGPU_SHIM_PFD(u32, uint32_t) RDGPU_SHIM_PFD(f32, float)
+RDGPU_SHIM_PFD(f64, double) RDGPU_SHIM_PFD(i64, int64_t) RDGPU_SHIM_PFD(u64, uint64_t)
 #undef RDGPU_SHIM_PFD
 template <class T>
 int c_pf_flowdirs(const T *, T, int, int, uint8_t *) { unsupported("PriorityFloodFlowdirs_Barnes2014"); }

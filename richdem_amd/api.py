@@ -159,8 +159,6 @@ def pf_flowdirs_dev(dem, nodata, dirs) -> None:
     if dirs.dtype != torch.uint8 or tuple(dirs.shape) != (h, w) or not dirs.is_contiguous() or not dirs.is_cuda:
         raise RdgpuError("pf_flowdirs_dev: dirs must be a contiguous uint8 CUDA tensor of the DEM's shape")
     s = _torch_elev_suffix(dem)
-    if s not in ("u8", "i8", "i16", "u16", "i32", "u32", "f32"):
-        raise RdgpuError("pf_flowdirs_dev: 8 / 16 / 32-bit element types only")
     check(getattr(lib(), f"rdgpu_pf_flowdirs_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
                                                        ctypes.c_void_p(dirs.data_ptr()), _stream_ptr()), "rdgpu_pf_flowdirs_dev")
 
@@ -184,8 +182,6 @@ def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
         raise RdgpuError("pf_flowdirs: expected a 2-D numpy array")
     dem = np.ascontiguousarray(dem)
     s = _suffix(dem.dtype)
-    if s not in ("u8", "i8", "i16", "u16", "i32", "u32", "f32"):
-        raise RdgpuError("pf_flowdirs: 8 / 16 / 32-bit element types only")
     h, w = dem.shape
     out = np.empty((h, w), np.uint8)
     check(getattr(lib(), f"rdgpu_pf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,

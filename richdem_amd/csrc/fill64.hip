@@ -213,6 +213,17 @@ static void watersheds64_device(T *d_z, T nodata, int w, int h, int topology, in
               (const uint64_t *)r.uniq, n);
 }
 
+// PriorityFloodFlowdirs only compares elevations too: the u32 engine (pfdirs.hip) on the ranks
+extern "C" int rdgpu_pf_flowdirs_dev_u32(const uint32_t *, uint32_t, int, int, uint8_t *, void *);
+template <class T>
+static void pf_flowdirs64_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, hipStream_t s) {
+  check64(d_z, w, h, 8, "rdgpu_pf_flowdirs");
+  if (!d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: null pointer");
+  const Ranks r = dense_ranks<T>(d_z, (uint64_t)w * h, s);
+  const int rc = rdgpu_pf_flowdirs_dev_u32(r.rk, nodata_rank<T>(r, nodata, s), w, h, d_dirs, s);
+  if (rc) throw Error(rc, rdgpu_last_error());
+}
+
 // host-pointer forms: H2D, the device form, D2H of what the call produces
 template <class T, class F>
 static void with_device_copy(T *dem, int w, int h, bool copy_back, F &&fn) {
@@ -329,3 +340,22 @@ RD_FILL64_API(u64, uint64_t)
 RD_F2_64_API(f64, double)
 RD_F2_64_API(i64, int64_t)
 RD_F2_64_API(u64, uint64_t)
+
+#define RD_PFD64_API(SUF, T)                                                                                           \
+  extern "C" int rdgpu_pf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int w, int h, uint8_t *d_dirs, void *stream) {  \
+    return guarded([&] { pf_flowdirs64_device<T>(d_dem, nodata, w, h, d_dirs, (hipStream_t)stream); });                \
+  }                                                                                                                    \
+  extern "C" int rdgpu_pf_flowdirs_##SUF(const T *dem, T nodata, int w, int h, uint8_t *dirs) {                        \
+    return guarded([&] {                                                                                               \
+      if (!dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: null pointer");                                        \
+      with_device_copy<T>(const_cast<T *>(dem), w, h, false, [&](T *d) {                                               \
+        uint8_t *dd = Workspace::get().buf<uint8_t>("host.mask64", (size_t)w * h);                                     \
+        pf_flowdirs64_device<T>(d, nodata, w, h, dd, nullptr);                                                         \
+        RD_HIP(hipStreamSynchronize(nullptr));                                                                         \
+        RD_HIP(hipMemcpy(dirs, dd, (size_t)w * h, hipMemcpyDeviceToHost));                                             \
+      });                                                                                                              \
+    });                                                                                                                \
+  }
+RD_PFD64_API(f64, double)
+RD_PFD64_API(i64, int64_t)
+RD_PFD64_API(u64, uint64_t)

@@ -58,6 +58,10 @@ def test_nodata_cells_and_other_dtypes(rd, orc):
     for dt in (np.uint16, np.int16, np.uint32):
         d = rng.permutation(60 * 50).reshape(50, 60).astype(dt)
         assert np.array_equal(rd.pf_flowdirs(d, nodata=dt(0)), orc.port.pf_flowdirs(d, dt(0))), dt
+    for dt in (np.float64, np.int64, np.uint64):          # the 64-bit types run on the dense value ranks
+        d = (rng.permutation(64 * 45).reshape(45, 64).astype(np.float64) * 1e12 + (1 << 60 if dt == np.uint64 else 0)).astype(dt)
+        assert np.unique(d).size == d.size
+        assert np.array_equal(rd.pf_flowdirs(d, nodata=dt(0)), orc.port.pf_flowdirs(d, dt(0))), dt
     small = rng.permutation(200).reshape(10, 20).astype(np.uint8)
     assert np.array_equal(rd.pf_flowdirs(small, nodata=np.uint8(255)), orc.port.pf_flowdirs(small, np.uint8(255)))
 
@@ -85,4 +89,4 @@ def test_border_only_rasters_and_errors(rd, orc):
         dem = np.arange(shape[0] * shape[1], dtype=np.float32).reshape(shape)
         assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.float32(-1)), orc.port.pf_flowdirs(dem, np.float32(-1))), shape
     with pytest.raises(rd.RdgpuError):
-        rd.pf_flowdirs(np.zeros((4, 4), np.float64))
+        rd.pf_flowdirs(np.zeros((4, 4), np.complex64))
