@@ -8,10 +8,14 @@
 //      label_this :331-355                   -> k_ccl_*           (components of the equal-elevation 8-graph:
 //                                                in LDS per tile, lock-free union-find across tile borders;
 //                                                root = lowest cell index)
-//      BuildAwayGradient :152-198            -> k_flat_bfs_*<AWAY>  (level-synchronous multi-source BFS: one
-//      BuildTowardsCombinedGradient :241-298 -> k_flat_bfs_*<TOWARDS> launch per wide level, one persistent
-//                                                workgroup for the long tail of narrow levels)
-//   d8_flow_flats / d8_masked_FlowDir :96-116, :42-65 -> k_flat_dirs
+//      BuildAwayGradient :152-198            -> k_relax_bits<1>   (breadth-first search on bitmaps, a wavefront per 64 x 64
+//      BuildTowardsCombinedGradient :241-298 -> k_relax_bits<2>    tile to its local fixed point: rounds over the active tiles
+//                                                while the front is wide, then ONE resident launch that pulls tiles from
+//                                                queues -- k_relax_bits_async; the away search runs on a side stream
+//                                                beside the towards search's tail)
+//   d8_flow_flats / d8_masked_FlowDir :96-116, :42-65 -> k_flat_dirs (full mask), k_flat_dirs_levels (directions-only entry)
+// ResolveFlatsEpsilon (flats/flats.hpp:21-28) runs the same searches over FindFlats' cells, with the labels (k_ccl_*) on a
+// side stream beside the searches' tail.
 //
 // The reference's outputs depend only on BFS *levels* and on the *partition* into flats, both of which
 // are order independent, so the parallel formulation reproduces flat_mask and the directions exactly.
