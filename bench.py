@@ -154,7 +154,8 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None) -> dict:
         out["priority_flood_flowdirs"] = stage_entry(t_pf, n_cells, STAGE_BYTES["priority_flood_flowdirs"])
         ps = rd.pf_flowdirs_stats()
         out["priority_flood_flowdirs"].update({"input": "the unfilled bench DEM", "levels": ps["levels"],
-                                               "cells_ambiguous_by_ties": ps["unresolved"]})
+                                               "cells_with_an_equal_elevation_twin": ps["twins"],
+                                               "directions_decided_among_ties": ps["unresolved"]})
     return out
 
 

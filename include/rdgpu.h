@@ -158,13 +158,13 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
 /* PriorityFloodFlowdirs_Barnes2014(elevations, flowdirs) -- depressions/Barnes2014.hpp:483-555: D8 directions of the flood
  * that does not raise the DEM; every cell points at the neighbour that was flooded first (border cells off the raster, NoData
  * cells 0).  Identical to the reference on DEMs WITHOUT equal elevations (its queue breaks ties by insertion order, which only
- * the serial sweep defines); cells whose direction stays ambiguous because of ties are counted in the stats and get their
- * lowest-numbered candidate.  One whole-raster fill per nesting level of the depressions: provided, not tuned.
+ * the serial sweep defines): the stats count the cells with an equal-elevation twin (none: the result is exact) and the
+ * cells whose direction was decided by neighbour number.  One whole-raster fill per nesting level of the depressions: provided, not tuned.
  * The highest value of an 8 / 16 / 32-bit element type (+inf for float) must not occur in the DEM. */
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
-  uint32_t reserved;
-  uint64_t unresolved;  /* cells with more than one candidate left */
+  uint32_t twins;       /* cells whose elevation occurs more than once in the raster: 0 => the result is the reference's */
+  uint64_t unresolved;  /* cells whose direction was decided by neighbour number among equal candidates */
 } rdgpu_pf_flowdirs_stats;
 int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);
 #define RDGPU_DECL_PFD(SUF, T)                                                                              \

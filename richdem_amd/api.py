@@ -164,13 +164,13 @@ def pf_flowdirs_dev(dem, nodata, dirs) -> None:
 
 
 class _PfdStats(ctypes.Structure):
-    _fields_ = [("levels", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("unresolved", ctypes.c_uint64)]
+    _fields_ = [("levels", ctypes.c_uint32), ("twins", ctypes.c_uint32), ("unresolved", ctypes.c_uint64)]
 
 
 def pf_flowdirs_stats() -> dict:
     st = _PfdStats()
     check(lib().rdgpu_pf_flowdirs_get_stats(ctypes.byref(st)), "rdgpu_pf_flowdirs_get_stats")
-    return {"levels": st.levels, "unresolved": st.unresolved}
+    return {"levels": st.levels, "twins": st.twins, "unresolved": st.unresolved}
 
 
 def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
@@ -187,11 +187,13 @@ def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     check(getattr(lib(), f"rdgpu_pf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
                                                    out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_pf_flowdirs")
     st = pf_flowdirs_stats()
-    if st["unresolved"]:
+    if st["unresolved"] or st["twins"]:
         import warnings
 
-        warnings.warn(f"pf_flowdirs: {st['unresolved']} cells have equal-elevation candidates; the reference breaks such ties "
-                      "by the insertion order of its queue, this result by neighbour number", RuntimeWarning)
+        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell ({st['unresolved']} directions "
+                      "were decided among equal-elevation candidates); the reference breaks such ties by the insertion order of "
+                      "its queue, this result by neighbour number -- identical results are only guaranteed without equal "
+                      "elevations", RuntimeWarning)
     return out
 
 

@@ -119,6 +119,20 @@ __global__ __launch_bounds__(128) void k_sum_counters(unsigned long long *counte
   counters[threadIdx.x] = 0;
 }
 
+// Equal elevations anywhere in the raster: one bit per possible 32-bit key (512 MB), a cell whose bit is set already has a
+// twin.  No twins => the result is the reference's (the proof in the header needs distinct elevations, nothing else).
+template <class T>
+__global__ __launch_bounds__(NT) void k_twins(const T *__restrict__ z, uint64_t n, uint32_t *bits, unsigned long long *counters) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  uint32_t twins = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t k = Key32<T>::to(z[c]), bit = 1u << (k & 31u);
+    if (atomicOr(&bits[k >> 5], bit) & bit) twins++;
+  }
+  for (int o = 32; o > 0; o >>= 1) twins += __shfl_down(twins, o, 64);
+  if ((threadIdx.x & 63) == 0 && twins) atomicAdd(&counters[(blockIdx.x & 63) * 2], (unsigned long long)twins);   // striped
+}
+
 // candidates of every cell at the start: all eight neighbours of an interior cell, none for a border cell
 __global__ __launch_bounds__(NT) void k_init_cand(uint8_t *cand, int w, int h) {
   const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
@@ -194,6 +208,19 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   unsigned long long *counters = ws.buf<unsigned long long>("pfd.counters", 128 + 4);
   unsigned long long *sums = counters + 128;   // [0] undecided, [1] wet, [2] unresolved
   RD_HIP(hipMemsetAsync(counters, 0, (128 + 4) * sizeof(unsigned long long), s));
+  {
+    const char *env = getenv("RDGPU_PFD_TWINS");   // =0: skip the equal-elevation census (512 MB of bits)
+    if (!(env && env[0] == '0')) {
+      uint32_t *bits = ws.buf<uint32_t>("pfd.keybits", (size_t)1 << 27);
+      RD_HIP(hipMemsetAsync(bits, 0, (size_t)1 << 29, s));
+      RD_LAUNCH("pfd.twins", (k_twins<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, n, bits, counters);
+      RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
+      unsigned long long tw = 0;
+      RD_HIP(hipMemcpyAsync(&tw, sums, sizeof tw, hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      g_stats.twins = (uint32_t)std::min<unsigned long long>(tw, 0xFFFFFFFFull);
+    }
+  }
   RD_LAUNCH("pfd.init", k_init_cand, dim3(sgrid(n)), dim3(NT), 0, s, cand, w, h);
   if (w > 2 && h > 2) {
     T *F = ws.buf<T>("pfd.level", n);

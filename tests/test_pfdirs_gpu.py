@@ -32,7 +32,7 @@ def test_random_permutations(rd, orc, shape):
     dem = rng.permutation(h * w).reshape(h, w).astype(np.int32)
     got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
     assert np.array_equal(got, orc.port.pf_flowdirs(dem, np.int32(-9999)))
-    assert rd.pf_flowdirs_stats()["unresolved"] == 0
+    assert rd.pf_flowdirs_stats()["unresolved"] == 0 and rd.pf_flowdirs_stats()["twins"] == 0
 
 
 @pytest.mark.parametrize("seed,shape", [(1, (200, 260)), (2, (333, 190)), (3, (512, 512))])
@@ -76,7 +76,7 @@ def test_ties_are_counted_not_hidden(rd, orc):
         warnings.simplefilter("always")
         got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
     st = rd.pf_flowdirs_stats()
-    assert st["unresolved"] > 0 and any("equal-elevation" in str(x.message) for x in wlist)
+    assert st["unresolved"] > 0 and st["twins"] >= dem.size - 6 and any("equal-elevation" in str(x.message) for x in wlist)
     exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
     warnings.warn(f"pf_flowdirs with ties (6 elevations, 80 x 100): {float((got != exp).mean()):.3f} of the cells differ from the "
                   f"reference's, {st['unresolved']} cells reported as ambiguous")
