@@ -46,6 +46,23 @@ def test_fractal_terrain_without_ties(rd, orc, seed, shape):
     assert st["unresolved"] == 0 and st["levels"] >= 3
 
 
+def test_rank_permutation_of_a_3000_square_terrain(rd, orc):
+    """Many 64 x 64 tiles, lakes hundreds of cells across, every elevation distinct (the terrain's ranks): 9 million cells
+    against the stable-queue sweep, a few hundred nesting levels."""
+    n = 3000
+    z = fractal_dem(n, n, seed=3).astype(np.float64)
+    rng = np.random.default_rng(12)
+    order = np.argsort(z.ravel() + rng.random(n * n) * 1e-9, kind="stable")
+    ranks = np.empty(n * n, np.int32)
+    ranks[order] = np.arange(n * n, dtype=np.int32)
+    dem = ranks.reshape(n, n)
+    got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
+    exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
+    st = rd.pf_flowdirs_stats()
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    assert st["twins"] == 0 and st["unresolved"] == 0 and st["levels"] > 30
+
+
 def test_nodata_cells_and_other_dtypes(rd, orc):
     rng = np.random.default_rng(7)
     dem = rng.permutation(90 * 70).reshape(70, 90).astype(np.float32)
