@@ -2032,7 +2032,8 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
   RD_HIP(hipGetDevice(&dev));
   RD_HIP(hipDeviceGetAttribute(&r.cus, hipDeviceAttributeMultiprocessorCount, dev));
   RD_HIP(hipDeviceGetAttribute(&r.rate_khz, hipDeviceAttributeWallClockRate, dev));
-  const unsigned long long budget = (unsigned long long)std::max(r.rate_khz, 1000) * 1000ull * 10ull;   // ten seconds of wall_clock64 ticks
+  // twenty seconds of wall_clock64 ticks (an attribute that reads 0 is taken as the usual 100 MHz)
+  const unsigned long long budget = (unsigned long long)std::max(r.rate_khz, 100000) * 1000ull * 20ull;
   uint32_t *last = b.ctr + (BITS_BATCH - 1);   // (its own counter word: the rounds' words may not have been read back yet)
   RD_HIP(hipMemsetAsync(last, 0, sizeof(uint32_t), s));
   RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
