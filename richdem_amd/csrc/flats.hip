@@ -1998,8 +1998,8 @@ static uint32_t async_threshold() {
   return env ? (uint32_t)strtoul(env, nullptr, 10) : 20000u;
 }
 
-struct AsyncInfo { uint32_t visits, launches; };
-static thread_local AsyncInfo g_async_info = {0, 0};
+struct AsyncInfo { uint32_t visits, launches, failures; };
+static thread_local AsyncInfo g_async_info = {0, 0, 0};
 
 // What relax_rounds_bits / the static search hand to the code around them when the search reaches its tail: mark() before
 // the resident launch is enqueued (the place for an event the side work waits on), go() after it (the resident
@@ -2059,7 +2059,9 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
 }
 
 // the end state, checked on the host (s is synchronised here): no abort, every counter pair equal, every queue drained
-static void async_check(const AsyncRun &r, const char *name, hipStream_t s) {
+// Returns false (and says so on stderr) when the launch gave up: the levels are valid upper bounds then, and the caller
+// finishes the search in rounds from "every tile active" (the fixed point does not depend on the schedule).
+static bool async_check(const AsyncRun &r, const char *name, hipStream_t s) {
   std::vector<uint32_t> all(AQ_WORDS);
   RD_HIP(hipMemcpyAsync(all.data(), r.Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
@@ -2069,25 +2071,30 @@ static void async_check(const AsyncRun &r, const char *name, hipStream_t s) {
     queued += all[qi * AQ_STRIDE + 1] - all[qi * AQ_STRIDE + 0];
     pushes += all[qi * AQ_STRIDE + 1];
   }
-  if (all[AQ_G_ABORT] != 0 || enq != done || queued != 0)
-    throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: the asynchronous search did not finish (abort " + std::to_string(all[AQ_G_ABORT]) +
-                                   ", " + std::to_string(enq - done) + " tiles pending, " + std::to_string(queued) +
-                                   " queued); RDGPU_FLAT_ASYNC=0 runs the rounds to the end");
+  if (all[AQ_G_ABORT] != 0 || enq != done || queued != 0) {
+    fprintf(stderr, "rdgpu flat resolution: the asynchronous search (%s) gave up (abort %u, %llu tiles pending, %llu queued); "
+                    "finishing in rounds\n", name, all[AQ_G_ABORT], (unsigned long long)(enq - done), (unsigned long long)queued);
+    g_async_info.failures++;
+    return false;
+  }
   g_async_info.visits += all[AQ_G_VISITS];
   g_async_info.launches++;
   if (getenv("RDGPU_FLAT_TRACE"))
     fprintf(stderr, "%s asynchronous tail: %u visits, %llu pushes, %u wavefronts on %d CUs, ticks (%d kHz): in visits %llu, longest wavefront %u\n",
             name, all[AQ_G_VISITS], (unsigned long long)pushes, r.blocks * 4u, r.cus, r.rate_khz,
             (unsigned long long)all[AQ_G_BUSY] | ((unsigned long long)all[AQ_G_BUSY + 1] << 32), all[AQ_G_SPAN]);
+  return true;
 }
 
 template <int SEED_LEVEL>
 static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h, const char *name, hipStream_t s,
-                                  RowWin win = RowWin{0, -1, nullptr, nullptr}, const Beside *beside = nullptr) {
+                                  RowWin win = RowWin{0, -1, nullptr, nullptr}, const Beside *beside = nullptr,
+                                  bool allow_async = true) {
   if (win.hi < 0) win.hi = h;   // single device: all rows, no ghost rows
   uint32_t *hw = Workspace::get().host_words();
   const bool trace = getenv("RDGPU_FLAT_TRACE") != nullptr;
-  const uint32_t async_below = async_threshold();
+  uint32_t async_below = allow_async ? async_threshold() : 0u;
+  if (allow_async && getenv("RDGPU_FLAT_ASYNC_FAIL")) async_below = std::max(async_below, 1u);   // (tests: the recovery path below)
   uint32_t rounds = 0, grid = (b.ntiles + 3) / 4;   // any tile may be active in the first batch
   for (;;) {
     // with the asynchronous tail ahead the batches are short (the switch is decided on the host, from the counts)
@@ -2129,8 +2136,13 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
     }
     if (async_below && hw[batch - 1] < async_below) {
       const AsyncRun run = async_enqueue<SEED_LEVEL>(b, D, w, h, name, s, win, false, beside);
-      async_check(run, name, s);
-      return rounds + 1;
+      beside = nullptr;   // (its callbacks have run)
+      if (async_check(run, name, s) && !getenv("RDGPU_FLAT_ASYNC_FAIL")) return rounds + 1;
+      // the tail gave up (or the test switch says so): rounds to the end, from every tile
+      RD_HIP(hipMemsetAsync(b.tflags, 1, b.ntiles, s));
+      async_below = 0;
+      grid = (b.ntiles + 3) / 4;
+      continue;
     }
     grid = std::min<uint32_t>((b.ntiles + 3) / 4, std::max<uint32_t>(256u, (2u * most + 3) / 4));
     if (rounds > (1u << 26)) throw Error(RDGPU_ERR_HIP, "rdgpu flat resolution: relaxation did not terminate");
@@ -2211,12 +2223,16 @@ static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, i
   return sa;
 }
 // on a stream that has waited for the side stream: the end state of the tail, and the number of rounds that had work
-static uint32_t finish_away_static(const StaticAway &sa, hipStream_t s) {
+static uint32_t finish_away_static(const StaticAway &sa, int32_t *A, int w, int h, hipStream_t s) {
   uint32_t counts[AWAY_STATIC_ROUNDS];
   RD_HIP(hipMemcpyAsync(counts, sa.b.ctr, sizeof counts, hipMemcpyDeviceToHost, s));
-  async_check(sa.run, "flats.relax_away", s);   // (synchronises s)
+  const bool ok = async_check(sa.run, "flats.relax_away", s);   // (synchronises s)
   uint32_t rounds = 1;
   for (int k = 0; k < AWAY_STATIC_ROUNDS; k++) rounds += counts[k] != 0;
+  if (!ok || getenv("RDGPU_FLAT_ASYNC_FAIL")) {   // the tail gave up: rounds to the end, from every tile, on this stream
+    RD_HIP(hipMemsetAsync(sa.b.tflags, 1, sa.b.ntiles, s));
+    rounds += relax_rounds_bits<1>(sa.b, A, w, h, "flats.relax_away", s, RowWin{0, -1, nullptr, nullptr}, nullptr, false);
+  }
   return rounds;
 }
 
@@ -2324,7 +2340,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
     g_fstats.noflow_cells = c3[2];
     if (away_started) {
       RD_HIP(hipStreamWaitEvent(s, alane->join, 0));
-      g_fstats.away_levels = finish_away_static(sa, s);
+      g_fstats.away_levels = finish_away_static(sa, A, w, h, s);
     } else if (c3[0] > 0 && c3[1] > 0) {
       A = ws.buf<int32_t>("flats.away", n);
       g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
@@ -2436,13 +2452,7 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
       A = ws.buf<int32_t>("flats.away", n);
       g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
     }
-    if (started) {
-      const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
-      RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
-                (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
-      g_fstats.away_levels = finish_away_static(sa, s);   // (checked while the directions are being written)
-      return;
-    }
+    if (started) g_fstats.away_levels = finish_away_static(sa, A, w, h, s);
   } else {
     uint32_t *low = nullptr, *highall = nullptr;
     uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;

@@ -143,11 +143,12 @@ def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000", "RDGPU_FLAT_AWAY_BESIDE=0", "RDGPU_FLAT_ASYNC_BLOCKS=3",
-                                    "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1"])
+                                    "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1", "RDGPU_FLAT_ASYNC_FAIL=1"])
 def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     """The bitmap search in rounds to the end, with its asynchronous tail from the first batch on (k_relax_bits_async),
     with the away search after instead of beside the towards tail, on three resident blocks; ResolveFlatsEpsilon with the
-    older label path, on one stream, on three: the fixed point does not depend on the schedule -- directions and
+    older label path, on one stream, on three; a tail that is declared failed and finished in rounds from every tile
+    (RDGPU_FLAT_ASYNC_FAIL): the fixed point does not depend on the schedule -- directions and
     epsilon-resolved elevations equal the oracle's under every switch, on lakes that span many 64 x 64 tiles."""
     k, v = switch.split("=")
     dem = orc.port.fill(fractal_dem_int(1300, 900, 73, 0.01))
