@@ -165,6 +165,35 @@ def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
 
 
+def test_device_entries_on_a_side_stream_of_the_caller(rd, orc):
+    """The _dev_ entries of flat resolution, ResolveFlatsEpsilon and FA_D8 fork internal side streams from the CALLER's
+    stream and join them again: on a non-default torch stream, with work queued before and after, the results are the
+    oracle's."""
+    import torch
+
+    dem = orc.port.fill(fractal_dem(900, 700, seed=75) * np.float32(0.03)).astype(np.float32)
+    dem = np.floor(dem).astype(np.float32)
+    nd = np.float32(-9999)
+    edirs = orc.port.flat_resolution(dem, nd)
+    eeps = orc.port.resolve_flats_epsilon(dem, nd)
+    efa = orc.port.fa_d8(eeps, nd)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        z = torch.from_numpy(dem).cuda(non_blocking=True)
+        z2 = z * 1.0                                             # (queued work the calls must come after)
+        dirs = torch.empty(z.shape, dtype=torch.uint8, device="cuda")
+        rd.d8_flow_directions_dev(z2, nd, dirs, flats=True)
+        e = z2.clone()
+        rd.resolve_flats_epsilon_dev(e, nd)
+        acc = torch.ones(z.shape, dtype=torch.float64, device="cuda")
+        rd.fa_d8_dev(e, nd, acc)
+        acc2 = acc + 0.0                                         # (... and work that must come after them)
+    st.synchronize()
+    assert np.array_equal(dirs.cpu().numpy(), edirs)
+    assert e.cpu().numpy().tobytes() == eeps.tobytes()
+    assert np.array_equal(acc2.cpu().numpy(), efa)
+
+
 def test_open_water_tiles(rd, orc):
     """Flats that cover whole 64x64 tiles (the bitmap engine's chamfer path for tiles in which every cell takes part):
     a lake floor with outlets on different sides, with and without islands next to the open tiles, tile-aligned and not,
