@@ -171,7 +171,10 @@ int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);
   int rdgpu_pf_flowdirs_##SUF(const T *dem, T nodata, int width, int height, uint8_t *dirs);                \
   int rdgpu_pf_flowdirs_dev_##SUF(const T *d_dem, T nodata, int width, int height, uint8_t *d_dirs, void *hip_stream); \
   /* building block: the D8 fill with interior outlets (cells flagged in d_outlet drain like border cells) */ \
-  int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int width, int height, void *hip_stream);
+  int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int width, int height, void *hip_stream); \
+  /* ... d_skip (per 64 x 64 tile, optional): 1 / 2 = nothing but outlets in the tile and around it (1: first time) */ \
+  int rdgpu_fill_outlets_skip_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip, int width, int height, \
+                                        void *hip_stream);
 RDGPU_DECL_PFD(u8, uint8_t)
 RDGPU_DECL_PFD(i8, int8_t)
 RDGPU_DECL_PFD(i16, int16_t)

@@ -560,7 +560,8 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
                                                int w, int h, uint32_t B, uint32_t tilesX, uint32_t ntiles,
                                                const uint32_t *__restrict__ tiles_in, uint32_t nwork,
                                                uint8_t *alive_out, EdgeOut eo,
-                                               const uint32_t *__restrict__ tile_base = nullptr, uint32_t dtx = 0) {
+                                               const uint32_t *__restrict__ tile_base = nullptr, uint32_t dtx = 0,
+                                               const uint8_t *__restrict__ skip = nullptr) {
   __shared__ __attribute__((aligned(8))) uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   // The component table: in the pair pass it is only needed AFTER the pairs are reduced, when the keys are dead, so it
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(NTHR) void k_scan(const T *__restrict__ z, const ui
   if (wi >= nwork) return;
   const uint32_t t = tiles_in ? tiles_in[wi] : wi;
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
+  if (L16 && skip && skip[(uint32_t)(y0 / DH) * dtx + (uint32_t)(x0 / DW)]) return;   // nothing but outlets here, ring included
   if (!EMIT)
     for (int i = threadIdx.x; i < SC_SLOTS; i += NTHR) { tab_id[i] = 0xFFFFFFFFu; tab_val[i] = ~0ull; tab_cross[i] = 0; }
   if (EMIT)
@@ -1868,9 +1870,13 @@ struct FusedBuf {
 
 // OUTLETS: cells flagged in `outlet` drain like the raster's border cells (interior outlets: the restricted fills of
 // pfdirs.hip); the instantiation of the plain fill does not look at the pointer.
+// There, all outlets of a tile share ONE node (slot 0: a tile of walls has thousands of them), node 0 of the table is a
+// global "outside" node, and `skip` (optional, per descent tile) names the tiles that hold nothing but outlets, ring
+// included: they get no work -- label 0 everywhere (written once: skip == 1; 2: written before), node 0.
 template <class T, int TOPO, bool VEC, bool OUTLETS = false>
 __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
-                                                    uint32_t tilesX, uint32_t ntiles, const uint8_t *__restrict__ outlet = nullptr) {
+                                                    uint32_t tilesX, uint32_t ntiles, const uint8_t *__restrict__ outlet = nullptr,
+                                                    const uint8_t *__restrict__ skip = nullptr) {
   __shared__ uint32_t sk[DLH * DLW];
   // rows of LPD = 66 entries: with 64 two-byte entries every row starts on the same LDS bank and the jumps' gathers --
   // neighbouring columns of different rows -- collide (29 % of the kernel's LDS cycles, r03e)
@@ -1881,6 +1887,15 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
+  if (OUTLETS && skip && skip[t]) {
+    if (threadIdx.x == 0) { fo.tile_base[t] = 0; fo.tile_count[t] = 1; }
+    if (skip[t] == 1) {
+      const int lx_ = threadIdx.x & (DW - 1), gx_ = x0 + lx_;
+      for (int ly_ = threadIdx.x >> 6; ly_ < DH; ly_ += NTHR / 64)
+        if (gx_ < w && y0 + ly_ < h) fo.lab16[(size_t)(y0 + ly_) * w + gx_] = 0;
+    }
+    return;
+  }
   {
     constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
     Quad<T> zq[QPT];
@@ -1990,12 +2005,17 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   }
   __syncthreads();
   // ---- nodes: every root of the tile gets a local slot; pits a dense basin id --------------------------------------
-  uint32_t rootmask = 0, pitmask = 0;
+  uint32_t rootmask = 0, pitmask = 0, outmask = 0;
 #pragma unroll
   for (int j = 0; j < DH / 4; j++) {
     const int gy = y0 + ly0 + j;
     const uint16_t v = lp[(ly0 + j) * LPD + lx];
-    const bool root = (gx < w) & (gy < h) & (v >= LTERM_BASE);
+    bool root = (gx < w) & (gy < h) & (v >= LTERM_BASE);
+    if (OUTLETS) {   // the tile's outlets share slot 0
+      const bool outroot = root & ((v & 15u) == 9u);
+      outmask |= (outroot ? 1u : 0u) << j;
+      root &= !outroot;
+    }
     rootmask |= (root ? 1u : 0u) << j;
     pitmask |= ((root & ((v & 15u) == 0u)) ? 1u : 0u) << j;
   }
@@ -2009,7 +2029,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t nr = (wtot[0] >> 16) + (wtot[1] >> 16) + (wtot[2] >> 16) + (wtot[3] >> 16);
+    const uint32_t nr = (wtot[0] >> 16) + (wtot[1] >> 16) + (wtot[2] >> 16) + (wtot[3] >> 16) + (OUTLETS ? 1u : 0u);
     const uint32_t np = (wtot[0] & 0xFFFFu) + (wtot[1] & 0xFFFFu) + (wtot[2] & 0xFFFFu) + (wtot[3] & 0xFFFFu);
     const unsigned long long old = atomicAdd(fo.counters, ((unsigned long long)nr << 32) | np);
     pbase = (uint32_t)old;
@@ -2026,7 +2046,11 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   {
     uint32_t pre = incl - mine;
     for (int k = 0; k < (int)(threadIdx.x >> 6); k++) pre += wtot[k];
-    uint32_t slot = pre >> 16, pit = pbase + (pre & 0xFFFFu);
+    uint32_t slot = (pre >> 16) + (OUTLETS ? 1u : 0u), pit = pbase + (pre & 0xFFFFu);
+    if (OUTLETS) {
+      if (threadIdx.x == 0 && gfits) fo.G[nodes0] = OUTP;
+      for (uint32_t m = outmask; m; m &= m - 1) lp[(ly0 + __ffs((int)m) - 1) * LPD + lx] = (uint16_t)ROOT_TAG;   // slot 0
+    }
     for (uint32_t m = rootmask; m; m &= m - 1) {
       const int j = __ffs((int)m) - 1;
       const int ly = ly0 + j;
@@ -2085,10 +2109,12 @@ __global__ __launch_bounds__(NTHR) void k_node_levels(const uint32_t *__restrict
 template <class T, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__restrict__ lab16, const uint32_t *__restrict__ lvl,
                                                      const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_count,
-                                                     int w, int h, uint32_t tilesX, uint32_t ntiles) {
+                                                     int w, int h, uint32_t tilesX, uint32_t ntiles,
+                                                     const uint8_t *__restrict__ skip = nullptr) {
   __shared__ uint32_t sl[DH * DW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
+  if (skip && skip[t]) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
   const int qx = threadIdx.x & 15, ry = threadIdx.x >> 4;   // 16 quads per row, rows ry, ry + 16, ry + 32, ry + 48
   const int gx = x0 + 4 * qx;
@@ -2139,7 +2165,7 @@ __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__res
 // The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
 // provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
 template <class T, int TOPO>
-static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr) {
+static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr, const uint8_t *skip = nullptr) {
   const char *fe = getenv("RDGPU_FILL_FUSED");   // =0: the classic four-pass fill (A/B and tests)
   if (fe && fe[0] == '0') return false;
   const char *env_edges = getenv("RDGPU_FILL_EDGES");
@@ -2165,18 +2191,23 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   fo.overflow = dflags + 5;
   uint32_t *curN = ws.buf<uint32_t>("fused.curN", fo.gcap);
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
+  if (outlet) {   // node 0: the "outside" node of the skipped tiles
+    static const uint32_t one = 1u, outp = OUTP;
+    RD_HIP(hipMemcpyAsync(dflags + 9, &one, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    RD_HIP(hipMemcpyAsync(fo.G, &outp, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  }
   if (outlet && vec)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              outlet);
+              outlet, skip);
   else if (outlet)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              outlet);
+              outlet, skip);
   else if (vec)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr);
   else
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   if (hw[1] != 0) return false;   // more nodes than the table holds: nothing was written to the DEM
@@ -2219,11 +2250,11 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
       if (vec)
         RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
-                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx);
+                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
       else
         RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, false, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
-                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx);
+                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
       RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, dflags + 4);
       g_stats.scan_tiles += ntiles;
     } else {
@@ -2276,10 +2307,10 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
             lvl);
   if (vec)
     RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
-              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt);
+              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt, skip);
   else
     RD_LAUNCH("fill.finalize", (k_finalize16<T, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
-              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt);
+              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt, skip);
   return true;
 }
 
@@ -2296,11 +2327,11 @@ static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
 
 // The D8 fill with interior outlets (cells flagged in d_outlet drain like border cells).
 template <class T>
-static void fill_outlets_device(T *d_z, const uint8_t *d_outlet, int w, int h, hipStream_t s) {
+static void fill_outlets_device(T *d_z, const uint8_t *d_outlet, const uint8_t *d_skip, int w, int h, hipStream_t s) {
   check_fill_args(d_z, w, h, 8);
   if (!d_outlet) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_outlets: null outlet mask");
   if (w <= 2 || h <= 2) return;   // every cell is a border cell
-  if (fill_fused<T, 8>(d_z, w, h, s, d_outlet)) return;
+  if (fill_fused<T, 8>(d_z, w, h, s, d_outlet, d_skip)) return;
   FillBuffers fb;   // (the compact labels ran out of table space, or are switched off: the classic path)
   BufAlloc ws_alloc{false, nullptr};
   fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s, d_outlet);
@@ -2654,7 +2685,11 @@ using namespace rdgpu;
     return guarded([&] { fill_host<T>(dem, w, h, topology); });                                   \
   }                                                                                               \
   extern "C" int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int w, int h, void *stream) { \
-    return rdgpu::guarded([&] { rdgpu::fill_outlets_device<T>(d_dem, d_outlet, w, h, (hipStream_t)stream); });    \
+    return rdgpu::guarded([&] { rdgpu::fill_outlets_device<T>(d_dem, d_outlet, nullptr, w, h, (hipStream_t)stream); }); \
+  }                                                                                                \
+  extern "C" int rdgpu_fill_outlets_skip_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip, int w, int h, \
+                                                   void *stream) {                                 \
+    return rdgpu::guarded([&] { rdgpu::fill_outlets_device<T>(d_dem, d_outlet, d_skip, w, h, (hipStream_t)stream); }); \
   }                                                                                                \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
     return guarded([&] { fill_device<T>(d_dem, w, h, topology, (hipStream_t)stream); });          \

@@ -24,7 +24,7 @@
 
 #include <limits>
 
-#define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_dev_##SUF(T *, const uint8_t *, int, int, void *); \
+#define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_skip_dev_##SUF(T *, const uint8_t *, const uint8_t *, int, int, void *); \
                            extern "C" int rdgpu_fill_dev_##SUF(T *, int, int, int, void *);
 RD_OUTLETS(u8, uint8_t) RD_OUTLETS(i8, int8_t) RD_OUTLETS(i16, int16_t) RD_OUTLETS(u16, uint16_t) RD_OUTLETS(i32, int32_t)
 RD_OUTLETS(u32, uint32_t) RD_OUTLETS(f32, float)
@@ -86,27 +86,44 @@ __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T 
 }
 
 // The next level's problem, in place over this level's fill: a wet cell (below its level) keeps its elevation, everything
-// else becomes a wall; outlet = wet cell next to THE cell whose elevation is its level.  counters[1]: wet cells.
+// else becomes a wall; outlet = wet cell next to THE cell whose elevation is its level -- and every wall (a wall as an
+// outlet changes no level: a path over it costs the wall's height; it spares the fill the walls' basins).
+// counters[1]: wet cells.  active[]: per 64 x 64 tile of the fill, "a wet cell in the tile or next to it".
+constexpr int FT = 64;   // the fill's descent tiles (fill.hip: DW = DH = 64)
 template <class T>
-__global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, int w, int h,
-                                                   unsigned long long *counters) {
+__global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, uint8_t *active, int w,
+                                                   int h, unsigned long long *counters) {
   const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  const int ftx = (w + FT - 1) / FT;
   uint32_t nwet = 0;
   for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
     const T f = F[c], e = z[c];
     const bool wet = f > e && f < wall_value<T>();
-    uint8_t o = 0;
+    uint8_t o = 1;
     if (wet) {
       nwet++;
+      o = 0;
       const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);   // (a wet cell is never on the raster's border)
 #pragma unroll
       for (int k = 1; k <= 8; k++) o |= z[(size_t)(y + ndy(k)) * w + (x + ndx(k))] == f ? 1 : 0;
+      const int tx0 = (x - 1) / FT, tx1 = (x + 1) / FT, ty0 = (y - 1) / FT, ty1 = (y + 1) / FT;
+      for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) active[(size_t)ty * ftx + tx] = 1;
     }
     outlet[c] = o;
     F[c] = wet ? e : wall_value<T>();
   }
   for (int o = 32; o > 0; o >>= 1) nwet += __shfl_down(nwet, o, 64);
   if ((threadIdx.x & 63) == 0 && nwet) atomicAdd(&counters[(blockIdx.x & 63) * 2 + 1], (unsigned long long)nwet);
+}
+
+// skip state of the fill's tiles for the coming level: 0 = has work, 1 = nothing but walls for the first time (its labels
+// are written once more), 2 = the same as before.  A tile never gets work again: the wet set only shrinks.
+__global__ __launch_bounds__(NT) void k_skip_state(uint8_t *skip, uint8_t *active, uint32_t ntiles) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t >= ntiles) return;
+  skip[t] = active[t] ? 0 : (skip[t] ? 2 : 1);
+  active[t] = 0;
 }
 
 __global__ __launch_bounds__(128) void k_sum_counters(unsigned long long *counters, unsigned long long *out) {
@@ -186,7 +203,9 @@ struct Calls;
   template <>                                                                                                        \
   struct Calls<T> {                                                                                                  \
     static int fill(T *d, int w, int h, void *s) { return rdgpu_fill_dev_##SUF(d, w, h, 8, s); }                     \
-    static int fill_outlets(T *d, const uint8_t *o, int w, int h, void *s) { return rdgpu_fill_outlets_dev_##SUF(d, o, w, h, s); } \
+    static int fill_outlets(T *d, const uint8_t *o, const uint8_t *k, int w, int h, void *s) {                      \
+      return rdgpu_fill_outlets_skip_dev_##SUF(d, o, k, w, h, s);                                                    \
+    }                                                                                                                \
   };
 RD_CALLS(u8, uint8_t) RD_CALLS(i8, int8_t) RD_CALLS(i16, int16_t) RD_CALLS(u16, uint16_t) RD_CALLS(i32, int32_t)
 RD_CALLS(u32, uint32_t) RD_CALLS(f32, float)
@@ -225,13 +244,20 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   if (w > 2 && h > 2) {
     T *F = ws.buf<T>("pfd.level", n);
     uint8_t *outlet = ws.buf<uint8_t>("pfd.outlet", n);
+    const uint32_t ftiles = (uint32_t)(((w + FT - 1) / FT) * ((h + FT - 1) / FT));
+    uint8_t *skip = ws.buf<uint8_t>("pfd.skip", ftiles), *active = ws.buf<uint8_t>("pfd.active", ftiles);
+    RD_HIP(hipMemsetAsync(skip, 0, ftiles, s));
+    RD_HIP(hipMemsetAsync(active, 0, ftiles, s));
+    const char *sparse_env = getenv("RDGPU_PFD_SPARSE");   // =0: every level over the whole raster (A/B and tests)
+    const bool sparse = !(sparse_env && sparse_env[0] == '0');
     RD_HIP(hipMemcpyAsync(F, d_z, n * sizeof(T), hipMemcpyDeviceToDevice, s));
     check_rc(Calls<T>::fill(F, w, h, (void *)s));
     unsigned long long host[2] = {0, 0}, last_open = ~0ull, last_wet = ~0ull;
     for (;;) {
       g_stats.levels++;
       RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2);
-      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, F, outlet, w, h, counters);
+      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters);
+      RD_LAUNCH("pfd.skip_state", k_skip_state, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, skip, active, ftiles);
       RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
       RD_HIP(hipMemcpyAsync(host, sums, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
@@ -239,7 +265,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
       last_open = host[0];
       last_wet = host[1];
-      check_rc(Calls<T>::fill_outlets(F, outlet, w, h, (void *)s));
+      check_rc(Calls<T>::fill_outlets(F, outlet, sparse ? skip : nullptr, w, h, (void *)s));
     }
   }
   RD_LAUNCH("pfd.finish", (k_finish<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, (const uint8_t *)cand, d_dirs, w, h, sums + 2);

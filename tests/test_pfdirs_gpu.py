@@ -101,6 +101,21 @@ def test_ties_are_counted_not_hidden(rd, orc):
     assert got[0, 1] == 3 and got[-1, 1] == 7 and got[1, 0] == 1 and got[1, -1] == 5 and got[0, 0] == 2
 
 
+def test_sparse_levels_give_the_same_directions(rd, orc, monkeypatch):
+    """From the second level on the fills skip the 64 x 64 tiles that hold nothing but walls (RDGPU_PFD_SPARSE=0: every level
+    over the whole raster): same directions, with and without equal elevations."""
+    rng = np.random.default_rng(21)
+    tie_free = _distinct(fractal_dem(1400, 1100, seed=77), rng)
+    with_ties = np.floor(fractal_dem(1400, 1100, seed=78) * np.float32(2.0)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a1, b1 = rd.pf_flowdirs(tie_free, nodata=np.float32(-9999)), rd.pf_flowdirs(with_ties, nodata=np.float32(-9999))
+        monkeypatch.setenv("RDGPU_PFD_SPARSE", "0")
+        a0, b0 = rd.pf_flowdirs(tie_free, nodata=np.float32(-9999)), rd.pf_flowdirs(with_ties, nodata=np.float32(-9999))
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+    assert np.array_equal(a1, orc.port.pf_flowdirs(tie_free, np.float32(-9999)))
+
+
 def test_border_only_rasters_and_errors(rd, orc):
     for shape in [(1, 1), (1, 5), (2, 2), (2, 9)]:
         dem = np.arange(shape[0] * shape[1], dtype=np.float32).reshape(shape)
