@@ -47,15 +47,22 @@ static inline uint32_t sgrid(uint64_t n) { return (uint32_t)std::min<uint64_t>((
 
 // One level of the comparison.  F holds this level's fill.  A cell with more than one candidate keeps those of the lowest
 // level; one of them whose own elevation IS that level ends the comparison.  counters[0]: cells still undecided.
+constexpr int FT = 64;   // the fill's descent tiles (fill.hip: DW = DH = 64); the kernels here walk the raster tile by tile
 template <class T>
 __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T *__restrict__ F, uint8_t *cand, int w, int h,
-                                               unsigned long long *counters, unsigned long long *ambiguous) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+                                               unsigned long long *counters, unsigned long long *ambiguous,
+                                               const uint8_t *__restrict__ skip) {
+  // (a tile of walls, ring included, holds no undecided cell: an undecided cell's candidates were wet a level ago)
+  if (skip[blockIdx.x]) return;
+  const int ftx = (w + FT - 1) / FT;
+  const int x = (int)(blockIdx.x % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(blockIdx.x / (uint32_t)ftx) * FT;
   uint32_t open = 0, amb = 0;
-  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+  for (int ly = (int)(threadIdx.x >> 6); ly < FT; ly += NT / 64) {
+    const int y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    const size_t c = (size_t)y * w + x;
     const uint32_t m = cand[c];
     if ((m & (m - 1u)) == 0u) continue;   // decided (or a border cell: 0)
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
     T fv[8], zv[8];
 #pragma unroll
     for (int k = 1; k <= 8; k++) {   // (an interior cell: all eight neighbours exist)
@@ -89,21 +96,23 @@ __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T 
 // else becomes a wall; outlet = wet cell next to THE cell whose elevation is its level -- and every wall (a wall as an
 // outlet changes no level: a path over it costs the wall's height; it spares the fill the walls' basins).
 // counters[1]: wet cells.  active[]: per 64 x 64 tile of the fill, "a wet cell in the tile or next to it".
-constexpr int FT = 64;   // the fill's descent tiles (fill.hip: DW = DH = 64)
 template <class T>
 __global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, uint8_t *active, int w,
-                                                   int h, unsigned long long *counters) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+                                                   int h, unsigned long long *counters, const uint8_t *__restrict__ skip) {
+  if (skip[blockIdx.x]) return;   // walls and outlets already, and for good
   const int ftx = (w + FT - 1) / FT;
+  const int x = (int)(blockIdx.x % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(blockIdx.x / (uint32_t)ftx) * FT;
   uint32_t nwet = 0;
-  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+  for (int ly = (int)(threadIdx.x >> 6); ly < FT; ly += NT / 64) {
+    const int y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    const size_t c = (size_t)y * w + x;
     const T f = F[c], e = z[c];
     const bool wet = f > e && f < wall_value<T>();
     uint8_t o = 1;
-    if (wet) {
+    if (wet) {   // (a wet cell is never on the raster's border)
       nwet++;
       o = 0;
-      const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);   // (a wet cell is never on the raster's border)
 #pragma unroll
       for (int k = 1; k <= 8; k++) o |= z[(size_t)(y + ndy(k)) * w + (x + ndx(k))] == f ? 1 : 0;
       const int tx0 = (x - 1) / FT, tx1 = (x + 1) / FT, ty0 = (y - 1) / FT, ty1 = (y + 1) / FT;
@@ -255,8 +264,10 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     unsigned long long host[2] = {0, 0}, last_open = ~0ull, last_wet = ~0ull;
     for (;;) {
       g_stats.levels++;
-      RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2);
-      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters);
+      RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(ftiles), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2,
+                (const uint8_t *)skip);
+      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(ftiles), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters,
+                (const uint8_t *)skip);
       RD_LAUNCH("pfd.skip_state", k_skip_state, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, skip, active, ftiles);
       RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
       RD_HIP(hipMemcpyAsync(host, sums, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
