@@ -2275,24 +2275,24 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
       ein = eout;
     }
     RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
-    for (;;) {
-      RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
-      RD_LAUNCH("fill.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 32, dflags);
-      RD_HIP(hipMemcpyAsync(hw, dflags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      if (hw[0] == 0) break;
-    }
+    // One pass: a thread follows its chain of hooks for up to 16384 steps (the chains of a round are a handful of hooks
+    // long; the classic path's 32 steps per pass and a host read-back after every pass cost nine round trips per fill).
+    // "A chain was left unfinished" is read back with the round's counts below and sends the raster to the classic path,
+    // whose loop repeats the pass: nothing has been written to the DEM yet.
+    RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
+    RD_LAUNCH("fill.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 1 << 14, dflags);
     RD_LAUNCH("fill.update_basins", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
     RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
     RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
               dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, dflags, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
-    const uint32_t next = hw[0];
+    if (hw[0] != 0) return false;
+    const uint32_t next = hw[2];
     if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
-    if (first && hw[3] != 0) return false;   // the pair list overflowed: the DEM is untouched, the classic path takes over
+    if (first && hw[5] != 0) return false;   // the pair list overflowed: the DEM is untouched, the classic path takes over
     nroots = next;
-    nedges = hw[2];
+    nedges = hw[4];
     if (first) {
       g_stats.edge_records = nedges;
       pcap[1] = std::max<size_t>(nedges, 1);
