@@ -174,7 +174,11 @@ int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);
   int rdgpu_fill_outlets_dev_##SUF(T *d_dem, const uint8_t *d_outlet, int width, int height, void *hip_stream); \
   /* ... d_skip (per 64 x 64 tile, optional): 1 / 2 = nothing but outlets in the tile and around it (1: first time) */ \
   int rdgpu_fill_outlets_skip_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip, int width, int height, \
-                                        void *hip_stream);
+                                        void *hip_stream);                                                    \
+  /* ... d_lists: [tiles in state 0 or 1 | their 64 x 32 pair-pass tiles (state 0) | tiles in state 0], `stride` entries each, \
+     counts3 (host): their lengths -- the raster kernels are launched over the lists only */                  \
+  int rdgpu_fill_outlets_lists_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip, const uint32_t *d_lists, \
+                                         uint32_t stride, const uint32_t *counts3, int width, int height, void *hip_stream);
 RDGPU_DECL_PFD(u8, uint8_t)
 RDGPU_DECL_PFD(i8, int8_t)
 RDGPU_DECL_PFD(i16, int16_t)

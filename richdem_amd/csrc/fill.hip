@@ -1876,7 +1876,9 @@ struct FusedBuf {
 template <class T, int TOPO, bool VEC, bool OUTLETS = false>
 __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
                                                     uint32_t tilesX, uint32_t ntiles, const uint8_t *__restrict__ outlet = nullptr,
-                                                    const uint8_t *__restrict__ skip = nullptr) {
+                                                    const uint8_t *__restrict__ skip = nullptr,
+                                                    const uint32_t *__restrict__ tlist = nullptr) {
+  // tlist (optional, with OUTLETS): the tiles to work on, one block each (ntiles = the raster's tiles all the same)
   __shared__ uint32_t sk[DLH * DLW];
   // rows of LPD = 66 entries: with 64 two-byte entries every row starts on the same LDS bank and the jumps' gathers --
   // neighbouring columns of different rows -- collide (29 % of the kernel's LDS cycles, r03e)
@@ -1884,7 +1886,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   __shared__ uint16_t lp[DH * LPD];
   __shared__ uint32_t wtot[NTHR / 64];
   __shared__ uint32_t pbase, rbase, nroots_s;
-  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  const uint32_t t = (OUTLETS && tlist) ? tlist[blockIdx.x] : xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
   if (OUTLETS && skip && skip[t]) {
@@ -2110,9 +2112,10 @@ template <class T, bool VEC>
 __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__restrict__ lab16, const uint32_t *__restrict__ lvl,
                                                      const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_count,
                                                      int w, int h, uint32_t tilesX, uint32_t ntiles,
-                                                     const uint8_t *__restrict__ skip = nullptr) {
+                                                     const uint8_t *__restrict__ skip = nullptr,
+                                                     const uint32_t *__restrict__ tlist = nullptr) {
   __shared__ uint32_t sl[DH * DW];
-  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  const uint32_t t = tlist ? tlist[blockIdx.x] : xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   if (skip && skip[t]) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
@@ -2164,8 +2167,15 @@ __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__res
 
 // The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
 // provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
+// lists (optional, with skip): device arrays [descent tiles to visit | scan tiles to visit | tiles to finalize], each of
+// `stride` entries, and their lengths on the host
+struct SparseLists {
+  const uint32_t *d = nullptr;
+  uint32_t stride = 0, n[3] = {0, 0, 0};
+};
 template <class T, int TOPO>
-static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr, const uint8_t *skip = nullptr) {
+static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr, const uint8_t *skip = nullptr,
+                       const SparseLists *lists = nullptr) {
   const char *fe = getenv("RDGPU_FILL_FUSED");   // =0: the classic four-pass fill (A/B and tests)
   if (fe && fe[0] == '0') return false;
   const char *env_edges = getenv("RDGPU_FILL_EDGES");
@@ -2196,18 +2206,22 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
     RD_HIP(hipMemcpyAsync(dflags + 9, &one, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     RD_HIP(hipMemcpyAsync(fo.G, &outp, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   }
+  const bool listed = outlet && skip && lists && lists->d;
+  const uint32_t *dl = listed ? lists->d : nullptr, *sl_ = listed ? lists->d + lists->stride : nullptr,
+                 *fl = listed ? lists->d + 2 * (size_t)lists->stride : nullptr;
+  if (listed && lists->n[0] == 0) return true;   // nothing but walls anywhere: nothing to raise
   if (outlet && vec)
-    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              outlet, skip);
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, true>), dim3(listed ? lists->n[0] : xcd_grid(dnt)), dim3(NTHR), 0, s,
+              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl);
   else if (outlet)
-    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              outlet, skip);
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, true>), dim3(listed ? lists->n[0] : xcd_grid(dnt)), dim3(NTHR), 0, s,
+              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl);
   else if (vec)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr, (const uint8_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   else
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr, (const uint8_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   if (hw[1] != 0) return false;   // more nodes than the table holds: nothing was written to the DEM
@@ -2247,14 +2261,17 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
     if (first) {   // round 1: the one raster pass (components gathered from the node table)
-      if (vec)
-        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
+      const uint32_t nwork = listed ? lists->n[1] : ntiles;
+      if (nwork == 0) {
+        // (no tile holds a wet cell although basins exist: cannot happen -- a pit is a wet cell; kept safe)
+      } else if (vec)
+        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(nwork)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
-                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
+                  sl_, nwork, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
       else
-        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, false, true, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z,
+        RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, false, true, true>), dim3(xcd_grid(nwork)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
-                  (const uint32_t *)nullptr, ntiles, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
+                  sl_, nwork, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
       RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, dflags + 4);
       g_stats.scan_tiles += ntiles;
     } else {
@@ -2305,12 +2322,15 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *lvl = fo.G;   // (the node table is dead: its storage holds the nodes' levels)
   RD_LAUNCH("fill.node_levels", k_node_levels, dim3(cdiv(NN, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc, NN,
             lvl);
+  if (listed && lists->n[2] == 0) return true;
   if (vec)
-    RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
-              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt, skip);
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(listed ? lists->n[2] : xcd_grid(dnt)), dim3(NTHR), 0, s, d_z,
+              (const uint16_t *)fo.lab16, (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx,
+              dnt, skip, fl);
   else
-    RD_LAUNCH("fill.finalize", (k_finalize16<T, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fo.lab16,
-              (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx, dnt, skip);
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, false>), dim3(listed ? lists->n[2] : xcd_grid(dnt)), dim3(NTHR), 0, s, d_z,
+              (const uint16_t *)fo.lab16, (const uint32_t *)lvl, (const uint32_t *)fo.tile_base, (const uint32_t *)fo.tile_count, w, h, dtx,
+              dnt, skip, fl);
   return true;
 }
 
@@ -2327,11 +2347,12 @@ static void fill_device(T *d_z, int w, int h, int topology, hipStream_t s) {
 
 // The D8 fill with interior outlets (cells flagged in d_outlet drain like border cells).
 template <class T>
-static void fill_outlets_device(T *d_z, const uint8_t *d_outlet, const uint8_t *d_skip, int w, int h, hipStream_t s) {
+static void fill_outlets_device(T *d_z, const uint8_t *d_outlet, const uint8_t *d_skip, int w, int h, hipStream_t s,
+                                const SparseLists *lists = nullptr) {
   check_fill_args(d_z, w, h, 8);
   if (!d_outlet) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_outlets: null outlet mask");
   if (w <= 2 || h <= 2) return;   // every cell is a border cell
-  if (fill_fused<T, 8>(d_z, w, h, s, d_outlet, d_skip)) return;
+  if (fill_fused<T, 8>(d_z, w, h, s, d_outlet, d_skip, lists)) return;
   FillBuffers fb;   // (the compact labels ran out of table space, or are switched off: the classic path)
   BufAlloc ws_alloc{false, nullptr};
   fill_local_phase<T, 8>(d_z, w, h, 0, 0, ws_alloc, fb, s, d_outlet);
@@ -2690,6 +2711,16 @@ using namespace rdgpu;
   extern "C" int rdgpu_fill_outlets_skip_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip, int w, int h, \
                                                    void *stream) {                                 \
     return rdgpu::guarded([&] { rdgpu::fill_outlets_device<T>(d_dem, d_outlet, d_skip, w, h, (hipStream_t)stream); }); \
+  }                                                                                                \
+  extern "C" int rdgpu_fill_outlets_lists_dev_##SUF(T *d_dem, const uint8_t *d_outlet, const uint8_t *d_skip,             \
+                                                    const uint32_t *d_lists, uint32_t stride, const uint32_t *counts3, int w, \
+                                                    int h, void *stream) {                         \
+    return rdgpu::guarded([&] {                                                                    \
+      rdgpu::SparseLists l;                                                                        \
+      l.d = d_lists; l.stride = stride;                                                            \
+      for (int k = 0; k < 3; k++) l.n[k] = counts3[k];                                             \
+      rdgpu::fill_outlets_device<T>(d_dem, d_outlet, d_skip, w, h, (hipStream_t)stream, &l);       \
+    });                                                                                            \
   }                                                                                                \
   extern "C" int rdgpu_fill_dev_##SUF(T *d_dem, int w, int h, int topology, void *stream) {       \
     return guarded([&] { fill_device<T>(d_dem, w, h, topology, (hipStream_t)stream); });          \

@@ -24,7 +24,8 @@
 
 #include <limits>
 
-#define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_skip_dev_##SUF(T *, const uint8_t *, const uint8_t *, int, int, void *); \
+#define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_lists_dev_##SUF(T *, const uint8_t *, const uint8_t *, const uint32_t *, uint32_t, \
+                                                                           const uint32_t *, int, int, void *);                          \
                            extern "C" int rdgpu_fill_dev_##SUF(T *, int, int, int, void *);
 RD_OUTLETS(u8, uint8_t) RD_OUTLETS(i8, int8_t) RD_OUTLETS(i16, int16_t) RD_OUTLETS(u16, uint16_t) RD_OUTLETS(i32, int32_t)
 RD_OUTLETS(u32, uint32_t) RD_OUTLETS(f32, float)
@@ -51,11 +52,12 @@ constexpr int FT = 64;   // the fill's descent tiles (fill.hip: DW = DH = 64); t
 template <class T>
 __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T *__restrict__ F, uint8_t *cand, int w, int h,
                                                unsigned long long *counters, unsigned long long *ambiguous,
-                                               const uint8_t *__restrict__ skip) {
-  // (a tile of walls, ring included, holds no undecided cell: an undecided cell's candidates were wet a level ago)
-  if (skip[blockIdx.x]) return;
+                                               const uint32_t *__restrict__ tiles) {
+  // one block per tile of the list: the tiles that held a wet cell, ring included, a level ago (a tile of walls holds no
+  // undecided cell: an undecided cell's candidates were wet then)
+  const uint32_t t = tiles[blockIdx.x];
   const int ftx = (w + FT - 1) / FT;
-  const int x = (int)(blockIdx.x % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(blockIdx.x / (uint32_t)ftx) * FT;
+  const int x = (int)(t % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(t / (uint32_t)ftx) * FT;
   uint32_t open = 0, amb = 0;
   for (int ly = (int)(threadIdx.x >> 6); ly < FT; ly += NT / 64) {
     const int y = y0 + ly;
@@ -98,10 +100,11 @@ __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T 
 // counters[1]: wet cells.  active[]: per 64 x 64 tile of the fill, "a wet cell in the tile or next to it".
 template <class T>
 __global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, uint8_t *active, int w,
-                                                   int h, unsigned long long *counters, const uint8_t *__restrict__ skip) {
-  if (skip[blockIdx.x]) return;   // walls and outlets already, and for good
+                                                   int h, unsigned long long *counters, const uint32_t *__restrict__ tiles) {
+  // (the same list: everywhere else the raster is walls and outlets already, and for good)
+  const uint32_t t = tiles[blockIdx.x];
   const int ftx = (w + FT - 1) / FT;
-  const int x = (int)(blockIdx.x % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(blockIdx.x / (uint32_t)ftx) * FT;
+  const int x = (int)(t % (uint32_t)ftx) * FT + (int)(threadIdx.x & 63), y0 = (int)(t / (uint32_t)ftx) * FT;
   uint32_t nwet = 0;
   for (int ly = (int)(threadIdx.x >> 6); ly < FT; ly += NT / 64) {
     const int y = y0 + ly;
@@ -127,12 +130,38 @@ __global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F
 }
 
 // skip state of the fill's tiles for the coming level: 0 = has work, 1 = nothing but walls for the first time (its labels
-// are written once more), 2 = the same as before.  A tile never gets work again: the wet set only shrinks.
-__global__ __launch_bounds__(NT) void k_skip_state(uint8_t *skip, uint8_t *active, uint32_t ntiles) {
+// are written once more), 2 = the same as before.  A tile never gets work again: the wet set only shrinks.  And the
+// lists the sparse kernels are launched over: tiles in state 0 or 1 (the fill's descent pass), the 64 x 32 tiles of the
+// tiles in state 0 (its pair pass), the tiles in state 0 (its last pass; the two kernels here).  counts: their lengths.
+__global__ __launch_bounds__(NT) void k_skip_state(uint8_t *skip, uint8_t *active, uint32_t ntiles, uint32_t ftx, uint32_t scan_rows,
+                                                   uint32_t *lists, uint32_t stride, uint32_t *counts) {
+  __shared__ uint32_t base[3], cnt[3];
+  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  __syncthreads();
   const uint32_t t = blockIdx.x * NT + threadIdx.x;
-  if (t >= ntiles) return;
-  skip[t] = active[t] ? 0 : (skip[t] ? 2 : 1);
-  active[t] = 0;
+  uint32_t st = 2, pos[3] = {0, 0, 0};
+  if (t < ntiles) {
+    st = active[t] ? 0 : (skip[t] ? 2 : 1);
+    skip[t] = (uint8_t)st;
+    active[t] = 0;
+  }
+  const uint32_t ty = t / ftx, tx = t - ty * ftx;
+  const uint32_t nscan = st == 0 ? (2 * ty + 1 < scan_rows ? 2u : 1u) : 0u;
+  if (st <= 1) pos[0] = atomicAdd(&cnt[0], 1u);
+  if (nscan) pos[1] = atomicAdd(&cnt[1], nscan);
+  if (st == 0) pos[2] = atomicAdd(&cnt[2], 1u);
+  __syncthreads();
+  if (threadIdx.x < 3) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (st <= 1) lists[base[0] + pos[0]] = t;
+  for (uint32_t k = 0; k < nscan; k++) lists[stride + base[1] + pos[1] + k] = (2 * ty + k) * ftx + tx;
+  if (st == 0) lists[2 * (size_t)stride + base[2] + pos[2]] = t;
+}
+
+// every tile, for the first level
+__global__ __launch_bounds__(NT) void k_all_tiles(uint32_t *list, uint32_t ntiles) {
+  const uint32_t t = blockIdx.x * NT + threadIdx.x;
+  if (t < ntiles) list[t] = t;
 }
 
 __global__ __launch_bounds__(128) void k_sum_counters(unsigned long long *counters, unsigned long long *out) {
@@ -212,8 +241,9 @@ struct Calls;
   template <>                                                                                                        \
   struct Calls<T> {                                                                                                  \
     static int fill(T *d, int w, int h, void *s) { return rdgpu_fill_dev_##SUF(d, w, h, 8, s); }                     \
-    static int fill_outlets(T *d, const uint8_t *o, const uint8_t *k, int w, int h, void *s) {                      \
-      return rdgpu_fill_outlets_skip_dev_##SUF(d, o, k, w, h, s);                                                    \
+    static int fill_outlets(T *d, const uint8_t *o, const uint8_t *k, const uint32_t *l, uint32_t st, const uint32_t *c3, int w,  \
+                            int h, void *s) {                                                                        \
+      return rdgpu_fill_outlets_lists_dev_##SUF(d, o, k, l, st, c3, w, h, s);                                        \
     }                                                                                                                \
   };
 RD_CALLS(u8, uint8_t) RD_CALLS(i8, int8_t) RD_CALLS(i16, int16_t) RD_CALLS(u16, uint16_t) RD_CALLS(i32, int32_t)
@@ -257,26 +287,39 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     uint8_t *skip = ws.buf<uint8_t>("pfd.skip", ftiles), *active = ws.buf<uint8_t>("pfd.active", ftiles);
     RD_HIP(hipMemsetAsync(skip, 0, ftiles, s));
     RD_HIP(hipMemsetAsync(active, 0, ftiles, s));
-    const char *sparse_env = getenv("RDGPU_PFD_SPARSE");   // =0: every level over the whole raster (A/B and tests)
+    const char *sparse_env = getenv("RDGPU_PFD_SPARSE");   // =0: every level's fill over the whole raster (A/B and tests)
     const bool sparse = !(sparse_env && sparse_env[0] == '0');
+    const uint32_t ftx = (uint32_t)((w + FT - 1) / FT), scan_rows = (uint32_t)((h + 31) / 32), stride = 2 * ftiles;
+    uint32_t *lists = ws.buf<uint32_t>("pfd.lists", 3 * (size_t)stride);
+    uint32_t *lcounts = ws.buf<uint32_t>("pfd.lcounts", 4);
+    uint32_t *cur_tiles = lists + 2 * (size_t)stride;   // the tiles the two kernels here walk: all of them at first
+    uint32_t ncur = ftiles;
+    RD_LAUNCH("pfd.all_tiles", k_all_tiles, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, cur_tiles, ftiles);
     RD_HIP(hipMemcpyAsync(F, d_z, n * sizeof(T), hipMemcpyDeviceToDevice, s));
     check_rc(Calls<T>::fill(F, w, h, (void *)s));
     unsigned long long host[2] = {0, 0}, last_open = ~0ull, last_wet = ~0ull;
+    uint32_t hcounts[3] = {0, 0, 0};
     for (;;) {
       g_stats.levels++;
-      RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(ftiles), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2,
-                (const uint8_t *)skip);
-      RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(ftiles), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters,
-                (const uint8_t *)skip);
-      RD_LAUNCH("pfd.skip_state", k_skip_state, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, skip, active, ftiles);
+      if (ncur) {
+        RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(ncur), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2,
+                  (const uint32_t *)cur_tiles);
+        RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(ncur), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters,
+                  (const uint32_t *)cur_tiles);
+      }
+      RD_HIP(hipMemsetAsync(lcounts, 0, 4 * sizeof(uint32_t), s));
+      RD_LAUNCH("pfd.skip_state", k_skip_state, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, skip, active, ftiles, ftx, scan_rows, lists,
+                stride, lcounts);
       RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
       RD_HIP(hipMemcpyAsync(host, sums, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipMemcpyAsync(hcounts, lcounts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
+      ncur = hcounts[2];
       if (host[0] == 0 || host[1] == 0) break;                       // every cell decided / nothing wet any more
       if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
       last_open = host[0];
       last_wet = host[1];
-      check_rc(Calls<T>::fill_outlets(F, outlet, sparse ? skip : nullptr, w, h, (void *)s));
+      check_rc(Calls<T>::fill_outlets(F, outlet, skip, sparse ? lists : nullptr, stride, hcounts, w, h, (void *)s));
     }
   }
   RD_LAUNCH("pfd.finish", (k_finish<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, (const uint8_t *)cand, d_dirs, w, h, sums + 2);
