@@ -99,7 +99,7 @@ def stage_entry(seconds: float, cells: int, bytes_per_cell: int, n_gpus: int = 1
             "alg_GBps": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_GBS * n_gpus), 4)}
 
 
-def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None) -> dict:
+def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: bool = True) -> dict:
     """The path after the fill on one GPU, HBM-resident, through the C-ABI `_dev_` entry points.  W = the filled DEM,
     Z = the unfilled one (for PriorityFloodEpsilon, the other fill of depressions.hpp)."""
     n_cells = W.numel()
@@ -147,6 +147,8 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None) -> dict:
         es = rd.epsilon_stats()
         out["priority_flood_epsilon"].update({"input": "the unfilled bench DEM (PriorityFloodEpsilon_Original semantics)",
                                               **{k: es[k] for k in ("rounds", "tie_sources") if k in es}})
+        if not pf_flowdirs:
+            return out
         # PriorityFloodFlowdirs_Barnes2014: one fill per nesting level of the depressions (seconds, not milliseconds: once)
         del E
         pdirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
@@ -183,6 +185,8 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--no-stages", action="store_true", help="skip the directions / flat resolution / accumulation stages")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer end-to-end measurement")
+    ap.add_argument("--no-pf-flowdirs", action="store_true",
+                    help="skip the PriorityFloodFlowdirs stage (324 more fills: the profiling passes' per-launch averages are the headline fill's)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE line, the JSON of rank 0.  Libraries print there too (RCCL: "Librccl path : ...",
@@ -294,7 +298,7 @@ def main():
     }
     if not args.no_stages:
         out["stages"] = {"fill": stage_entry(dt / args.steps, cells, 8)}
-        out["stages"].update(run_stages(rd, torch, W, -9999.0, Z=Z))
+        out["stages"].update(run_stages(rd, torch, W, -9999.0, Z=Z, pf_flowdirs=not args.no_pf_flowdirs))
     if not args.no_host:
         del W
         bufs.clear()

@@ -62,7 +62,8 @@ def main():
     steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1"]
     # the profiling passes run the fill only, or (--path) the fill and the stages after it; never the host path
-    prof_tail = ["--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-host"] + ([] if "--path" in sys.argv else ["--no-stages"])
+    prof_tail = (["--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-host", "--no-pf-flowdirs"]
+                 + ([] if "--path" in sys.argv else ["--no-stages"]))
     what = "path40k" if "--path" in sys.argv else "fill40k"
     os.makedirs(OUT, exist_ok=True)
     log = os.path.join(OUT, f"{tag}_bench.log")
@@ -153,5 +154,13 @@ def main():
     print(line.strip())
 
 
+def _drop_raw(tag):
+    """the raw rocprofv3 output (hundreds of MB with the stages' thousands of launches) stays on the box: gpurun merges at
+    most 64 MiB back, and the summaries above are what profiles/ keeps"""
+    for sub in ("stats", "fetch", "write", "sq"):
+        shutil.rmtree(os.path.join(OUT, f"{tag}_{sub}"), ignore_errors=True)
+
+
 if __name__ == "__main__":
     main()
+    _drop_raw(sys.argv[1])
