@@ -16,9 +16,12 @@
 // set of candidate neighbours: those with the lowest F_0, among them those with the lowest F_1, ...; a candidate whose
 // sequence has ended (its elevation IS the level) is the phase cell itself and wins.
 // The number of levels is the longest run of successive descents of the flood inside a depression (35 on a 200 x 200
-// fractal DEM, more on larger ones): this entry point is provided for completeness, not tuned -- every level is a
-// whole-raster fill.  With equal elevations the reference's order depends on its insertion counters; cells whose
-// candidates cannot be separated are counted (rdgpu_pf_flowdirs_get_stats) and given their lowest-numbered candidate.
+// fractal DEM, 324 at 40000 x 40000), and the wet set shrinks by ~8 % a level: from the second level on walls are outlets
+// too, the fill's 64 x 64 tiles that hold nothing but walls (ring included) are skipped for good, and every kernel is
+// launched over compacted lists of the tiles that still have work (k_skip_state).  40000 x 40000: 1.5 s.
+// With equal elevations the reference's order depends on its insertion counters: `twins` counts the cells whose elevation
+// occurs more than once (0 => the result is the reference's), `unresolved` the directions that were decided by neighbour
+// number among equal candidates (rdgpu_pf_flowdirs_get_stats).
 // tests/tools/proto_pf_flowdirs.py is the same algorithm in numpy, checked against the oracle.
 #include "common.hpp"
 
