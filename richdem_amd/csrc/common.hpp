@@ -64,10 +64,19 @@ int guarded(F &&fn) {
   }
 }
 
-// The same mapping of exceptions to return codes WITHOUT a lock: for entry points that only orchestrate per-device
-// workers, each of which takes its own device's lock (rdgpu_*_multi_*).
+// The same mapping of exceptions to return codes WITHOUT a device lock: for entry points that only orchestrate
+// per-device workers, each of which takes its own device's lock for its phase (rdgpu_*_multi_*).  The blocks of such a
+// call are staged in workspace buffers named by shard index and the device locks are released between the phases, so two
+// orchestrators at once would overwrite each other's blocks: ONE of them runs at a time (r04).  No caller of
+// these entries holds a device lock (the plain entries route here BEFORE they lock), so the order orchestrator -> device
+// cannot deadlock.
+inline std::mutex &orchestrator_mutex() {
+  static std::mutex m;
+  return m;
+}
 template <class F>
 int unlocked(F &&fn) {
+  std::lock_guard<std::mutex> one_orchestrator(orchestrator_mutex());
   try {
     fn();
     return RDGPU_OK;

@@ -246,6 +246,39 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
         raise
 
 
+def fill_depressions_blocks(dem, world: int, topology="D8") -> None:
+    """The fill protocol with every row block driven by this one process on one GPU, block after block (tests, tools;
+    BASELINE configs[3] on a single device): local phase of every block, the payloads stacked as the all-gather would,
+    ONE graph solve on the GPU, finish of every block -- `dem` (HBM-resident, 32-bit element type) is filled in place."""
+    import torch
+
+    topo = _TOPO.get(topology)
+    if topo is None:
+        raise RdgpuError("Unknown topology!")
+    h, w = dem.shape
+    blocks = [dem[a:b] for a, b in row_split(h, world)]
+    engs, keys, edges = [], [], []
+    try:
+        for s, blk in enumerate(blocks):
+            e = GpuShardEngine()
+            engs.append(e)
+            k, ed = e.begin_dev(blk, s > 0, s + 1 < world, topo)
+            keys.append(k)
+            edges.append(ed)
+        cap = max(int(ed.shape[0]) for ed in edges)
+        edges_all = torch.zeros((world, cap, 3), dtype=torch.int32, device=dem.device)
+        for s, ed in enumerate(edges):
+            edges_all[s, : ed.shape[0]] = ed
+        counts = torch.tensor([int(ed.shape[0]) for ed in edges], dtype=torch.int32, device=dem.device)
+        levels = graph_solve_dev(torch.stack(keys), edges_all, counts, topo)
+        for s, e in enumerate(engs):
+            e.finish_dev(levels[s].contiguous())
+    except BaseException:
+        for e in engs:
+            e.abort()
+        raise
+
+
 # ---------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of the BASELINE DEM over N row blocks
 # ---------------------------------------------------------------------------------------------------
@@ -773,4 +806,59 @@ def d8_flow_accum_sharded(dirs_block, area_block, nodata: int = 255, group=None,
     except BaseException:
         if hasattr(eng, "abort"):
             eng.abort()
+        raise
+
+
+def d8_flow_accum_blocks(dirs, area, world: int, nodata: int = 255) -> int:
+    """d8_flow_accum over `world` row blocks driven by this one process on one GPU (tests, tools; BASELINE configs[4]
+    on a single device): the one-exchange protocol -- begin_local of every block, (outbox, links) stacked as the all-gather
+    would, accum_link_solve, add_paths, finish -- or, when the directions hold a loop, the iterated protocol.  `area`
+    (HBM-resident, the requested output type) receives the accumulation.  Returns the number of exchanges."""
+    import torch
+
+    h, w = dirs.shape
+    spl = row_split(h, world)
+    blocks = [dirs[a:b] for a, b in spl]
+    above = lambda s: blocks[s - 1][-1] if s > 0 else None            # noqa: E731
+    below = lambda s: blocks[s + 1][0] if s + 1 < world else None     # noqa: E731
+    shards = []
+    try:
+        boxes, links, pend = [], [], []
+        for s, blk in enumerate(blocks):
+            sh = GpuAccumShard()
+            shards.append(sh)
+            sh.begin_local(blk, nodata, above(s), below(s))
+            boxes.append(sh.outbox())
+            lk, pn = sh.links()
+            links.append(lk)
+            pend.append(pn)
+        inflow = None
+        if int(torch.cat([p.reshape(-1) for p in pend]).sum().item()) == 0:
+            inflow = accum_link_solve(torch.stack(boxes), torch.stack(links), world, w)
+        if inflow is not None:
+            for s, sh in enumerate(shards):
+                sh.add_paths(inflow[s, 0] if s > 0 else None, inflow[s, 1] if s + 1 < world else None)
+                sh.finish(area[spl[s][0]:spl[s][1]])
+            return 1
+        for sh in shards:
+            sh.abort()
+        shards = []
+        for s, blk in enumerate(blocks):
+            sh = GpuAccumShard()
+            shards.append(sh)
+            sh.begin(blk, nodata, above(s), below(s))
+        rounds = 1
+        while True:
+            outs = [sh.outbox() for sh in shards]
+            rounds += 1
+            if not any(bool((o != 0).any().item()) for o in outs):
+                break
+            for s, sh in enumerate(shards):
+                sh.inject(outs[s - 1][1] if s > 0 else None, outs[s + 1][0] if s + 1 < world else None)
+        for s, sh in enumerate(shards):
+            sh.finish(area[spl[s][0]:spl[s][1]])
+        return rounds
+    except BaseException:
+        for sh in shards:
+            sh.abort()
         raise

@@ -217,11 +217,88 @@ def s3_digests(size=40000, seed=3, out=None, keep=None):
     print("wrote", out, {k: float(v) for k, v in times.items()})
 
 
+S3_SAMPLE_STRIDE = 982451653            # prime, coprime to 40000^2: sample j sits at cell (j * stride) mod (n*n)
+
+
+def s3_sample_positions(n_cells: int, k: int) -> np.ndarray:
+    """k distinct, quasi-uniform cell indices, reproducible in numpy and torch without wrapping arithmetic"""
+    j = np.arange(k, dtype=np.int64)
+    return (j * np.int64(S3_SAMPLE_STRIDE)) % np.int64(n_cells)
+
+
+def _block_digests(a, rows=1000, cols=1000):
+    """one digest per rows x cols block (the digest's position term is the cell's index in the WHOLE raster)"""
+    from digest import _K1, _K2, _K3, _bits_np
+    h, w = a.shape
+    out = np.zeros((-(-h // rows), -(-w // cols)), np.uint64)
+    with np.errstate(over="ignore"):
+        for by, y0 in enumerate(range(0, h, rows)):
+            band = np.ascontiguousarray(a[y0:y0 + rows])
+            v = _bits_np(band)
+            idx = (np.arange(y0, y0 + band.shape[0], dtype=np.int64)[:, None] * np.int64(w)
+                   + np.arange(w, dtype=np.int64)[None, :])
+            x = v * _K1 + idx * _K2
+            x ^= x >> np.int64(32)
+            x *= _K3
+            for bx, x0 in enumerate(range(0, w, cols)):
+                out[by, bx] = np.uint64(x[:, x0:x0 + cols].sum(dtype=np.int64).astype(np.uint64))
+    return out
+
+
+def s3_f2(which, size=40000, seed=3):
+    """SURVEY 8(f2) at FULL size: the compiled reference's PriorityFloodFlowdirs / PriorityFloodEpsilon /
+    PriorityFloodWatersheds / PriorityFlood_Barnes2014_max_dep(100) on the UNFILLED 40000 x 40000 bench DEM, one
+    function per invocation (`--s3-f2 flowdirs|epsilon|watersheds|maxdep`, 10-20 GB and 5-15 minutes of one core
+    each).  Committed per function (tests/golden/ref_s3_f2_<which>.npz): band digests, one digest per 1000 x 1000 block,
+    and the reference's VALUES at a fixed quasi-uniform sample of cells (s3_sample_positions) -- the float32 bench DEM
+    cannot avoid equal elevations, so for the three tie-sensitive outputs the GPU test COUNTS the sampled cells that
+    differ (an estimate of the differing fraction, with the blocks that hold a difference) instead of asserting zero;
+    max_dep is asserted equal."""
+    import time
+    from digest import BAND_ROWS, band_digests_np
+    oracle.build()
+    R = oracle.ref
+    assert R.available
+    n = size
+    z = np.empty((n, n), np.float32)
+    for y0 in range(0, n, 2000):
+        z[y0:y0 + 2000] = fractal_dem(n, min(2000, n - y0), seed, y0=y0)
+    nd = np.float32(-9999.0)
+    k = {"flowdirs": 1 << 22, "epsilon": 1 << 19, "watersheds": 1 << 19, "maxdep": 1 << 16}[which]
+    pos = s3_sample_positions(n * n, k)
+    t0 = time.perf_counter()
+    if which == "flowdirs":
+        out = R.pf_flowdirs(z, nd)
+    elif which == "epsilon":
+        out = R.fill_epsilon(z, nd, 8)
+    elif which == "watersheds":
+        out = R.watersheds(z, nd, 8, False)[0]
+    elif which == "maxdep":
+        out = R.fill_max_dep(z, 100, 8)
+    else:
+        raise SystemExit("unknown output " + which)
+    secs = time.perf_counter() - t0
+    g = {"size": np.int64(n), "seed": np.int64(seed), "band_rows": np.int64(BAND_ROWS), "sample_k": np.int64(k),
+         "sample_stride": np.int64(S3_SAMPLE_STRIDE), "ref_seconds": np.float64(round(secs, 2)),
+         "bands": band_digests_np(out), "blocks": _block_digests(out), "sample": out.ravel()[pos]}
+    if which in ("epsilon", "maxdep"):
+        g["cells_changed"] = np.int64((out != z).sum())
+    if which == "watersheds":
+        g["labels"] = np.int64(out.max())
+    path = os.path.join(HERE, f"ref_s3_f2_{which}.npz" if n == 40000 else f"ref_s3_f2_{which}_{n}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, round(secs, 1), "s", os.path.getsize(path), "bytes", flush=True)
+
+
 if __name__ == "__main__":
     if "--s3-digests" in sys.argv:
         sys.path.insert(0, HERE)
         size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000
         s3_digests(size)
+    elif "--s3-f2" in sys.argv:
+        sys.path.insert(0, HERE)
+        size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000
+        s3_f2(sys.argv[sys.argv.index("--s3-f2") + 1], size)
     elif "--f2" in sys.argv:
         f2()
     else:

@@ -464,3 +464,54 @@ def test_two_host_threads_share_the_library(rd, orc):
         t.join()
     assert not errors, errors[:2]
 
+
+
+def test_two_host_threads_in_the_multi_device_entries(rd, orc):
+    """The multi-device entries stage their row blocks in workspace buffers named by shard index and release the device
+    locks between their phases; two of them at once (two Python threads: ctypes and the pybind module release the GIL)
+    would overwrite each other's blocks.  One orchestrator runs at a time (csrc/common.hpp `unlocked`); with
+    RDGPU_DEVICES=0,0-style lists both threads go through exactly that code on one GPU.  Rasters of different sizes so
+    that a shared staging buffer would be reallocated under the other thread."""
+    import ctypes
+    import threading
+
+    from richdem_amd._lib import check, lib
+    from richdem_amd.synth import fractal_dem
+
+    a = fractal_dem(900, 700, seed=311)
+    b = fractal_dem(410, 1300, seed=312)
+    ea, eb = orc.port.fill(a, 8), orc.port.fill(b, 8)
+    da = orc.port.flat_resolution(ea, np.float32(-9999))
+    aa = orc.port.d8_flow_accum(da, 255, np.float64)
+    errors = []
+
+    def fill_multi(z, devs):
+        out = z.copy()
+        arr = (ctypes.c_int * len(devs))(*devs)
+        h, w = out.shape
+        check(lib().rdgpu_fill_multi_f32(out.ctypes.data_as(ctypes.c_void_p), w, h, 8, arr, len(devs)), "rdgpu_fill_multi_f32")
+        return out
+
+    def worker(kind):
+        try:
+            for _ in range(8):
+                if kind == 0:
+                    assert np.array_equal(fill_multi(a, [0, 0, 0]), ea)
+                elif kind == 1:
+                    assert np.array_equal(fill_multi(b, [0, 0]), eb)
+                else:
+                    h, w = da.shape
+                    area = np.empty((h, w), np.float64)
+                    arr = (ctypes.c_int * 4)(0, 0, 0, 0)
+                    check(lib().rdgpu_d8_flow_accum_multi_f64(da.ctypes.data_as(ctypes.c_void_p), 255, w, h,
+                                                              area.ctypes.data_as(ctypes.c_void_p), arr, 4), "rdgpu_d8_flow_accum_multi_f64")
+                    assert np.array_equal(area, aa)
+        except BaseException as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 2, 0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
