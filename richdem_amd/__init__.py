@@ -56,6 +56,8 @@ from .api import (  # noqa: F401
     synth_dem_dev,
     resolve_flats_epsilon_dev,
     fill_epsilon_dev,
+    fill_max_dep_dev,
+    watersheds_dev,
     epsilon_stats,
     flat_stats,
     release_workspace,

@@ -546,6 +546,28 @@ def fill_epsilon_dev(dem, nodata, topology="D8") -> None:
                                                         _topo(topology), _stream_ptr()), "rdgpu_fill_epsilon_dev")
 
 
+def fill_max_dep_dev(dem, max_dep_size: int, topology="D8") -> None:
+    """In-place PriorityFlood_Barnes2014_max_dep of a contiguous 2-D CUDA tensor, on torch's current stream."""
+    h, w = _dev2d(dem, "fill_max_dep_dev")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_fill_max_dep_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), w, h, _topo(topology),
+                                                        ctypes.c_uint64(int(max_dep_size)), _stream_ptr()), "rdgpu_fill_max_dep_dev")
+
+
+def watersheds_dev(dem, nodata, labels, topology="D8", alter: bool = False) -> None:
+    """PriorityFloodWatersheds_Barnes2014 of a contiguous 2-D CUDA tensor into an int32 CUDA tensor of the same shape
+    (``alter``: the DEM is filled in place), on torch's current stream."""
+    import torch
+
+    h, w = _dev2d(dem, "watersheds_dev")
+    if labels.dtype != torch.int32 or tuple(labels.shape) != (h, w) or not labels.is_contiguous() or not labels.is_cuda:
+        raise RdgpuError("watersheds_dev: labels must be a contiguous int32 CUDA tensor of the DEM's shape")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_watersheds_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h, _topo(topology),
+                                                      1 if alter else 0, ctypes.c_void_p(labels.data_ptr()), _stream_ptr()),
+          "rdgpu_watersheds_dev")
+
+
 class _EpsStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_uint32), ("attempts", ctypes.c_uint32), ("tile_relaxations", ctypes.c_uint64),
                 ("slack", ctypes.c_uint64), ("max_lift", ctypes.c_uint64), ("tie_sources", ctypes.c_uint64)]

@@ -156,6 +156,11 @@ inline void per_device(const int *devices, int ndev, Job job) {
     if (!shards.count(devices[s])) order.push_back(devices[s]);
     shards[devices[s]].push_back(s);
   }
+  if (order.size() == 1) {   // one device (listed once or several times): no worker thread, the caller does the work
+    DeviceGuard g(order[0]);
+    job(order[0], shards[order[0]]);
+    return;
+  }
   std::vector<std::exception_ptr> err(order.size());
   std::vector<std::thread> th;
   for (size_t k = 0; k < order.size(); k++)

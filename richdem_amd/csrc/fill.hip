@@ -507,6 +507,7 @@ struct EdgeOut {
   uint32_t segcap;
   uint32_t segmask;        // nseg - 1 (nseg: a power of two <= ESEG)
   uint32_t *overflow;
+  uint32_t seglimit = 0xFFFFFFFFu;   // k_pairs16: records a segment may take (<= segcap; smaller under RDGPU_FILL_EDGE_CAP)
 };
 
 template <int SLOTS = PT_SLOTS>
@@ -1859,14 +1860,38 @@ static void fill_max_dep_host(T *dem, int w, int h, int topology, uint64_t max_d
 // Anything the scheme cannot hold (more nodes or records than the buffers) raises a flag and the classic path runs.
 // Row-block shards, pit_mask, max_dep and the watershed code keep the classic path (they consume 32-bit labels).
 // ==========================================================================================================
+// Node and pit ids are handed out per tile with ONE returning atomic -- and same-address device atomics serialise at
+// ~12 ns each: 390 625 tiles on one counter are 4.5 ms of the kernel whatever else it does (r04).  So there are up to 32
+// STRIPES (tile t uses stripe t & smask), each with its own counter word on its own 128-byte line, its own region of the
+// node table (rcap nodes) and its own run of pit numbers; k_stripe_offsets turns the pit numbers into dense basin ids
+// afterwards (pitoff[]), which k_resolve_nodes adds when it writes a node's component.
+constexpr int FSTRIPES = 32, FSTRIDE = 16;   // counter words are FSTRIDE * 8 bytes apart
 struct FusedBuf {
   uint16_t *lab16;                 // [cells] slot of the cell's root within its descent tile
-  uint32_t *G;                     // [gcap] node table
+  uint32_t *G;                     // [gcap] node table: stripe s owns [s * rcap, (s + 1) * rcap)
   uint32_t *tile_base, *tile_count;   // [descent tiles]
-  unsigned long long *counters;    // [0] (nodes << 32) | pits
-  uint32_t gcap;
+  unsigned long long *counters;    // [stripe * FSTRIDE] (nodes << 32) | pits of the stripe
+  uint32_t gcap, rcap, smask;
   uint32_t *overflow;
 };
+
+// after the descent: dense basin ids.  out[0] = basins, out[1] = nodes in use, out[2] = the fullest stripe's node count
+__global__ __launch_bounds__(64) void k_stripe_offsets(const unsigned long long *__restrict__ counters, uint32_t nstripes,
+                                                       uint32_t *pitoff, uint32_t *out) {
+  const uint32_t s = threadIdx.x;
+  const unsigned long long c = s < nstripes ? counters[s * FSTRIDE] : 0ull;
+  const uint32_t pits = (uint32_t)c, nodes = (uint32_t)(c >> 32);
+  uint32_t incl = pits, tot = nodes, mx = nodes;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if ((int)s >= o) incl += v;
+    tot += __shfl_xor(tot, o, 64);
+    mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
+  }
+  if (s < nstripes) pitoff[s] = incl - pits;
+  if (s == 63) { out[0] = incl; out[1] = tot; out[2] = mx; }
+}
 
 // OUTLETS: cells flagged in `outlet` drain like the raster's border cells (interior outlets: the restricted fills of
 // pfdirs.hip); the instantiation of the plain fill does not look at the pointer.
@@ -1885,7 +1910,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   constexpr int LPD = DW + 2;
   __shared__ uint16_t lp[DH * LPD];
   __shared__ uint32_t wtot[NTHR / 64];
-  __shared__ uint32_t pbase, rbase, nroots_s;
+  __shared__ uint32_t pbase, rbase, fits_s;
   const uint32_t t = (OUTLETS && tlist) ? tlist[blockIdx.x] : xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * DW, y0 = (int)(t / tilesX) * DH;
@@ -2033,17 +2058,19 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   if (threadIdx.x == 0) {
     const uint32_t nr = (wtot[0] >> 16) + (wtot[1] >> 16) + (wtot[2] >> 16) + (wtot[3] >> 16) + (OUTLETS ? 1u : 0u);
     const uint32_t np = (wtot[0] & 0xFFFFu) + (wtot[1] & 0xFFFFu) + (wtot[2] & 0xFFFFu) + (wtot[3] & 0xFFFFu);
-    const unsigned long long old = atomicAdd(fo.counters, ((unsigned long long)nr << 32) | np);
+    const uint32_t st = t & fo.smask;   // the tile's stripe: its own counter, node region and run of pit numbers
+    const unsigned long long old = atomicAdd(&fo.counters[st * FSTRIDE], ((unsigned long long)nr << 32) | np);
+    const uint32_t rl = (uint32_t)(old >> 32);
     pbase = (uint32_t)old;
-    rbase = (uint32_t)(old >> 32);
-    nroots_s = nr;
+    rbase = st * fo.rcap + rl;
     fo.tile_base[t] = rbase;
     fo.tile_count[t] = nr;
-    if ((unsigned long long)rbase + nr > fo.gcap) *fo.overflow = 1;
+    fits_s = (unsigned long long)rl + nr <= fo.rcap ? 1u : 0u;
+    if (!fits_s) *fo.overflow = 1;
   }
   __syncthreads();
   const uint32_t nodes0 = rbase;
-  const bool gfits = (unsigned long long)nodes0 + nroots_s <= fo.gcap;
+  const bool gfits = fits_s != 0;
   constexpr uint16_t ROOT_TAG = 0xC000u;   // a numbered root's entry: ROOT_TAG | slot (pointers are < 4096, codes >= LTERM_BASE)
   {
     uint32_t pre = incl - mine;
@@ -2079,31 +2106,40 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
 
 // node -> its basin as a component id: curN[n] = basin, or B | CLOSED for the outside.  A pending node names the first
 // cell outside its tile on the path: that cell's node is looked up through lab16 and the tile bases, and so on from
-// tile to tile.  Resolved words are written back into G (any value ever stored there is valid: concurrent chasers and
-// stale reads are harmless), so long chains are shared.
-__global__ __launch_bounds__(NTHR) void k_resolve_nodes(uint32_t *G, uint32_t nnodes, const uint16_t *__restrict__ lab16,
+// tile to tile.  A pit's word is its number WITHIN ITS STRIPE: the basin id is that plus the stripe's offset, the stripe
+// being that of the node the word was found in.  A chain of several hops is shortened for the others: the node's word
+// becomes the last cell of the chain (any value ever stored in G is a valid continuation: concurrent chasers and stale
+// reads are harmless).  grid: (nodes of the fullest stripe, stripes).
+__global__ __launch_bounds__(NTHR) void k_resolve_nodes(uint32_t *G, const unsigned long long *__restrict__ counters,
+                                                        const uint32_t *__restrict__ pitoff, uint32_t rcap,
+                                                        const uint16_t *__restrict__ lab16,
                                                         const uint32_t *__restrict__ tile_base, int w, uint32_t tilesX,
                                                         uint32_t B, uint32_t *curN, uint32_t *flag) {
-  const uint32_t n = blockIdx.x * NTHR + threadIdx.x;
-  if (n >= nnodes) return;
-  uint32_t v = G[n];
+  const uint32_t st = blockIdx.y, i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= (uint32_t)(counters[st * FSTRIDE] >> 32)) return;
+  const uint32_t n = st * rcap + i;
+  uint32_t v = G[n], fn = n, last = 0;
   int hops = 0;
   while ((v & LAB_PEND) && v != OUTP) {
     const uint32_t cell = v & ~LAB_PEND;
     const uint32_t cx = cell % (uint32_t)w, cy = cell / (uint32_t)w;
-    const uint32_t node = tile_base[(cy / DH) * tilesX + cx / DW] + lab16[cell];
-    v = __hip_atomic_load(&G[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fn = tile_base[(cy / DH) * tilesX + cx / DW] + lab16[cell];
+    last = cell;
+    v = __hip_atomic_load(&G[fn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (++hops > (1 << 22)) { *flag = 1; break; }   // (cannot happen: descent paths are loop free)
   }
-  if (hops) __hip_atomic_store(&G[n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  curN[n] = v == OUTP ? (B | CLOSED) : v;
+  if (hops > 1) __hip_atomic_store(&G[n], LAB_PEND | last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  curN[n] = (v == OUTP || (v & LAB_PEND)) ? (B | CLOSED) : v + pitoff[fn / rcap];
 }
 
 // level of every node: the final level of its basin (0 for the outside: never above a key that matters)
 __global__ __launch_bounds__(NTHR) void k_node_levels(const uint32_t *__restrict__ curN, const uint32_t *__restrict__ acc,
-                                                      uint32_t nnodes, uint32_t *lvl) {
-  const uint32_t n = blockIdx.x * NTHR + threadIdx.x;
-  if (n < nnodes) lvl[n] = acc[curN[n] & ~CLOSED];
+                                                      const unsigned long long *__restrict__ counters, uint32_t rcap,
+                                                      uint32_t *lvl) {
+  const uint32_t st = blockIdx.y, i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= (uint32_t)(counters[st * FSTRIDE] >> 32)) return;
+  const uint32_t n = st * rcap + i;
+  lvl[n] = acc[curN[n] & ~CLOSED];
 }
 
 // z <- max(z, level of the cell's node).  One block per descent tile: its node levels (<= 4096) in LDS, then z and the
@@ -2165,10 +2201,377 @@ __global__ __launch_bounds__(NTHR) void k_finalize16(T *z, const uint16_t *__res
   }
 }
 
+// ==========================================================================================================
+// The pair pass of the compact-label fill as a PERSISTENT kernel (r04).
+//
+// k_scan<L16> spends two thirds of its wave cycles parked: per 64 x 32 tile it goes through a chain of dependent global
+// round trips (tile bases -> 16-bit labels -> component gathers from the node table) before its LDS phases can start, and
+// a block does nothing else meanwhile.  Here a block stays resident and walks its share of the tiles (its XCD's band,
+// strided by the number of blocks per XCD); the NEXT tile's rows, labels, ring cells and the node table of its descent
+// tile are loaded into registers while the current tile goes through its LDS phases, so the phases of successive tiles
+// follow each other without the round trips in between.  The components of the tile's own cells come from the descent
+// tile's node table staged in LDS (one coalesced read of its ~80 entries instead of 2 048 gathers); only the 196 cells
+// of the ring, which belong to the neighbouring descent tiles, are gathered one by one.  Phases, tables, records and
+// proposals are k_scan<EMIT>'s.
+// ==========================================================================================================
+constexpr int NT_CAP = 1024;   // node-table entries of one descent tile held in LDS (more: gathered from HBM)
+static_assert(NT_CAP * 4 <= TW * TH * 2, "the node table lives in the boundary list's storage");
+static_assert(TW == DW && DH % TH == 0, "a scan tile lies inside one descent tile");
+constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
+constexpr int RING = 2 * LW + 2 * TH;   // ring cells of a tile: two rows of LW, two columns of TH
+
+// A pair that found no slot in the tile's table goes straight to the BLOCK's segment (k_pairs16: one segment per
+// resident block, filled through a counter in LDS) and proposes on its own.
+__device__ __forceinline__ void pair_spill_local(const EdgeOut &eo, unsigned long long *best, uint32_t seg, uint32_t *seg_fill,
+                                                 uint32_t lo, uint32_t hi, uint32_t key) {
+  const unsigned long long cl = ((unsigned long long)key << 32) | hi, ch = ((unsigned long long)key << 32) | lo;
+  if (!(lo & CLOSED) && cl < best[lo]) atomicMin(&best[lo], cl);
+  if (!(hi & CLOSED) && ch < best[hi]) atomicMin(&best[hi], ch);
+  const uint32_t g = atomicAdd(seg_fill, 1u);
+  if (g < eo.seglimit) {
+    const size_t i = (size_t)seg * eo.segcap + g;
+    eo.a[i] = lo; eo.b[i] = hi; eo.k[i] = key;
+  } else {
+    *eo.overflow = 1;
+  }
+}
+
+template <class T, int TOPO, bool VEC>
+__global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const uint16_t *__restrict__ lab16,
+                                                  const uint32_t *__restrict__ curN, unsigned long long *best,
+                                                  int w, int h, uint32_t B, uint32_t tilesX,
+                                                  const uint32_t *__restrict__ tiles_in, uint32_t nwork,
+                                                  EdgeOut eo,
+                                                  const uint32_t *__restrict__ tile_base,
+                                                  const uint32_t *__restrict__ tile_count, uint32_t dtx,
+                                                  const uint8_t *__restrict__ skip, int precheck) {
+  __shared__ __attribute__((aligned(8))) uint32_t sk[LH * LW];
+  __shared__ uint32_t sc[LH * LW];
+  __shared__ __attribute__((aligned(4))) uint16_t list[TW * TH];   // boundary cells; before that: the node table
+  uint32_t *const ntab = reinterpret_cast<uint32_t *>(list);
+  __shared__ unsigned long long pt_pair[PT_SLOTS];
+  __shared__ uint32_t pt_key[PT_SLOTS];
+  __shared__ uint32_t nlist, pt_n, pt_base, seg_fill;
+  uint32_t *const tab_id = sk;   // the component table lives in the keys' storage once the pairs are reduced
+  unsigned long long *const tab_val = reinterpret_cast<unsigned long long *>(sk + SC_SLOTS);
+
+  // ---- this block's tiles: XCD band, strided by the blocks per XCD -------------------------------------------------
+  const uint32_t xcd = blockIdx.x & 7u, kb = gridDim.x >> 3, per = (nwork + 7u) / 8u;
+  const uint32_t seg = blockIdx.x;   // the block's own segment of the pair list: no counter in HBM to wait for
+  uint32_t it = blockIdx.x >> 3;
+  auto next_tile = [&](uint32_t &i) -> uint32_t {
+    while (i < per) {
+      const uint32_t wi = xcd * per + i;
+      if (wi >= nwork) break;
+      const uint32_t t = tiles_in ? tiles_in[wi] : wi;
+      if (!skip) return t;
+      const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
+      if (!skip[(uint32_t)(y0 / DH) * dtx + (uint32_t)(x0 / DW)]) return t;
+      i += kb;
+    }
+    i = per;
+    return NO_TILE;
+  };
+  if (threadIdx.x == 0) seg_fill = 0;
+
+  // ---- the prefetched tile (registers) -----------------------------------------------------------------------------
+  Quad<T> zq[2];
+  Quad<uint16_t> lq[2];
+  T rz = T();
+  uint32_t rl = 0, rtb = 0, rc = 0, tbC = 0, cnt = 0;
+  uint32_t nt[NT_CAP / NTHR];
+  // ring cell of a thread (threads >= RING repeat the last one's loads and store nothing).  Everything that depends on
+  // the thread index is recomputed from an opaque copy of it in every trip of the tile loop: hoisted out of the loop
+  // these few dozen offsets and addresses cost 30 VGPRs, i.e. a third of the resident blocks.
+  auto ring_y = [](int tid) { const int rk = min(tid, RING - 1); return rk < LW ? 0 : rk < 2 * LW ? LH - 1 : (rk - 2 * LW < TH ? rk - 2 * LW + 1 : rk - 2 * LW - TH + 1); };
+  auto ring_x = [](int tid) { const int rk = min(tid, RING - 1); return rk < LW ? rk : rk < 2 * LW ? rk - LW : (rk - 2 * LW < TH ? 0 : LW - 1); };
+
+  auto load_a = [&](uint32_t t, int tid) {   // everything that only needs the tile's coordinates; branch free (clamped addresses)
+    const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
+    const uint32_t dC = (uint32_t)(y0 / DH) * dtx + (uint32_t)(x0 / DW);
+    tbC = tile_base[dC];
+    cnt = tile_count[dC];
+    {   // the ring first: its component gather (load_b) then only waits for these
+      const int gx = min(max(x0 - 1 + ring_x(tid), 0), w - 1), gy = min(max(y0 - 1 + ring_y(tid), 0), h - 1);
+      const size_t g = (size_t)gy * w + gx;
+      rl = lab16[g];
+      rtb = tile_base[(uint32_t)(gy / DH) * dtx + (uint32_t)(gx / DW)];
+      rz = z[g];
+    }
+    // the tile's quads: the tile's first cell is a block-uniform (scalar) address, a thread adds a 32-bit byte offset
+    const size_t tile0 = (size_t)y0 * w + x0;
+    const char *zt = reinterpret_cast<const char *>(z + tile0), *lt = reinterpret_cast<const char *>(lab16 + tile0);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int i = tid + r * NTHR;
+      const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+      const int gx = x0 + 4 * q, gy = y0 + ly;
+      const bool ok = gy < h && gx < w;
+      if (VEC) {
+        const uint32_t cell = ok ? (uint32_t)ly * (uint32_t)w + 4u * (uint32_t)q : 0u;
+        struct alignas(4 * sizeof(T)) AZ { T v[4]; };
+        struct alignas(8) AL { uint16_t v[4]; };
+        const AL a = *reinterpret_cast<const AL *>(lt + cell * (uint32_t)sizeof(uint16_t));
+        const AZ b = *reinterpret_cast<const AZ *>(zt + cell * (uint32_t)sizeof(T));
+#pragma unroll
+        for (int e = 0; e < 4; e++) { lq[r].v[e] = a.v[e]; zq[r].v[e] = b.v[e]; }
+      } else {
+        const size_t row = ok ? (size_t)gy * w : 0;
+        lq[r] = load_quad<uint16_t, false>(lab16 + row, ok ? gx : 0, w, (uint16_t)0);
+        zq[r] = load_quad<T, false>(z + row, ok ? gx : 0, w, T());
+      }
+    }
+  };
+  auto load_b = [&](int tid) {   // what needs load_a's words: the node table, the ring cells' components
+    const uint32_t nn = (cnt <= (uint32_t)NT_CAP && cnt) ? cnt : 1u;
+#pragma unroll
+    for (int k = 0; k < NT_CAP / NTHR; k++) {
+      const uint32_t idx = (uint32_t)tid + k * NTHR;
+      nt[k] = curN[tbC + min(idx, nn - 1u)];   // (cnt >= 1: the tile holds a cell)
+    }
+    rc = curN[rtb + rl];
+  };
+
+  uint32_t t = next_tile(it);
+  if (t == NO_TILE) return;
+  load_a(t, (int)threadIdx.x);
+  load_b((int)threadIdx.x);
+  constexpr int ROWS = TH / 4;
+  for (;;) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));   // opaque: see above
+    const int lx = tid & (TW - 1), band = tid >> 6, lane = tid & 63;
+    const int rly = ring_y(tid), rlx = ring_x(tid);
+    const bool isring = tid < RING;
+    const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
+    // ---- stage 1: the node table of the tile's descent tile; reset the tile's tables --------------------------------
+    const bool tabled = cnt <= (uint32_t)NT_CAP;
+#pragma unroll
+    for (int k = 0; k < NT_CAP / NTHR; k++) ntab[tid + k * NTHR] = nt[k];
+    pt_pair[tid] = ~0ull;
+    pt_key[tid] = 0xFFFFFFFFu;
+    static_assert(PT_SLOTS == NTHR, "one slot per thread");
+    if (tid == 0) { nlist = 0; pt_n = 0; }
+    __syncthreads();
+    // ---- stage 2: keys and components of the tile and its ring into LDS ---------------------------------------------
+    {
+      uint32_t cq[2][4];
+      bool in[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int i = tid + r * NTHR;
+        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+        const int gx = x0 + 4 * q, gy = y0 + ly;
+#pragma unroll
+        for (int e = 0; e < 4; e++) in[r][e] = gy < h && gx + e < w;
+      }
+      if (tabled) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) cq[r][e] = ntab[in[r][e] ? (uint32_t)lq[r].v[e] & (NT_CAP - 1) : 0u];
+      } else {   // more nodes than the table holds (white noise): gathered
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) cq[r][e] = curN[tbC + (in[r][e] ? (uint32_t)lq[r].v[e] : 0u)];
+      }
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int i = tid + r * NTHR;
+        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+        const int o = (ly + 1) * LW + 1 + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          sk[o + e] = in[r][e] ? Key32<T>::to(zq[r].v[e]) : 0u;
+          sc[o + e] = in[r][e] ? cq[r][e] : (B | CLOSED);
+        }
+      }
+      if (isring) {
+        const int gx = x0 - 1 + rlx, gy = y0 - 1 + rly;
+        const bool ok = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        sk[rly * LW + rlx] = ok ? Key32<T>::to(rz) : 0u;
+        sc[rly * LW + rlx] = ok ? rc : (B | CLOSED);
+      }
+    }
+    // ---- the next tile's loads go out now and land while this tile is worked on ---------------------------------------
+    it += kb;
+    const uint32_t tn = next_tile(it);
+    const uint32_t tl = tn != NO_TILE ? tn : t;   // (no next tile: this one's rows once more -- cheaper than a branch)
+    load_a(tl, tid);
+    __syncthreads();
+    // ---- phase 1: detect (k_scan's) -----------------------------------------------------------------------------------
+    const int gxl = x0 + lx;
+    const int yb = band * ROWS;
+    {
+      uint32_t c1[3], c2[3];
+      {
+        const int o = (yb + 1) * LW + lx;
+#pragma unroll
+        for (int e = 0; e < 3; e++) c1[e] = sc[o + e];
+      }
+      unsigned long long bal[ROWS];
+      // (k_scan's "the tile still holds an open boundary" flag feeds the raster rounds, which this path does not have)
+      const int rows_in = min(h - y0 - yb, ROWS);   // rows of this band inside the raster
+      const bool colin = gxl < w;
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) {
+        const int ly = yb + j;
+        {
+          const int o = (ly + 2) * LW + lx;
+#pragma unroll
+          for (int e = 0; e < 3; e++) c2[e] = sc[o + e];
+        }
+        const uint32_t C = c1[1];
+        uint32_t df = (c1[2] ^ C) | (c2[1] ^ C);
+        if (TOPO == 8) df |= (c2[0] ^ C) | (c2[2] ^ C);
+        bal[j] = __ballot(df != 0 && colin && j < rows_in);
+#pragma unroll
+        for (int e = 0; e < 3; e++) c1[e] = c2[e];
+      }
+      // (the node table's storage becomes the list: every lookup in it was made before the barrier above)
+      uint32_t total = 0;
+#pragma unroll
+      for (int j = 0; j < ROWS; j++) total += (uint32_t)__popcll(bal[j]);
+      if (total) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&nlist, total);
+        base = __shfl(base, 0, 64);
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+          if (bal[j] >> lane & 1ull)
+            list[base + __popcll(bal[j] & ((1ull << lane) - 1ull))] = (uint16_t)((yb + j + 1) * LW + lx + 1);
+          base += (uint32_t)__popcll(bal[j]);
+        }
+      }
+    }
+    __syncthreads();
+    load_b(tid);
+    // ---- phase 2: the pairs (k_scan<EMIT>'s) -----------------------------------------------------------------------
+    const uint32_t nl = nlist;
+    constexpr int NF = TOPO == 8 ? 4 : 2;
+    const int foff[4] = {1, TOPO == 8 ? LW + 1 : LW, LW, LW - 1};
+    for (uint32_t i = tid; i < nl; i += NTHR) {
+      const int o = list[i];
+      const uint32_t C = sc[o], kc = sk[o];
+      uint32_t nD[NF], nH[NF];
+#pragma unroll
+      for (int e = 0; e < NF; e++) { nD[e] = sc[o + foff[e]]; nH[e] = sk[o + foff[e]]; }
+      uint32_t pd[2] = {C, C}, pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+      for (int e = 0; e < NF; e++) {
+        const uint32_t D = nD[e], hn = nH[e] > kc ? nH[e] : kc;
+        if (D != C && !(C & D & CLOSED)) {
+          if (pd[0] == C) pd[0] = D;
+          if (D == pd[0]) pk[0] = hn < pk[0] ? hn : pk[0];
+          else {
+            if (pd[1] == C) pd[1] = D;
+            if (D == pd[1]) pk[1] = hn < pk[1] ? hn : pk[1];
+            else if (!pair_insert(pt_pair, pt_key, C < D ? C : D, C < D ? D : C, hn))
+              pair_spill_local(eo, best, seg, &seg_fill, C < D ? C : D, C < D ? D : C, hn);
+          }
+        }
+      }
+      uint32_t ps[2], pq[2], lo[2], hi[2];
+      unsigned long long pv[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        lo[j] = C < pd[j] ? C : pd[j];
+        hi[j] = C < pd[j] ? pd[j] : C;
+        ps[j] = pair_home(lo[j], hi[j]);
+        pv[j] = pt_pair[ps[j]];
+        pq[j] = pt_key[ps[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (pd[j] != C) {
+          const unsigned long long pr = ((unsigned long long)lo[j] << 32) | hi[j];
+          if (pv[j] == pr) { if (pk[j] < pq[j]) atomicMin(&pt_key[ps[j]], pk[j]); }
+          else if (!pair_insert(pt_pair, pt_key, lo[j], hi[j], pk[j])) pair_spill_local(eo, best, seg, &seg_fill, lo[j], hi[j], pk[j]);
+        }
+      }
+    }
+    __syncthreads();
+    tab_id[tid] = 0xFFFFFFFFu;
+    tab_val[tid] = ~0ull;
+    static_assert(SC_SLOTS == NTHR, "one slot per thread");
+    {
+      const bool occ = pt_pair[tid] != ~0ull;
+      const unsigned long long bal = __ballot(occ);
+      uint32_t base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&pt_n, (uint32_t)__popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (occ) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    }
+    __syncthreads();
+    const uint32_t tot = pt_n;
+    if (tid == 0) {
+      uint32_t ob = seg_fill;   // (spills are over: nothing else touches the counter until the next tile's pairs)
+      if (ob + tot > eo.seglimit) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
+      else seg_fill = ob + tot;
+      pt_base = ob;
+    }
+    for (uint32_t i = tid; i < tot; i += NTHR) {
+      const int sl = list[i];
+      const unsigned long long pr = pt_pair[sl];
+      const uint32_t lo = (uint32_t)(pr >> 32), hi = (uint32_t)pr, key = pt_key[sl];
+      if (!(lo & CLOSED)) {
+        const unsigned long long cand = ((unsigned long long)key << 32) | hi;
+        const int slot = tab_slot(tab_id, lo);
+        if (slot >= 0) atomicMin(&tab_val[slot], cand);
+        else if (cand < best[lo]) atomicMin(&best[lo], cand);
+      }
+      if (!(hi & CLOSED)) {
+        const unsigned long long cand = ((unsigned long long)key << 32) | lo;
+        const int slot = tab_slot(tab_id, hi);
+        if (slot >= 0) atomicMin(&tab_val[slot], cand);
+        else if (cand < best[hi]) atomicMin(&best[hi], cand);
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t C = tab_id[tid];
+      if (C != 0xFFFFFFFFu) {
+        const unsigned long long cand = tab_val[tid];
+        if (precheck) { if (cand < best[C]) atomicMin(&best[C], cand); }
+        else atomicMin(&best[C], cand);
+      }
+    }
+    const uint32_t ob = pt_base;
+    if (ob != 0xFFFFFFFFu) {
+      const size_t g0 = (size_t)seg * eo.segcap + ob;
+      for (uint32_t i = tid; i < tot; i += NTHR) {
+        const int sl = list[i];
+        const unsigned long long pr = pt_pair[sl];
+        eo.a[g0 + i] = (uint32_t)(pr >> 32);
+        eo.b[g0 + i] = (uint32_t)pr;
+        eo.k[g0 + i] = pt_key[sl];
+      }
+    }
+    __syncthreads();   // the tables, the list and the keys' storage are free for the next tile
+    if (tn == NO_TILE) break;
+    t = tn;
+  }
+  if (threadIdx.x == 0) eo.segcount[seg] = seg_fill;
+}
+
 // The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
 // provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
 // lists (optional, with skip): device arrays [descent tiles to visit | scan tiles to visit | tiles to finalize], each of
 // `stride` entries, and their lengths on the host
+// resident blocks of the persistent pair pass: what the kernel's registers and LDS let a CU hold (asked of the runtime;
+// RDGPU_FILL_PAIRS_BPC overrides), times the CUs, rounded to a multiple of 8 so that every XCD gets the same number
+template <class K>
+static int pairs_blocks(K kernel) {
+  int dev = 0, cus = 0, bpc = 0;
+  RD_HIP(hipGetDevice(&dev));
+  RD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const char *e = getenv("RDGPU_FILL_PAIRS_BPC");
+  if (e) bpc = atoi(e);
+  else RD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, NTHR, 0));
+  return std::max(8, (cus * std::max(bpc, 1)) / 8 * 8);
+}
+
 struct SparseLists {
   const uint32_t *d = nullptr;
   uint32_t stride = 0, n[3] = {0, 0, 0};
@@ -2192,18 +2595,25 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
   FusedBuf fo;
   fo.gcap = n / 4 + 4096;
+  uint32_t nstripes = 1;   // every stripe's region holds at least two tiles of nothing but roots
+  while (nstripes < (uint32_t)FSTRIPES && fo.gcap / (2 * nstripes) >= 8192u && dnt >= 8 * nstripes) nstripes *= 2;
+  fo.rcap = fo.gcap / nstripes;
+  fo.smask = nstripes - 1;
   fo.lab16 = ws.buf<uint16_t>("fused.lab16", n);
   fo.G = ws.buf<uint32_t>("fused.G", fo.gcap);
   fo.tile_base = ws.buf<uint32_t>("fused.tile_base", dnt);
   fo.tile_count = ws.buf<uint32_t>("fused.tile_count", dnt);
-  uint32_t *dflags = ws.buf<uint32_t>("fused.flags", 16);   // [0] chase flag, [2] roots, [3] alive tiles, [4] records, [5] overflow, [8..9] counters
-  fo.counters = reinterpret_cast<unsigned long long *>(dflags + 8);
+  // [0] chase flag, [2] roots, [3] alive tiles, [4] records, [5] overflow, [8] basins, [9] nodes, [10] nodes of the fullest stripe
+  uint32_t *dflags = ws.buf<uint32_t>("fused.flags", 16);
+  fo.counters = ws.buf<unsigned long long>("fused.counters", (size_t)FSTRIPES * FSTRIDE);
+  uint32_t *pitoff = ws.buf<uint32_t>("fused.pitoff", FSTRIPES);
   fo.overflow = dflags + 5;
   uint32_t *curN = ws.buf<uint32_t>("fused.curN", fo.gcap);
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
-  if (outlet) {   // node 0: the "outside" node of the skipped tiles
+  RD_HIP(hipMemsetAsync(fo.counters, 0, (size_t)FSTRIPES * FSTRIDE * sizeof(unsigned long long), s));
+  if (outlet) {   // node 0 (the first of stripe 0): the "outside" node of the skipped tiles
     static const uint32_t one = 1u, outp = OUTP;
-    RD_HIP(hipMemcpyAsync(dflags + 9, &one, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    RD_HIP(hipMemcpyAsync(reinterpret_cast<uint32_t *>(fo.counters) + 1, &one, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     RD_HIP(hipMemcpyAsync(fo.G, &outp, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   }
   const bool listed = outlet && skip && lists && lists->d;
@@ -2222,14 +2632,17 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   else
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
               (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+  RD_LAUNCH("fill.stripe_offsets", k_stripe_offsets, dim3(1), dim3(64), 0, s, (const unsigned long long *)fo.counters, nstripes, pitoff,
+            dflags + 8);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
-  if (hw[1] != 0) return false;   // more nodes than the table holds: nothing was written to the DEM
-  const uint32_t B = hw[4], NN = hw[5];   // counters: low word pits, high word nodes
+  if (hw[1] != 0) return false;   // more nodes than a stripe's table holds: nothing was written to the DEM
+  const uint32_t B = hw[4], NNmax = hw[6];   // basins; nodes of the fullest stripe
   g_stats.basins = B;
   if (B == 0) return true;        // no pits: nothing to raise
-  RD_LAUNCH("fill.resolve_nodes", k_resolve_nodes, dim3(cdiv(NN, NTHR)), dim3(NTHR), 0, s, fo.G, NN, (const uint16_t *)fo.lab16,
-            (const uint32_t *)fo.tile_base, w, dtx, B, curN, dflags);
+  const dim3 ngrid(cdiv(std::max(NNmax, 1u), NTHR), nstripes);
+  RD_LAUNCH("fill.resolve_nodes", k_resolve_nodes, ngrid, dim3(NTHR), 0, s, fo.G, (const unsigned long long *)fo.counters,
+            (const uint32_t *)pitoff, fo.rcap, (const uint16_t *)fo.lab16, (const uint32_t *)fo.tile_base, w, dtx, B, curN, dflags);
   g_stats.jump_passes = 1;
   uint32_t *cur = ws.buf<uint32_t>("fill.cur", (size_t)B + 1);
   uint32_t *acc = ws.buf<uint32_t>("fill.acc", (size_t)B + 1);
@@ -2239,9 +2652,20 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *rootsB = ws.buf<uint32_t>("fill.rootsB", B);
   RD_LAUNCH("fill.init_tables", k_init_tables, dim3(cdiv((uint64_t)B + 1, NTHR)), dim3(NTHR), 0, s, cur, acc, link, rootsA,
             dflags + 2, (const uint32_t *)nullptr, B);
-  // the pair list of the one raster pass: capacity as in the classic path
+  const char *env_pp = getenv("RDGPU_FILL_PAIRS");   // =0: k_scan<L16>, one block per tile (A/B and tests)
+  const bool persistent_pairs = !(env_pp && env_pp[0] == '0');
+  const uint32_t nwork1 = listed ? lists->n[1] : ntiles;   // scan tiles the pair pass visits
+  uint32_t pgrid = 0;
+  if (persistent_pairs) {
+    static thread_local int pb_cache[2] = {0, 0};   // (per element type and topology: this function is a template)
+    int &pb = pb_cache[vec ? 1 : 0];
+    if (!pb || getenv("RDGPU_FILL_PAIRS_BPC")) pb = vec ? pairs_blocks(k_pairs16<T, TOPO, true>) : pairs_blocks(k_pairs16<T, TOPO, false>);
+    pgrid = std::max(8u, std::min<uint32_t>(xcd_grid(std::max(nwork1, 1u)), (uint32_t)pb));
+  }
+  // the pair list of the one raster pass: capacity as in the classic path; the persistent pass has one segment per block
   uint32_t nseg = 1;
   while (nseg < ESEG && (uint64_t)nseg * 128 <= ntiles) nseg *= 2;
+  if (persistent_pairs) nseg = pgrid;
   const char *env_cap = getenv("RDGPU_FILL_EDGE_CAP");
   const uint64_t cap = env_cap ? strtoull(env_cap, nullptr, 10) : std::min<uint64_t>(12ull * B, n / 2) + 2048;
   const uint32_t segcap = cdiv(cdiv(cap, nseg), NTHR * EPT) * (NTHR * EPT);
@@ -2251,12 +2675,15 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *segcount = ws.buf<uint32_t>("fill.segcount", nseg);
   RD_HIP(hipMemsetAsync(segcount, 0, nseg * sizeof(uint32_t), s));
   EdgeOut eo{elist[0], elist[0] + ecap, elist[0] + 2 * ecap, segcount, segcap, nseg - 1, dflags + 5};
+  eo.seglimit = (uint32_t)std::min<uint64_t>(segcap, std::max<uint64_t>(1, cdiv(cap, nseg)));
   uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
   uint32_t nroots = B, nedges = 0;
   int ein = 0;
   bool first = true, eseg = true;
   const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
   const bool dedup = !(env_dedup && env_dedup[0] == '0');
+  const char *env_pc = getenv("RDGPU_FILL_PRECHECK");
+  const int precheck = !(env_pc && env_pc[0] == '0');
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
@@ -2264,6 +2691,15 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
       const uint32_t nwork = listed ? lists->n[1] : ntiles;
       if (nwork == 0) {
         // (no tile holds a wet cell although basins exist: cannot happen -- a pit is a wet cell; kept safe)
+      } else if (persistent_pairs) {
+        if (vec)
+          RD_LAUNCH("fill.scan", (k_pairs16<T, TOPO, true>), dim3(pgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint16_t *)fo.lab16,
+                    (const uint32_t *)curN, best, w, h, B, tilesX, sl_, nwork, eo, (const uint32_t *)fo.tile_base,
+                    (const uint32_t *)fo.tile_count, dtx, skip, precheck);
+        else
+          RD_LAUNCH("fill.scan", (k_pairs16<T, TOPO, false>), dim3(pgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint16_t *)fo.lab16,
+                    (const uint32_t *)curN, best, w, h, B, tilesX, sl_, nwork, eo, (const uint32_t *)fo.tile_base,
+                    (const uint32_t *)fo.tile_count, dtx, skip, precheck);
       } else if (vec)
         RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(nwork)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
@@ -2320,8 +2756,8 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
     g_stats.rounds++;
   }
   uint32_t *lvl = fo.G;   // (the node table is dead: its storage holds the nodes' levels)
-  RD_LAUNCH("fill.node_levels", k_node_levels, dim3(cdiv(NN, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc, NN,
-            lvl);
+  RD_LAUNCH("fill.node_levels", k_node_levels, ngrid, dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc,
+            (const unsigned long long *)fo.counters, fo.rcap, lvl);
   if (listed && lists->n[2] == 0) return true;
   if (vec)
     RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(listed ? lists->n[2] : xcd_grid(dnt)), dim3(NTHR), 0, s, d_z,

@@ -1,0 +1,229 @@
+"""SURVEY 8(f2) at FULL size, quantified: the other outputs of the Priority-Flood sweep on the UNFILLED 40000 x 40000 bench
+DEM against the COMPILED REFERENCE (tests/golden/ref_s3_f2_<output>.npz, made once by `make_golden.py --s3-f2 <output>`:
+PriorityFloodFlowdirs_Barnes2014 838 s, PriorityFlood_Barnes2014_max_dep(100) 809 s, PriorityFloodEpsilon_Barnes2014 and
+PriorityFloodWatersheds_Barnes2014 of one core each).  Per output the file holds one digest per 1000-row band, one per
+1000 x 1000 block, and the reference's VALUES at a fixed quasi-uniform sample of cells (cell (j * 982451653) mod 1.6e9).
+
+* max_dep: the pockets are order free; which of them one flooding cell joins into one run is not (counted: a handful of
+  blocks at this size).
+* PriorityFloodFlowdirs follows the reference's stable queue only where elevations are distinct, the
+  epsilon fill and the watershed labels follow std::priority_queue's pop order among equal elevations -- and a float32 raster
+  of 1.6e9 cells cannot avoid equal elevations.  For these three the test COUNTS: bands and blocks whose digest differs, and
+  the sampled cells that differ (an estimate of the differing fraction; +- 3 / sqrt(hits) relative).  The numbers go to the
+  test's warning line, to gpurun_out/s3_f2.json (-> profiles/) and bench.py repeats the sample count beside the two f2 stage
+  times (`cells_differing_from_reference`).  Bounds asserted: the fractions measured in r04 with a factor of safety."""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, GOLDEN)
+from digest import band_digests_torch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def block_digests_torch(t, rows=1000, cols=1000):
+    """tests/golden/make_golden.py::_block_digests on a CUDA tensor"""
+    import torch
+
+    from digest import _K1, _K2, _K3
+
+    h, w = t.shape
+    k1, k2, k3 = int(_K1), int(_K2), int(_K3)
+    out = np.zeros((-(-h // rows), -(-w // cols)), np.uint64)
+    for by, y0 in enumerate(range(0, h, rows)):
+        band = t[y0:y0 + rows]
+        if band.dtype == torch.float32:
+            v = band.contiguous().view(torch.int32).to(torch.int64)
+        else:
+            v = band.to(torch.int64)
+        idx = (torch.arange(y0, y0 + band.shape[0], dtype=torch.int64, device=t.device)[:, None] * w
+               + torch.arange(w, dtype=torch.int64, device=t.device)[None, :])
+        x = v * k1 + idx * k2
+        x = x ^ (x >> 32)
+        x = x * k3
+        nb = -(-w // cols)
+        pad = nb * cols - w
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad))
+        out[by] = x.view(band.shape[0], nb, cols).sum(dim=(0, 2), dtype=torch.int64).cpu().numpy().view(np.uint64)
+    return out
+
+
+def sample_of(t, g):
+    import torch
+
+    k, stride = int(g["sample_k"]), int(g["sample_stride"])
+    pos = (torch.arange(k, dtype=torch.int64, device=t.device) * stride) % t.numel()
+    return t.reshape(-1)[pos], pos
+
+
+def compare(name, out, g, report, same=None):
+    """digests + sample of `out` against the reference file g; `same(got, ref)` -> bool tensor for the sample (default ==)"""
+    import torch
+
+    rows = int(g["band_rows"])
+    bands = band_digests_torch(out, rows)
+    blocks = block_digests_torch(out)
+    got, _ = sample_of(out, g)
+    ref = torch.from_numpy(g["sample"]).to(out.device)
+    eq = (got == ref) if same is None else same(got, ref)
+    k = int(g["sample_k"])
+    ndiff = int((~eq).sum().item())
+    report[name] = {"bands_differing": int((bands != g["bands"]).sum()), "bands": int(g["bands"].size),
+                    "blocks_differing": int((blocks != g["blocks"]).sum()), "blocks": int(g["blocks"].size),
+                    "sample_cells": k, "sample_differing": ndiff, "fraction": ndiff / k,
+                    "estimated_cells_differing": int(round(ndiff / k * out.numel())),
+                    "reference_seconds_one_core": float(g["ref_seconds"])}
+    return report[name]
+
+
+def _load(which):
+    path = os.path.join(GOLDEN, f"ref_s3_f2_{which}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (make_golden.py --s3-f2 {which})")
+    g = np.load(path)
+    assert int(g["size"]) == 40000
+    return g
+
+
+def _write(report):
+    path = os.path.join(ROOT, "gpurun_out", "s3_f2.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    old = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            old = json.load(f)
+    old.update(report)
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1)
+
+
+def _dem(rd, g):
+    import torch
+
+    n = int(g["size"])
+    Z = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    rd.synth_dem_dev(Z, seed=int(g["seed"]))
+    return Z
+
+
+def test_s3_max_dep_equals_the_reference(rd):
+    import torch
+
+    g = _load("maxdep")
+    Z = _dem(rd, g)
+    W = Z.clone()
+    rd.fill_max_dep_dev(W, 100)
+    torch.cuda.synchronize()
+    rep = {}
+    r = compare("max_dep_100", W, g, rep)
+    r["cells_changed"] = int((W != Z).sum().item())
+    _write(rep)
+    r["reference_cells_changed"] = int(g["cells_changed"])
+    _write(rep)
+    # r04, first full-size comparison: the pockets are order free, but WHICH pockets one flooding cell unites into one run
+    # (and so whether the run stays under the size limit) follows the heap's order among equal elevations -- 6 of the 1600
+    # blocks hold a difference, 135 of 2.49e7 raised cells.  Counted like the other tie-sensitive outputs, and bounded.
+    warnings.warn(f"PriorityFlood_Barnes2014_max_dep(100) at 40000^2 vs the compiled reference: {r['blocks_differing']} of "
+                  f"{r['blocks']} blocks hold a difference, {r['cells_changed']} cells raised vs {r['reference_cells_changed']}, "
+                  f"{r['sample_differing']} of {r['sample_cells']} sampled cells differ", UserWarning)
+    assert r["sample_differing"] <= 2 and r["blocks_differing"] <= 24, r
+    assert abs(r["cells_changed"] - r["reference_cells_changed"]) <= 4000, r
+    del Z, W
+    rd.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_s3_pf_flowdirs_difference_is_counted(rd):
+    import torch
+
+    g = _load("flowdirs")
+    Z = _dem(rd, g)
+    dirs = torch.empty(Z.shape, dtype=torch.uint8, device="cuda")
+    rd.pf_flowdirs_dev(Z, -9999.0, dirs)
+    torch.cuda.synchronize()
+    rep = {}
+    r = compare("priority_flood_flowdirs", dirs, g, rep)
+    r.update({k: int(v) for k, v in rd.pf_flowdirs_stats().items()})
+    _write(rep)
+    warnings.warn(f"PriorityFloodFlowdirs at 40000^2 vs the compiled reference: {r['sample_differing']} of {r['sample_cells']} sampled "
+                  f"cells differ (~{r['estimated_cells_differing']} cells, fraction {r['fraction']:.2e}); {r['blocks_differing']} of "
+                  f"{r['blocks']} blocks hold a difference; twins {r['twins']}, unresolved {r['unresolved']}", UserWarning)
+    assert r["fraction"] < 2e-3, r          # r04: see profiles/r04_s3_f2.json
+    del Z, dirs
+    rd.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_s3_epsilon_difference_is_counted(rd):
+    import torch
+
+    g = _load("epsilon")
+    Z = _dem(rd, g)
+    E = Z.clone()
+    rd.fill_epsilon_dev(E, -9999.0)
+    torch.cuda.synchronize()
+    rep = {}
+    r = compare("priority_flood_epsilon", E, g, rep)
+    got, _ = sample_of(E, g)
+    ref = torch.from_numpy(g["sample"]).cuda()
+    steps = (ref.view(torch.int32).to(torch.int64) - got.view(torch.int32).to(torch.int64))
+    r["sample_above_reference"] = int((got > ref).sum().item())       # the order-free surface is a lower bound
+    r["max_steps_below_reference"] = int(steps.max().item())
+    r["cells_changed"] = int((E != Z).sum().item())
+    r["reference_cells_changed"] = int(g["cells_changed"])
+    r["tie_sources"] = int(rd.epsilon_stats()["tie_sources"])
+    _write(rep)
+    warnings.warn(f"PriorityFloodEpsilon at 40000^2 vs the compiled reference: {r['sample_differing']} of {r['sample_cells']} sampled "
+                  f"cells differ (fraction {r['fraction']:.4f}, at most {r['max_steps_below_reference']} representable steps below, "
+                  f"{r['sample_above_reference']} above); tie sources {r['tie_sources']}", UserWarning)
+    assert r["sample_above_reference"] == 0, r
+    del Z, E
+    rd.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_s3_watersheds_difference_is_counted(rd):
+    import torch
+
+    g = _load("watersheds")
+    Z = _dem(rd, g)
+    lab = torch.empty(Z.shape, dtype=torch.int32, device="cuda")
+    rd.watersheds_dev(Z, -9999.0, lab)
+    torch.cuda.synchronize()
+    got = sample_of(lab, g)[0].cpu().numpy().astype(np.int64)
+    ref = g["sample"].astype(np.int64)
+    # The numbering follows the pop order too, so the PARTITIONS are compared, on the sample: of the pairs of sampled cells
+    # that share a watershed in one result (neighbours in the sample sorted by that result's label), how many are
+    # separated in the other.  The same cells are unlabelled (-1: NoData connected to the border) in both.
+    k = int(g["sample_k"])
+    assert np.array_equal(got == -1, ref == -1)
+
+    def split(a, b):
+        o = np.argsort(a, kind="stable")
+        sa, sb = a[o], b[o]
+        pair = (sa[1:] == sa[:-1]) & (sa[1:] != -1)
+        return int(pair.sum()), int((pair & (sb[1:] != sb[:-1])).sum())
+
+    pr, sr = split(ref, got)
+    pg, sg = split(got, ref)
+    rep = {"priority_flood_watersheds": {"sample_cells": k, "labels": int(lab.max().item()), "reference_labels": int(g["labels"]),
+                                         "pairs_in_one_reference_watershed": pr, "of_them_separated_here": sr,
+                                         "pairs_in_one_watershed_here": pg, "of_them_separated_in_the_reference": sg,
+                                         "fraction": (sr + sg) / max(pr + pg, 1),
+                                         "reference_seconds_one_core": float(g["ref_seconds"])}}
+    _write(rep)
+    r = rep["priority_flood_watersheds"]
+    warnings.warn(f"PriorityFloodWatersheds at 40000^2 vs the compiled reference: of {pr} sampled pairs inside one reference "
+                  f"watershed {sr} are separated here, of {pg} pairs inside one watershed here {sg} are separated in the reference "
+                  f"(fraction {r['fraction']:.4f}); labels {r['labels']} vs {r['reference_labels']}", UserWarning)
+    del Z, lab
+    rd.release_workspace()
+    torch.cuda.empty_cache()
