@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 #: SURVEY.md section 8d, algorithmic bytes per cell
 STAGE_BYTES = {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
-               "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8, "priority_flood_flowdirs": 5}
+               "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8, "priority_flood_flowdirs": 5,
+               "dinf_flow_directions": 8, "fa_tarboton": 20}   # D-infinity: f32 in + f32 angle out; f32 dem + f64 weights in + f64 out
 
 
 def cpu_baseline(Z, sample: int):
@@ -136,6 +137,22 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
     out["fa_d8"] = stage_entry(t_fa, n_cells, 20)
     out["fa_d8"]["input"] = "fill -> ResolveFlatsEpsilon output, unit weights"
     out["fa_d8"]["max_accum"] = float(area.max().item())
+    # D-infinity (north_star names it beside D8): the angle raster (dinf_flow_directions) and FA_Tarboton on the epsilon-resolved
+    # DEM, where every cell drains
+    ang = torch.empty(W.shape, dtype=torch.float32, device="cuda")
+    rd.dinf_flow_directions_dev(E, nodata, ang)
+    out["dinf_flow_directions"] = stage_entry(_best(lambda: rd.dinf_flow_directions_dev(E, nodata, ang), reps, sync), n_cells,
+                                              STAGE_BYTES["dinf_flow_directions"])
+    del ang
+    area.fill_(1.0)
+    rd.fa_tarboton_dev(E, nodata, area)
+    t_ft = 1e30
+    for _ in range(reps):
+        area.fill_(1.0)
+        t_ft = min(t_ft, _best(lambda: rd.fa_tarboton_dev(E, nodata, area), 1, sync))
+    out["fa_tarboton"] = stage_entry(t_ft, n_cells, STAGE_BYTES["fa_tarboton"])
+    out["fa_tarboton"]["input"] = "fill -> ResolveFlatsEpsilon output, unit weights"
+    out["fa_tarboton"]["max_accum"] = float(area.max().item())
     del area
     if Z is not None:
         rd.fill_epsilon_dev(E.copy_(Z), nodata)
@@ -147,6 +164,7 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         es = rd.epsilon_stats()
         out["priority_flood_epsilon"].update({"input": "the unfilled bench DEM (PriorityFloodEpsilon_Original semantics)",
                                               **{k: es[k] for k in ("rounds", "tie_sources") if k in es}})
+        out["priority_flood_epsilon"]["cells_differing_from_reference"] = _differing(torch, E, "epsilon")
         if not pf_flowdirs:
             return out
         # PriorityFloodFlowdirs_Barnes2014: one fill per nesting level of the depressions (seconds, not milliseconds: once)
@@ -158,7 +176,27 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         out["priority_flood_flowdirs"].update({"input": "the unfilled bench DEM", "levels": ps["levels"],
                                                "cells_with_an_equal_elevation_twin": ps["twins"],
                                                "directions_decided_among_ties": ps["unresolved"]})
+        out["priority_flood_flowdirs"]["cells_differing_from_reference"] = _differing(torch, pdirs, "flowdirs")
     return out
+
+
+def _differing(torch, out, which: str):
+    """The stage's output against the COMPILED REFERENCE's values at a fixed sample of cells of the 40000 x 40000 bench DEM
+    (tests/golden/ref_s3_f2_<which>.npz, make_golden.py --s3-f2; the same comparison as tests/test_s3_f2_gpu.py).  The
+    reference's result with equal elevations follows its queue's order: this says how far the stage's output is from it."""
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", f"ref_s3_f2_{which}.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if int(g["size"]) != out.shape[0] or out.shape[0] != out.shape[1]:
+        return None
+    k, stride = int(g["sample_k"]), int(g["sample_stride"])
+    pos = (torch.arange(k, dtype=torch.int64, device=out.device) * stride) % out.numel()
+    nd = int((out.reshape(-1)[pos] != torch.from_numpy(g["sample"]).to(out.device)).sum().item())
+    return {"sample_cells": k, "sample_differing": nd, "estimated_fraction": nd / k, "estimated_cells": int(round(nd / k * out.numel())),
+            "source": f"tests/golden/ref_s3_f2_{which}.npz (compiled reference, {float(g['ref_seconds']):.0f} s of one core)"}
 
 
 def host_path(rd, torch, Z, reps: int = 2) -> dict:

@@ -317,6 +317,30 @@ void barnes_flat_resolution_d8(E &elevations, F &flowdirs, bool alter) {
   flowdirs.templateCopy(elevations);    // flat_resolution.hpp:604
 }
 
+// accum_t other than double (the reference's FA_* / FlowAccumulation are templated on it,
+// methods/flow_accumulation.hpp:14-28, flow_accumulation_generic.hpp:33-34): the engine accumulates in double; an
+// Array2D<float> / Array2D<int32_t> / ... accumulation array is staged through a double copy (weights in, result out,
+// converted as a C++ assignment would).  Equal to the reference whenever every partial sum is exactly representable in
+// accum_t -- unit or integer-valued weights with totals below 2^24 for float and (because the reference forms
+// `float proportion * accum_t` before it adds) for the integer types as well; beyond that the reference's own value is a
+// product of float rounding in its queue's order.
+namespace detail {
+template <class G, class Fn>
+void with_double_accum(G &accum, Fn fn) {
+  using A = elem_t<G>;
+  static_assert(std::is_arithmetic<A>::value, "the accumulation array must hold an arithmetic type");
+  if constexpr (std::is_same<A, double>::value) {
+    fn(accum.data());
+  } else {
+    const size_t n = (size_t)accum.width() * (size_t)accum.height();
+    std::vector<double> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (double)accum.data()[i];
+    fn(tmp.data());
+    for (size_t i = 0; i < n; i++) accum.data()[i] = (A)tmp[i];
+  }
+}
+}  // namespace detail
+
 // ---- accumulation ------------------------------------------------------------------------------
 // richdem::d8_flow_accum(const Array2D<T>& flowdirs, Array2D<U>& area)   methods/d8_methods.hpp:47-139
 template <class F, class G>
@@ -336,28 +360,28 @@ void d8_flow_accum(const F &flowdirs, G &area) {
 template <class E, class G>
 void FA_D8(const E &elevations, G &accum) {
   using T = detail::elem_t<E>;
-  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FA_D8: the accumulation array must be Array2D<double>");
-  accum.setNoData(-1.0);                // ACCUM_NO_DATA, flow_accumulation_generic.hpp:40
+  accum.setNoData((detail::elem_t<G>)-1);   // ACCUM_NO_DATA, flow_accumulation_generic.hpp:40
   if (accum.width() != elevations.width() || accum.height() != elevations.height())   // :42-43
     throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
   if (elevations.width() == 0 || elevations.height() == 0) return;
-  detail::check(detail::c_fa_d8((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(),
-                                accum.data()),
-                "FA_D8");
+  detail::with_double_accum(accum, [&](double *a) {
+    detail::check(detail::c_fa_d8((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), a),
+                  "FA_D8");
+  });
 }
 
 // richdem::FA_Tarboton / FA_Dinfinity(const Array2D<elev_t>&, Array2D<accum_t>&)   methods/flow_accumulation.hpp:16-17
 template <class E, class G>
 void FA_Tarboton(const E &elevations, G &accum) {
   using T = detail::elem_t<E>;
-  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FA_Tarboton: the accumulation array must be Array2D<double>");
-  accum.setNoData(-1.0);
+  accum.setNoData((detail::elem_t<G>)-1);
   if (accum.width() != elevations.width() || accum.height() != elevations.height())
     throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
   if (elevations.width() == 0 || elevations.height() == 0) return;
-  detail::check(detail::c_fa_dinf((const T *)elevations.data(), elevations.noData(), elevations.width(),
-                                  elevations.height(), accum.data()),
-                "FA_Tarboton");
+  detail::with_double_accum(accum, [&](double *a) {
+    detail::check(detail::c_fa_dinf((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), a),
+                  "FA_Tarboton");
+  });
 }
 template <class E, class G>
 void FA_Dinfinity(const E &elevations, G &accum) { FA_Tarboton(elevations, accum); }
@@ -367,14 +391,13 @@ namespace detail {
 template <class E, class G>
 void fa_mfd(const E &elevations, G &accum, int method, double xparam, const char *who) {
   using T = elem_t<E>;
-  static_assert(std::is_same<elem_t<G>, double>::value, "FA_*: the accumulation array must be Array2D<double>");
-  accum.setNoData(-1.0);
+  accum.setNoData((elem_t<G>)-1);
   if (accum.width() != elevations.width() || accum.height() != elevations.height())
     throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
   if (elevations.width() == 0 || elevations.height() == 0) return;
-  check(c_fa_mfd((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), method, xparam,
-                 accum.data()),
-        who);
+  with_double_accum(accum, [&](double *a) {
+    check(c_fa_mfd((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), method, xparam, a), who);
+  });
 }
 }  // namespace detail
 template <class E, class G>
@@ -451,13 +474,14 @@ void FM_OCallaghan(const E &elevations, P &props) {
 // accum is in/out: pre-loaded with the flow each cell generates.
 template <class P, class G>
 void FlowAccumulation(const P &props, G &accum) {
-  static_assert(std::is_same<detail::elem_t<G>, double>::value, "FlowAccumulation: the accumulation array must be Array2D<double>");
-  accum.setNoData(-1.0);                // ACCUM_NO_DATA, :40
+  accum.setNoData((detail::elem_t<G>)-1);   // ACCUM_NO_DATA, :40
   if (accum.width() != props.width() || accum.height() != props.height())   // :42-43
     throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
   if (props.width() == 0 || props.height() == 0) return;
   const float *p9 = detail::raw3(const_cast<P &>(props), 0);   // (the reference's accessor is non-const; read only)
-  detail::check(rdgpu_flow_accumulation_f64(p9, props.width(), props.height(), accum.data()), "FlowAccumulation");
+  detail::with_double_accum(accum, [&](double *a) {
+    detail::check(rdgpu_flow_accumulation_f64(p9, props.width(), props.height(), a), "FlowAccumulation");
+  });
 }
 
 // richdem::pit_mask<topo>(const Array2D<T>&, Array2D<uint8_t>&)   depressions/Barnes2014.hpp:593-676

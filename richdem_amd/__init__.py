@@ -57,6 +57,8 @@ from .api import (  # noqa: F401
     resolve_flats_epsilon_dev,
     fill_epsilon_dev,
     fill_max_dep_dev,
+    dinf_flow_directions_dev,
+    fa_tarboton_dev,
     watersheds_dev,
     epsilon_stats,
     flat_stats,

@@ -176,8 +176,9 @@ def pf_flowdirs_stats() -> dict:
 def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     """PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555): uint8 D8 directions in which every cell
     points at the neighbour the (non-raising) flood reached first; NoData cells 0.  Equal to the reference on DEMs without
-    equal elevations; with ties the reference follows its queue's insertion order -- a RuntimeWarning reports cells
-    whose direction stayed ambiguous (pf_flowdirs_stats()["unresolved"])."""
+    equal elevations; with ties the reference follows its queue's insertion order, this engine the raster order of the equal
+    cells (the flood runs on the raster's unique ranks) -- a RuntimeWarning reports the number of cells with a twin
+    (pf_flowdirs_stats()["twins"])."""
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("pf_flowdirs: expected a 2-D numpy array")
     dem = np.ascontiguousarray(dem)
@@ -190,10 +191,11 @@ def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     if st["unresolved"] or st["twins"]:
         import warnings
 
-        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell ({st['unresolved']} directions "
-                      "were decided among equal-elevation candidates); the reference breaks such ties by the insertion order of "
-                      "its queue, this result by neighbour number -- identical results are only guaranteed without equal "
-                      "elevations", RuntimeWarning)
+        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell; the reference orders equal "
+                      "elevations by the insertion counters of its queue, this engine floods the raster's unique ranks (equal "
+                      "cells in raster order) -- the reference's answer for that order of the ties"
+                      + (f"; {st['unresolved']} directions were decided among equal candidates" if st["unresolved"] else ""),
+                      RuntimeWarning)
     return out
 
 
@@ -544,6 +546,32 @@ def fill_epsilon_dev(dem, nodata, topology="D8") -> None:
     s = _torch_elev_suffix(dem)
     check(getattr(lib(), f"rdgpu_fill_epsilon_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
                                                         _topo(topology), _stream_ptr()), "rdgpu_fill_epsilon_dev")
+
+
+def dinf_flow_directions_dev(dem, nodata, angles) -> None:
+    """dinf_flow_directions (flowmet/dinf_flowdirs.hpp:128-152) of a contiguous 2-D CUDA tensor into a float32 CUDA tensor
+    of the same shape, on torch's current stream."""
+    import torch
+
+    h, w = _dev2d(dem, "dinf_flow_directions_dev")
+    if angles.dtype != torch.float32 or tuple(angles.shape) != (h, w) or not angles.is_contiguous() or not angles.is_cuda:
+        raise RdgpuError("dinf_flow_directions_dev: angles must be a contiguous float32 CUDA tensor of the DEM's shape")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_dinf_flowdirs_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+                                                         ctypes.c_void_p(angles.data_ptr()), _stream_ptr()), "rdgpu_dinf_flowdirs_dev")
+
+
+def fa_tarboton_dev(dem, nodata, accum) -> None:
+    """FA_Tarboton / FA_Dinfinity (methods/flow_accumulation.hpp:16-17): accum (float64 CUDA tensor, in: the cells' weights,
+    out: the accumulation) from the DEM, on torch's current stream."""
+    import torch
+
+    h, w = _dev2d(dem, "fa_tarboton_dev")
+    if accum.dtype != torch.float64 or tuple(accum.shape) != (h, w) or not accum.is_contiguous() or not accum.is_cuda:
+        raise RdgpuError("fa_tarboton_dev: accum must be a contiguous float64 CUDA tensor of the DEM's shape")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_fa_tarboton_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+                                                       ctypes.c_void_p(accum.data_ptr()), _stream_ptr()), "rdgpu_fa_tarboton_dev")
 
 
 def fill_max_dep_dev(dem, max_dep_size: int, topology="D8") -> None:

@@ -25,6 +25,8 @@
 // tests/tools/proto_pf_flowdirs.py is the same algorithm in numpy, checked against the oracle.
 #include "common.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <limits>
 
 #define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_lists_dev_##SUF(T *, const uint8_t *, const uint8_t *, const uint32_t *, uint32_t, \
@@ -237,6 +239,37 @@ __global__ __launch_bounds__(NT) void k_finish(const T *__restrict__ z, T nodata
 }
 
 static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0};
+static thread_local bool g_rank_pass = false;   // the call runs on the unique ranks of another raster (see pf_flowdirs_device)
+
+// ---- equal elevations: the flood on UNIQUE RANKS (r04) ----------------------------------------------------------------------
+// With equal elevations the reference's pop order follows its insertion counters.  What this engine can do exactly is a
+// tie-free raster; so a raster with twins is replaced by its rank permutation -- position in the order of (elevation, cell
+// index), from one stable radix sort of (key, cell) pairs -- and flooded exactly.  That is the reference's answer for SOME
+// stable order of the equal cells (raster order instead of insertion order), and far closer to it than deciding ties late,
+// by neighbour number, inside the nesting levels: at 6000^2 of the bench generator (31 % distinct values) 731 cells differ
+// from the compiled reference instead of 123 165 (scratch measurement, r04; the full-size figure is in
+// tests/test_s3_f2_gpu.py's report).
+template <class T>
+__global__ __launch_bounds__(NT) void k_rank_keys(const T *__restrict__ z, uint32_t *keys, uint32_t *idx, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    keys[c] = Key32<T>::to(z[c]);
+    idx[c] = (uint32_t)c;
+  }
+}
+__global__ __launch_bounds__(NT) void k_rank_scatter(const uint32_t *__restrict__ sidx, uint32_t *rk, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) rk[sidx[i]] = (uint32_t)i;
+}
+// interior NoData cells carry no direction (:545-548); the rank pass cannot see which cells those are
+template <class T>
+__global__ __launch_bounds__(NT) void k_nodata_dirs(const T *__restrict__ z, T nodata, uint8_t *dirs, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    if (x > 0 && y > 0 && x < w - 1 && y < h - 1 && z[c] == nodata) dirs[c] = 0;
+  }
+}
 
 template <class T>
 struct Calls;
@@ -271,7 +304,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   RD_HIP(hipMemsetAsync(counters, 0, (128 + 4) * sizeof(unsigned long long), s));
   {
     const char *env = getenv("RDGPU_PFD_TWINS");   // =0: skip the equal-elevation census (512 MB of bits)
-    if (!(env && env[0] == '0')) {
+    if (!(env && env[0] == '0') && !g_rank_pass) {
       uint32_t *bits = ws.buf<uint32_t>("pfd.keybits", (size_t)1 << 27);
       RD_HIP(hipMemsetAsync(bits, 0, (size_t)1 << 29, s));
       RD_LAUNCH("pfd.twins", (k_twins<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, n, bits, counters);
@@ -280,6 +313,32 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       RD_HIP(hipMemcpyAsync(&tw, sums, sizeof tw, hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
       g_stats.twins = (uint32_t)std::min<unsigned long long>(tw, 0xFFFFFFFFull);
+    }
+  }
+  {
+    const char *re = getenv("RDGPU_PFD_RANKS");   // =0: ties decided inside the levels, by neighbour number (r03; A/B and tests)
+    if (g_stats.twins != 0 && !g_rank_pass && !(re && re[0] == '0')) {
+      uint32_t *keys = ws.buf<uint32_t>("pfd.rkeys", n), *skeys = ws.buf<uint32_t>("pfd.rskeys", n);
+      uint32_t *idx = ws.buf<uint32_t>("pfd.ridx", n), *sidx = ws.buf<uint32_t>("pfd.rsidx", n);
+      RD_LAUNCH("pfd.rank_keys", (k_rank_keys<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, keys, idx, n);
+      size_t tb = 0;   // (LSD radix sort: stable, so equal keys stay in raster order)
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+      void *tmp = ws.buf("pfd.rtmp", tb);
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+      uint32_t *rk = keys;   // (the unsorted keys are dead)
+      RD_LAUNCH("pfd.rank_scatter", k_rank_scatter, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sidx, rk, n);
+      const rdgpu_pf_flowdirs_stats mine = g_stats;
+      g_rank_pass = true;
+      try {
+        pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
+      } catch (...) {
+        g_rank_pass = false;
+        throw;
+      }
+      g_rank_pass = false;
+      g_stats.twins = mine.twins;
+      RD_LAUNCH("pfd.nodata_dirs", (k_nodata_dirs<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, d_dirs, w, h);
+      return;
     }
   }
   RD_LAUNCH("pfd.init", k_init_cand, dim3(sgrid(n)), dim3(NT), 0, s, cand, w, h);

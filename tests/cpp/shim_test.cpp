@@ -161,6 +161,14 @@ int main() {
     bool threw = false;
     try { rdgpu::FA_D8(dem, wrong); } catch (const std::runtime_error &) { threw = true; }
     EXPECT(threw);
+    // accum_t = float / int32_t (the reference's FA_D8<elev_t, accum_t> is templated on it): totals below 2^24 are exact
+    Arr<float> af(dem, 1.0f);
+    Arr<int32_t> ai(dem, 1);
+    rdgpu::FA_D8(dem, af);
+    rdgpu::FA_D8(dem, ai);
+    bool same = af.noData() == -1.0f && ai.noData() == -1;
+    for (size_t i = 0; i < e.size() && same; i++) same = af.data()[i] == (float)e[i] && ai.data()[i] == (int32_t)e[i];
+    EXPECT(same);
   }
   // rd_flow_accumulation's other deterministic methods: FA_Quinn / FA_Holmgren / FA_Freeman / FA_D4
   {

@@ -290,11 +290,52 @@ def s3_f2(which, size=40000, seed=3):
     print("wrote", path, round(secs, 1), "s", os.path.getsize(path), "bytes", flush=True)
 
 
+def s2_dinf(size=10000, seed=2):
+    """D-infinity on the record (north_star names it beside D8): the compiled reference's dinf_flow_directions
+    (flowmet/dinf_flowdirs.hpp:128-152) and FA_Tarboton (methods/flow_accumulation.hpp:16 = FM_Tarboton,
+    flowmet/Tarboton1997.hpp:14-144, + FlowAccumulation) on the FILLED 10000 x 10000 DEM G(seed=2) (BASELINE configs[1]'s
+    raster).  Committed (ref_s2_dinf.npz): band digests of the float32 angles and of the accumulation cast to float32 --
+    exact equality is the common case, reported per band -- and both outputs at a fixed sample of cells, from which the GPU
+    test builds the ULP histogram (tolerance: 1 float32 ULP, north_star)."""
+    import time
+    from digest import BAND_ROWS, band_digests_np
+    oracle.build()
+    R = oracle.ref
+    assert R.available
+    n = size
+    z = np.empty((n, n), np.float32)
+    for y0 in range(0, n, 2000):
+        z[y0:y0 + 2000] = fractal_dem(n, min(2000, n - y0), seed, y0=y0)
+    nd = np.float32(-9999.0)
+    W = R.fill(z, 8)
+    del z
+    k = 1 << 18
+    pos = s3_sample_positions(n * n, k)
+    t0 = time.perf_counter()
+    ang = R.dinf_flowdirs(W, nd)
+    t_ang = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fa = R.fa_tarboton(W, nd)
+    t_fa = time.perf_counter() - t0
+    fa32 = fa.astype(np.float32)
+    g = {"size": np.int64(n), "seed": np.int64(seed), "band_rows": np.int64(BAND_ROWS), "sample_k": np.int64(k),
+         "sample_stride": np.int64(S3_SAMPLE_STRIDE), "fill": band_digests_np(W),
+         "dinf_bands": band_digests_np(ang), "dinf_sample": ang.ravel()[pos],
+         "fa_tarboton_f32_bands": band_digests_np(fa32), "fa_tarboton_sample": fa.ravel()[pos], "fa_tarboton_max": np.float64(fa.max()),
+         "ref_seconds/dinf_flow_directions": np.float64(round(t_ang, 2)), "ref_seconds/fa_tarboton": np.float64(round(t_fa, 2))}
+    path = os.path.join(HERE, "ref_s2_dinf.npz" if n == 10000 else f"ref_s2_dinf_{n}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, t_ang, t_fa, os.path.getsize(path), flush=True)
+
+
 if __name__ == "__main__":
     if "--s3-digests" in sys.argv:
         sys.path.insert(0, HERE)
         size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000
         s3_digests(size)
+    elif "--s2-dinf" in sys.argv:
+        sys.path.insert(0, HERE)
+        s2_dinf(int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 10000)
     elif "--s3-f2" in sys.argv:
         sys.path.insert(0, HERE)
         size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000

@@ -55,7 +55,8 @@ def test_stage_entry():
     assert abs(e["frac_of_peak"] - 9.6 / 0.181 / 8000) < 1e-4 and abs(e["Mcells_s"] - 1600 / 0.181) < 0.1
     assert bench.STAGE_BYTES == {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d8_flow_accum": 9,
                                  "resolve_flats_epsilon": 8, "fa_d8": 20, "priority_flood_epsilon": 8,
-                                 "priority_flood_flowdirs": 5}
+                                 "priority_flood_flowdirs": 5,
+                                 "dinf_flow_directions": 8, "fa_tarboton": 20}   # SURVEY.md section 8d; D-infinity: a11 / VERDICT r03 #8
 
 
 def test_bench_stdout_is_reserved_for_the_json_line():
