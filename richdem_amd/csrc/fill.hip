@@ -2636,7 +2636,7 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
             dflags + 8);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
-  if (hw[1] != 0) return false;   // more nodes than a stripe's table holds: nothing was written to the DEM
+  if (hw[1] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: node table overflow (nstripes %u rcap %u)\n", nstripes, fo.rcap); return false; }   // more nodes than a stripe's table holds: nothing was written to the DEM
   const uint32_t B = hw[4], NNmax = hw[6];   // basins; nodes of the fullest stripe
   g_stats.basins = B;
   if (B == 0) return true;        // no pits: nothing to raise
@@ -2675,7 +2675,7 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *segcount = ws.buf<uint32_t>("fill.segcount", nseg);
   RD_HIP(hipMemsetAsync(segcount, 0, nseg * sizeof(uint32_t), s));
   EdgeOut eo{elist[0], elist[0] + ecap, elist[0] + 2 * ecap, segcount, segcap, nseg - 1, dflags + 5};
-  eo.seglimit = (uint32_t)std::min<uint64_t>(segcap, std::max<uint64_t>(1, cdiv(cap, nseg)));
+  eo.seglimit = env_cap ? (uint32_t)std::min<uint64_t>(segcap, std::max<uint64_t>(1, cdiv(cap, nseg))) : segcap;   // (the cap given on purpose is enforced to the record: the overflow tests)
   uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
   uint32_t nroots = B, nedges = 0;
   int ein = 0;
@@ -2740,10 +2740,10 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
               dflags + 2);
     RD_HIP(hipMemcpyAsync(hw, dflags, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
-    if (hw[0] != 0) return false;
+    if (hw[0] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: hook chain unfinished\n"); return false; }
     const uint32_t next = hw[2];
     if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
-    if (first && hw[5] != 0) return false;   // the pair list overflowed: the DEM is untouched, the classic path takes over
+    if (first && hw[5] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair list overflow (B %u cap %llu nseg %u segcap %u nwork %u)\n", B, (unsigned long long)cap, nseg, segcap, nwork1); return false; }   // the pair list overflowed: the DEM is untouched, the classic path takes over
     nroots = next;
     nedges = hw[4];
     if (first) {

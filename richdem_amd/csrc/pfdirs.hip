@@ -27,6 +27,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
+
 #include <limits>
 
 #define RD_OUTLETS(SUF, T) extern "C" int rdgpu_fill_outlets_lists_dev_##SUF(T *, const uint8_t *, const uint8_t *, const uint32_t *, uint32_t, \
@@ -359,6 +361,9 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     RD_LAUNCH("pfd.all_tiles", k_all_tiles, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, cur_tiles, ftiles);
     RD_HIP(hipMemcpyAsync(F, d_z, n * sizeof(T), hipMemcpyDeviceToDevice, s));
     check_rc(Calls<T>::fill(F, w, h, (void *)s));
+    const bool trace = getenv("RDGPU_PFD_TRACE") != nullptr;   // per level: time, tiles, counts (stderr)
+    const auto t_start = std::chrono::steady_clock::now();
+    double t_last = 0;
     unsigned long long host[2] = {0, 0}, last_open = ~0ull, last_wet = ~0ull;
     uint32_t hcounts[3] = {0, 0, 0};
     for (;;) {
@@ -376,6 +381,12 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       RD_HIP(hipMemcpyAsync(host, sums, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       RD_HIP(hipMemcpyAsync(hcounts, lcounts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
+      if (trace) {
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        fprintf(stderr, "pfd level %u: %.2f ms  tiles walked %u  undecided %llu wet %llu  lists %u %u %u\n", g_stats.levels, now - t_last, ncur,
+                host[0], host[1], hcounts[0], hcounts[1], hcounts[2]);
+        t_last = now;
+      }
       ncur = hcounts[2];
       if (host[0] == 0 || host[1] == 0) break;                       // every cell decided / nothing wet any more
       if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
