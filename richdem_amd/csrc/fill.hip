@@ -1335,6 +1335,13 @@ struct FillBuffers {
   uint32_t *lab = nullptr, *cur = nullptr, *acc = nullptr, *tid = nullptr;
   uint32_t B = 0;
   bool trivial = false;   // nothing to raise (no interior, or no pits)
+  // the compact-label local phase of a row-block shard (r04): no 32-bit label per cell, but the 16-bit slots, the tiles'
+  // node bases and counts, node -> basin (curN), and per node its level (lvl) and watershed terminal (nodeW)
+  bool compact = false;
+  uint16_t *lab16 = nullptr;
+  uint32_t *tile_base = nullptr, *tile_count = nullptr, *curN = nullptr, *lvl = nullptr, *nodeW = nullptr;
+  unsigned long long *counters = nullptr;
+  uint32_t rcap = 0, nstripes = 0, nnmax = 0;
 };
 
 struct BufAlloc {   // where persistent buffers come from: the shared workspace, or owned hipMalloc
@@ -1595,6 +1602,10 @@ static void fill_finalize(T *d_z, int w, int h, const FillBuffers &fb, hipStream
   const uint32_t sgrid = std::min(cdiv(n, NTHR), 256u * 32u);
   RD_LAUNCH("fill.finalize", (k_finalize<T>), dim3(sgrid), dim3(NTHR), 0, s, d_z, fb.lab, fb.acc, n, fb.B);
 }
+
+// a shard's finish on compact labels: the nodes' levels from the (raised) basin levels, then the raster pass
+template <class T>
+static void fill_finalize16(T *d_z, int w, int h, const FillBuffers &fb, hipStream_t s);
 
 static void check_fill_args(const void *p, int w, int h, int topology) {
   if (!p) throw Error(RDGPU_ERR_ARG, "rdgpu_fill: null DEM pointer");
@@ -1898,11 +1909,14 @@ __global__ __launch_bounds__(64) void k_stripe_offsets(const unsigned long long 
 // There, all outlets of a tile share ONE node (slot 0: a tile of walls has thousands of them), node 0 of the table is a
 // global "outside" node, and `skip` (optional, per descent tile) names the tiles that hold nothing but outlets, ring
 // included: they get no work -- label 0 everywhere (written once: skip == 1; 2: written before), node 0.
-template <class T, int TOPO, bool VEC, bool OUTLETS = false>
+// CUT: the raster is a row-block shard -- the cells of an open first / last row are frozen terminals (own roots, numbered
+// like pits, never draining), not border cells.
+template <class T, int TOPO, bool VEC, bool OUTLETS = false, bool CUT = false>
 __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, FusedBuf fo, int w, int h,
                                                     uint32_t tilesX, uint32_t ntiles, const uint8_t *__restrict__ outlet = nullptr,
                                                     const uint8_t *__restrict__ skip = nullptr,
-                                                    const uint32_t *__restrict__ tlist = nullptr) {
+                                                    const uint32_t *__restrict__ tlist = nullptr, int open_top = 0,
+                                                    int open_bottom = 0) {
   // tlist (optional, with OUTLETS): the tiles to work on, one block each (ntiles = the raster's tiles all the same)
   __shared__ uint32_t sk[DLH * DLW];
   // rows of LPD = 66 entries: with 64 two-byte entries every row starts on the same LDS bank and the jumps' gathers --
@@ -1990,8 +2004,14 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
       const uint16_t ldrain = inside ? (uint16_t)(ty * LPD + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
       const bool incell = (gx < w) & (gy < h);
       bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
+      bool stays = !drains;
+      if (CUT) {
+        const bool cutrow = ((gy == 0) & (open_top != 0)) | ((gy == h - 1) & (open_bottom != 0));
+        border = (gx == 0) | (gx == w - 1) | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);
+        stays |= cutrow;
+      }
       if (OUTLETS) border |= incell && outlet[(size_t)gy * w + gx] != 0;
-      const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : !drains ? LTERM_BASE : ldrain;
+      const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : stays ? LTERM_BASE : ldrain;
       lp[ly * LPD + lx] = l;
 #pragma unroll
       for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
@@ -2114,7 +2134,8 @@ __global__ __launch_bounds__(NTHR) void k_resolve_nodes(uint32_t *G, const unsig
                                                         const uint32_t *__restrict__ pitoff, uint32_t rcap,
                                                         const uint16_t *__restrict__ lab16,
                                                         const uint32_t *__restrict__ tile_base, int w, uint32_t tilesX,
-                                                        uint32_t B, uint32_t *curN, uint32_t *flag) {
+                                                        uint32_t B, uint32_t *curN, uint32_t *flag,
+                                                        const uint32_t *__restrict__ tid = nullptr) {
   const uint32_t st = blockIdx.y, i = blockIdx.x * NTHR + threadIdx.x;
   if (i >= (uint32_t)(counters[st * FSTRIDE] >> 32)) return;
   const uint32_t n = st * rcap + i;
@@ -2129,7 +2150,114 @@ __global__ __launch_bounds__(NTHR) void k_resolve_nodes(uint32_t *G, const unsig
     if (++hops > (1 << 22)) { *flag = 1; break; }   // (cannot happen: descent paths are loop free)
   }
   if (hops > 1) __hip_atomic_store(&G[n], LAB_PEND | last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  curN[n] = (v == OUTP || (v & LAB_PEND)) ? (B | CLOSED) : v + pitoff[fn / rcap];
+  if (v == OUTP || (v & LAB_PEND)) { curN[n] = B | CLOSED; return; }
+  const uint32_t b = v + pitoff[fn / rcap];
+  curN[n] = (tid && tid[b] != NO_TID) ? (b | CLOSED) : b;   // a shard's cut-row terminals are closed components
+}
+
+// A shard's cut-row cells are roots of their tiles with a pit number of their own: tid[basin] = terminal id (top row: x,
+// bottom row: w + x), straight from the node table (a pit's word needs no chase), before the nodes are resolved.
+__global__ __launch_bounds__(NTHR) void k_mark_terminals16(const uint16_t *__restrict__ lab16, const uint32_t *__restrict__ tile_base,
+                                                           const uint32_t *__restrict__ G, const uint32_t *__restrict__ pitoff,
+                                                           uint32_t rcap, uint32_t *tid, int w, int h, uint32_t dtx, int open_top,
+                                                           int open_bottom) {
+  const int x = blockIdx.x * NTHR + threadIdx.x;
+  if (x <= 0 || x >= w - 1) return;
+  if (open_top) {
+    const uint32_t node = tile_base[(uint32_t)(x / DW)] + lab16[x];
+    tid[G[node] + pitoff[node / rcap]] = (uint32_t)x;
+  }
+  if (open_bottom) {
+    const uint32_t node = tile_base[(uint32_t)((h - 1) / DH) * dtx + (uint32_t)(x / DW)] + lab16[(size_t)(h - 1) * w + x];
+    tid[G[node] + pitoff[node / rcap]] = (uint32_t)(w + x);
+  }
+}
+
+// per node: the terminal id of its watershed after the local rounds (NO_TID: it drains to the true border inside the shard)
+__global__ __launch_bounds__(NTHR) void k_node_watersheds(const uint32_t *__restrict__ curN, const uint32_t *__restrict__ cur,
+                                                          const uint32_t *__restrict__ tid,
+                                                          const unsigned long long *__restrict__ counters, uint32_t rcap, uint32_t B,
+                                                          uint32_t *nodeW) {
+  const uint32_t st = blockIdx.y, i = blockIdx.x * NTHR + threadIdx.x;
+  if (i >= (uint32_t)(counters[st * FSTRIDE] >> 32)) return;
+  const uint32_t n = st * rcap + i;
+  const uint32_t c = cur[curN[n] & ~CLOSED] & ~CLOSED;
+  nodeW[n] = c == B ? NO_TID : tid[c];
+}
+
+// k_shard_edges on the compact labels: a cell's watershed terminal and locally filled level come from its NODE
+// (tile base + 16-bit slot -> nodeW / lvl) instead of label -> component -> terminal.
+template <class T, int TOPO>
+__global__ __launch_bounds__(NTHR) void k_shard_edges16(const T *__restrict__ z, const uint16_t *__restrict__ lab16,
+                                                        const uint32_t *__restrict__ tile_base, uint32_t dtx,
+                                                        const uint32_t *__restrict__ nodeW, const uint32_t *__restrict__ lvl,
+                                                        int w, int h, unsigned long long *hkeys, uint32_t *hvals, uint32_t hmask,
+                                                        uint32_t *overflow, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ uint32_t sl[ELH * ELW];
+  __shared__ uint32_t sw[ELH * ELW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * EW, y0 = (int)(t / tilesX) * EH;
+  constexpr int IPT = (ELH * ELW + NTHR - 1) / NTHR;
+  uint32_t nv[IPT], kv[IPT];
+  bool ok[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {   // batch 1: slot, node base of the cell's descent tile, elevation key
+    const int i = threadIdx.x + r * NTHR;
+    const int ly = i / ELW, lx = i - ly * ELW;
+    const int gx = x0 - 1 + lx, gy = y0 + ly;
+    ok[r] = i < ELH * ELW && gx >= 0 && gx < w && gy < h;
+    const int cx = ok[r] ? gx : 0, cy = ok[r] ? gy : 0;
+    const size_t g = (size_t)cy * w + cx;
+    nv[r] = tile_base[(uint32_t)(cy / DH) * dtx + (uint32_t)(cx / DW)] + lab16[g];
+    kv[r] = Key32<T>::to(z[g]);
+  }
+  uint32_t wv[IPT], av[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {   // batch 2: the node's watershed terminal and level
+    wv[r] = nodeW[nv[r]];
+    av[r] = lvl[nv[r]];
+  }
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {
+    const int i = threadIdx.x + r * NTHR;
+    if (i < ELH * ELW) {
+      sl[i] = ok[r] ? wv[r] : E_INVALID;
+      sw[i] = av[r] > kv[r] ? av[r] : kv[r];   // (the outside's level is 0)
+    }
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (EW - 1), ly0 = threadIdx.x >> 6;
+#pragma unroll 2
+  for (int j = 0; j < EH / 4; j++) {
+    const int ly = ly0 + 4 * j;
+    const int o = ly * ELW + lx + 1;
+    const uint32_t la = sl[o];
+    if (la == E_INVALID) continue;
+    const uint32_t wa = sw[o];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (TOPO == 4 && (k == 1 || k == 3)) continue;
+      const int q = o + (k == 0 ? 1 : k == 1 ? ELW - 1 : k == 2 ? ELW : ELW + 1);
+      const uint32_t lb = sl[q];
+      if (lb == la || lb == E_INVALID) continue;
+      const uint32_t wb = sw[q];
+      const uint32_t pass = wa > wb ? wa : wb;
+      const uint32_t lo = la < lb ? la : lb, hi = la < lb ? lb : la;
+      const unsigned long long key = (((unsigned long long)lo << 32) | hi) + 1ull;
+      uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & hmask;
+      for (uint32_t probe = 0;; probe++) {
+        if (probe > hmask) { *overflow = 1; break; }
+        unsigned long long cur_k = __hip_atomic_load(&hkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur_k == 0) cur_k = atomicCAS(&hkeys[slot], 0ull, key);
+        if (cur_k == 0 || cur_k == key) {
+          if (__hip_atomic_load(&hvals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pass) atomicMin(&hvals[slot], pass);
+          break;
+        }
+        slot = (slot + 1) & hmask;
+      }
+    }
+  }
 }
 
 // level of every node: the final level of its basin (0 for the outside: never above a key that matters)
@@ -2555,6 +2683,24 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
   if (threadIdx.x == 0) eo.segcount[seg] = seg_fill;
 }
 
+template <class T>
+static void fill_finalize16(T *d_z, int w, int h, const FillBuffers &fb, hipStream_t s) {
+  if (fb.trivial) return;
+  const uint32_t dtx = cdiv(w, DW), dnt = dtx * cdiv(h, DH);
+  const dim3 ngrid(cdiv(std::max(fb.nnmax, 1u), NTHR), fb.nstripes);
+  RD_LAUNCH("fill.node_levels", k_node_levels, ngrid, dim3(NTHR), 0, s, (const uint32_t *)fb.curN, (const uint32_t *)fb.acc,
+            (const unsigned long long *)fb.counters, fb.rcap, fb.lvl);
+  const bool vec = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(d_z) % (4 * sizeof(T))) == 0;
+  if (vec)
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fb.lab16,
+              (const uint32_t *)fb.lvl, (const uint32_t *)fb.tile_base, (const uint32_t *)fb.tile_count, w, h, dtx, dnt,
+              (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+  else
+    RD_LAUNCH("fill.finalize", (k_finalize16<T, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, d_z, (const uint16_t *)fb.lab16,
+              (const uint32_t *)fb.lvl, (const uint32_t *)fb.tile_base, (const uint32_t *)fb.tile_count, w, h, dtx, dnt,
+              (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+}
+
 // The compact-label fill's host side.  false: the DEM does not fit the scheme's buffers (more nodes or pair records than
 // provided for: e.g. white noise) or it was switched off -- the DEM has not been changed, the classic path runs.
 // lists (optional, with skip): device arrays [descent tiles to visit | scan tiles to visit | tiles to finalize], each of
@@ -2576,9 +2722,14 @@ struct SparseLists {
   const uint32_t *d = nullptr;
   uint32_t stride = 0, n[3] = {0, 0, 0};
 };
+// keep (with alloc): the call is a row-block shard's local phase -- open_top / open_bottom name its cut rows, the tables the
+// shard needs later (labels, node tables, basins' components and levels, terminal ids) come from `alloc` and are handed
+// over in *keep, and the DEM is NOT raised (rdgpu_fill_shard_finish does that, after the levels of the cut-row
+// terminals are known).
 template <class T, int TOPO>
 static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outlet = nullptr, const uint8_t *skip = nullptr,
-                       const SparseLists *lists = nullptr) {
+                       const SparseLists *lists = nullptr, FillBuffers *keep = nullptr, BufAlloc *alloc = nullptr,
+                       int open_top = 0, int open_bottom = 0) {
   const char *fe = getenv("RDGPU_FILL_FUSED");   // =0: the classic four-pass fill (A/B and tests)
   if (fe && fe[0] == '0') return false;
   const char *env_edges = getenv("RDGPU_FILL_EDGES");
@@ -2599,16 +2750,22 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   while (nstripes < (uint32_t)FSTRIPES && fo.gcap / (2 * nstripes) >= 8192u && dnt >= 8 * nstripes) nstripes *= 2;
   fo.rcap = fo.gcap / nstripes;
   fo.smask = nstripes - 1;
-  fo.lab16 = ws.buf<uint16_t>("fused.lab16", n);
-  fo.G = ws.buf<uint32_t>("fused.G", fo.gcap);
-  fo.tile_base = ws.buf<uint32_t>("fused.tile_base", dnt);
-  fo.tile_count = ws.buf<uint32_t>("fused.tile_count", dnt);
+  const bool sharded = keep != nullptr;
+  if (sharded && !(open_top || open_bottom)) return false;   // (a block without a cut is the whole raster: the caller's other path)
+  // what outlives the call in a shard comes from the shard's allocator
+  auto persistent = [&](const char *name, size_t bytes) -> void * {
+    return sharded ? (void *)alloc->get<uint8_t>(name, bytes) : ws.buf(name, bytes);
+  };
+  fo.lab16 = (uint16_t *)persistent("fused.lab16", (size_t)n * 2);
+  fo.G = (uint32_t *)persistent("fused.G", (size_t)fo.gcap * 4);
+  fo.tile_base = (uint32_t *)persistent("fused.tile_base", (size_t)dnt * 4);
+  fo.tile_count = (uint32_t *)persistent("fused.tile_count", (size_t)dnt * 4);
   // [0] chase flag, [2] roots, [3] alive tiles, [4] records, [5] overflow, [8] basins, [9] nodes, [10] nodes of the fullest stripe
   uint32_t *dflags = ws.buf<uint32_t>("fused.flags", 16);
-  fo.counters = ws.buf<unsigned long long>("fused.counters", (size_t)FSTRIPES * FSTRIDE);
+  fo.counters = (unsigned long long *)persistent("fused.counters", (size_t)FSTRIPES * FSTRIDE * 8);
   uint32_t *pitoff = ws.buf<uint32_t>("fused.pitoff", FSTRIPES);
   fo.overflow = dflags + 5;
-  uint32_t *curN = ws.buf<uint32_t>("fused.curN", fo.gcap);
+  uint32_t *curN = (uint32_t *)persistent("fused.curN", (size_t)fo.gcap * 4);
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
   RD_HIP(hipMemsetAsync(fo.counters, 0, (size_t)FSTRIPES * FSTRIDE * sizeof(unsigned long long), s));
   if (outlet) {   // node 0 (the first of stripe 0): the "outside" node of the skipped tiles
@@ -2622,16 +2779,22 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   if (listed && lists->n[0] == 0) return true;   // nothing but walls anywhere: nothing to raise
   if (outlet && vec)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, true>), dim3(listed ? lists->n[0] : xcd_grid(dnt)), dim3(NTHR), 0, s,
-              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl);
+              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl, 0, 0);
   else if (outlet)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, true>), dim3(listed ? lists->n[0] : xcd_grid(dnt)), dim3(NTHR), 0, s,
-              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl);
+              (const T *)d_z, fo, w, h, dtx, dnt, outlet, skip, dl, 0, 0);
+  else if (sharded && vec)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true, false, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx,
+              dnt, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr, open_top, open_bottom);
+  else if (sharded)
+    RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false, false, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx,
+              dnt, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr, open_top, open_bottom);
   else if (vec)
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, true>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0, 0);
   else
     RD_LAUNCH("fill.descent", (k_descent16<T, TOPO, false>), dim3(xcd_grid(dnt)), dim3(NTHR), 0, s, (const T *)d_z, fo, w, h, dtx, dnt,
-              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr);
+              (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint32_t *)nullptr, 0, 0);
   RD_LAUNCH("fill.stripe_offsets", k_stripe_offsets, dim3(1), dim3(64), 0, s, (const unsigned long long *)fo.counters, nstripes, pitoff,
             dflags + 8);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -2639,19 +2802,40 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   if (hw[1] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: node table overflow (nstripes %u rcap %u)\n", nstripes, fo.rcap); return false; }   // more nodes than a stripe's table holds: nothing was written to the DEM
   const uint32_t B = hw[4], NNmax = hw[6];   // basins; nodes of the fullest stripe
   g_stats.basins = B;
+  if (sharded) {
+    *keep = FillBuffers();
+    keep->B = B;
+    if (B == 0) { keep->trivial = true; return true; }   // no pits and no terminals: nothing to raise
+  }
   if (B == 0) return true;        // no pits: nothing to raise
   const dim3 ngrid(cdiv(std::max(NNmax, 1u), NTHR), nstripes);
+  uint32_t *tid = nullptr;
+  if (sharded) {
+    tid = alloc->get<uint32_t>("fill.tid", (size_t)B + 1);
+    RD_HIP(hipMemsetAsync(tid, 0xFF, ((size_t)B + 1) * sizeof(uint32_t), s));
+    RD_LAUNCH("fill.mark_terminals", k_mark_terminals16, dim3(cdiv(w, NTHR)), dim3(NTHR), 0, s, (const uint16_t *)fo.lab16,
+              (const uint32_t *)fo.tile_base, (const uint32_t *)fo.G, (const uint32_t *)pitoff, fo.rcap, tid, w, h, dtx, open_top,
+              open_bottom);
+  }
   RD_LAUNCH("fill.resolve_nodes", k_resolve_nodes, ngrid, dim3(NTHR), 0, s, fo.G, (const unsigned long long *)fo.counters,
-            (const uint32_t *)pitoff, fo.rcap, (const uint16_t *)fo.lab16, (const uint32_t *)fo.tile_base, w, dtx, B, curN, dflags);
+            (const uint32_t *)pitoff, fo.rcap, (const uint16_t *)fo.lab16, (const uint32_t *)fo.tile_base, w, dtx, B, curN, dflags,
+            (const uint32_t *)tid);
   g_stats.jump_passes = 1;
-  uint32_t *cur = ws.buf<uint32_t>("fill.cur", (size_t)B + 1);
-  uint32_t *acc = ws.buf<uint32_t>("fill.acc", (size_t)B + 1);
+  uint32_t *cur = sharded ? alloc->get<uint32_t>("fill.cur", (size_t)B + 1) : ws.buf<uint32_t>("fill.cur", (size_t)B + 1);
+  uint32_t *acc = sharded ? alloc->get<uint32_t>("fill.acc", (size_t)B + 1) : ws.buf<uint32_t>("fill.acc", (size_t)B + 1);
   unsigned long long *best = ws.buf<unsigned long long>("fill.best", (size_t)B + 1);
   unsigned long long *link = ws.buf<unsigned long long>("fill.link", (size_t)B + 1);
   uint32_t *rootsA = ws.buf<uint32_t>("fill.rootsA", B);
   uint32_t *rootsB = ws.buf<uint32_t>("fill.rootsB", B);
+  RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
   RD_LAUNCH("fill.init_tables", k_init_tables, dim3(cdiv((uint64_t)B + 1, NTHR)), dim3(NTHR), 0, s, cur, acc, link, rootsA,
-            dflags + 2, (const uint32_t *)nullptr, B);
+            dflags + 2, (const uint32_t *)tid, B);
+  uint32_t nroots0 = B;
+  if (sharded) {   // the frozen terminals are no roots: the list was compacted, its length comes back
+    RD_HIP(hipMemcpyAsync(hw, dflags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    nroots0 = hw[0];
+  }
   const char *env_pp = getenv("RDGPU_FILL_PAIRS");   // =0: k_scan<L16>, one block per tile (A/B and tests)
   const bool persistent_pairs = !(env_pp && env_pp[0] == '0');
   const uint32_t nwork1 = listed ? lists->n[1] : ntiles;   // scan tiles the pair pass visits
@@ -2677,7 +2861,7 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   EdgeOut eo{elist[0], elist[0] + ecap, elist[0] + 2 * ecap, segcount, segcap, nseg - 1, dflags + 5};
   eo.seglimit = env_cap ? (uint32_t)std::min<uint64_t>(segcap, std::max<uint64_t>(1, cdiv(cap, nseg))) : segcap;   // (the cap given on purpose is enforced to the record: the overflow tests)
   uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
-  uint32_t nroots = B, nedges = 0;
+  uint32_t nroots = nroots0, nedges = 0;
   int ein = 0;
   bool first = true, eseg = true;
   const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
@@ -2758,6 +2942,17 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *lvl = fo.G;   // (the node table is dead: its storage holds the nodes' levels)
   RD_LAUNCH("fill.node_levels", k_node_levels, ngrid, dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc,
             (const unsigned long long *)fo.counters, fo.rcap, lvl);
+  if (sharded) {   // the watershed of every node, and everything rdgpu_fill_shard_export / _finish need
+    uint32_t *nodeW = alloc->get<uint32_t>("fused.nodeW", fo.gcap);
+    RD_LAUNCH("fill.node_watersheds", k_node_watersheds, ngrid, dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)cur,
+              (const uint32_t *)tid, (const unsigned long long *)fo.counters, fo.rcap, B, nodeW);
+    keep->compact = true;
+    keep->cur = cur; keep->acc = acc; keep->tid = tid;
+    keep->lab16 = fo.lab16; keep->tile_base = fo.tile_base; keep->tile_count = fo.tile_count;
+    keep->curN = curN; keep->lvl = lvl; keep->nodeW = nodeW; keep->counters = fo.counters;
+    keep->rcap = fo.rcap; keep->nstripes = nstripes; keep->nnmax = NNmax;
+    return true;
+  }
   if (listed && lists->n[2] == 0) return true;
   if (vec)
     RD_LAUNCH("fill.finalize", (k_finalize16<T, true>), dim3(listed ? lists->n[2] : xcd_grid(dnt)), dim3(NTHR), 0, s, d_z,
@@ -2871,10 +3066,15 @@ static void shard_edges(rdgpu_fill_shard *sh) {
     RD_HIP(hipMemsetAsync(hvals, 0xFF, (size_t)hsize * 4, s));
     RD_HIP(hipMemsetAsync(ctr, 0, 16, s));
     const uint32_t etx = cdiv(w, EW), ent = etx * cdiv(h, EH);
-    RD_LAUNCH("shard.edges", (k_shard_edges<T, TOPO>), dim3(xcd_grid(ent)), dim3(NTHR), 0, s,
-              (const T *)sh->d_dem, (const uint32_t *)sh->fb.lab, (const uint32_t *)sh->fb.cur,
-              (const uint32_t *)sh->fb.acc, (const uint32_t *)sh->fb.tid, sh->fb.B, w, h, hkeys, hvals, hsize - 1, ctr, etx,
-              ent);
+    if (sh->fb.compact)
+      RD_LAUNCH("shard.edges", (k_shard_edges16<T, TOPO>), dim3(xcd_grid(ent)), dim3(NTHR), 0, s, (const T *)sh->d_dem,
+                (const uint16_t *)sh->fb.lab16, (const uint32_t *)sh->fb.tile_base, cdiv(w, DW), (const uint32_t *)sh->fb.nodeW,
+                (const uint32_t *)sh->fb.lvl, w, h, hkeys, hvals, hsize - 1, ctr, etx, ent);
+    else
+      RD_LAUNCH("shard.edges", (k_shard_edges<T, TOPO>), dim3(xcd_grid(ent)), dim3(NTHR), 0, s,
+                (const T *)sh->d_dem, (const uint32_t *)sh->fb.lab, (const uint32_t *)sh->fb.cur,
+                (const uint32_t *)sh->fb.acc, (const uint32_t *)sh->fb.tid, sh->fb.B, w, h, hkeys, hvals, hsize - 1, ctr, etx,
+                ent);
     uint32_t *edges = (uint32_t *)nullptr;
     if (sh->cached) {
       edges = ws.buf<uint32_t>("shard.edges", (size_t)hsize * 3);
@@ -2917,8 +3117,22 @@ static rdgpu_fill_shard *shard_begin(T *d_dem, int w, int h, int topology, int o
       Workspace::get().pin();   // (its tables live in the workspace: release_workspace() is refused while it is alive)
     }
     BufAlloc alloc{!sh->cached, &sh->owned, sh->cached};
-    if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
-    else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
+    // the local phase on compact labels (r04: the whole-raster engine with the cut rows as frozen terminals); the classic
+    // 32-bit-label phase where that does not apply (RDGPU_SHARD_FUSED=0, tiny blocks, tables that do not fit)
+    const char *sf = getenv("RDGPU_SHARD_FUSED");
+    bool done = false;
+    if (!(sf && sf[0] == '0') && !sh->open_top && !sh->open_bottom) {
+      // a block without a cut is the whole raster (one rank): the plain compact-label fill, raised at once -- nothing is
+      // left for the exchange or for finish
+      done = topology == 8 ? fill_fused<T, 8>(d_dem, w, h, s) : fill_fused<T, 4>(d_dem, w, h, s);
+      if (done) { sh->fb = FillBuffers(); sh->fb.trivial = true; }
+    } else if (!(sf && sf[0] == '0'))
+      done = topology == 8 ? fill_fused<T, 8>(d_dem, w, h, s, nullptr, nullptr, nullptr, &sh->fb, &alloc, sh->open_top, sh->open_bottom)
+                           : fill_fused<T, 4>(d_dem, w, h, s, nullptr, nullptr, nullptr, &sh->fb, &alloc, sh->open_top, sh->open_bottom);
+    if (!done) {
+      if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
+      else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
+    }
     sh->stats = g_stats;
     if (!sh->fb.trivial && sh->fb.tid) {
       if (topology == 8) shard_edges<T, 8>(sh);
@@ -2956,7 +3170,8 @@ static void shard_finish(rdgpu_fill_shard *sh, const uint32_t *levels2w) {
       RD_LAUNCH("shard.apply", k_shard_apply, dim3(cdiv(sh->fb.B, NTHR)), dim3(NTHR), 0, s,
                 (const uint32_t *)sh->fb.cur, sh->fb.acc, (const uint32_t *)sh->fb.tid, (const uint32_t *)dl, sh->fb.B);
     }
-    fill_finalize<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
+    if (sh->fb.compact) fill_finalize16<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
+    else fill_finalize<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
   }
   RD_HIP(hipStreamSynchronize(s));   // levels2w is caller memory; buffers are freed next
 }
@@ -3124,7 +3339,8 @@ static void shard_finish_dev(rdgpu_fill_shard *sh, const uint32_t *d_levels2w) {
       RD_LAUNCH("shard.apply", k_shard_apply, dim3(cdiv(sh->fb.B, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)sh->fb.cur,
                 sh->fb.acc, (const uint32_t *)sh->fb.tid, d_levels2w, sh->fb.B);
     }
-    fill_finalize<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
+    if (sh->fb.compact) fill_finalize16<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
+    else fill_finalize<T>((T *)sh->d_dem, sh->w, sh->h, sh->fb, s);
   }
   RD_HIP(hipStreamSynchronize(s));   // the handle's buffers are freed next
 }
