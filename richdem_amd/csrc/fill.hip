@@ -1967,9 +1967,12 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
     }
   }
   __syncthreads();
-  const int lx = threadIdx.x & (DW - 1), ly0 = (threadIdx.x >> 6) * (DH / 4);
+  // (the wavefront's index as a SCALAR: everything derived from the row -- bounds tests, LDS row offsets -- then runs on the
+  // scalar unit; this kernel is bound by VALU issue, 4 cycles per wave instruction)
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lx = threadIdx.x & (DW - 1), ly0 = wave_s * (DH / 4);
   const int gx = x0 + lx;
-  {   // descent pointers: k_descent's loop (no cut rows here)
+  {   // descent pointers: k_descent's loop
     uint32_t k0[3], k1[3], k2[3];
 #pragma unroll
     for (int e = 0; e < 3; e++) { k0[e] = sk[ly0 * DLW + lx + e]; k1[e] = sk[(ly0 + 1) * DLW + lx + e]; }
@@ -2094,7 +2097,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   constexpr uint16_t ROOT_TAG = 0xC000u;   // a numbered root's entry: ROOT_TAG | slot (pointers are < 4096, codes >= LTERM_BASE)
   {
     uint32_t pre = incl - mine;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) pre += wtot[k];
+    for (int k = 0; k < wave_s; k++) pre += wtot[k];
     uint32_t slot = (pre >> 16) + (OUTLETS ? 1u : 0u), pit = pbase + (pre & 0xFFFFu);
     if (OUTLETS) {
       if (threadIdx.x == 0 && gfits) fo.G[nodes0] = OUTP;
@@ -2468,7 +2471,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
   for (;;) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));   // opaque: see above
-    const int lx = tid & (TW - 1), band = tid >> 6, lane = tid & 63;
+    const int lx = tid & (TW - 1), band = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int rly = ring_y(tid), rlx = ring_x(tid);
     const bool isring = tid < RING;
     const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;

@@ -62,7 +62,7 @@ def main():
     steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1"]
     # the profiling passes run the fill only, or (--path) the fill and the stages after it; never the host path
-    prof_tail = (["--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-host", "--no-pf-flowdirs"]
+    prof_tail = (["--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--no-host", "--no-pf-flowdirs", "--no-draining-mfd"]
                  + ([] if "--path" in sys.argv else ["--no-stages"]))
     what = "path40k" if "--path" in sys.argv else "fill40k"
     os.makedirs(OUT, exist_ok=True)
@@ -99,7 +99,7 @@ def main():
         for r in rows:
             f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f}\n")
     # per-launch HBM traffic of the fill's kernels, under the names the library's profiler (and bench.py) uses
-    names = {"k_scan": "fill.scan", "k_descent": "fill.descent", "k_descent16": "fill.descent", "k_tile_label": "fill.tile_label",
+    names = {"k_scan": "fill.scan", "k_pairs16": "fill.scan", "k_descent": "fill.descent", "k_descent16": "fill.descent", "k_tile_label": "fill.tile_label",
              "k_finalize": "fill.finalize", "k_finalize_tiled": "fill.finalize", "k_finalize16": "fill.finalize",
              "k_edge_round": "fill.edge_round", "k_resolve_nodes": "fill.resolve_nodes"}
     per = {}
@@ -116,7 +116,7 @@ def main():
             fill_kernels = ("k_descent", "k_descent16", "k_resolve_nodes", "k_node_levels", "k_finalize16", "k_tile_label", "k_scan",
                             "k_edge_round", "k_finalize", "k_finalize_tiled", "k_hook",
                             "k_chase_links", "k_update_basins", "k_compact_roots", "k_best_reset", "k_init_tables",
-                            "k_compact_alive", "k_sum_segments", "k_chase", "k_label_cells")
+                            "k_compact_alive", "k_sum_segments", "k_chase", "k_label_cells", "k_pairs16", "k_stripe_offsets")
             # launches counted by the profiling command's fills (1 timed + the instrumented pass of bench.py)
             nfill = max(1, sum(r[1] for r in rows if r[0].split("<")[0] in ("rdgpu::k_descent", "rdgpu::k_descent16")))
             per_fill = sum(r[4] * r[1] for r in rows if r[0].split("<")[0].replace("rdgpu::", "") in fill_kernels) / nfill
