@@ -1884,6 +1884,11 @@ struct FusedBuf {
   unsigned long long *counters;    // [stripe * FSTRIDE] (nodes << 32) | pits of the stripe
   uint32_t gcap, rcap, smask;
   uint32_t *overflow;
+  // the first and last column of every descent tile as compact records (key, slot), [tile][side][row]: the pair pass takes
+  // its tiles' ring columns from these -- read from the raster a ring column costs a 64-byte sector per row and array
+  // for one cell (12.5 GB per pass at S3 once the neighbouring tile's rows are no longer in L2; r04a counters)
+  uint32_t *edgeK = nullptr;
+  uint16_t *edgeS = nullptr;
 };
 
 // after the descent: dense basin ids.  out[0] = basins, out[1] = nodes in use, out[2] = the fullest stripe's node count
@@ -2124,6 +2129,16 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
     const uint16_t v = lp[ly * LPD + lx];
     const uint16_t rv = lp[v < (uint16_t)(LPD * DH) ? v : ly * LPD + lx];
     if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = (uint16_t)(rv & 0x0FFFu);
+  }
+  // the tile's first and last column as compact records for the pair pass: two wavefronts, one row per lane, coalesced
+  // (cells past the raster's end are written too and never read)
+  if (fo.edgeK && threadIdx.x < 2 * DH) {
+    const int side = threadIdx.x >> 6, ly = threadIdx.x & (DH - 1), lxe = side ? DW - 1 : 0;
+    const uint16_t v = lp[ly * LPD + lxe];
+    const uint16_t rv = lp[v < (uint16_t)(LPD * DH) ? v : ly * LPD + lxe];
+    const size_t e = ((size_t)t * 2 + side) * DH + ly;
+    fo.edgeK[e] = sk[(ly + 1) * DLW + lxe + 1];
+    fo.edgeS[e] = (uint16_t)(rv & 0x0FFFu);
   }
 }
 
@@ -2375,7 +2390,8 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
                                                   EdgeOut eo,
                                                   const uint32_t *__restrict__ tile_base,
                                                   const uint32_t *__restrict__ tile_count, uint32_t dtx,
-                                                  const uint8_t *__restrict__ skip, int precheck) {
+                                                  const uint8_t *__restrict__ skip, int precheck,
+                                                  const uint32_t *__restrict__ edgeK, const uint16_t *__restrict__ edgeS) {
   __shared__ __attribute__((aligned(8))) uint32_t sk[LH * LW];
   __shared__ uint32_t sc[LH * LW];
   __shared__ __attribute__((aligned(4))) uint16_t list[TW * TH];   // boundary cells; before that: the node table
@@ -2386,21 +2402,27 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
   uint32_t *const tab_id = sk;   // the component table lives in the keys' storage once the pairs are reduced
   unsigned long long *const tab_val = reinterpret_cast<unsigned long long *>(sk + SC_SLOTS);
 
-  // ---- this block's tiles: XCD band, strided by the blocks per XCD -------------------------------------------------
+  // ---- this block's tiles: a RUN of consecutive tiles of its XCD's band.  Consecutive tiles are neighbours in a tile row:
+  // the left ring column of a tile was loaded a tile ago (L2), and what its right ring column fetches -- one 64-byte sector
+  // per row and array for a single cell -- is what the next tile's rows start with.  Strided over the blocks instead
+  // (tile j, j + blocks, ...) every ring column missed: 21.8 GB fetched per launch instead of 11 (r04a counters).
   const uint32_t xcd = blockIdx.x & 7u, kb = gridDim.x >> 3, per = (nwork + 7u) / 8u;
   const uint32_t seg = blockIdx.x;   // the block's own segment of the pair list: no counter in HBM to wait for
-  uint32_t it = blockIdx.x >> 3;
+  const uint32_t run = (per + kb - 1u) / kb;
+  uint32_t it = (blockIdx.x >> 3) * run;
+  const uint32_t it_end = min(it + run, per);
+  constexpr uint32_t kstep = 1u;
   auto next_tile = [&](uint32_t &i) -> uint32_t {
-    while (i < per) {
+    while (i < it_end) {
       const uint32_t wi = xcd * per + i;
       if (wi >= nwork) break;
       const uint32_t t = tiles_in ? tiles_in[wi] : wi;
       if (!skip) return t;
       const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
       if (!skip[(uint32_t)(y0 / DH) * dtx + (uint32_t)(x0 / DW)]) return t;
-      i += kb;
+      i += kstep;
     }
-    i = per;
+    i = it_end;
     return NO_TILE;
   };
   if (threadIdx.x == 0) seg_fill = 0;
@@ -2409,7 +2431,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
   Quad<T> zq[2];
   Quad<uint16_t> lq[2];
   T rz = T();
-  uint32_t rl = 0, rtb = 0, rc = 0, tbC = 0, cnt = 0;
+  uint32_t rl = 0, rtb = 0, rc = 0, tbC = 0, cnt = 0, rkey = 0;
   uint32_t nt[NT_CAP / NTHR];
   // ring cell of a thread (threads >= RING repeat the last one's loads and store nothing).  Everything that depends on
   // the thread index is recomputed from an opaque copy of it in every trip of the tile loop: hoisted out of the loop
@@ -2423,10 +2445,17 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
     tbC = tile_base[dC];
     cnt = tile_count[dC];
     {   // the ring first: its component gather (load_b) then only waits for these
-      const int gx = min(max(x0 - 1 + ring_x(tid), 0), w - 1), gy = min(max(y0 - 1 + ring_y(tid), 0), h - 1);
-      const size_t g = (size_t)gy * w + gx;
-      rl = lab16[g];
-      rtb = tile_base[(uint32_t)(gy / DH) * dtx + (uint32_t)(gx / DW)];
+      const int rx = ring_x(tid), ry = ring_y(tid);
+      const int gx = min(max(x0 - 1 + rx, 0), w - 1), gy = min(max(y0 - 1 + ry, 0), h - 1);
+      // a ring COLUMN cell comes from the neighbouring descent tile's edge records (edgeK / edgeS, when the descent
+      // wrote them): the left ring column is that tile's last column, the right one its first
+      const bool col = edgeK && ry >= 1 && ry <= TH && tid < RING;
+      const uint32_t dtn = (uint32_t)(gy / DH) * dtx + (uint32_t)(gx / DW);
+      const size_t e = ((size_t)dtn * 2 + (rx == 0 ? 1 : 0)) * DH + (uint32_t)(gy % DH);
+      const size_t g = col ? (size_t)y0 * w + x0 : (size_t)gy * w + gx;   // (a column cell reads nothing new from the raster)
+      rtb = tile_base[dtn];
+      rl = col ? (uint32_t)edgeS[e] : (uint32_t)lab16[g];
+      rkey = col ? edgeK[e] : 0u;
       rz = z[g];
     }
     // the tile's quads: the tile's first cell is a block-uniform (scalar) address, a thread adds a 32-bit byte offset
@@ -2521,12 +2550,13 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
       if (isring) {
         const int gx = x0 - 1 + rlx, gy = y0 - 1 + rly;
         const bool ok = gx >= 0 && gx < w && gy >= 0 && gy < h;
-        sk[rly * LW + rlx] = ok ? Key32<T>::to(rz) : 0u;
+        const bool col = edgeK && rly >= 1 && rly <= TH;
+        sk[rly * LW + rlx] = ok ? (col ? rkey : Key32<T>::to(rz)) : 0u;
         sc[rly * LW + rlx] = ok ? rc : (B | CLOSED);
       }
     }
     // ---- the next tile's loads go out now and land while this tile is worked on ---------------------------------------
-    it += kb;
+    it += kstep;
     const uint32_t tn = next_tile(it);
     const uint32_t tl = tn != NO_TILE ? tn : t;   // (no next tile: this one's rows once more -- cheaper than a branch)
     load_a(tl, tid);
@@ -2769,6 +2799,11 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   uint32_t *pitoff = ws.buf<uint32_t>("fused.pitoff", FSTRIPES);
   fo.overflow = dflags + 5;
   uint32_t *curN = (uint32_t *)persistent("fused.curN", (size_t)fo.gcap * 4);
+  const char *env_edge = getenv("RDGPU_FILL_EDGECOLS");   // =0: ring columns from the raster (A/B)
+  if (!outlet && !(env_edge && env_edge[0] == '0')) {   // (with outlets, tiles are skipped: their records would be stale)
+    fo.edgeK = ws.buf<uint32_t>("fused.edgeK", (size_t)dnt * 2 * DH);
+    fo.edgeS = ws.buf<uint16_t>("fused.edgeS", (size_t)dnt * 2 * DH);
+  }
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * sizeof(uint32_t), s));
   RD_HIP(hipMemsetAsync(fo.counters, 0, (size_t)FSTRIPES * FSTRIDE * sizeof(unsigned long long), s));
   if (outlet) {   // node 0 (the first of stripe 0): the "outside" node of the skipped tiles
@@ -2882,11 +2917,11 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
         if (vec)
           RD_LAUNCH("fill.scan", (k_pairs16<T, TOPO, true>), dim3(pgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint16_t *)fo.lab16,
                     (const uint32_t *)curN, best, w, h, B, tilesX, sl_, nwork, eo, (const uint32_t *)fo.tile_base,
-                    (const uint32_t *)fo.tile_count, dtx, skip, precheck);
+                    (const uint32_t *)fo.tile_count, dtx, skip, precheck, (const uint32_t *)fo.edgeK, (const uint16_t *)fo.edgeS);
         else
           RD_LAUNCH("fill.scan", (k_pairs16<T, TOPO, false>), dim3(pgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint16_t *)fo.lab16,
                     (const uint32_t *)curN, best, w, h, B, tilesX, sl_, nwork, eo, (const uint32_t *)fo.tile_base,
-                    (const uint32_t *)fo.tile_count, dtx, skip, precheck);
+                    (const uint32_t *)fo.tile_count, dtx, skip, precheck, (const uint32_t *)fo.edgeK, (const uint16_t *)fo.edgeS);
       } else if (vec)
         RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, true, true, true>), dim3(xcd_grid(nwork)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
