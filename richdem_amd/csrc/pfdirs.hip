@@ -188,8 +188,11 @@ __global__ __launch_bounds__(NT) void k_twins(const T *__restrict__ z, uint64_t 
   const uint64_t stride = (uint64_t)gridDim.x * NT;
   uint32_t twins = 0;
   for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
-    const uint32_t k = Key32<T>::to(z[c]), bit = 1u << (k & 31u);
-    if (atomicOr(&bits[k >> 5], bit) & bit) twins++;
+    const T v = z[c];
+    const uint32_t k = Key32<T>::to(v), bit = 1u << (k & 31u);
+    // (a cell that holds the type's highest value -- the levels' WALL -- counts as well: the wall must lie above every
+    // elevation, and on the ranks, which a count > 0 sends the raster to, it does)
+    if ((atomicOr(&bits[k >> 5], bit) & bit) || !(v < wall_value<T>())) twins++;
   }
   for (int o = 32; o > 0; o >>= 1) twins += __shfl_down(twins, o, 64);
   if ((threadIdx.x & 63) == 0 && twins) atomicAdd(&counters[(blockIdx.x & 63) * 2], (unsigned long long)twins);   // striped
@@ -259,6 +262,17 @@ __global__ __launch_bounds__(NT) void k_rank_keys(const T *__restrict__ z, uint3
     idx[c] = (uint32_t)c;
   }
 }
+// census on the sorted keys (rasters below 2^26 cells: no 512 MB bitmap for a 200 x 200 DEM -- ADVICE r03): cells whose key
+// equals their predecessor's, and cells holding the levels' wall value (see k_twins)
+__global__ __launch_bounds__(NT) void k_sorted_twins(const uint32_t *__restrict__ skeys, uint64_t n, uint32_t wall_key,
+                                                     unsigned long long *counters) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  uint32_t twins = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride)
+    if ((i > 0 && skeys[i] == skeys[i - 1]) || skeys[i] >= wall_key) twins++;
+  for (int o = 32; o > 0; o >>= 1) twins += __shfl_down(twins, o, 64);
+  if ((threadIdx.x & 63) == 0 && twins) atomicAdd(&counters[(blockIdx.x & 63) * 2], (unsigned long long)twins);
+}
 __global__ __launch_bounds__(NT) void k_rank_scatter(const uint32_t *__restrict__ sidx, uint32_t *rk, uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * NT;
   for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) rk[sidx[i]] = (uint32_t)i;
@@ -304,9 +318,30 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   unsigned long long *counters = ws.buf<unsigned long long>("pfd.counters", 128 + 4);
   unsigned long long *sums = counters + 128;   // [0] undecided, [1] wet, [2] unresolved
   RD_HIP(hipMemsetAsync(counters, 0, (128 + 4) * sizeof(unsigned long long), s));
+  bool sorted = false;   // (keys, cells) are already sorted: the census of a small raster
+  uint32_t *keys = nullptr, *skeys = nullptr, *idx = nullptr, *sidx = nullptr;
+  auto sort_cells = [&]() {   // (LSD radix sort: stable, so equal keys stay in raster order)
+    keys = ws.buf<uint32_t>("pfd.rkeys", n); skeys = ws.buf<uint32_t>("pfd.rskeys", n);
+    idx = ws.buf<uint32_t>("pfd.ridx", n); sidx = ws.buf<uint32_t>("pfd.rsidx", n);
+    RD_LAUNCH("pfd.rank_keys", (k_rank_keys<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, keys, idx, n);
+    size_t tb = 0;
+    RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+    void *tmp = ws.buf("pfd.rtmp", tb);
+    RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+    sorted = true;
+  };
   {
-    const char *env = getenv("RDGPU_PFD_TWINS");   // =0: skip the equal-elevation census (512 MB of bits)
-    if (!(env && env[0] == '0') && !g_rank_pass) {
+    const char *env = getenv("RDGPU_PFD_TWINS");   // =0: skip the equal-elevation census
+    if (!(env && env[0] == '0') && !g_rank_pass && n < ((uint64_t)1 << 26)) {
+      sort_cells();
+      RD_LAUNCH("pfd.sorted_twins", k_sorted_twins, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)skeys, n,
+                Key32<T>::to(wall_value<T>()), counters);
+      RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
+      unsigned long long tw = 0;
+      RD_HIP(hipMemcpyAsync(&tw, sums, sizeof tw, hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      g_stats.twins = (uint32_t)std::min<unsigned long long>(tw, 0xFFFFFFFFull);
+    } else if (!(env && env[0] == '0') && !g_rank_pass) {   // 512 MB of bits: small beside a raster of >= 2^26 cells
       uint32_t *bits = ws.buf<uint32_t>("pfd.keybits", (size_t)1 << 27);
       RD_HIP(hipMemsetAsync(bits, 0, (size_t)1 << 29, s));
       RD_LAUNCH("pfd.twins", (k_twins<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, n, bits, counters);
@@ -320,13 +355,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   {
     const char *re = getenv("RDGPU_PFD_RANKS");   // =0: ties decided inside the levels, by neighbour number (r03; A/B and tests)
     if (g_stats.twins != 0 && !g_rank_pass && !(re && re[0] == '0')) {
-      uint32_t *keys = ws.buf<uint32_t>("pfd.rkeys", n), *skeys = ws.buf<uint32_t>("pfd.rskeys", n);
-      uint32_t *idx = ws.buf<uint32_t>("pfd.ridx", n), *sidx = ws.buf<uint32_t>("pfd.rsidx", n);
-      RD_LAUNCH("pfd.rank_keys", (k_rank_keys<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, keys, idx, n);
-      size_t tb = 0;   // (LSD radix sort: stable, so equal keys stay in raster order)
-      RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
-      void *tmp = ws.buf("pfd.rtmp", tb);
-      RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+      if (!sorted) sort_cells();
       uint32_t *rk = keys;   // (the unsorted keys are dead)
       RD_LAUNCH("pfd.rank_scatter", k_rank_scatter, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sidx, rk, n);
       const rdgpu_pf_flowdirs_stats mine = g_stats;

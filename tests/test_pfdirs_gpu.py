@@ -156,3 +156,24 @@ def test_border_only_rasters_and_errors(rd, orc):
         assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.float32(-1)), orc.port.pf_flowdirs(dem, np.float32(-1))), shape
     with pytest.raises(rd.RdgpuError):
         rd.pf_flowdirs(np.zeros((4, 4), np.complex64))
+
+
+def test_the_types_highest_value_in_the_dem(rd, orc):
+    """The levels' walls are the element type's highest value (+inf for floats); a DEM that holds that value itself -- 255 in
+    a uint8 raster -- is flooded on its unique ranks, where no cell reaches the wall."""
+    rng = np.random.default_rng(12)
+    dem = (16 + rng.permutation(240)).reshape(15, 16).astype(np.uint8)     # distinct values 16..255: 255 is in the DEM
+    assert dem.max() == 255 and np.unique(dem).size == dem.size
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rd.pf_flowdirs(dem, nodata=np.uint8(0))
+    assert np.array_equal(got, orc.port.pf_flowdirs(dem, np.uint8(0)))      # tie free: the reference's answer
+    f = np.full((40, 50), 5.0, np.float32) + rng.random((40, 50)).astype(np.float32)
+    f[10:14, 20:24] = np.inf          # a mesa of +inf: a wall inside the DEM
+    order = np.argsort(f.ravel(), kind="stable")
+    ranks = np.empty(f.size, np.int32)
+    ranks[order] = np.arange(f.size, dtype=np.int32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rd.pf_flowdirs(f, nodata=np.float32(-9999))
+    assert np.array_equal(got, orc.port.pf_flowdirs(ranks.reshape(f.shape), np.int32(-9999)))
