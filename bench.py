@@ -185,7 +185,8 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         ps = rd.pf_flowdirs_stats()
         out["priority_flood_flowdirs"].update({"input": "the unfilled bench DEM", "levels": ps["levels"],
                                                "cells_with_an_equal_elevation_twin": ps["twins"],
-                                               "directions_decided_among_ties": ps["unresolved"]})
+                                               "tie_order_passes": ps["tie_passes"],
+                                               "cells_with_an_unsettled_tie_order": ps["unresolved"]})
         out["priority_flood_flowdirs"]["cells_differing_from_reference"] = _differing(torch, pdirs, "flowdirs")
     return out
 

@@ -164,7 +164,10 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
   uint32_t twins;       /* cells whose elevation occurs more than once in the raster: 0 => the result is the reference's */
-  uint64_t unresolved;  /* cells whose direction was decided by neighbour number among equal candidates */
+  uint64_t unresolved;  /* twins != 0: cells whose place in the tie order was still moving when the passes ran out (0: the
+                           result is the reference's); RDGPU_PFD_RANKS=0: directions decided by neighbour number */
+  uint32_t tie_passes;  /* passes of the tie order's fixed point (floods beyond the first) */
+  uint32_t reserved;
 } rdgpu_pf_flowdirs_stats;
 int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);
 #define RDGPU_DECL_PFD(SUF, T)                                                                              \

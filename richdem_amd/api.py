@@ -164,21 +164,23 @@ def pf_flowdirs_dev(dem, nodata, dirs) -> None:
 
 
 class _PfdStats(ctypes.Structure):
-    _fields_ = [("levels", ctypes.c_uint32), ("twins", ctypes.c_uint32), ("unresolved", ctypes.c_uint64)]
+    _fields_ = [("levels", ctypes.c_uint32), ("twins", ctypes.c_uint32), ("unresolved", ctypes.c_uint64),
+                ("tie_passes", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 def pf_flowdirs_stats() -> dict:
     st = _PfdStats()
     check(lib().rdgpu_pf_flowdirs_get_stats(ctypes.byref(st)), "rdgpu_pf_flowdirs_get_stats")
-    return {"levels": st.levels, "twins": st.twins, "unresolved": st.unresolved}
+    return {"levels": st.levels, "twins": st.twins, "unresolved": st.unresolved, "tie_passes": st.tie_passes}
 
 
 def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     """PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555): uint8 D8 directions in which every cell
-    points at the neighbour the (non-raising) flood reached first; NoData cells 0.  Equal to the reference on DEMs without
-    equal elevations; with ties the reference follows its queue's insertion order, this engine the raster order of the equal
-    cells (the flood runs on the raster's unique ranks) -- a RuntimeWarning reports the number of cells with a twin
-    (pf_flowdirs_stats()["twins"])."""
+    points at the neighbour the (non-raising) flood reached first; NoData cells 0.  Equal to the reference, equal
+    elevations included: the reference's stable queue pops equal elevations in order of insertion, and that order is found
+    as a fixed point -- the flood runs on the raster's unique ranks of (elevation, discovery time) until the ranks
+    reproduce themselves (pf_flowdirs_stats(): "twins" cells with an equal elsewhere, "tie_passes" extra floods; a
+    RuntimeWarning only if the passes ran out, "unresolved" != 0)."""
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("pf_flowdirs: expected a 2-D numpy array")
     dem = np.ascontiguousarray(dem)
@@ -188,14 +190,12 @@ def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     check(getattr(lib(), f"rdgpu_pf_flowdirs_{s}")(dem.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h,
                                                    out.ctypes.data_as(ctypes.c_void_p)), "rdgpu_pf_flowdirs")
     st = pf_flowdirs_stats()
-    if st["unresolved"] or st["twins"]:
+    if st["unresolved"]:
         import warnings
 
-        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell; the reference orders equal "
-                      "elevations by the insertion counters of its queue, this engine floods the raster's unique ranks (equal "
-                      "cells in raster order) -- the reference's answer for that order of the ties"
-                      + (f"; {st['unresolved']} directions were decided among equal candidates" if st["unresolved"] else ""),
-                      RuntimeWarning)
+        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell and the order of {st['unresolved']} "
+                      "of them among their equals was still moving when the passes ran out (RDGPU_PFD_TIE_PASSES): the result is "
+                      "the reference's only where those ties do not decide", RuntimeWarning)
     return out
 
 

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT) void k_finish(const T *__restrict__ z, T nodata
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(unresolved, (unsigned long long)bad);
 }
 
-static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0};
+static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0, 0, 0};
 static thread_local bool g_rank_pass = false;   // the call runs on the unique ranks of another raster (see pf_flowdirs_device)
 
 // ---- equal elevations: the flood on UNIQUE RANKS (r04) ----------------------------------------------------------------------
@@ -277,6 +277,173 @@ __global__ __launch_bounds__(NT) void k_rank_scatter(const uint32_t *__restrict_
   const uint64_t stride = (uint64_t)gridDim.x * NT;
   for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) rk[sidx[i]] = (uint32_t)i;
 }
+
+// ---- equal elevations, EXACTLY (r04): the stable queue's order as a fixed point ---------------------------------------------
+// The reference pops equal elevations in the order they were pushed: cell c's tie key is its DISCOVERY time
+//     tau(c) = (pop rank R of the cell that closed c, position of c among that cell's pushes in d8_order),
+// border cells first, in the order of the reference's two set-up loops (:508-528).  For a tie-free raster the flood's pop
+// order has a closed form on the tree of directions: with parent'(c) = c's nearest ancestor of GREATER elevation, a cell's
+// key of nested fill levels (header) is the path root -> c of the tree T' so defined, and the lexicographic order of those
+// keys, a prefix first, is the PREORDER of T' with children sorted by elevation.  So: flood the unique ranks of (z, tau)
+// exactly, read R off the result, form the discovery times, rank again, until the ranks stop moving.  A fixed point is the
+// reference's order: if the first m pops of a pass are the reference's, the queue after them holds the same cells with the
+// same parents, their new tie keys are their true discovery times, and pop m + 1 is the reference's as well -- and since
+// every pass is an exact flood of SOME order, the passes converge from the front.  Passes needed: the longest chain of tie
+// decisions that depend on earlier ones -- 2 on float terrain, the breadth-first depth of the largest plateau on integer
+// DEMs (tests/test_pfdirs_gpu.py asserts == the compiled reference on the reference's own tie-heavy vectors).
+constexpr uint32_t T_ROOT = 0xFFFFFFFFu;
+
+// parent cell in the tree of directions (T_ROOT: a border cell -- pushed before the flood starts)
+__global__ __launch_bounds__(NT) void k_tie_parents(const uint8_t *__restrict__ dirs, uint32_t *par, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    const int d = dirs[c];
+    const bool border = x == 0 || y == 0 || x == w - 1 || y == h - 1;
+    par[c] = (border || d == 0) ? T_ROOT : (uint32_t)((size_t)(y + ndy(d)) * w + (x + ndx(d)));
+  }
+}
+
+// one round of "nearest ancestor of greater rank" by pointer jumping: every ancestor strictly between c and g[c] has a
+// smaller rank than c, so while g[c] is smaller too, g[g[c]] -- whatever another lane has made of it meanwhile -- is the
+// next candidate
+__global__ __launch_bounds__(NT) void k_tie_greater(const uint32_t *__restrict__ rk, uint32_t *g, uint64_t n, uint32_t *changed) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  bool ch = false;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    uint32_t a = g[c];
+    const uint32_t r = rk[c];
+    int hops = 0;
+    while (a != T_ROOT && rk[a] < r && hops < 8) { a = __hip_atomic_load(&g[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hops++; }
+    if (hops) { __hip_atomic_store(&g[c], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ch |= (a != T_ROOT && rk[a] < r); }
+  }
+  if (__any(ch) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+
+// depth in T' by pointer doubling (ping-pong): anc / dist -> anc2 / dist2
+__global__ __launch_bounds__(NT) void k_tie_depth(const uint32_t *__restrict__ anc, const uint32_t *__restrict__ dist, uint32_t *anc2,
+                                                  uint32_t *dist2, uint64_t n, uint32_t *changed) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  bool ch = false;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t a = anc[c];
+    uint32_t d = dist[c], a2 = a;
+    if (a != T_ROOT) { d += dist[a]; a2 = anc[a]; ch |= a2 != T_ROOT; }
+    anc2[c] = a2;
+    dist2[c] = d;
+  }
+  if (__any(ch) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+
+__global__ __launch_bounds__(NT) void k_tie_init(const uint32_t *__restrict__ g, uint32_t *anc, uint32_t *dist, uint32_t *size,
+                                                 uint32_t *cells, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    anc[c] = g[c];
+    dist[c] = 1;          // depth 1: a child of the virtual root
+    size[c] = 1;
+    cells[c] = (uint32_t)c;
+  }
+}
+
+// first index of every depth in the cells sorted by depth: start[d] for d = 1 .. maxd, start[maxd + 1] = n
+__global__ __launch_bounds__(NT) void k_tie_bucket_starts(const uint32_t *__restrict__ sdepth, uint64_t n, uint32_t *start) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+    const uint32_t d = sdepth[i], dp = i ? sdepth[i - 1] : 0u;
+    for (uint32_t k = dp + 1; k <= d; k++) start[k] = (uint32_t)i;
+    if (i == n - 1) start[d + 1] = (uint32_t)n;
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_tie_sizes_up(const uint32_t *__restrict__ cells, uint32_t lo, uint32_t hi,
+                                                     const uint32_t *__restrict__ g, uint32_t *size) {
+  const uint32_t i = lo + blockIdx.x * NT + threadIdx.x;
+  if (i >= hi) return;
+  const uint32_t c = cells[i];
+  atomicAdd(&size[g[c]], size[c]);   // (depth >= 2: g[c] is a cell)
+}
+
+// sibling order: key = (parent' + 1) << 32 | own rank
+__global__ __launch_bounds__(NT) void k_tie_sibling_keys(const uint32_t *__restrict__ g, const uint32_t *__restrict__ rk,
+                                                         unsigned long long *keys, uint32_t *cells, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    keys[c] = ((unsigned long long)(g[c] + 1u) << 32) | rk[c];
+    cells[c] = (uint32_t)c;
+  }
+}
+// in sibling order: the subtree size of every element (for the scan) and, where a run of siblings starts, its index
+__global__ __launch_bounds__(NT) void k_tie_gather_sizes(const unsigned long long *__restrict__ skeys, const uint32_t *__restrict__ scells,
+                                                         const uint32_t *__restrict__ size, unsigned long long *ssize, uint32_t *head,
+                                                         uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+    ssize[i] = size[scells[i]];
+    head[i] = (i == 0 || (skeys[i] >> 32) != (skeys[i - 1] >> 32)) ? (uint32_t)i : 0u;
+  }
+}
+// off[c] = subtree sizes of c's smaller siblings
+__global__ __launch_bounds__(NT) void k_tie_offsets(const uint32_t *__restrict__ scells, const unsigned long long *__restrict__ scan,
+                                                    const uint32_t *__restrict__ headpos, uint32_t *off, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) off[scells[i]] = (uint32_t)(scan[i] - scan[headpos[i]]);
+}
+// preorder rank, one depth at a time from the top: R(c) = R(parent') + 1 + off(c); children of the virtual root: off(c)
+__global__ __launch_bounds__(NT) void k_tie_ranks_down(const uint32_t *__restrict__ cells, uint32_t lo, uint32_t hi,
+                                                       const uint32_t *__restrict__ g, const uint32_t *__restrict__ off, uint32_t *R) {
+  const uint32_t i = lo + blockIdx.x * NT + threadIdx.x;
+  if (i >= hi) return;
+  const uint32_t c = cells[i], p = g[c];
+  R[c] = (p == T_ROOT ? 0u : R[p] + 1u) + off[c];
+}
+
+// discovery time: border cells in the order of the reference's set-up loops (:508-519: for x: (x, 0), (x, h - 1); for
+// y = 1 .. h - 2: (0, y), (w - 1, y)), then (pop rank of the closing cell, position among its pushes in d8_order)
+__global__ __launch_bounds__(NT) void k_tie_tau(const uint8_t *__restrict__ dirs, const uint32_t *__restrict__ par,
+                                                const uint32_t *__restrict__ R, unsigned long long *tau, uint32_t *cells, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  const unsigned long long nb = 2ull * w + 2ull * h;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    unsigned long long t;
+    if (y == 0) t = 2ull * x;
+    else if (y == h - 1) t = 2ull * x + 1;
+    else if (x == 0) t = 2ull * w + 2ull * (y - 1);
+    else if (x == w - 1) t = 2ull * w + 2ull * (y - 1) + 1;
+    else {
+      const int d = dirs[c];                                  // towards the closing cell; it pushed c in direction inverse(d)
+      const int inv = d == 0 ? 0 : ((d + 3) & 7) + 1;         // d8_inverse: 1<->5, 2<->6, 3<->7, 4<->8
+      const int pos = (inv & 1) ? (inv - 1) >> 1 : 4 + ((inv - 2) >> 1);   // d8_order = 1,3,5,7,2,4,6,8
+      const uint32_t p = par[c];
+      t = nb + (p == T_ROOT ? 0ull : ((unsigned long long)R[p] + 1ull) * 8ull + (unsigned long long)pos);
+    }
+    tau[c] = t;
+    cells[c] = (uint32_t)c;
+  }
+}
+__global__ __launch_bounds__(NT) void k_tie_gather_keys(const uint32_t *__restrict__ zkey, const uint32_t *__restrict__ order,
+                                                        uint32_t *out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = zkey[order[i]];
+}
+// new ranks from the final order; counts the cells whose rank moved
+__global__ __launch_bounds__(NT) void k_tie_new_ranks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ rk_old,
+                                                      uint32_t *rk_new, uint64_t n, unsigned long long *moved) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  uint32_t m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+    const uint32_t c = order[i];
+    rk_new[c] = (uint32_t)i;
+    m += rk_old[c] != (uint32_t)i;
+  }
+  for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&moved[(blockIdx.x & 63) * 2], (unsigned long long)m);
+}
+struct MaxU32 {
+  __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
 // interior NoData cells carry no direction (:545-548); the rank pass cannot see which cells those are
 template <class T>
 __global__ __launch_bounds__(NT) void k_nodata_dirs(const T *__restrict__ z, T nodata, uint8_t *dirs, int w, int h) {
@@ -313,7 +480,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_pf_flowdirs: raster too large");
   const uint64_t n = (uint64_t)w * h;
   Workspace &ws = Workspace::get();
-  g_stats = rdgpu_pf_flowdirs_stats{0, 0, 0};
+  g_stats = rdgpu_pf_flowdirs_stats{0, 0, 0, 0, 0};
   uint8_t *cand = ws.buf<uint8_t>("pfd.cand", n);
   unsigned long long *counters = ws.buf<unsigned long long>("pfd.counters", 128 + 4);
   unsigned long long *sums = counters + 128;   // [0] undecided, [1] wet, [2] unresolved
@@ -356,18 +523,136 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     const char *re = getenv("RDGPU_PFD_RANKS");   // =0: ties decided inside the levels, by neighbour number (r03; A/B and tests)
     if (g_stats.twins != 0 && !g_rank_pass && !(re && re[0] == '0')) {
       if (!sorted) sort_cells();
-      uint32_t *rk = keys;   // (the unsorted keys are dead)
+      uint32_t *rk = ws.buf<uint32_t>("pfd.rk", n);
       RD_LAUNCH("pfd.rank_scatter", k_rank_scatter, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sidx, rk, n);
       const rdgpu_pf_flowdirs_stats mine = g_stats;
+      const char *tp = getenv("RDGPU_PFD_TIE_PASSES");   // passes of the tie order's fixed point (0: raster order, r04's first version)
+      const uint32_t max_passes = tp ? (uint32_t)strtoul(tp, nullptr, 10) : 1000u;
+      uint32_t passes = 0, levels_total = 0;
+      unsigned long long moved = 0;
       g_rank_pass = true;
       try {
-        pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
+        for (;;) {
+          pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
+          levels_total += g_stats.levels;
+          if (passes >= max_passes) break;
+          passes++;
+          // ---- the discovery times under this pass's flood, and the ranks of (z, discovery time) -----------------------
+          uint32_t *zkey = keys;   // (keys still holds every cell's key: k_rank_keys' output, untouched by the sort)
+          uint32_t *par = ws.buf<uint32_t>("pfd.t.par", n), *g = ws.buf<uint32_t>("pfd.t.g", n);
+          uint32_t *ancA = ws.buf<uint32_t>("pfd.t.ancA", n), *ancB = ws.buf<uint32_t>("pfd.t.ancB", n);
+          uint32_t *dstA = ws.buf<uint32_t>("pfd.t.dstA", n), *dstB = ws.buf<uint32_t>("pfd.t.dstB", n);
+          uint32_t *size = ws.buf<uint32_t>("pfd.t.size", n), *cellsA = ws.buf<uint32_t>("pfd.t.cellsA", n);
+          uint32_t *cellsB = ws.buf<uint32_t>("pfd.t.cellsB", n);
+          uint32_t *flag = ws.buf<uint32_t>("pfd.t.flag", 4);
+          uint32_t *hw = ws.host_words();
+          RD_LAUNCH("pfd.tie.parents", k_tie_parents, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, par, w, h);
+          RD_HIP(hipMemcpyAsync(g, par, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          for (int round = 0;; round++) {   // nearest ancestor of greater elevation
+            RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+            RD_LAUNCH("pfd.tie.greater", k_tie_greater, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)rk, g, n, flag);
+            RD_HIP(hipMemcpyAsync(hw, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            RD_HIP(hipStreamSynchronize(s));
+            if (hw[0] == 0) break;
+            if (round > 10000) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the record tree did not settle (internal error)");
+          }
+          RD_LAUNCH("pfd.tie.init", k_tie_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, ancA, dstA, size, cellsA, n);
+          for (int round = 0;; round++) {   // depth in T' (pointer doubling)
+            RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+            RD_LAUNCH("pfd.tie.depth", k_tie_depth, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)ancA, (const uint32_t *)dstA, ancB,
+                      dstB, n, flag);
+            std::swap(ancA, ancB);
+            std::swap(dstA, dstB);
+            RD_HIP(hipMemcpyAsync(hw, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            RD_HIP(hipStreamSynchronize(s));
+            if (hw[0] == 0) break;
+            if (round > 64) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: depth doubling did not settle (internal error)");
+          }
+          uint32_t *depth = dstA, *sdepth = dstB;   // cells bucketed by depth
+          size_t tb = 0;
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, depth, sdepth, cellsA, cellsB, (int)n, 0, 32, s));
+          void *tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, depth, sdepth, cellsA, cellsB, (int)n, 0, 32, s));
+          RD_HIP(hipMemcpyAsync(hw, sdepth + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+          RD_HIP(hipStreamSynchronize(s));
+          const uint32_t maxd = hw[0];
+          uint32_t *dstart = ws.buf<uint32_t>("pfd.t.dstart", (size_t)maxd + 2);
+          RD_LAUNCH("pfd.tie.buckets", k_tie_bucket_starts, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sdepth, n, dstart);
+          std::vector<uint32_t> hstart((size_t)maxd + 2);
+          RD_HIP(hipMemcpyAsync(hstart.data(), dstart, ((size_t)maxd + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+          RD_HIP(hipStreamSynchronize(s));
+          const uint32_t *bcells = cellsB;   // cells in order of depth
+          for (uint32_t d = maxd; d >= 2; d--) {   // subtree sizes, deepest first
+            const uint32_t lo = hstart[d], hi = hstart[d + 1];
+            if (hi > lo)
+              RD_LAUNCH("pfd.tie.sizes", k_tie_sizes_up, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, bcells, lo, hi, (const uint32_t *)g, size);
+          }
+          // siblings in order of elevation; off(c) = subtree sizes of c's smaller siblings
+          unsigned long long *k64 = ws.buf<unsigned long long>("pfd.t.k64a", n), *sk64 = ws.buf<unsigned long long>("pfd.t.k64b", n);
+          uint32_t *scells = ancA, *ucells = ancB;   // (the doubling's ancestor arrays are dead)
+          RD_LAUNCH("pfd.tie.sibling_keys", k_tie_sibling_keys, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, (const uint32_t *)rk, k64,
+                    ucells, n);
+          tb = 0;
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k64, sk64, ucells, scells, (int)n, 0, 64, s));
+          tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k64, sk64, ucells, scells, (int)n, 0, 64, s));
+          unsigned long long *ssize = k64;   // (the unsorted keys are dead)
+          uint32_t *head = ucells, *headpos = cellsA, *off = dstB;   // (cellsA, sdepth: dead)
+          RD_LAUNCH("pfd.tie.gather_sizes", k_tie_gather_sizes, dim3(sgrid(n)), dim3(NT), 0, s, (const unsigned long long *)sk64,
+                    (const uint32_t *)scells, (const uint32_t *)size, ssize, head, n);
+          unsigned long long *scan = ws.buf<unsigned long long>("pfd.t.scan", n);
+          tb = 0;
+          RD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ssize, scan, (int)n, s));
+          tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ssize, scan, (int)n, s));
+          tb = 0;
+          RD_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, head, headpos, MaxU32(), (int)n, s));
+          tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, headpos, MaxU32(), (int)n, s));
+          RD_LAUNCH("pfd.tie.offsets", k_tie_offsets, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)scells,
+                    (const unsigned long long *)scan, (const uint32_t *)headpos, off, n);
+          uint32_t *R = size;   // (the sizes are dead once the offsets exist)
+          for (uint32_t d = 1; d <= maxd; d++) {   // preorder ranks, from the top
+            const uint32_t lo = hstart[d], hi = hstart[d + 1];
+            if (hi > lo)
+              RD_LAUNCH("pfd.tie.ranks", k_tie_ranks_down, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, bcells, lo, hi, (const uint32_t *)g,
+                        (const uint32_t *)off, R);
+          }
+          // discovery times -> order by (elevation, discovery time): sort by the time, then stably by the key
+          unsigned long long *tau = sk64, *stau = k64;
+          uint32_t *c0 = ancB, *c1 = ancA;
+          RD_LAUNCH("pfd.tie.tau", k_tie_tau, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, (const uint32_t *)par, (const uint32_t *)R,
+                    tau, c0, w, h);
+          tb = 0;
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
+          tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
+          uint32_t *zk = cellsA, *zks = dstB;   // keys in discovery order
+          RD_LAUNCH("pfd.tie.gather_keys", k_tie_gather_keys, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)zkey, (const uint32_t *)c1, zk, n);
+          tb = 0;
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, zk, zks, c1, c0, (int)n, 0, 32, s));
+          tmp = ws.buf("pfd.rtmp", tb);
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, zk, zks, c1, c0, (int)n, 0, 32, s));
+          uint32_t *rk_new = par;   // (the parents are dead)
+          RD_HIP(hipMemsetAsync(counters, 0, 128 * sizeof(unsigned long long), s));
+          RD_LAUNCH("pfd.tie.new_ranks", k_tie_new_ranks, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)c0, (const uint32_t *)rk, rk_new, n,
+                    counters);
+          RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
+          RD_HIP(hipMemcpyAsync(&moved, sums, sizeof moved, hipMemcpyDeviceToHost, s));
+          RD_HIP(hipStreamSynchronize(s));
+          if (getenv("RDGPU_PFD_TRACE")) fprintf(stderr, "pfd tie pass %u: %llu ranks moved, record tree depth %u\n", passes, moved, maxd);
+          if (moved == 0) break;   // the order reproduces itself: it is the reference's
+          RD_HIP(hipMemcpyAsync(rk, rk_new, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        }
       } catch (...) {
         g_rank_pass = false;
         throw;
       }
       g_rank_pass = false;
       g_stats.twins = mine.twins;
+      g_stats.levels = levels_total;
+      g_stats.tie_passes = passes;
+      g_stats.unresolved = moved;   // ranks still moving when the passes ran out (0: the reference's order)
       RD_LAUNCH("pfd.nodata_dirs", (k_nodata_dirs<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, d_dirs, w, h);
       return;
     }

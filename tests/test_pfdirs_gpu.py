@@ -2,12 +2,15 @@
 depressions (csrc/pfdirs.hip) against the oracle's restatement of the reference's stable-queue sweep, which is pinned to
 the compiled reference (tests/test_oracle_pinning.py).  Equal on DEMs without equal elevations; with ties the cells that
 stay ambiguous are counted."""
+import os
 import warnings
 
 import numpy as np
 import pytest
 
-from richdem_amd.synth import fractal_dem
+from conftest import GOLDEN
+
+from richdem_amd.synth import fractal_dem, fractal_dem_int
 
 pytestmark = pytest.mark.gpu
 
@@ -83,56 +86,68 @@ def test_nodata_cells_and_other_dtypes(rd, orc):
     assert np.array_equal(rd.pf_flowdirs(small, nodata=np.uint8(255)), orc.port.pf_flowdirs(small, np.uint8(255)))
 
 
-def test_ties_are_counted_not_hidden(rd, orc, monkeypatch):
-    """Equal elevations: the reference's answer follows its insertion counters.  The engine floods the raster's UNIQUE RANKS
-    -- equal cells ordered by cell index -- exactly: a direction for every cell, the reference's own answer for the raster
-    with its ties broken in raster order (asserted: equal to the restatement run on that rank raster), a warning, and the
-    count of cells with a twin.  RDGPU_PFD_RANKS=0 keeps r03's late tie-breaking inside the levels (reports `unresolved`).
-    How far either is from the reference on the tied raster is measured, not hidden."""
+def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
+    """Equal elevations: the reference's stable queue (GridCellZk_low_pq, common/grid_cell.hpp:101-122) pops them in order of
+    insertion, so its directions are a function of the DEM -- and the engine's are THE SAME: the tie order is found as the
+    fixed point of "discovery time under the flood of (elevation, discovery time)" (csrc/pfdirs.hip).  The reference's own
+    tie-heavy vectors (tests/golden/ref_pf_flowdirs_ties.npz, compiled reference), random few-level rasters, a flat raster, a
+    quantised terrain with large plateaus, NoData regions."""
+    t = np.load(os.path.join(GOLDEN, "ref_pf_flowdirs_ties.npz"))
+    for name in ("ties_i32", "ties_nodata_f32"):
+        dem = t[f"{name}/dem"]
+        got = rd.pf_flowdirs(dem, nodata=dem.dtype.type(-9999))
+        st = rd.pf_flowdirs_stats()
+        assert st["unresolved"] == 0 and st["twins"] > 0 and st["tie_passes"] >= 1, st
+        assert np.array_equal(got, t[f"{name}/pf_flowdirs"]), (name, int((got != t[f"{name}/pf_flowdirs"]).sum()), st)
     rng = np.random.default_rng(9)
-    dem = rng.integers(0, 6, (80, 100)).astype(np.int32)
-    with warnings.catch_warnings(record=True) as wlist:
-        warnings.simplefilter("always")
-        got = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
-    st = rd.pf_flowdirs_stats()
-    assert st["unresolved"] == 0 and st["twins"] >= dem.size - 6 and any("equal" in str(x.message) for x in wlist)
+    cases = {"6 levels": rng.integers(0, 6, (80, 100)).astype(np.int32),
+             "2 levels": rng.integers(0, 2, (50, 70)).astype(np.uint8),
+             "flat": np.zeros((33, 47), np.int16),
+             "plateaus": fractal_dem_int(300, 260, 32, 0.05),
+             "terrain, integer": fractal_dem_int(400, 300, 31, 1.0),
+             "float32 terrain (local ties)": fractal_dem(700, 500, seed=3)}
+    holes = rng.integers(0, 40, (90, 120)).astype(np.float32)
+    holes[rng.random(holes.shape) < 0.06] = -9999.0
+    holes[30:45, 50:80] = -9999.0
+    holes[:, :4] = -9999.0
+    cases["NoData regions"] = holes
+    for name, dem in cases.items():
+        nd = dem.dtype.type(-9999) if dem.dtype.kind in "if" and dem.dtype.itemsize > 1 else dem.dtype.type(255)
+        got = rd.pf_flowdirs(dem, nodata=nd)
+        st = rd.pf_flowdirs_stats()
+        exp = orc.port.pf_flowdirs(dem, nd)
+        assert st["unresolved"] == 0, (name, st)
+        assert np.array_equal(got, exp), (name, int((got != exp).sum()), dem.size, st)
+    # the two earlier tie rules stay selectable, and say what they are
+    dem = cases["6 levels"]
+    exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
+    monkeypatch.setenv("RDGPU_PFD_TIE_PASSES", "0")          # equal cells in raster order: one exact flood of the unique ranks
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        raster_order = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
     order = np.argsort(dem.ravel(), kind="stable")
     ranks = np.empty(dem.size, np.int32)
     ranks[order] = np.arange(dem.size, dtype=np.int32)
-    assert np.array_equal(got, orc.port.pf_flowdirs(ranks.reshape(dem.shape), np.int32(-9999)))
-    exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
-    monkeypatch.setenv("RDGPU_PFD_RANKS", "0")
+    assert np.array_equal(raster_order, orc.port.pf_flowdirs(ranks.reshape(dem.shape), np.int32(-9999)))
+    monkeypatch.delenv("RDGPU_PFD_TIE_PASSES")
+    monkeypatch.setenv("RDGPU_PFD_RANKS", "0")               # r03: ties decided inside the levels, by neighbour number
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         late = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
-    st0 = rd.pf_flowdirs_stats()
-    assert st0["unresolved"] > 0
-    warnings.warn(f"pf_flowdirs with ties (6 elevations, 80 x 100): {float((got != exp).mean()):.3f} of the cells differ from the "
-                  f"reference's on unique ranks, {float((late != exp).mean()):.3f} with ties decided inside the levels "
-                  f"({st0['unresolved']} cells reported as ambiguous there)")
-    for g in (got, late):
-        assert g.shape == dem.shape and g[1:-1, 1:-1].min() >= 1 and g.max() <= 8
-        assert g[0, 1] == 3 and g[-1, 1] == 7 and g[1, 0] == 1 and g[1, -1] == 5 and g[0, 0] == 2
+    assert rd.pf_flowdirs_stats()["unresolved"] > 0
+    warnings.warn(f"pf_flowdirs, 6 elevations on 80 x 100: fixed point 0.000 of the cells differ from the reference, raster-order "
+                  f"ties {float((raster_order != exp).mean()):.3f}, ties inside the levels {float((late != exp).mean()):.3f}")
 
 
 def test_ties_with_nodata_cells(rd, orc):
-    """NoData cells flood with their NoData value as elevation (two of them are already a tie): on the ranks they take part
-    like any cell and come out with direction 0 where they are interior cells."""
+    """NoData cells flood with their NoData value as elevation (two of them are already a tie) and come out with direction 0
+    where they are interior cells: equal to the reference."""
     rng = np.random.default_rng(10)
     dem = (rng.integers(0, 50, (70, 90))).astype(np.float32)
     dem[rng.random(dem.shape) < 0.05] = -9999.0
     dem[20:30, 40:55] = -9999.0
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        got = rd.pf_flowdirs(dem, nodata=np.float32(-9999))
-    order = np.argsort(dem.ravel(), kind="stable")
-    ranks = np.empty(dem.size, np.int32)
-    ranks[order] = np.arange(dem.size, dtype=np.int32)
-    exp = orc.port.pf_flowdirs(ranks.reshape(dem.shape), np.int32(-9999))
-    interior = np.zeros(dem.shape, bool)
-    interior[1:-1, 1:-1] = True
-    exp[(dem == -9999.0) & interior] = 0
-    assert np.array_equal(got, exp)
+    got = rd.pf_flowdirs(dem, nodata=np.float32(-9999))
+    assert np.array_equal(got, orc.port.pf_flowdirs(dem, np.float32(-9999)))
 
 
 def test_sparse_levels_give_the_same_directions(rd, orc, monkeypatch):
@@ -170,10 +185,5 @@ def test_the_types_highest_value_in_the_dem(rd, orc):
     assert np.array_equal(got, orc.port.pf_flowdirs(dem, np.uint8(0)))      # tie free: the reference's answer
     f = np.full((40, 50), 5.0, np.float32) + rng.random((40, 50)).astype(np.float32)
     f[10:14, 20:24] = np.inf          # a mesa of +inf: a wall inside the DEM
-    order = np.argsort(f.ravel(), kind="stable")
-    ranks = np.empty(f.size, np.int32)
-    ranks[order] = np.arange(f.size, dtype=np.int32)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        got = rd.pf_flowdirs(f, nodata=np.float32(-9999))
-    assert np.array_equal(got, orc.port.pf_flowdirs(ranks.reshape(f.shape), np.int32(-9999)))
+    got = rd.pf_flowdirs(f, nodata=np.float32(-9999))
+    assert np.array_equal(got, orc.port.pf_flowdirs(f, np.float32(-9999)))
