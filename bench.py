@@ -179,7 +179,9 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         # PriorityFloodFlowdirs_Barnes2014: one fill per nesting level of the depressions (seconds, not milliseconds: once)
         del E
         pdirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
-        rd.pf_flowdirs_dev(Z, nodata, pdirs)                                       # workspace growth (the rank sort's 26 GB): not timed
+        os.environ["RDGPU_PFD_TIE_PASSES"] = "1"                                   # workspace growth (~100 GB of sort and tree buffers):
+        rd.pf_flowdirs_dev(Z, nodata, pdirs)                                       # one pass of the tie order, not timed
+        del os.environ["RDGPU_PFD_TIE_PASSES"]
         t_pf = _best(lambda: rd.pf_flowdirs_dev(Z, nodata, pdirs), 1, sync)
         out["priority_flood_flowdirs"] = stage_entry(t_pf, n_cells, STAGE_BYTES["priority_flood_flowdirs"])
         ps = rd.pf_flowdirs_stats()

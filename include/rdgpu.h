@@ -157,10 +157,11 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
  * std::priority_queue's pop order. */
 /* PriorityFloodFlowdirs_Barnes2014(elevations, flowdirs) -- depressions/Barnes2014.hpp:483-555: D8 directions of the flood
  * that does not raise the DEM; every cell points at the neighbour that was flooded first (border cells off the raster, NoData
- * cells 0).  Identical to the reference on DEMs WITHOUT equal elevations (its queue breaks ties by insertion order, which only
- * the serial sweep defines): the stats count the cells with an equal-elevation twin (none: the result is exact) and the
- * cells whose direction was decided by neighbour number.  One whole-raster fill per nesting level of the depressions: provided, not tuned.
- * The highest value of an 8 / 16 / 32-bit element type (+inf for float) must not occur in the DEM. */
+ * cells 0).  Identical to the reference, equal elevations included: the reference's queue breaks ties by insertion order
+ * (GridCellZk_low_pq, common/grid_cell.hpp:101-122) and that order is reproduced as a fixed point -- one exact
+ * flood of the raster's unique ranks per pass, until the ranks reproduce themselves (2 passes on float terrain, the
+ * breadth-first depth of the largest plateau on integer DEMs; RDGPU_PFD_TIE_PASSES caps them, the stats say whether the
+ * order had settled).  One fill per nesting level of the depressions per pass: exact first, not tuned. */
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
   uint32_t twins;       /* cells whose elevation occurs more than once in the raster: 0 => the result is the reference's */

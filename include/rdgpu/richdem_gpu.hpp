@@ -272,8 +272,8 @@ void dirs_into(const E &elevations, F &flowdirs, Fn fn, const char *who) {
 }  // namespace detail
 
 // richdem::PriorityFloodFlowdirs_Barnes2014(const Array2D<T>&, Array2D<d8_flowdir_t>&)   depressions/Barnes2014.hpp:483-555
-// flowdirs resized to the DEM, NoData = NO_FLOW (0) (:495-496).  Identical to the reference on DEMs without equal
-// elevations (rdgpu.h; rdgpu_pf_flowdirs_get_stats counts the cells that ties left ambiguous).
+// flowdirs resized to the DEM, NoData = NO_FLOW (0) (:495-496).  Identical to the reference, equal elevations included
+// (rdgpu.h; rdgpu_pf_flowdirs_get_stats says how many passes the tie order took).
 template <class E, class F>
 void PriorityFloodFlowdirs_Barnes2014(const E &elevations, F &flowdirs) {
   static_assert(std::is_same<detail::elem_t<F>, uint8_t>::value, "PriorityFloodFlowdirs_Barnes2014: flowdirs must be Array2D<d8_flowdir_t>");

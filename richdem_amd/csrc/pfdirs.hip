@@ -1,5 +1,5 @@
 // pfdirs.hip -- PriorityFloodFlowdirs_Barnes2014 (reference include/richdem/depressions/Barnes2014.hpp:483-555) without a
-// priority queue, for DEMs WITHOUT equal elevations.
+// priority queue.
 //
 // The reference floods the DEM without raising it on a queue ordered by (elevation, insertion counter); a cell's
 // direction points at the neighbour that was popped first.  With distinct elevations the pop order is the
@@ -14,15 +14,16 @@
 // So: one fill per nesting level -- the compact-label fill of fill.hip with walls (the highest value of the type)
 // everywhere outside the wet cells and OUTLETS at the entry cells (rdgpu_fill_outlets_dev_*) -- and per cell a shrinking
 // set of candidate neighbours: those with the lowest F_0, among them those with the lowest F_1, ...; a candidate whose
-// sequence has ended (its elevation IS the level) is the phase cell itself and wins.
-// The number of levels is the longest run of successive descents of the flood inside a depression (35 on a 200 x 200
-// fractal DEM, 324 at 40000 x 40000), and the wet set shrinks by ~8 % a level: from the second level on walls are outlets
-// too, the fill's 64 x 64 tiles that hold nothing but walls (ring included) are skipped for good, and every kernel is
-// launched over compacted lists of the tiles that still have work (k_skip_state).  40000 x 40000: 1.5 s.
-// With equal elevations the reference's order depends on its insertion counters: `twins` counts the cells whose elevation
-// occurs more than once (0 => the result is the reference's), `unresolved` the directions that were decided by neighbour
-// number among equal candidates (rdgpu_pf_flowdirs_get_stats).
-// tests/tools/proto_pf_flowdirs.py is the same algorithm in numpy, checked against the oracle.
+// sequence has ended (its elevation IS the level) is the phase cell itself and wins.  From the second level on walls are
+// outlets too, the fill's 64 x 64 tiles that hold nothing but walls are skipped for good, and every kernel is launched over
+// compacted lists of the tiles that still have work (k_skip_state).
+// EQUAL ELEVATIONS (r04): the reference's stable queue pops them in order of insertion, so its output is a function of the
+// DEM -- and it is reproduced: a raster with twins is flooded on its UNIQUE RANKS of (elevation, tie key), and the tie key
+// is iterated to the fixed point "discovery time under the flood it induces" (k_tie_* below): equal to the compiled
+// reference on its own tie-heavy vectors and, digest for digest, on the 40000 x 40000 bench DEM (1.58e9 cells with a twin;
+// 4 floods, 19 s).  `twins`, `tie_passes`, `unresolved` (ranks still moving when RDGPU_PFD_TIE_PASSES ran out: 0 = exact)
+// in rdgpu_pf_flowdirs_get_stats.  RDGPU_PFD_RANKS=0: ties decided inside the levels by neighbour number (r03).
+// tests/tools/proto_pf_flowdirs.py is the tie-free algorithm in numpy, checked against the oracle.
 #include "common.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -247,13 +248,11 @@ static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0, 0, 0};
 static thread_local bool g_rank_pass = false;   // the call runs on the unique ranks of another raster (see pf_flowdirs_device)
 
 // ---- equal elevations: the flood on UNIQUE RANKS (r04) ----------------------------------------------------------------------
-// With equal elevations the reference's pop order follows its insertion counters.  What this engine can do exactly is a
-// tie-free raster; so a raster with twins is replaced by its rank permutation -- position in the order of (elevation, cell
-// index), from one stable radix sort of (key, cell) pairs -- and flooded exactly.  That is the reference's answer for SOME
-// stable order of the equal cells (raster order instead of insertion order), and far closer to it than deciding ties late,
-// by neighbour number, inside the nesting levels: at 6000^2 of the bench generator (31 % distinct values) 731 cells differ
-// from the compiled reference instead of 123 165 (scratch measurement, r04; the full-size figure is in
-// tests/test_s3_f2_gpu.py's report).
+// What this engine can do exactly is a tie-free raster; so a raster with twins is replaced by a rank permutation -- position
+// in the order of (elevation, tie key), stable radix sorts of (key, cell) pairs -- and flooded exactly.  First tie key: the
+// cell index (the reference's answer for the raster with its ties broken in raster order: at 6000^2 of the bench generator,
+// 31 % distinct values, 731 cells differ from the compiled reference instead of the 123 165 of deciding ties late, inside
+// the levels); then the discovery times the flood itself implies, to their fixed point (below).
 template <class T>
 __global__ __launch_bounds__(NT) void k_rank_keys(const T *__restrict__ z, uint32_t *keys, uint32_t *idx, uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * NT;
