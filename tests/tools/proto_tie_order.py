@@ -1,102 +1,115 @@
-"""CPU prototype: the stable-queue flood's tie order as the fixed point of  tau <- discovery order under the flood on (z, tau) ranks.
-R (pop rank of a tie-free flood) = preorder of the record tree T' (parent' = nearest ancestor with greater elevation), children by elevation."""
-import numpy as np, sys
-sys.path.insert(0, '/root/repo')
-import oracle
-R = oracle.ref
-DX = [0, -1, -1, 0, 1, 1, 1, 0, -1]; DY = [0, 0, -1, -1, -1, 0, 1, 1, 1]
+"""The stable queue's tie order as a fixed point -- the scheme of csrc/pfdirs.hip (k_tie_*) on the CPU, around any exact
+TIE-FREE PriorityFloodFlowdirs (here: the oracle's restatement / the compiled reference run on rank rasters).
+
+PriorityFloodFlowdirs_Barnes2014 (depressions/Barnes2014.hpp:483-555) pops equal elevations in order of insertion
+(GridCellZk_low_pq, common/grid_cell.hpp:101-122): a cell's tie key is its DISCOVERY time
+    tau(c) = (pop rank of the cell that closed c, position of c among that cell's pushes in d8_order),
+border cells first, in the order of the set-up loops (:508-519).  For a tie-free raster the pop rank is the PREORDER of the
+record tree T' (parent'(c) = nearest ancestor of greater elevation in the tree of directions), children sorted by elevation.
+Iterating  ranks(z, tau) -> exact flood -> tau  until the ranks reproduce themselves gives the reference's directions."""
+import numpy as np
+
+DX = [0, -1, -1, 0, 1, 1, 1, 0, -1]
+DY = [0, 0, -1, -1, -1, 0, 1, 1, 1]
 D8_ORDER = [1, 3, 5, 7, 2, 4, 6, 8]
 INV = [0, 5, 6, 7, 8, 1, 2, 3, 4]
 
+
 def border_push_index(w, h):
-    idx = np.full((h, w), -1, np.int64); k = 0
+    """position of every border cell in the reference's initial pushes (:508-519); returns (index raster, count)"""
+    idx = np.full((h, w), -1, np.int64)
+    k = 0
     for x in range(w):
-        for y in ((0, h - 1)):
-            if idx[y, x] < 0: idx[y, x] = k
+        for y in (0, h - 1):
+            if idx[y, x] < 0:
+                idx[y, x] = k
             k += 1
     for y in range(1, h - 1):
         for x in (0, w - 1):
-            if idx[y, x] < 0: idx[y, x] = k
+            if idx[y, x] < 0:
+                idx[y, x] = k
             k += 1
     return idx, k
 
+
 def pop_ranks(rk, dirs):
-    h, w = rk.shape; n = h * w
-    par = np.full(n, -1, np.int64)
-    for y in range(1, h - 1):
-        for x in range(1, w - 1):
-            d = dirs[y, x]; par[y * w + x] = (y + DY[d]) * w + (x + DX[d])
-    r = rk.ravel()
-    # nearest greater ancestor
-    g = par.copy()
-    order = np.argsort(r)            # process in any order; do it by chasing (serial prototype)
-    for c in range(n):
-        a = g[c]
-        while a >= 0 and r[a] < r[c]: a = par[a] if False else a_next(a, g, par, r, r[c])
-        g[c] = a
-    return par, g
-
-def a_next(a, g, par, r, rc):
-    a = par[a]
-    while a >= 0 and r[a] < rc: a = par[a]
-    return a
-
-def preorder(rk, dirs):
-    h, w = rk.shape; n = h * w
+    """(parent cell, pop rank) of a TIE-FREE flood from its directions: preorder of the record tree"""
+    h, w = rk.shape
+    n = h * w
     r = rk.ravel()
     par = np.full(n, -1, np.int64)
     for y in range(1, h - 1):
         for x in range(1, w - 1):
-            d = int(dirs[y, x]); par[y * w + x] = (y + DY[d]) * w + (x + DX[d])
-    g = np.full(n, -1, np.int64)
+            d = int(dirs[y, x])
+            par[y * w + x] = (y + DY[d]) * w + (x + DX[d])
+    g = np.full(n, -1, np.int64)                      # nearest ancestor of greater rank
     for c in range(n):
         a = par[c]
-        while a >= 0 and r[a] < r[c]: a = par[a]
+        while a >= 0 and r[a] < r[c]:
+            a = par[a]
         g[c] = a
     kids = [[] for _ in range(n + 1)]
-    for c in range(n): kids[g[c] if g[c] >= 0 else n].append(c)
-    for k in kids: k.sort(key=lambda c: r[c])
-    Rk = np.zeros(n, np.int64); t = 0
+    for c in range(n):
+        kids[g[c] if g[c] >= 0 else n].append(c)
+    for k in kids:
+        k.sort(key=lambda c: r[c])
+    R = np.zeros(n, np.int64)
+    t = 0
     stack = [iter(kids[n])]
     while stack:
         try:
-            c = next(stack[-1]); Rk[c] = t; t += 1; stack.append(iter(kids[c]))
+            c = next(stack[-1])
+            R[c] = t
+            t += 1
+            stack.append(iter(kids[c]))
         except StopIteration:
             stack.pop()
-    return par, Rk
+    return par, R
 
-def exact(z, maxit=200):
-    h, w = z.shape; n = h * w
+
+def flowdirs_with_ties(z, tie_free_flood, maxit=1000):
+    """directions of the stable-queue flood of z (any ties), given `tie_free_flood(rank raster int32) -> directions`;
+    returns (directions, floods run)"""
+    h, w = z.shape
+    n = h * w
     bidx, nb = border_push_index(w, h)
     tau = np.arange(n, dtype=np.int64)
     zr = z.ravel()
     prev = None
+    dirs = None
     for it in range(maxit):
-        order = np.lexsort((tau, zr)); rk = np.empty(n, np.int32); rk[order] = np.arange(n, dtype=np.int32)
-        if prev is not None and np.array_equal(rk, prev): return dirs, it
+        order = np.lexsort((tau, zr))
+        rk = np.empty(n, np.int32)
+        rk[order] = np.arange(n, dtype=np.int32)
+        if prev is not None and np.array_equal(rk, prev):
+            return dirs, it
         prev = rk
-        dirs = R.pf_flowdirs(rk.reshape(h, w), np.int32(-9999))
-        par, Rk = preorder(rk.reshape(h, w), dirs)
+        dirs = tie_free_flood(rk.reshape(h, w))
+        par, R = pop_ranks(rk.reshape(h, w), dirs)
         tau = np.empty(n, np.int64)
+        fd = dirs.ravel()
         for c in range(n):
-            if par[c] < 0: tau[c] = bidx.ravel()[c]
+            if par[c] < 0:
+                tau[c] = bidx.ravel()[c]
             else:
-                d = int(dirs.ravel()[c]); pos = D8_ORDER.index(INV[d])
-                tau[c] = nb + Rk[par[c]] * 8 + pos
-    return dirs, -1
+                tau[c] = nb + R[par[c]] * 8 + D8_ORDER.index(INV[int(fd[c])])
+    raise AssertionError("the tie order did not settle")
 
-rng = np.random.default_rng(9)
-from richdem_amd.synth import fractal_dem_int, fractal_dem
-cases = {"6 levels 40x50": rng.integers(0, 6, (40, 50)).astype(np.int32),
-         "3 levels 30x30": rng.integers(0, 3, (30, 30)).astype(np.int32),
-         "flat 20x25": np.zeros((20, 25), np.int32),
-         "G_int 80x70 x0.05": fractal_dem_int(80, 70, 32, 0.05),
-         "G_int 120x100 x1": fractal_dem_int(120, 100, 31, 1.0),
-         "float 200x150": fractal_dem(200, 150, 3)}
-t = np.load('/root/repo/tests/golden/ref_pf_flowdirs_ties.npz')
-cases["golden ties_i32"] = t["ties_i32/dem"]
-for name, z in cases.items():
-    ref = R.pf_flowdirs(z, z.dtype.type(-9999))
-    got, it = exact(z)
-    # check also the claim R = preorder on the final iteration: pop order of reference? (not available) -- directions suffice
-    print(name, "iterations", it, "differ", int((got != ref).sum()), "of", z.size, flush=True)
+
+if __name__ == "__main__":
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import oracle
+    from richdem_amd.synth import fractal_dem, fractal_dem_int
+
+    oracle.build()
+    B = oracle.ref if oracle.ref.available else oracle.port
+    rng = np.random.default_rng(9)
+    cases = {"6 levels 40x50": rng.integers(0, 6, (40, 50)).astype(np.int32), "flat 20x25": np.zeros((20, 25), np.int32),
+             "G_int 80x70 x0.05": fractal_dem_int(80, 70, 32, 0.05), "float 200x150": fractal_dem(200, 150, 3)}
+    for name, z in cases.items():
+        ref = B.pf_flowdirs(z, z.dtype.type(-9999))
+        got, it = flowdirs_with_ties(z, lambda rk: B.pf_flowdirs(rk, np.int32(-9999)))
+        print(name, "floods", it, "cells differing from the reference", int((got != ref).sum()), "of", z.size, flush=True)
