@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk(const uint8_t *__rest
   const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
   stage_dirs<ALW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
   __syncthreads();
-  const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (AW - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
   // pending inflows (from anywhere) + own area
   for (int j = 0; j < AH / 4; j++) {
     const int ly = ly0 + 4 * j, o = (ly + 1) * ALW + lx + 1;
@@ -292,7 +292,7 @@ __device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uin
                                            uint8_t *sd, uint16_t *lp) {
   stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
   __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
 #pragma unroll 4
   for (int j = 0; j < LT / 4; j++) {
     // branch-free (a cell without a direction "targets" itself for the lookup): these kernels are bound by instruction
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
   link_stage(dirs, nodata, w, h, x0, y0, sd, lp);
-  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
   uint32_t dpk[LT / 16];   // the thread's own direction bytes (four per VGPR): the exits' directions
 #pragma unroll
   for (int j = 0; j < LT / 4; j++) {
@@ -536,7 +536,7 @@ __device__ __forceinline__ void link_final_walk_tile(const uint32_t t, const uin
     ext_blk[slot] = (uint8_t)blocked;
   }
   __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
   uint32_t tgs[LT / 4];   // in-tile target of the thread's cells (NOTGT: none)
   uint32_t datamask = 0;
 #pragma unroll 4
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
       }
     }
   }
-  const int lx = threadIdx.x & (LT - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
   uint16_t a[LT / 4];      // the 2^k-th ancestor of the thread's cells (ANC_NONE: the path is shorter)
   uint32_t datamask = 0, act = 0;
 #pragma unroll 4
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(NTHR) void k_acc_tile_prewalk_f64(const uint8_t *__
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * AW, y0 = (int)(t / tilesX) * AH;
   stage_dirs<ALW, NTHR>(dirs, w, h, x0, y0, (uint8_t)255, sd);
-  const int lx = threadIdx.x & (AW - 1), ly0 = threadIdx.x >> 6;
+  const int lx = threadIdx.x & (AW - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
   {
     double wv[AH / 4];
 #pragma unroll

@@ -526,7 +526,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       RD_LAUNCH("pfd.rank_scatter", k_rank_scatter, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sidx, rk, n);
       const rdgpu_pf_flowdirs_stats mine = g_stats;
       const char *tp = getenv("RDGPU_PFD_TIE_PASSES");   // passes of the tie order's fixed point (0: raster order, r04's first version)
-      const uint32_t max_passes = tp ? (uint32_t)strtoul(tp, nullptr, 10) : 1000u;
+      const uint32_t max_passes = (w <= 2 || h <= 2) ? 0u : tp ? (uint32_t)strtoul(tp, nullptr, 10) : 1000u;   // (no interior cell: no tie to order)
       uint32_t passes = 0, levels_total = 0;
       unsigned long long moved = 0;
       g_rank_pass = true;

@@ -118,6 +118,9 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
         exp = orc.port.pf_flowdirs(dem, nd)
         assert st["unresolved"] == 0, (name, st)
         assert np.array_equal(got, exp), (name, int((got != exp).sum()), dem.size, st)
+    for shape in [(3, 3), (3, 4), (4, 4), (5, 3), (3, 9), (2, 7), (1, 5), (6, 2)]:      # the smallest rasters, all ties
+        for dem in (np.zeros(shape, np.int32), rng.integers(0, 2, shape).astype(np.int32)):
+            assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.int32(-9999)), orc.port.pf_flowdirs(dem, np.int32(-9999))), (shape, dem)
     # the two earlier tie rules stay selectable, and say what they are
     dem = cases["6 levels"]
     exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
