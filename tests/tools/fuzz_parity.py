@@ -152,6 +152,15 @@ def main():
             perm[order] = np.arange(h * w, dtype=np.int32)
             pd = perm.reshape(h, w)
             chk("pf_flowdirs", np.array_equal(rd.pf_flowdirs(pd, nodata=np.int32(-9999)), P.pf_flowdirs(pd, np.int32(-9999))))
+            # ... and on the terrain itself, equal elevations and NoData cells as they are (r04: the stable queue's tie order;
+            # small rasters only -- a plateau takes as many floods as it is deep)
+            if h * w <= 20000 and dem.dtype != np.float64 and dem.dtype.itemsize <= 4:
+                import warnings
+
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    got = rd.pf_flowdirs(dem, nodata=nd)
+                chk("pf_flowdirs_ties", np.array_equal(got, P.pf_flowdirs(dem, nd)) and rd.pf_flowdirs_stats()["unresolved"] == 0)
         except Exception as e:   # noqa: BLE001
             bad.append(f"EXC {tag}: {type(e).__name__}: {e}")
     kinds = {}
