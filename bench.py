@@ -164,6 +164,9 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
                                                      "max_accum": float(area.max().item())}
     del area
     if Z is not None:
+        sync()
+        rd.release_workspace()            # the stages above keep ~80 GB of scratch; the two below bring their own
+        torch.cuda.empty_cache()
         rd.fill_epsilon_dev(E.copy_(Z), nodata)
         t_eps = 1e30
         for _ in range(reps):
@@ -178,6 +181,9 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
             return out
         # PriorityFloodFlowdirs_Barnes2014: one fill per nesting level of the depressions (seconds, not milliseconds: once)
         del E
+        sync()
+        rd.release_workspace()
+        torch.cuda.empty_cache()
         pdirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
         os.environ["RDGPU_PFD_TIE_PASSES"] = "1"                                   # workspace growth (~100 GB of sort and tree buffers):
         rd.pf_flowdirs_dev(Z, nodata, pdirs)                                       # one pass of the tie order, not timed

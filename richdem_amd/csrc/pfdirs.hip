@@ -389,12 +389,13 @@ __global__ __launch_bounds__(NT) void k_tie_offsets(const uint32_t *__restrict__
   for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) off[scells[i]] = (uint32_t)(scan[i] - scan[headpos[i]]);
 }
 // preorder rank, one depth at a time from the top: R(c) = R(parent') + 1 + off(c); children of the virtual root: off(c)
+// (in place: R[c] holds off(c) until c's depth is processed; its parent' is shallower, i.e. a rank already)
 __global__ __launch_bounds__(NT) void k_tie_ranks_down(const uint32_t *__restrict__ cells, uint32_t lo, uint32_t hi,
-                                                       const uint32_t *__restrict__ g, const uint32_t *__restrict__ off, uint32_t *R) {
+                                                       const uint32_t *__restrict__ g, uint32_t *R) {
   const uint32_t i = lo + blockIdx.x * NT + threadIdx.x;
   if (i >= hi) return;
   const uint32_t c = cells[i], p = g[c];
-  R[c] = (p == T_ROOT ? 0u : R[p] + 1u) + off[c];
+  R[c] = (p == T_ROOT ? 0u : R[p] + 1u) + R[c];
 }
 
 // discovery time: border cells in the order of the reference's set-up loops (:508-519: for x: (x, 0), (x, h - 1); for
@@ -486,9 +487,16 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
   RD_HIP(hipMemsetAsync(counters, 0, (128 + 4) * sizeof(unsigned long long), s));
   bool sorted = false;   // (keys, cells) are already sorted: the census of a small raster
   uint32_t *keys = nullptr, *skeys = nullptr, *idx = nullptr, *sidx = nullptr;
+  // Scratch of the rank machinery: six persistent 4-byte arrays (keys, ranks, parents, record-tree parents, sizes / pop
+  // ranks, cells by depth) + ONE pool of 24 bytes per cell whose three 8-byte thirds are handed from phase to phase (the
+  // first version named every array: 100 bytes per cell, 160 GB at 40000^2, which does not fit beside a caller's rasters)
+  uint8_t *pool = nullptr;
+  auto pool4 = [&](int third, int half) { return reinterpret_cast<uint32_t *>(pool + ((size_t)third * 2 + half) * n * 4); };
+  auto pool8 = [&](int third) { return reinterpret_cast<unsigned long long *>(pool + (size_t)third * n * 8); };
   auto sort_cells = [&]() {   // (LSD radix sort: stable, so equal keys stay in raster order)
-    keys = ws.buf<uint32_t>("pfd.rkeys", n); skeys = ws.buf<uint32_t>("pfd.rskeys", n);
-    idx = ws.buf<uint32_t>("pfd.ridx", n); sidx = ws.buf<uint32_t>("pfd.rsidx", n);
+    pool = ws.buf<uint8_t>("pfd.t.pool", (size_t)n * 24);
+    keys = ws.buf<uint32_t>("pfd.rkeys", n); skeys = pool4(0, 0);
+    idx = pool4(0, 1); sidx = pool4(1, 0);
     RD_LAUNCH("pfd.rank_keys", (k_rank_keys<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, keys, idx, n);
     size_t tb = 0;
     RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
@@ -539,10 +547,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           // ---- the discovery times under this pass's flood, and the ranks of (z, discovery time) -----------------------
           uint32_t *zkey = keys;   // (keys still holds every cell's key: k_rank_keys' output, untouched by the sort)
           uint32_t *par = ws.buf<uint32_t>("pfd.t.par", n), *g = ws.buf<uint32_t>("pfd.t.g", n);
-          uint32_t *ancA = ws.buf<uint32_t>("pfd.t.ancA", n), *ancB = ws.buf<uint32_t>("pfd.t.ancB", n);
-          uint32_t *dstA = ws.buf<uint32_t>("pfd.t.dstA", n), *dstB = ws.buf<uint32_t>("pfd.t.dstB", n);
-          uint32_t *size = ws.buf<uint32_t>("pfd.t.size", n), *cellsA = ws.buf<uint32_t>("pfd.t.cellsA", n);
-          uint32_t *cellsB = ws.buf<uint32_t>("pfd.t.cellsB", n);
+          uint32_t *size = ws.buf<uint32_t>("pfd.t.size", n), *bcells = ws.buf<uint32_t>("pfd.t.bcells", n);
           uint32_t *flag = ws.buf<uint32_t>("pfd.t.flag", 4);
           uint32_t *hw = ws.host_words();
           RD_LAUNCH("pfd.tie.parents", k_tie_parents, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, par, w, h);
@@ -555,8 +560,10 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
             if (hw[0] == 0) break;
             if (round > 10000) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the record tree did not settle (internal error)");
           }
+          // ---- depth in T' (pointer doubling), cells bucketed by depth: pool thirds 0 / 1 ping-pong, 2 holds the cells ----
+          uint32_t *ancA = pool4(0, 0), *dstA = pool4(0, 1), *ancB = pool4(1, 0), *dstB = pool4(1, 1), *cellsA = pool4(2, 0);
           RD_LAUNCH("pfd.tie.init", k_tie_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, ancA, dstA, size, cellsA, n);
-          for (int round = 0;; round++) {   // depth in T' (pointer doubling)
+          for (int round = 0;; round++) {
             RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
             RD_LAUNCH("pfd.tie.depth", k_tie_depth, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)ancA, (const uint32_t *)dstA, ancB,
                       dstB, n, flag);
@@ -567,11 +574,11 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
             if (hw[0] == 0) break;
             if (round > 64) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: depth doubling did not settle (internal error)");
           }
-          uint32_t *depth = dstA, *sdepth = dstB;   // cells bucketed by depth
+          uint32_t *depth = dstA, *sdepth = dstB;
           size_t tb = 0;
-          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, depth, sdepth, cellsA, cellsB, (int)n, 0, 32, s));
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, depth, sdepth, cellsA, bcells, (int)n, 0, 32, s));
           void *tmp = ws.buf("pfd.rtmp", tb);
-          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, depth, sdepth, cellsA, cellsB, (int)n, 0, 32, s));
+          RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, depth, sdepth, cellsA, bcells, (int)n, 0, 32, s));
           RD_HIP(hipMemcpyAsync(hw, sdepth + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
           RD_HIP(hipStreamSynchronize(s));
           const uint32_t maxd = hw[0];
@@ -580,53 +587,52 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           std::vector<uint32_t> hstart((size_t)maxd + 2);
           RD_HIP(hipMemcpyAsync(hstart.data(), dstart, ((size_t)maxd + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
           RD_HIP(hipStreamSynchronize(s));
-          const uint32_t *bcells = cellsB;   // cells in order of depth
           for (uint32_t d = maxd; d >= 2; d--) {   // subtree sizes, deepest first
             const uint32_t lo = hstart[d], hi = hstart[d + 1];
             if (hi > lo)
-              RD_LAUNCH("pfd.tie.sizes", k_tie_sizes_up, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, bcells, lo, hi, (const uint32_t *)g, size);
+              RD_LAUNCH("pfd.tie.sizes", k_tie_sizes_up, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, (const uint32_t *)bcells, lo, hi,
+                        (const uint32_t *)g, size);
           }
-          // siblings in order of elevation; off(c) = subtree sizes of c's smaller siblings
-          unsigned long long *k64 = ws.buf<unsigned long long>("pfd.t.k64a", n), *sk64 = ws.buf<unsigned long long>("pfd.t.k64b", n);
-          uint32_t *scells = ancA, *ucells = ancB;   // (the doubling's ancestor arrays are dead)
+          // ---- siblings in order of elevation; off(c) = subtree sizes of c's smaller siblings (the whole pool is free) ----
+          unsigned long long *k64 = pool8(0), *sk64 = pool8(1);
+          uint32_t *ucells = pool4(2, 0), *scells = pool4(2, 1);
           RD_LAUNCH("pfd.tie.sibling_keys", k_tie_sibling_keys, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, (const uint32_t *)rk, k64,
                     ucells, n);
           tb = 0;
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k64, sk64, ucells, scells, (int)n, 0, 64, s));
           tmp = ws.buf("pfd.rtmp", tb);
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k64, sk64, ucells, scells, (int)n, 0, 64, s));
-          unsigned long long *ssize = k64;   // (the unsorted keys are dead)
-          uint32_t *head = ucells, *headpos = cellsA, *off = dstB;   // (cellsA, sdepth: dead)
+          unsigned long long *ssize = k64;   // (the unsorted keys are dead); scanned in place
+          uint32_t *head = ucells;           // (the unsorted cells are dead); scanned in place
           RD_LAUNCH("pfd.tie.gather_sizes", k_tie_gather_sizes, dim3(sgrid(n)), dim3(NT), 0, s, (const unsigned long long *)sk64,
                     (const uint32_t *)scells, (const uint32_t *)size, ssize, head, n);
-          unsigned long long *scan = ws.buf<unsigned long long>("pfd.t.scan", n);
           tb = 0;
-          RD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ssize, scan, (int)n, s));
+          RD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ssize, ssize, (int)n, s));
           tmp = ws.buf("pfd.rtmp", tb);
-          RD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ssize, scan, (int)n, s));
+          RD_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ssize, ssize, (int)n, s));
           tb = 0;
-          RD_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, head, headpos, MaxU32(), (int)n, s));
+          RD_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tb, head, head, MaxU32(), (int)n, s));
           tmp = ws.buf("pfd.rtmp", tb);
-          RD_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, headpos, MaxU32(), (int)n, s));
+          RD_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tb, head, head, MaxU32(), (int)n, s));
+          uint32_t *R = size;   // offsets first, pop ranks in place (the sizes are dead: ssize holds what was needed of them)
           RD_LAUNCH("pfd.tie.offsets", k_tie_offsets, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)scells,
-                    (const unsigned long long *)scan, (const uint32_t *)headpos, off, n);
-          uint32_t *R = size;   // (the sizes are dead once the offsets exist)
-          for (uint32_t d = 1; d <= maxd; d++) {   // preorder ranks, from the top
+                    (const unsigned long long *)ssize, (const uint32_t *)head, R, n);
+          for (uint32_t d = 1; d <= maxd; d++) {   // preorder ranks, from the top: R(c) = R(parent') + 1 + off(c), in place
             const uint32_t lo = hstart[d], hi = hstart[d + 1];
             if (hi > lo)
-              RD_LAUNCH("pfd.tie.ranks", k_tie_ranks_down, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, bcells, lo, hi, (const uint32_t *)g,
-                        (const uint32_t *)off, R);
+              RD_LAUNCH("pfd.tie.ranks", k_tie_ranks_down, dim3((hi - lo + NT - 1) / NT), dim3(NT), 0, s, (const uint32_t *)bcells, lo, hi,
+                        (const uint32_t *)g, R);
           }
-          // discovery times -> order by (elevation, discovery time): sort by the time, then stably by the key
+          // ---- discovery times -> order by (elevation, discovery time): sort by the time, then stably by the key ----------
           unsigned long long *tau = sk64, *stau = k64;
-          uint32_t *c0 = ancB, *c1 = ancA;
+          uint32_t *c0 = ucells, *c1 = scells;
           RD_LAUNCH("pfd.tie.tau", k_tie_tau, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, (const uint32_t *)par, (const uint32_t *)R,
                     tau, c0, w, h);
           tb = 0;
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
           tmp = ws.buf("pfd.rtmp", tb);
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
-          uint32_t *zk = cellsA, *zks = dstB;   // keys in discovery order
+          uint32_t *zk = pool4(1, 0), *zks = pool4(1, 1);   // (tau is dead) keys in discovery order
           RD_LAUNCH("pfd.tie.gather_keys", k_tie_gather_keys, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)zkey, (const uint32_t *)c1, zk, n);
           tb = 0;
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, zk, zks, c1, c0, (int)n, 0, 32, s));
