@@ -2402,16 +2402,17 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
   uint32_t *const tab_id = sk;   // the component table lives in the keys' storage once the pairs are reduced
   unsigned long long *const tab_val = reinterpret_cast<unsigned long long *>(sk + SC_SLOTS);
 
-  // ---- this block's tiles: a RUN of consecutive tiles of its XCD's band.  Consecutive tiles are neighbours in a tile row:
-  // the left ring column of a tile was loaded a tile ago (L2), and what its right ring column fetches -- one 64-byte sector
-  // per row and array for a single cell -- is what the next tile's rows start with.  Strided over the blocks instead
-  // (tile j, j + blocks, ...) every ring column missed: 21.8 GB fetched per launch instead of 11 (r04a counters).
+  // ---- this block's tiles: its XCD's band, strided over the XCD's blocks (tile j, j + blocks, ...), so that the blocks of
+  // an XCD work on neighbouring tiles at any time; RDGPU_FILL_PAIRS_STRIDED=0: a run of consecutive tiles per block
+  // (measured 0.15 ms slower; neither keeps the neighbours' rows in the 4 MB L2 for the ring columns -- hence the edge
+  // records: 22.9 GB fetched per launch without them, 12.5 with).
   const uint32_t xcd = blockIdx.x & 7u, kb = gridDim.x >> 3, per = (nwork + 7u) / 8u;
   const uint32_t seg = blockIdx.x;   // the block's own segment of the pair list: no counter in HBM to wait for
   const uint32_t run = (per + kb - 1u) / kb;
-  uint32_t it = (blockIdx.x >> 3) * run;
-  const uint32_t it_end = min(it + run, per);
-  constexpr uint32_t kstep = 1u;
+  const bool strided = (precheck & 2) != 0;
+  uint32_t it = strided ? (blockIdx.x >> 3) : (blockIdx.x >> 3) * run;
+  const uint32_t it_end = strided ? per : min(it + run, per);
+  const uint32_t kstep = strided ? kb : 1u;
   auto next_tile = [&](uint32_t &i) -> uint32_t {
     while (i < it_end) {
       const uint32_t wi = xcd * per + i;
@@ -2694,7 +2695,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
       const uint32_t C = tab_id[tid];
       if (C != 0xFFFFFFFFu) {
         const unsigned long long cand = tab_val[tid];
-        if (precheck) { if (cand < best[C]) atomicMin(&best[C], cand); }
+        if (precheck & 1) { if (cand < best[C]) atomicMin(&best[C], cand); }
         else atomicMin(&best[C], cand);
       }
     }
@@ -2905,7 +2906,8 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
   const bool dedup = !(env_dedup && env_dedup[0] == '0');
   const char *env_pc = getenv("RDGPU_FILL_PRECHECK");
-  const int precheck = !(env_pc && env_pc[0] == '0');
+  const char *env_st = getenv("RDGPU_FILL_PAIRS_STRIDED");
+  const int precheck = (!(env_pc && env_pc[0] == '0') ? 1 : 0) | (!(env_st && env_st[0] == '0') ? 2 : 0);
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
