@@ -422,6 +422,36 @@ __global__ __launch_bounds__(NT) void k_tie_tau(const uint8_t *__restrict__ dirs
     cells[c] = (uint32_t)c;
   }
 }
+// first tie key, before any flood: a cell on a slope is most likely closed by its LOWEST neighbour, so equal cells are
+// ordered by (that neighbour's key, position among its pushes) -- closer to the insertion order than the cell index, one
+// pass of the fixed point saved where ties are local (float terrain); any start converges
+__global__ __launch_bounds__(NT) void k_tie_tau0(const uint32_t *__restrict__ zkey, unsigned long long *tau, uint32_t *cells, int w, int h) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  const unsigned long long nb = 2ull * w + 2ull * h;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    unsigned long long t;
+    if (y == 0) t = 2ull * x;
+    else if (y == h - 1) t = 2ull * x + 1;
+    else if (x == 0) t = 2ull * w + 2ull * (y - 1);
+    else if (x == w - 1) t = 2ull * w + 2ull * (y - 1) + 1;
+    else {
+      uint32_t bk = 0xFFFFFFFFu;
+      int bd = 1;
+#pragma unroll
+      for (int k = 1; k <= 8; k++) {   // in d8_order, so that among equal lowest neighbours the first pusher wins
+        const int d = k <= 4 ? 2 * k - 1 : 2 * (k - 4);
+        const uint32_t kk = zkey[(size_t)(y + ndy(d)) * w + (x + ndx(d))];
+        if (kk < bk) { bk = kk; bd = d; }
+      }
+      const int inv = ((bd + 3) & 7) + 1;                                   // the direction in which that neighbour pushes c
+      const int pos = (inv & 1) ? (inv - 1) >> 1 : 4 + ((inv - 2) >> 1);
+      t = nb + (unsigned long long)bk * 8ull + (unsigned long long)pos;
+    }
+    tau[c] = t;
+    cells[c] = (uint32_t)c;
+  }
+}
 __global__ __launch_bounds__(NT) void k_tie_gather_keys(const uint32_t *__restrict__ zkey, const uint32_t *__restrict__ order,
                                                         uint32_t *out, uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * NT;
@@ -498,10 +528,29 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     keys = ws.buf<uint32_t>("pfd.rkeys", n); skeys = pool4(0, 0);
     idx = pool4(0, 1); sidx = pool4(1, 0);
     RD_LAUNCH("pfd.rank_keys", (k_rank_keys<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, keys, idx, n);
+    const char *ti = getenv("RDGPU_PFD_TIE_INIT");   // =0: equal cells start in raster order
     size_t tb = 0;
-    RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
-    void *tmp = ws.buf("pfd.rtmp", tb);
-    RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+    if (!(ti && ti[0] == '0') && w > 2 && h > 2) {
+      // equal cells start in the order of (lowest neighbour's key, push position): sort by that, then stably by the key
+      unsigned long long *tau = pool8(1), *stau = pool8(2);
+      uint32_t *c0 = pool4(0, 1), *c1 = pool4(0, 0);   // (idx = pool4(0, 1) is overwritten: the cells again)
+      RD_LAUNCH("pfd.tie.tau0", k_tie_tau0, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)keys, tau, c0, w, h);
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
+      void *tmp0 = ws.buf("pfd.rtmp", tb);
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp0, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
+      uint32_t *zk = pool4(1, 1);   // (tau = pool8(1) is dead)
+      RD_LAUNCH("pfd.tie.gather_keys", k_tie_gather_keys, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)keys, (const uint32_t *)c1, zk, n);
+      skeys = pool4(2, 0);
+      sidx = pool4(2, 1);           // (stau = pool8(2) is dead)
+      tb = 0;
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, zk, skeys, c1, sidx, (int)n, 0, 32, s));
+      void *tmp1 = ws.buf("pfd.rtmp", tb);
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp1, tb, zk, skeys, c1, sidx, (int)n, 0, 32, s));
+    } else {
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+      void *tmp = ws.buf("pfd.rtmp", tb);
+      RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, skeys, idx, sidx, (int)n, 0, 32, s));
+    }
     sorted = true;
   };
   {

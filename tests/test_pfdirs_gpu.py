@@ -125,6 +125,7 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
     dem = cases["6 levels"]
     exp = orc.port.pf_flowdirs(dem, np.int32(-9999))
     monkeypatch.setenv("RDGPU_PFD_TIE_PASSES", "0")          # equal cells in raster order: one exact flood of the unique ranks
+    monkeypatch.setenv("RDGPU_PFD_TIE_INIT", "0")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         raster_order = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
@@ -133,6 +134,8 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
     ranks[order] = np.arange(dem.size, dtype=np.int32)
     assert np.array_equal(raster_order, orc.port.pf_flowdirs(ranks.reshape(dem.shape), np.int32(-9999)))
     monkeypatch.delenv("RDGPU_PFD_TIE_PASSES")
+    assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.int32(-9999)), exp)     # (any first order converges: here raster order)
+    monkeypatch.delenv("RDGPU_PFD_TIE_INIT")
     monkeypatch.setenv("RDGPU_PFD_RANKS", "0")               # r03: ties decided inside the levels, by neighbour number
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
