@@ -515,3 +515,21 @@ def test_two_host_threads_in_the_multi_device_entries(rd, orc):
     for t in threads:
         t.join()
     assert not errors, errors[:2]
+
+
+@pytest.mark.parametrize("topo", ["D8", "D4"])
+def test_row_blocks_on_either_local_phase(rd, orc, monkeypatch, topo):
+    """A row block's local phase is the compact-label engine with the cut rows as frozen terminals (r04); the classic
+    32-bit-label phase stays selectable (RDGPU_SHARD_FUSED=0) and is what blocks fall back to: same surface from both, for
+    block counts that put cuts inside tiles, on tile borders and two rows apart, ragged widths included."""
+    rng = np.random.default_rng(17)
+    dems = [fractal_dem(517, 389, seed=61), np.floor(fractal_dem(256, 192, seed=62) * 0.03).astype(np.int32),
+            (rng.random((130, 67)) * 9).astype(np.float32)]
+    for dem in dems:
+        exp = orc.port.fill(dem, 8 if topo == "D8" else 4)
+        for shards in (2, 3, 6, dem.shape[0] // 2):
+            for fused in ("1", "0"):
+                monkeypatch.setenv("RDGPU_SHARD_FUSED", fused)
+                got = rd.FillDepressions(dem, topology=topo, shards=shards)
+                assert got.tobytes() == exp.tobytes(), (dem.shape, dem.dtype, shards, fused)
+    monkeypatch.delenv("RDGPU_SHARD_FUSED")
