@@ -31,105 +31,144 @@ __device__ __forceinline__ int mdx(int n) { return (n == 1 || n == 2 || n == 8) 
 __device__ __forceinline__ int mdy(int n) { return (n >= 2 && n <= 4) ? -1 : (n >= 6 && n <= 8) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
-// dinf_FlowDir, flowmet/dinf_flowdirs.hpp:45-115 (facet tables :21-27)
+// D-infinity per cell, on the 3 x 3 window of elevations (rows y-1, y, y+1; columns x-1, x, x+1).
+// Both kernels are LDS-tiled stencils (r04: 64 x 32 tiles + halo, the window slides down a column in registers, as
+// flowdirs.hip does): one thread per cell with sixteen neighbour loads and their 64-bit addresses was 36 ms at 40000^2.
+// The reference takes atan2 of every facet and then branches on the angle.  Which branch it takes follows from the two
+// slopes alone except within rounding of the thresholds (s1, s2 are differences of elevations, never -0.0):
+// r < 0 <=> s2 < 0; r > atan2(1, 1) <=> s1 <= 0 or s2 > s1.  So the angle is computed ONCE, for the facet that wins (the
+// steepest-facet comparison only needs s), and per facet only where s2 / s1 is within a margin of a threshold.  Results are
+// the reference's bit for bit (tests/test_s2_dinf_gpu.py: every band of the 10000^2 raster).
 // ------------------------------------------------------------------------------------------
+constexpr int DTW = 64, DTH = 32, DLW_ = DTW + 2, DLH_ = DTH + 2;
+
+template <class T>
+__device__ __forceinline__ void dinf_stage(const T *__restrict__ z, int w, int h, int x0, int y0, T *sz) {
+  constexpr int IPT = (DLH_ * DLW_ + NTHR - 1) / NTHR;
+  T zv[IPT];
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {   // clamped addresses: a cell outside the raster is never used as a neighbour
+    const int i = min((int)threadIdx.x + r * NTHR, DLH_ * DLW_ - 1);
+    const int ly = i / DLW_, lx = i - ly * DLW_;
+    const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
+    zv[r] = z[(size_t)gy * w + gx];
+  }
+#pragma unroll
+  for (int r = 0; r < IPT; r++) {
+    const int i = (int)threadIdx.x + r * NTHR;
+    if (i < DLH_ * DLW_) sz[i] = zv[r];
+  }
+}
+
+// dinf_FlowDir, flowmet/dinf_flowdirs.hpp:45-115 (facet tables :21-27), interior data cell; win[r][c]
+template <class T>
+__device__ __forceinline__ float dinf_cell(const T (&win)[3][3]) {
+  constexpr int dy_e1[8] = {0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[8] = {1, 0, 0, -1, -1, 0, 0, 1};
+  constexpr int dy_e2[8] = {-1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[8] = {1, 1, -1, -1, -1, -1, 1, 1};
+  constexpr double ac[8] = {0., 1., 1., 2., 2., 3., 3., 4.}, af[8] = {1., -1., 1., -1., 1., -1., 1., -1.};
+  int nmax = -1;
+  double smax = 0, rmax = 0, w1 = 0, w2 = 0;   // w1, w2: the winning facet's slopes when its angle is still owed
+  bool owed = false;
+  const double e0 = (double)win[1][1];
+  const double quarter = atan2(1.0, 1.0);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {                                      // :68-96
+    const double e1 = (double)win[1 + dy_e1[k]][1 + dx_e1[k]];
+    const double e2 = (double)win[1 + dy_e2[k]][1 + dx_e2[k]];
+    const double s1 = (e0 - e1) / 1.0, s2 = (e1 - e2) / 1.0;
+    int branch;   // 0: r < 0; 1: r > quarter; 2: in between (r = atan2(s2, s1))
+    if (s2 < 0) branch = 0;
+    else if (s1 <= 0) branch = (s1 == 0 && s2 == 0) ? 2 : 1;        // atan2(+0, +0) = 0; otherwise r >= pi / 2
+    else {
+      const double lo = s1 * (1.0 - 0x1p-40), hi = s1 * (1.0 + 0x1p-40);
+      if (s2 > hi) branch = 1;
+      else if (s2 < lo) branch = 2;
+      else branch = atan2(s2, s1) > quarter ? 1 : 2;                 // within rounding of the threshold: as the reference does
+    }
+    double s;
+    if (branch == 0) s = s1;
+    else if (branch == 1) s = (e0 - e2) / sqrt(2.0);
+    else s = sqrt(s1 * s1 + s2 * s2);
+    if (s > smax) {
+      smax = s; nmax = k;
+      rmax = branch == 1 ? quarter : 0.0;
+      owed = branch == 2;
+      w1 = s1; w2 = s2;
+    }
+  }
+  if (owed) rmax = atan2(w2, w1);
+  double rg = 0;                                                     // NO_FLOW
+  if (nmax != -1) rg = af[nmax] * rmax + ac[nmax] * M_PI / 2;
+  return (float)rg;
+}
+
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_dinf_dirs(const T *__restrict__ z, T nodata, float *__restrict__ out, int w,
-                                                    int h) {
-  const int dy_e1[8] = {0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[8] = {1, 0, 0, -1, -1, 0, 0, 1};
-  const int dy_e2[8] = {-1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[8] = {1, 1, -1, -1, -1, -1, 1, 1};
-  const double ac[8] = {0., 1., 1., 2., 2., 3., 3., 4.}, af[8] = {1., -1., 1., -1., 1., -1., 1., -1.};
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
-    if (z[c] == nodata) { out[c] = -1.0f; continue; }                 // dinf_NO_DATA, :147-148
-    if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {               // :46-63
-      double a;
-      if (x == 0 && y == 0) a = 3 * M_PI / 4;
-      else if (x == 0 && y == h - 1) a = 5 * M_PI / 4;
-      else if (x == w - 1 && y == 0) a = 1 * M_PI / 4;
-      else if (x == w - 1 && y == h - 1) a = 7 * M_PI / 4;
-      else if (x == 0) a = 4 * M_PI / 4;
-      else if (x == w - 1) a = 0 * M_PI / 4;
-      else if (y == 0) a = 2 * M_PI / 4;
-      else a = 6 * M_PI / 4;
-      out[c] = (float)a;
-      continue;
-    }
-    int nmax = -1;
-    double smax = 0, rmax = 0, w1 = 0, w2 = 0;   // w1, w2: the winning facet's slopes when its angle is still owed
-    bool owed = false;
-    const double e0 = (double)z[c];
-    const double quarter = atan2(1.0, 1.0);
-    // The reference takes atan2 of every facet and then branches on the angle (:83-91).  Which branch it takes follows
-    // from the slopes alone except within rounding of the two thresholds (s1, s2 are differences of elevations, never
-    // -0.0): r < 0 <=> s2 < 0; r > atan2(1, 1) <=> s1 <= 0 or s2 > s1.  So the angle is computed ONCE, for the facet that
-    // wins -- the steepest-facet comparison only needs s -- and per facet only where s2 / s1 is within 2^-40 of 1 (r04:
-    // 43.7 -> ms at 40000^2; double-precision atan2 was 7/8 of the kernel).  Results are the reference's bit for bit
-    // (tests/test_s2_dinf_gpu.py: every band of the 10000^2 raster).
+                                                    int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ T sz[DLH_ * DLW_];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * DTW, y0 = (int)(t / tilesX) * DTH;
+  dinf_stage<T>(z, w, h, x0, y0, sz);
+  __syncthreads();
+  const int lx = threadIdx.x & (DTW - 1), yb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (DTH / 4);
+  const int gx = x0 + lx;
+  T win[3][3];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {                                      // :68-96
-      const double e1 = (double)z[(size_t)(y + dy_e1[k]) * w + (x + dx_e1[k])];
-      const double e2 = (double)z[(size_t)(y + dy_e2[k]) * w + (x + dx_e2[k])];
-      const double s1 = (e0 - e1) / 1.0, s2 = (e1 - e2) / 1.0;
-      int branch;   // 0: r < 0; 1: r > quarter; 2: in between (r = atan2(s2, s1))
-      if (s2 < 0) branch = 0;
-      else if (s1 <= 0) branch = (s1 == 0 && s2 == 0) ? 2 : 1;        // atan2(+0, +0) = 0; otherwise r >= pi / 2
-      else {
-        const double lo = s1 * (1.0 - 0x1p-40), hi = s1 * (1.0 + 0x1p-40);
-        if (s2 > hi) branch = 1;
-        else if (s2 < lo) branch = 2;
-        else branch = atan2(s2, s1) > quarter ? 1 : 2;                 // within rounding of the threshold: as the reference does
-      }
-      double s;
-      if (branch == 0) s = s1;
-      else if (branch == 1) s = (e0 - e2) / sqrt(2.0);
-      else s = sqrt(s1 * s1 + s2 * s2);
-      if (s > smax) {
-        smax = s; nmax = k;
-        rmax = branch == 1 ? quarter : 0.0;
-        owed = branch == 2;
-        w1 = s1; w2 = s2;
-      }
-    }
-    if (owed) rmax = atan2(w2, w1);
-    double rg = 0;                                                     // NO_FLOW
-    if (nmax != -1) rg = af[nmax] * rmax + ac[nmax] * M_PI / 2;
-    out[c] = (float)rg;
+  for (int e = 0; e < 3; e++) { win[0][e] = sz[yb * DLW_ + lx + e]; win[1][e] = sz[(yb + 1) * DLW_ + lx + e]; }
+#pragma unroll 2
+  for (int j = 0; j < DTH / 4; j++) {
+    const int gy = y0 + yb + j;
+#pragma unroll
+    for (int e = 0; e < 3; e++) win[2][e] = sz[(yb + j + 2) * DLW_ + lx + e];
+    float a;
+    if (win[1][1] == nodata) a = -1.0f;                                  // dinf_NO_DATA, :147-148
+    else if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) {         // :46-63
+      double e;
+      if (gx == 0 && gy == 0) e = 3 * M_PI / 4;
+      else if (gx == 0 && gy == h - 1) e = 5 * M_PI / 4;
+      else if (gx == w - 1 && gy == 0) e = 1 * M_PI / 4;
+      else if (gx == w - 1 && gy == h - 1) e = 7 * M_PI / 4;
+      else if (gx == 0) e = 4 * M_PI / 4;
+      else if (gx == w - 1) e = 0 * M_PI / 4;
+      else if (gy == 0) e = 2 * M_PI / 4;
+      else e = 6 * M_PI / 4;
+      a = (float)e;
+    } else a = dinf_cell<T>(win);
+    if (gx < w && gy < h) out[(size_t)gy * w + gx] = a;
+#pragma unroll
+    for (int e = 0; e < 3; e++) { win[0][e] = win[1][e]; win[1][e] = win[2][e]; }
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // FM_Tarboton, flowmet/Tarboton1997.hpp:14-144 in compact form: rcv = first receiver n (0 none, 255
-// NoData), share = proportion to neighbour n, share2 = proportion to neighbour nwrap(n + 1).
+// NoData), share = proportion to neighbour n, share2 = proportion to neighbour nwrap(n + 1).  Interior data cell;
+// win[r][c] as above.
 // ------------------------------------------------------------------------------------------
 template <class T>
-__device__ __forceinline__ void tarboton_cell(const T *__restrict__ z, T nodata, int x, int y, int w, int h, int &rcv,
-                                              float &share, float &share2) {
-  const int dy_e1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[9] = {0, -1, 0, 0, 1, 1, 0, 0, -1};
-  const int dy_e2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[9] = {0, -1, -1, 1, 1, 1, 1, -1, -1};
-  const double af[9] = {0, -1., 1., -1., 1., -1., 1., -1., 1.};
+__device__ __forceinline__ void tarboton_cell(const T (&win)[3][3], T nodata, int &rcv, float &share, float &share2) {
+  constexpr int dy_e1[9] = {0, 0, -1, -1, 0, 0, 1, 1, 0}, dx_e1[9] = {0, -1, 0, 0, 1, 1, 0, 0, -1};
+  constexpr int dy_e2[9] = {0, -1, -1, -1, -1, 1, 1, 1, 1}, dx_e2[9] = {0, -1, -1, 1, 1, 1, 1, -1, -1};
+  constexpr double af[9] = {0, -1., 1., -1., 1., -1., 1., -1., 1.};
   const float dang = (float)atan2(1.0, 1.0);
   rcv = 0;
   share = 0.0f;
   share2 = 0.0f;
-  const size_t c = (size_t)y * w + x;
-  if (z[c] == nodata) { rcv = 255; return; }                           // :44-47
-  if (x == 0 || y == 0 || x == w - 1 || y == h - 1) return;            // :49-50
   int nmax = -1;
   double smax = 0, w1 = 0, w2 = 0;
   float rmax = 0;
   bool owed = false;
-  const double e0 = (double)z[c];
+  const double e0 = (double)win[1][1];
 #pragma unroll
   for (int n = 1; n <= 8; n++) {                                       // :56-92
-    const T v1 = z[(size_t)(y + dy_e1[n]) * w + (x + dx_e1[n])], v2 = z[(size_t)(y + dy_e2[n]) * w + (x + dx_e2[n])];
+    const T v1 = win[1 + dy_e1[n]][1 + dx_e1[n]], v2 = win[1 + dy_e2[n]][1 + dx_e2[n]];
     if (v1 == nodata || v2 == nodata) continue;
     const double e1 = (double)v1, e2 = (double)v2;
     const double s1 = (e0 - e1) / 1.0, s2 = (e1 - e2) / 1.0;
     // which of the reference's three branches (:83-91) the angle r = atan2(s2, s1) falls into follows from the slopes except
     // within a margin of the two thresholds (there: atan2, as the reference); the angle itself is only needed for the
-    // facet that wins (k_dinf_dirs above has the argument)
+    // facet that wins
     int branch;   // 0: r < 1e-7; 1: r > dang - 1e-7; 2: in between
     if (s2 < 0) branch = 0;
     else if (s1 <= 0) branch = (s1 == 0 && s2 == 0) ? 0 : 1;            // atan2(+0, +0) = 0; otherwise r >= pi / 2
@@ -168,19 +207,39 @@ __device__ __forceinline__ void tarboton_cell(const T *__restrict__ z, T nodata,
 
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_tarboton(const T *__restrict__ z, T nodata, uint8_t *__restrict__ rcv,
-                                                   float *__restrict__ sh1, float *__restrict__ sh2, int w, int h) {
-  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
-  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
-    int r;
-    float p, q;
-    tarboton_cell<T>(z, nodata, (int)(c % (uint64_t)w), (int)(c / (uint64_t)w), w, h, r, p, q);
-    rcv[c] = (uint8_t)r;
-    sh1[c] = p;
-    sh2[c] = q;
+                                                   float *__restrict__ sh1, float *__restrict__ sh2, int w, int h,
+                                                   uint32_t tilesX, uint32_t ntiles) {
+  __shared__ T sz[DLH_ * DLW_];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * DTW, y0 = (int)(t / tilesX) * DTH;
+  dinf_stage<T>(z, w, h, x0, y0, sz);
+  __syncthreads();
+  const int lx = threadIdx.x & (DTW - 1), yb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (DTH / 4);
+  const int gx = x0 + lx;
+  T win[3][3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) { win[0][e] = sz[yb * DLW_ + lx + e]; win[1][e] = sz[(yb + 1) * DLW_ + lx + e]; }
+#pragma unroll 2
+  for (int j = 0; j < DTH / 4; j++) {
+    const int gy = y0 + yb + j;
+#pragma unroll
+    for (int e = 0; e < 3; e++) win[2][e] = sz[(yb + j + 2) * DLW_ + lx + e];
+    int r = 0;
+    float p = 0.0f, q = 0.0f;
+    if (win[1][1] == nodata) r = 255;                                                     // :44-47
+    else if (!(gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1)) tarboton_cell<T>(win, nodata, r, p, q);   // :49-50: edges never flow
+    if (gx < w && gy < h) {
+      const size_t c = (size_t)gy * w + gx;
+      rcv[c] = (uint8_t)r;
+      sh1[c] = p;
+      sh2[c] = q;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) { win[0][e] = win[1][e]; win[1][e] = win[2][e]; }
   }
 }
 
-// expand the compact form into the reference's Array3D layout (9 floats per cell, index 9*i+n)
 __global__ __launch_bounds__(NTHR) void k_tarboton_props(const uint8_t *__restrict__ rcv, const float *__restrict__ sh1,
                                                          const float *__restrict__ sh2, float *__restrict__ props,
                                                          uint64_t n) {
@@ -548,7 +607,10 @@ static DinfAcc tarboton_device(const T *d_z, T nodata, int w, int h, hipStream_t
   Workspace &ws = Workspace::get();
   uint8_t *rcv = ws.buf<uint8_t>("mfd.rcv", n);
   float *sh1 = ws.buf<float>("mfd.sh1", n), *sh2 = ws.buf<float>("mfd.sh2", n);
-  RD_LAUNCH("mfd.tarboton", (k_tarboton<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, nodata, rcv, sh1, sh2, w, h);
+  {
+    const uint32_t dtilesX = (w + DTW - 1) / DTW, dntiles = dtilesX * ((h + DTH - 1) / DTH);
+    RD_LAUNCH("mfd.tarboton", (k_tarboton<T>), dim3(xcd_grid(dntiles)), dim3(NTHR), 0, s, d_z, nodata, rcv, sh1, sh2, w, h, dtilesX, dntiles);
+  }
   return DinfAcc{rcv, sh1, sh2};
 }
 
@@ -568,8 +630,9 @@ using namespace rdgpu;
     return guarded([&] {                                                                                        \
       if (!d_dem || !d_out) throw Error(RDGPU_ERR_ARG, "rdgpu_dinf_flowdirs: null pointer");                    \
       check_dims(w, h, "rdgpu_dinf_flowdirs");                                                                  \
-      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, (hipStream_t)st, \
-                d_dem, nodata, d_out, w, h);                                                                    \
+      const uint32_t dtx_ = (w + DTW - 1) / DTW, dnt_ = dtx_ * ((h + DTH - 1) / DTH);                               \
+      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(xcd_grid(dnt_)), dim3(NTHR), 0, (hipStream_t)st,            \
+                d_dem, nodata, d_out, w, h, dtx_, dnt_);                                                        \
     });                                                                                                         \
   }                                                                                                             \
   extern "C" int rdgpu_dinf_flowdirs_##SUF(const T *dem, T nodata, int w, int h, float *out) {                  \
@@ -579,8 +642,9 @@ using namespace rdgpu;
       T *d;                                                                                                     \
       host_dem<T>(dem, w, h, &d);                                                                               \
       float *o = Workspace::get().buf<float>("host.f32out", (size_t)w * h);                                     \
-      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, (hipStream_t) nullptr, \
-                (const T *)d, nodata, o, w, h);                                                                 \
+      const uint32_t dtx_ = (w + DTW - 1) / DTW, dnt_ = dtx_ * ((h + DTH - 1) / DTH);                               \
+      RD_LAUNCH("mfd.dinf_dirs", (k_dinf_dirs<T>), dim3(xcd_grid(dnt_)), dim3(NTHR), 0, (hipStream_t) nullptr,      \
+                (const T *)d, nodata, o, w, h, dtx_, dnt_);                                                     \
       RD_HIP(hipMemcpy(out, o, (size_t)w * h * 4, hipMemcpyDeviceToHost));                                      \
     });                                                                                                         \
   }                                                                                                             \
