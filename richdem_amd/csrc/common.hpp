@@ -162,12 +162,14 @@ inline void per_device(const int *devices, int ndev, Job job) {
     return;
   }
   std::vector<std::exception_ptr> err(order.size());
+  std::vector<const std::vector<int> *> mine(order.size());   // (looked up here: the workers must not touch the map)
+  for (size_t k = 0; k < order.size(); k++) mine[k] = &shards.at(order[k]);
   std::vector<std::thread> th;
   for (size_t k = 0; k < order.size(); k++)
     th.emplace_back([&, k] {
       try {
         DeviceGuard g(order[k]);
-        job(order[k], shards[order[k]]);
+        job(order[k], *mine[k]);
       } catch (...) {
         err[k] = std::current_exception();
       }
