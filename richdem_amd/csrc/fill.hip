@@ -1974,106 +1974,130 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   __syncthreads();
   // (the wavefront's index as a SCALAR: everything derived from the row -- bounds tests, LDS row offsets -- then runs on the
   // scalar unit; this kernel is bound by VALU issue, 4 cycles per wave instruction)
+  //
+  // r04d: the kernel's VALU work per row of 64 cells went 143 -> ~70 instructions by three changes.
+  //  * The 8-neighbour minimum WITH its position from row triples: min3 + "first of (a, b, c) equal to it" once per row,
+  //    used by the cell above and the cell below; the winner carries one packed word (pointer delta | exit code | which
+  //    column / row it lies in), so nothing is decoded afterwards.
+  //  * Roots point to THEMSELVES in lp and pointers are byte offsets: a jump is lp[lp[p]] with no compare or select, a
+  //    cell is finished when the two reads agree, and the wavefronts iterate on their own rows without barriers (every
+  //    value a racing read can see is an ancestor on the cell's path).  The exit codes stay in registers.
+  //  * Slots go to a 16-bit array laid over the keys (dead by then) at the SAME offsets as lp: label = slot16[p].
   const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = threadIdx.x & (DW - 1), ly0 = wave_s * (DH / 4);
   const int gx = x0 + lx;
-  {   // descent pointers: k_descent's loop
-    uint32_t k0[3], k1[3], k2[3];
-#pragma unroll
-    for (int e = 0; e < 3; e++) { k0[e] = sk[ly0 * DLW + lx + e]; k1[e] = sk[(ly0 + 1) * DLW + lx + e]; }
-#pragma unroll 4
-    for (int j = 0; j < DH / 4; j++) {
-      const int ly = ly0 + j, gy = y0 + ly;
-#pragma unroll
-      for (int e = 0; e < 3; e++) k2[e] = sk[(ly + 2) * DLW + lx + e];
-#define RD_Q(n) ((n) | (((n) / 3) << 4) | (((n) % 3) << 6))
-      const uint32_t kc = k1[1];
-      uint32_t bk, q;
+  constexpr int RPT = DH / 4;                      // rows per thread
+  static_assert(RPT == 16, "four code words of four bytes, 16-bit row masks");
+  uint16_t *const slot16 = reinterpret_cast<uint16_t *>(sk);   // valid once the keys are dead (after the edge keys are out)
+  const uint32_t selfb0 = (uint32_t)((ly0 * LPD + lx) * 2);
+  uint32_t p[RPT];                                 // the cell's pointer: byte offset into lp
+  uint32_t codes[RPT / 4] = {0, 0, 0, 0};          // one byte per row: 0 pit, 1..8 exit towards that neighbour, 9 drains off the raster
+  uint32_t rootmask = 0, pitmask = 0, outmask = 0;
+  {
+    // packed word of a candidate: [15:0] byte delta + 134, [19:16] exit code, [26:24] column 0 / 1 / 2, [27] row above, [29] row below
+    constexpr uint32_t WT0 = 0u | (1u << 16) | (1u << 24) | (1u << 27), WT1 = 2u | (2u << 16) | (1u << 25) | (1u << 27),
+                       WT2 = 4u | (3u << 16) | (1u << 26) | (1u << 27);
+    constexpr uint32_t WM0 = (uint32_t)(2 * LPD) | (4u << 16) | (1u << 24), WM2 = (uint32_t)(2 * LPD + 4) | (5u << 16) | (1u << 26);
+    constexpr uint32_t BADD = (uint32_t)(4 * LPD) + (5u << 16) + ((1u << 29) - (1u << 27));
+    const bool colin = gx < w, colborder = (gx == 0) | (gx == w - 1);
+    const uint32_t cmcol = lx == 0 ? (1u << 24) : lx == DW - 1 ? (1u << 26) : 0u;
+    uint32_t ta, tb, tc, tm, tW, ma, mb, mc, mm3, mW;   // the triples of the row above and of the cell's row
+    auto triple = [&](int r, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &m, uint32_t &W) {
+      a = sk[r * DLW + lx];
+      b = sk[r * DLW + lx + 1];
+      c = sk[r * DLW + lx + 2];
       if (TOPO == 8) {
-        bk = k0[0]; q = RD_Q(0);
-        { const bool t_ = k0[1] < bk; bk = t_ ? k0[1] : bk; q = t_ ? RD_Q(1) : q; }
-        { const bool t_ = k0[2] < bk; bk = t_ ? k0[2] : bk; q = t_ ? RD_Q(2) : q; }
-        { const bool t_ = k1[0] < bk; bk = t_ ? k1[0] : bk; q = t_ ? RD_Q(3) : q; }
-        { const bool t_ = k1[2] < bk; bk = t_ ? k1[2] : bk; q = t_ ? RD_Q(5) : q; }
-        { const bool t_ = k2[0] < bk; bk = t_ ? k2[0] : bk; q = t_ ? RD_Q(6) : q; }
-        { const bool t_ = k2[1] < bk; bk = t_ ? k2[1] : bk; q = t_ ? RD_Q(7) : q; }
-        { const bool t_ = k2[2] < bk; bk = t_ ? k2[2] : bk; q = t_ ? RD_Q(8) : q; }
+        m = min(min(a, b), c);
+        W = a == m ? WT0 : b == m ? WT1 : WT2;
       } else {
-        bk = k0[1]; q = RD_Q(1);
-        { const bool t_ = k1[0] < bk; bk = t_ ? k1[0] : bk; q = t_ ? RD_Q(3) : q; }
-        { const bool t_ = k1[2] < bk; bk = t_ ? k1[2] : bk; q = t_ ? RD_Q(5) : q; }
-        { const bool t_ = k2[1] < bk; bk = t_ ? k2[1] : bk; q = t_ ? RD_Q(7) : q; }
+        m = b;
+        W = WT1;
       }
-#undef RD_Q
-      const int n = (int)(q & 15u);
-      const bool drains = (bk < kc) | ((bk == kc) & (n < 4));
-      const int tx = lx + (int)(q >> 6 & 3u) - 1, ty = ly + (int)(q >> 4 & 3u) - 1;
-      const bool inside = (tx >= 0) & (tx < DW) & (ty >= 0) & (ty < DH);
-      const uint16_t ldrain = inside ? (uint16_t)(ty * LPD + tx) : (uint16_t)(LTERM_BASE | (uint16_t)(n < 4 ? n + 1 : n));
-      const bool incell = (gx < w) & (gy < h);
-      bool border = (gx == 0) | (gx == w - 1) | (gy == 0) | (gy == h - 1);
+    };
+    triple(ly0, ta, tb, tc, tm, tW);
+    triple(ly0 + 1, ma, mb, mc, mm3, mW);
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int ly = ly0 + j, gy = y0 + ly;   // (scalar)
+      uint32_t ba, bb, bc, bm, bW;
+      triple(ly + 2, ba, bb, bc, bm, bW);
+      const uint32_t kc = mb;
+      const bool midfirst = ma <= mc;
+      const uint32_t mm = midfirst ? ma : mc;
+      const uint32_t bk = min(min(tm, mm), bm);
+      const bool isT = tm == bk, isM = mm == bk;
+      const uint32_t wM = midfirst ? WM0 : WM2, wB = bW + BADD, wMB = isM ? wM : wB;
+      const uint32_t W = isT ? tW : wMB;
+      const bool drains = (bk < kc) | ((bk == kc) & (isT | (isM & midfirst)));
+      uint32_t cm = cmcol;
+      if (j == 0 && ly0 == 0) cm |= 1u << 27;                   // (only a wavefront's first / last row can be the tile's)
+      if (j == RPT - 1 && ly0 == DH - RPT) cm |= 1u << 29;
+      const bool outside = (W & cm) != 0u;
+      const uint32_t self = selfb0 + (uint32_t)(j * LPD * 2);
+      const bool incell = colin & (gy < h);
+      bool border = colborder | (gy == 0) | (gy == h - 1);
       bool stays = !drains;
       if (CUT) {
         const bool cutrow = ((gy == 0) & (open_top != 0)) | ((gy == h - 1) & (open_bottom != 0));
-        border = (gx == 0) | (gx == w - 1) | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);
+        border = colborder | ((gy == 0) & !open_top) | ((gy == h - 1) & !open_bottom);
         stays |= cutrow;
       }
       if (OUTLETS) border |= incell && outlet[(size_t)gy * w + gx] != 0;
-      const uint16_t l = !incell ? LTERM_BASE : border ? (uint16_t)(LTERM_BASE | 9) : stays ? LTERM_BASE : ldrain;
-      lp[ly * LPD + lx] = l;
-#pragma unroll
-      for (int e = 0; e < 3; e++) { k0[e] = k1[e]; k1[e] = k2[e]; }
+      const bool selfp = !incell | border | stays | outside;
+      const uint32_t rel = selfp ? (uint32_t)(2 * LPD + 2) : (W & 0xFFFFu);   // (the delta's bias: the cell itself)
+      p[j] = rel + (self - (uint32_t)(2 * LPD + 2));
+      *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lp) + self) = (uint16_t)p[j];
+      const uint32_t cexit = (W >> 16) & 15u, cin = stays ? 0u : cexit;
+      const uint32_t code = border ? 9u : cin;
+      codes[j >> 2] |= code << (8 * (j & 3));
+      bool root = incell & selfp;
+      if (OUTLETS) {   // the tile's outlets share slot 0
+        const bool outroot = root & border;
+        outmask |= (outroot ? 1u : 0u) << j;
+        root &= !outroot;
+      }
+      rootmask |= (root ? 1u : 0u) << j;
+      pitmask |= ((root & !border & stays) ? 1u : 0u) << j;
+      ta = ma; tb = mb; tc = mc; tm = mm3; tW = mW;
+      ma = ba; mb = bb; mc = bc; mm3 = bm; mW = bW;
     }
+    (void)ta; (void)tb; (void)tc;
+  }
+  // (the masks and codes are formed HERE, in vector registers: left to the compiler they sink below the jump loop, which
+  // keeps sixteen rows of lane masks alive in scalar registers and spills them lane by lane)
+  asm volatile("" : "+v"(rootmask), "+v"(pitmask), "+v"(outmask), "+v"(codes[0]), "+v"(codes[1]), "+v"(codes[2]), "+v"(codes[3]));
+  // the tile's first and last column: the KEYS of the compact records for the pair pass (before the keys' array is reused)
+  if (fo.edgeK && threadIdx.x < 2 * DH) {
+    const int side = threadIdx.x >> 6, lye = threadIdx.x & (DH - 1), lxe = side ? DW - 1 : 0;
+    fo.edgeK[((size_t)t * 2 + side) * DH + lye] = sk[(lye + 1) * DLW + lxe + 1];
   }
   __syncthreads();
-  {   // pointer jumping inside the tile (k_descent's loop)
-    uint32_t act = 0;
+  {   // pointer jumping inside the tile: every wavefront on its own rows until they all point to roots; no barriers
+    const char *const lpb = reinterpret_cast<const char *>(lp);
+    uint32_t gact = (1u << (RPT / 4)) - 1u;   // (scalar) groups of four rows with a pointer that may still move
+    for (int it = 0; gact != 0u && it < DW * DH; it++) {
+      asm volatile("" ::: "memory");   // (other wavefronts write lp meanwhile: nothing read from it is kept across passes)
 #pragma unroll
-    for (int j = 0; j < DH / 4; j++) act |= (lp[(ly0 + j) * LPD + lx] < LTERM_BASE ? 1u : 0u) << j;
-    for (int it = 0; it < 12; it++) {
-      int still = 0;
+      for (int g = 0; g < RPT / 4; g++) {
+        if (!(gact >> g & 1u)) continue;
+        uint32_t qv[4], rv[4];
 #pragma unroll
-      for (int g = 0; g < DH / 16; g++) {
-        if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
-        uint16_t pv[4], qv[4], rv[4];
+        for (int e = 0; e < 4; e++) qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * g + e) * LPD + lx];
-#pragma unroll
-        for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LTERM_BASE ? pv[e] : (ly0 + 4 * g + e) * LPD + lx];
-#pragma unroll
-        for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LTERM_BASE ? qv[e] : (ly0 + 4 * g + e) * LPD + lx];
+        for (int e = 0; e < 4; e++) rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]);
+        bool moving = false;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int j = 4 * g + e;
-          if (pv[e] < LTERM_BASE && qv[e] < LTERM_BASE) {
-            const bool more = rv[e] < LTERM_BASE;
-            lp[(ly0 + j) * LPD + lx] = more ? rv[e] : qv[e];
-            if (more) still = 1;
-            else act &= ~(1u << j);
-          } else {
-            act &= ~(1u << j);
-          }
+          moving |= rv[e] != qv[e];   // (equal: qv is a root, the cell is finished)
+          p[j] = rv[e];
+          *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lp) + selfb0 + (uint32_t)(j * LPD * 2)) = (uint16_t)rv[e];
         }
+        if (__ballot(moving) == 0ull) gact &= ~(1u << g);
       }
-      if (!__syncthreads_or(still)) break;
     }
   }
-  __syncthreads();
   // ---- nodes: every root of the tile gets a local slot; pits a dense basin id --------------------------------------
-  uint32_t rootmask = 0, pitmask = 0, outmask = 0;
-#pragma unroll
-  for (int j = 0; j < DH / 4; j++) {
-    const int gy = y0 + ly0 + j;
-    const uint16_t v = lp[(ly0 + j) * LPD + lx];
-    bool root = (gx < w) & (gy < h) & (v >= LTERM_BASE);
-    if (OUTLETS) {   // the tile's outlets share slot 0
-      const bool outroot = root & ((v & 15u) == 9u);
-      outmask |= (outroot ? 1u : 0u) << j;
-      root &= !outroot;
-    }
-    rootmask |= (root ? 1u : 0u) << j;
-    pitmask |= ((root & ((v & 15u) == 0u)) ? 1u : 0u) << j;
-  }
   const uint32_t mine = ((uint32_t)__popc(rootmask) << 16) | (uint32_t)__popc(pitmask);   // (<= 1024 each per wavefront)
   uint32_t incl = mine;
 #pragma unroll
@@ -2082,7 +2106,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
     if ((threadIdx.x & 63) >= o) incl += v;
   }
   if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
-  __syncthreads();
+  __syncthreads();   // (also: every wavefront's pointers are final, the keys are dead)
   if (threadIdx.x == 0) {
     const uint32_t nr = (wtot[0] >> 16) + (wtot[1] >> 16) + (wtot[2] >> 16) + (wtot[3] >> 16) + (OUTLETS ? 1u : 0u);
     const uint32_t np = (wtot[0] & 0xFFFFu) + (wtot[1] & 0xFFFFu) + (wtot[2] & 0xFFFFu) + (wtot[3] & 0xFFFFu);
@@ -2096,49 +2120,55 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
     fits_s = (unsigned long long)rl + nr <= fo.rcap ? 1u : 0u;
     if (!fits_s) *fo.overflow = 1;
   }
-  __syncthreads();
-  const uint32_t nodes0 = rbase;
-  const bool gfits = fits_s != 0;
-  constexpr uint16_t ROOT_TAG = 0xC000u;   // a numbered root's entry: ROOT_TAG | slot (pointers are < 4096, codes >= LTERM_BASE)
-  {
+  {   // (the roots' slots do not depend on the counter: written beside thread 0's atomic)
     uint32_t pre = incl - mine;
     for (int k = 0; k < wave_s; k++) pre += wtot[k];
-    uint32_t slot = (pre >> 16) + (OUTLETS ? 1u : 0u), pit = pbase + (pre & 0xFFFFu);
-    if (OUTLETS) {
-      if (threadIdx.x == 0 && gfits) fo.G[nodes0] = OUTP;
-      for (uint32_t m = outmask; m; m &= m - 1) lp[(ly0 + __ffs((int)m) - 1) * LPD + lx] = (uint16_t)ROOT_TAG;   // slot 0
-    }
+    uint32_t slot = (pre >> 16) + (OUTLETS ? 1u : 0u);
+    if (OUTLETS)
+      for (uint32_t m = outmask; m; m &= m - 1)
+        *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(slot16) + selfb0 + (uint32_t)((__ffs((int)m) - 1) * LPD * 2)) = 0;   // slot 0
     for (uint32_t m = rootmask; m; m &= m - 1) {
       const int j = __ffs((int)m) - 1;
-      const int ly = ly0 + j;
-      const int code = lp[ly * LPD + lx] & 15;
-      const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour (codes 1..8)
-      const int nr = n >= 6 ? 2 : n >= 3 ? 1 : 0, nc = n - 3 * nr;
-      const uint32_t pend = LAB_PEND | ((uint32_t)(y0 + ly + nr - 1) * (uint32_t)w + (uint32_t)(x0 + lx + nc - 1));
-      const uint32_t word = code == 0 ? pit++ : code == 9 ? OUTP : pend;
-      if (gfits) fo.G[nodes0 + slot] = word;
-      lp[ly * LPD + lx] = (uint16_t)(ROOT_TAG | slot);
+      *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(slot16) + selfb0 + (uint32_t)(j * LPD * 2)) = (uint16_t)slot;
       slot++;
     }
   }
   __syncthreads();
-  // a cell's label: the slot of its root (its own when it is one)
-#pragma unroll 4
-  for (int j = 0; j < DH / 4; j++) {
-    const int ly = ly0 + j, gy = y0 + ly;
-    const uint16_t v = lp[ly * LPD + lx];
-    const uint16_t rv = lp[v < (uint16_t)(LPD * DH) ? v : ly * LPD + lx];
-    if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = (uint16_t)(rv & 0x0FFFu);
+  const uint32_t nodes0 = rbase;
+  if (fits_s != 0) {
+    uint32_t pre = incl - mine;
+    for (int k = 0; k < wave_s; k++) pre += wtot[k];
+    uint32_t slot = (pre >> 16) + (OUTLETS ? 1u : 0u), pit = pbase + (pre & 0xFFFFu);
+    if (OUTLETS && threadIdx.x == 0) fo.G[nodes0] = OUTP;
+    for (uint32_t m = rootmask; m; m &= m - 1) {
+      const int j = __ffs((int)m) - 1;
+      const int ly = ly0 + j;
+      const uint32_t cw = j < 8 ? (j < 4 ? codes[0] : codes[1]) : (j < 12 ? codes[2] : codes[3]);
+      const int code = (int)(cw >> (8 * (j & 3)) & 15u);
+      const int n = code <= 4 ? code - 1 : code;   // 3x3 position of the root's descent neighbour (codes 1..8)
+      const int nr = n >= 6 ? 2 : n >= 3 ? 1 : 0, nc = n - 3 * nr;
+      const uint32_t pend = LAB_PEND | ((uint32_t)(y0 + ly + nr - 1) * (uint32_t)w + (uint32_t)(x0 + lx + nc - 1));
+      const uint32_t word = code == 0 ? pit++ : code == 9 ? OUTP : pend;
+      fo.G[nodes0 + slot] = word;
+      slot++;
+    }
   }
-  // the tile's first and last column as compact records for the pair pass: two wavefronts, one row per lane, coalesced
-  // (cells past the raster's end are written too and never read)
-  if (fo.edgeK && threadIdx.x < 2 * DH) {
-    const int side = threadIdx.x >> 6, ly = threadIdx.x & (DH - 1), lxe = side ? DW - 1 : 0;
-    const uint16_t v = lp[ly * LPD + lxe];
-    const uint16_t rv = lp[v < (uint16_t)(LPD * DH) ? v : ly * LPD + lxe];
-    const size_t e = ((size_t)t * 2 + side) * DH + ly;
-    fo.edgeK[e] = sk[(ly + 1) * DLW + lxe + 1];
-    fo.edgeS[e] = (uint16_t)(rv & 0x0FFFu);
+  // a cell's label: the slot of its root (its own when it is one)
+  {
+    const char *const sl = reinterpret_cast<const char *>(slot16);
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int gy = y0 + ly0 + j;
+      const uint16_t rv = *reinterpret_cast<const uint16_t *>(sl + p[j]);
+      if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = rv;   // (< 4096: not every cell of a tile can be a root)
+    }
+    // the tile's first and last column, the SLOTS of the compact records: two wavefronts, one row per lane, coalesced
+    // (cells past the raster's end are written too and never read)
+    if (fo.edgeS && threadIdx.x < 2 * DH) {
+      const int side = threadIdx.x >> 6, lye = threadIdx.x & (DH - 1), lxe = side ? DW - 1 : 0;
+      const uint16_t v = lp[lye * LPD + lxe];
+      fo.edgeS[((size_t)t * 2 + side) * DH + lye] = *reinterpret_cast<const uint16_t *>(sl + v);
+    }
   }
 }
 
