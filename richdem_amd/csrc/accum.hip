@@ -262,7 +262,6 @@ __global__ __launch_bounds__(NTHR) void k_acc_out_unit(const uint8_t *__restrict
 // complete inside its tile is blocked for good, and a border cell with an unfinished outside donor stays pending.
 constexpr int LT = 64, LLW = LT + 2;
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
-constexpr uint16_t LP_TERM = 0xF000u, LP_EXIT = 0xF001u;
 // The words of the link forest's nodes (exits): pending in-links in bits 40..63, total in bits 0..39.  The per-cell words
 // of the raster-wide walk keep their count in 8 bits (a cell has at most 8 donors), but an EXIT can be handed flow by
 // every exit of the neighbouring tiles whose path ends at it -- several hundred when a tile funnels everything it
@@ -281,32 +280,52 @@ __device__ __forceinline__ int border_slot(int lx, int ly) {
   return -1;
 }
 
-// stage the tile's directions (+ ring; cells outside the raster read as NoData) and, per cell, its in-tile donors
-// and its in-tile target / LP_EXIT / LP_TERM
 // The pointer tables of the tile passes are gathered at random by all 64 lanes; with rows of 64 two-byte entries every row
 // starts on the same LDS bank, so lanes that point at neighbouring columns of DIFFERENT rows -- the usual case: flow
 // converges -- collide.  Rows of LPS = 66 entries shift the banks by one per row (r03e: SQ_LDS_BANK_CONFLICT was 57 % of
 // k_acc_link_tile's LDS cycles, 44 % of k_acc_link_final_sums').  A cell's table index is ly * LPS + lx.
 constexpr int LPS = LT + 2;
-__device__ __forceinline__ void link_stage(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h, int x0, int y0,
-                                           uint8_t *sd, uint16_t *lp) {
-  stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
-  __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
-#pragma unroll 4
-  for (int j = 0; j < LT / 4; j++) {
-    // branch-free (a cell without a direction "targets" itself for the lookup): these kernels are bound by instruction
-    // issue, and a divergent branch costs more than the handful of selects it guards
-    const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
-    const uint8_t d = sd[o];
-    const bool flows = d != nodata && d >= 1 && d <= 8;
-    const int dd = flows ? d : 0;
-    const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
-    const bool into_data = sd[(ty + 1) * LLW + tx + 1] != nodata;   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
-    const bool inside = tx >= 0 && tx < LT && ty >= 0 && ty < LT;
-    lp[ly * LPS + lx] = !(flows && into_data) ? LP_TERM : inside ? (uint16_t)(ty * LPS + tx) : LP_EXIT;
+// ---- the tile passes' common front end (r04d) ---------------------------------------------------------------------
+// The staged directions: rows of SDW = 72 bytes with the tile's first column at byte SDO = 4, so that an interior tile is
+// staged with aligned 32-bit LDS stores from 32-bit global loads (one byte per load and a division per byte made the
+// staging a fifth of k_acc_link_tile's instructions).  Cells outside the raster read as `fill`.
+constexpr int SDW = 72, SDO = 4, SDH = LT + 2;
+__device__ __forceinline__ void stage_dirs_rows(const uint8_t *__restrict__ dirs, int w, int h, int x0, int y0, uint8_t fill,
+                                                uint8_t *sd) {
+  if (y0 >= 1 && y0 + LT < h && x0 + LT <= w) {   // (block-uniform) every row of the window lies in the raster
+    constexpr int NQ = SDH * (LT / 4), QPT = (NQ + NTHR - 1) / NTHR;
+    uint32_t v[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i < NQ) __builtin_memcpy(&v[r], dirs + (size_t)(y0 - 1 + (i >> 4)) * w + (x0 + 4 * (i & 15)), 4);   // (any alignment)
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i < NQ) *reinterpret_cast<uint32_t *>(sd + (i >> 4) * SDW + SDO + 4 * (i & 15)) = v[r];
+    }
+    if (threadIdx.x < 2 * SDH) {   // the two ring columns
+      const int ly = (int)threadIdx.x >> 1, side = (int)threadIdx.x & 1;
+      const int gx = side ? x0 + LT : x0 - 1;
+      sd[ly * SDW + (side ? SDO + LT : SDO - 1)] = (gx >= 0 && gx < w) ? dirs[(size_t)(y0 - 1 + ly) * w + gx] : fill;
+    }
+  } else {
+    for (int i = (int)threadIdx.x; i < SDH * SDH; i += NTHR) {
+      const int ly = i / SDH, lx = i - ly * SDH;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      sd[ly * SDW + SDO - 1 + lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? dirs[(size_t)gy * w + gx] : fill;
+    }
   }
 }
+// Per direction 1..8 (index e = d - 1), one byte each, looked up with v_perm_b32 (selector bytes 0..3 pick from the second
+// operand, 4..7 from the first, 0x0c gives 0): the target's offset in the staged rows (+73), in the pointer table (+67), and
+// which side of the tile it can leave through (1: left, 2: right, 4: top, 8: bottom).
+__device__ __forceinline__ uint32_t d8_byte(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+constexpr uint32_t D8_SD_LO = 0x02010048u, D8_SD_HI = 0x9091924Au;   // (dy * SDW + dx) + SDW + 1
+constexpr uint32_t D8_LP_LO = 0x02010042u, D8_LP_HI = 0x84858644u;   // (dy * LPS + dx) + LPS + 1
+constexpr uint32_t D8_FL_LO = 0x06040501u, D8_FL_HI = 0x09080A02u;
+static_assert(SDW == 72 && LPS == 66, "the byte tables above");
 
 __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
                                                         uint32_t tilesX, uint32_t ntiles, unsigned long long *nw,
@@ -316,118 +335,132 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
   // jumping): the exit totals are a histogram over those roots -- one LDS add per cell -- and no accumulation walk is
   // needed here at all (r02c ran the full last-arriver walk in this pass too: 20 of the stage's 47 ms).  Cells that
   // drain into a direction loop inside the tile have no root and are counted nowhere, as in the reference.
-  // The staged directions are only needed until every cell knows its target; their 4.3 KB then hold the counters.
-  __shared__ uint32_t cnt[LT * LPS];
-  __shared__ uint16_t lp[LT * LPS];
-  uint8_t *const sd = reinterpret_cast<uint8_t *>(cnt);
-  static_assert(LLW * LLW <= LT * LPS * 4, "the staged directions fit into the counters' storage");
+  // r04d (the kernel is bound by instruction issue; ~3000 -> ~1600 VALU instructions per wavefront): pointers are byte
+  // offsets and an EXIT points to ITSELF, a cell without a target to a self-pointing SINK entry -- a jump is two reads
+  // without compares or selects, finished when they agree; the border cells are published one per thread; the target's
+  // offsets come from byte tables; the directions are staged 32 bits at a time.
+  __shared__ uint32_t cnt[LT * LPS];      // [23:0] cells leaving through this exit, [31:24] the exit's direction
+  __shared__ uint16_t lp[LT * LPS + 2];
+  uint8_t *const sd = reinterpret_cast<uint8_t *>(cnt);   // the staged directions are dead before the counters are set
+  static_assert(SDH * SDW <= LT * LPS * 4, "the staged directions fit into the counters' storage");
+  constexpr uint32_t SINK2 = (uint32_t)(LT * LPS * 2);
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
-  link_stage(dirs, nodata, w, h, x0, y0, sd, lp);
+  stage_dirs_rows(dirs, w, h, x0, y0, nodata, sd);
+  if (threadIdx.x == 0) lp[LT * LPS] = (uint16_t)SINK2;
+  __syncthreads();
   const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
-  uint32_t dpk[LT / 16];   // the thread's own direction bytes (four per VGPR): the exits' directions
+  constexpr int RPT = LT / 4;
+  char *const lpb = reinterpret_cast<char *>(lp);
+  const uint32_t self0 = (uint32_t)((ly0 * LPS + lx) * 2);   // row j of the thread: self0 + j * 4 * LPS * 2
+  uint32_t p[RPT];          // the cells' pointers (byte offsets into lp)
+  uint32_t dex[RPT];        // an exit's direction << 24, else 0: the counters' first value
+  {
+    const uint32_t cmcol = lx == 0 ? 1u : lx == LT - 1 ? 2u : 0u;
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) {
-    const uint8_t d = sd[(ly0 + 4 * j + 1) * LLW + lx + 1];
-    if ((j & 3) == 0) dpk[j >> 2] = 0;
-    dpk[j >> 2] |= (uint32_t)d << (8 * (j & 3));
+    for (int j = 0; j < RPT; j++) {
+      const int ly = ly0 + 4 * j;
+      const int o = (ly + 1) * SDW + SDO + lx;
+      const uint32_t d = sd[o];
+      const uint32_t e = (d - 1u) & 7u, sel = e | 0x0c0c0c00u;
+      const bool flows = (d != nodata) & (d - 1u < 8u);
+      const uint32_t so = d8_byte(D8_SD_HI, D8_SD_LO, sel), lo = d8_byte(D8_LP_HI, D8_LP_LO, sel), fl = d8_byte(D8_FL_HI, D8_FL_LO, sel);
+      const bool into_data = sd[o + (int)so - (SDW + 1)] != nodata;   // else: off the DEM / into NoData: dropped (d8_methods.hpp:113-125)
+      uint32_t cm = cmcol;
+      if (j == 0 && ly0 == 0) cm |= 4u;                 // (only these two rows of a wavefront can be the tile's first / last)
+      if (j == RPT - 1 && ly0 == 3) cm |= 8u;
+      const bool leaves = (fl & cm) != 0u, goes = flows & into_data;
+      const uint32_t self = self0 + (uint32_t)(j * 4 * LPS * 2);
+      const uint32_t inp = self + 2u * lo - (uint32_t)(2 * (LPS + 1));
+      const uint32_t ex = leaves ? self : inp;
+      p[j] = goes ? ex : SINK2;
+      *reinterpret_cast<uint16_t *>(lpb + self) = (uint16_t)p[j];
+      dex[j] = (goes & leaves) ? d << 24 : 0u;
+    }
   }
-  // the last in-tile cell of every cell's path: pointer jumping (two batches of independent LDS reads per trip);
-  // twelve doublings cover any loop-free path of a 4096-cell tile, what still points at a non-terminal then runs into a loop
-  uint16_t keep[LT / 4];
+  __syncthreads();   // (every thread has read what it needs of sd)
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) keep[j] = lp[(ly0 + 4 * j) * LPS + lx];   // own entries before they are compressed
-  __syncthreads();   // (also: every thread has read what it needs of sd)
+  for (int j = 0; j < RPT; j++) cnt[(ly0 + 4 * j) * LPS + lx] = dex[j];
+  {
+    // two hops per trip with a barrier per trip: twelve trips cover any loop-free path of a 4096-cell tile; what still moves
+    // then runs round a direction loop.  A group of four rows whose cells are all finished is skipped with one scalar test.
+    uint32_t gact = (1u << (RPT / 4)) - 1u;
+#pragma unroll 1
+    for (int it = 0; it < 12; it++) {
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) cnt[(ly0 + 4 * j) * LPS + lx] = 0;
-  // (k_descent's loop: two hops per trip, a cell is finished once its pointer names a terminal, and a group of four rows
-  // whose cells are all finished is skipped with one scalar test -- this kernel is bound by instruction issue)
-  uint32_t act = 0;
+      for (int g = 0; g < RPT / 4; g++) {
+        if (!(gact >> g & 1u)) continue;
+        uint32_t qv[4], rv[4];
 #pragma unroll
-  for (int j = 0; j < LT / 4; j++) act |= (keep[j] < LP_TERM ? 1u : 0u) << j;
-  for (int it = 0; it < 12; it++) {
-    int still = 0;
+        for (int e = 0; e < 4; e++) qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]);
 #pragma unroll
-    for (int g = 0; g < LT / 16; g++) {
-      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;   // wave uniform
-      uint16_t pv[4], qv[4], rv[4];
+        for (int e = 0; e < 4; e++) rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]);
+        bool moving = false;
 #pragma unroll
-      for (int e = 0; e < 4; e++) pv[e] = lp[(ly0 + 4 * (4 * g + e)) * LPS + lx];
-#pragma unroll
-      for (int e = 0; e < 4; e++) qv[e] = lp[pv[e] < LP_TERM ? pv[e] : (ly0 + 4 * (4 * g + e)) * LPS + lx];
-#pragma unroll
-      for (int e = 0; e < 4; e++) rv[e] = lp[qv[e] < LP_TERM ? qv[e] : (ly0 + 4 * (4 * g + e)) * LPS + lx];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int j = 4 * g + e;
-        if (pv[e] < LP_TERM && qv[e] < LP_TERM) {
-          const bool more = rv[e] < LP_TERM;   // q is not the end of the path yet: jump to r and come back
-          lp[(ly0 + 4 * j) * LPS + lx] = more ? rv[e] : qv[e];
-          if (more) still = 1;
-          else act &= ~(1u << j);
-        } else {
-          act &= ~(1u << j);
+        for (int e = 0; e < 4; e++) {
+          const int j = 4 * g + e;
+          moving |= rv[e] != qv[e];   // (equal: qv points to itself -- an exit or the sink -- and the cell is finished)
+          p[j] = rv[e];
+          *reinterpret_cast<uint16_t *>(lpb + self0 + (uint32_t)(j * 4 * LPS * 2)) = (uint16_t)rv[e];
         }
+        if (__builtin_amdgcn_ballot_w64(moving) == 0ull) gact &= ~(1u << g);
+      }
+      if (!__syncthreads_or(gact != 0u)) break;
+    }
+  }
+  __syncthreads();
+  // every cell adds itself to the exit its path ends at (an exit to itself); a cell whose path ends nowhere, or never
+  // ends, adds nothing
+  {
+    const unsigned long long after = ~((2ull << lx) - 1ull);   // the lanes after this one
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t pj = p[j];
+      const uint32_t back = *reinterpret_cast<const uint16_t *>(lpb + pj);
+      const bool adds = (pj != SINK2) & (back == pj);
+      // Neighbouring cells of a row mostly leave through the same exit: a run of lanes with the same target adds its
+      // LENGTH once, from its first lane (same-address LDS atomics serialise: SQ_LDS_ADDR_CONFLICT was 26 % of this
+      // kernel's LDS cycles).  Lanes that add nothing get a target of their own: runs of length one.
+      const uint32_t tgt = adds ? pj : 0x10000u + (uint32_t)lx;
+      const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)tgt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      const unsigned long long heads = __builtin_amdgcn_ballot_w64(tgt != left);   // (lane 0 is a head: its "left" is the fill)
+      if (adds && tgt != left) {
+        const unsigned long long above = heads & after;                         // the heads after this lane
+        const int end = above ? __ffsll((long long)above) - 1 : 64;             // first lane of the next run
+        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + 2u * tgt), (uint32_t)(end - lx));
       }
     }
-    if (!__syncthreads_or(still)) break;
   }
   __syncthreads();
-  // every cell adds itself to the exit its path ends at (an exit to itself); anything else adds 0 to its own counter
-#pragma unroll 4
-  for (int j = 0; j < LT / 4; j++) {
-    const int c = (ly0 + 4 * j) * LPS + lx;
-    const uint16_t p = lp[c];
-    const uint16_t code = lp[p < LP_TERM ? p : c];   // p is terminal iff its own (uncompressed == compressed) entry is a code
-    const bool self_exit = keep[j] == LP_EXIT, via = keep[j] < LP_TERM && p < LP_TERM && code == LP_EXIT;
-    // Neighbouring cells of a row mostly leave through the same exit: a run of lanes with the same target adds its
-    // LENGTH once, from its first lane (same-address LDS atomics serialise: SQ_LDS_ADDR_CONFLICT was 26 % of this
-    // kernel's LDS cycles).  Lanes that add nothing target their own counter: runs of length one.
-    const bool adds = self_exit || via;
-    const uint32_t tgt = adds ? (uint32_t)(via ? p : c) : 0x10000u + (uint32_t)lx;
-    const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)tgt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const unsigned long long heads = __ballot(tgt != left);                  // (lane 0 is a head: its "left" is the fill)
-    if (adds && tgt != left) {
-      const unsigned long long above = heads & ~((2ull << lx) - 1ull);       // the heads after this lane
-      const int end = above ? __ffsll((long long)above) - 1 : 64;            // first lane of the next run
-      atomicAdd(&cnt[tgt], (uint32_t)(end - lx));
-    }
-  }
-  __syncthreads();
-  // what the border cells publish (252 of the tile's 256 slots; the four spare ones are marked unused)
-  if (threadIdx.x < 4) {
-    const size_t node = (size_t)t * 256 + 252 + threadIdx.x;
-    nw[node] = NOT_A_NODE << LK_SHIFT; next[node] = NO_NODE; rootslot[node] = 255;
-  }
-  for (int j = 0; j < LT / 4; j++) {
-    const int ly = ly0 + 4 * j;
-    const int slot = border_slot(lx, ly);
-    if (slot < 0) continue;
+  // what the border cells publish, one per thread (252 of the tile's 256 slots; the four spare ones are marked unused)
+  {
+    const int slot = (int)threadIdx.x;
     const size_t node = (size_t)t * 256 + slot;
-    const int c = ly * LPS + lx;
-    const bool is_exit = keep[j] == LP_EXIT;
-    // root: the cell itself when it is terminal, else the terminal its compressed pointer names
-    uint8_t rs = 255;
-    if (is_exit) rs = (uint8_t)slot;
-    else if (keep[j] < LP_TERM) {
-      const uint16_t p = lp[c];
-      if (p < LP_TERM) {
-        const uint16_t code = lp[p];
-        if (code == LP_EXIT) rs = (uint8_t)border_slot(p % LPS, p / LPS);
-      }
-    }
-    rootslot[node] = rs;
     unsigned long long word = NOT_A_NODE << LK_SHIFT;
     uint32_t tn = NO_NODE;
-    if (is_exit) {
-      word = (unsigned long long)cnt[c];   // complete by construction: every cell counted has a path to it
-      const uint8_t d = (uint8_t)(dpk[j >> 2] >> (8 * (j & 3)));
-      const int gx = x0 + lx + d8dx(d), gy = y0 + ly + d8dy(d);
-      tn = ((uint32_t)(gy / LT) * tilesX + (uint32_t)(gx / LT)) * 256u + (uint32_t)border_slot(gx % LT, gy % LT);
+    uint8_t rs = 255;
+    if (slot < 4 * LT - 4) {
+      const int bx = slot < LT ? slot : slot < 2 * LT ? slot - LT : slot < 3 * LT - 2 ? 0 : LT - 1;
+      const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
+      const uint32_t c2 = (uint32_t)((by * LPS + bx) * 2);
+      const uint32_t root = *reinterpret_cast<const uint16_t *>(lpb + c2);
+      const uint32_t back = *reinterpret_cast<const uint16_t *>(lpb + root);
+      if (root != SINK2 && back == root) {   // the path ends at an exit (the cell itself when it is one)
+        const int ri = (int)(root >> 1), ry = ri / LPS, rx = ri - ry * LPS;
+        rs = (uint8_t)border_slot(rx, ry);
+      }
+      if (root == c2) {
+        const uint32_t cw = cnt[by * LPS + bx];
+        word = (unsigned long long)(cw & 0xFFFFFFu);   // complete by construction: every cell counted has a path to it
+        const int d = (int)(cw >> 24);
+        const int gx = x0 + bx + d8dx(d), gy = y0 + by + d8dy(d);
+        tn = ((uint32_t)(gy / LT) * tilesX + (uint32_t)(gx / LT)) * 256u + (uint32_t)border_slot(gx % LT, gy % LT);
+      }
     }
     nw[node] = word;
     next[node] = tn;
+    rootslot[node] = rs;
   }
 }
 
@@ -640,19 +673,22 @@ __global__ __launch_bounds__(NTHR) void k_acc_link_final_list(const uint8_t *__r
 // of a raster below 2^31 cells: 32 bits (24 KB of LDS per tile instead of 38: five blocks per CU).  A tile with a
 // blocked donor, or whose pointers still move after twelve doublings (a direction loop), is appended to slow_tiles and
 // left to k_acc_link_final, which keeps the reference's partial sums there.
-constexpr uint16_t ANC_NONE = 0xFFFFu;
 template <class A>
 __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *__restrict__ dirs, uint8_t nodata, int w, int h,
                                                                uint32_t tilesX, uint32_t ntiles,
                                                                const unsigned long long *__restrict__ nw, A *__restrict__ area,
                                                                uint32_t *slow_tiles, uint32_t *slow_count) {
-  __shared__ uint8_t sd[LLW * LLW];
-  __shared__ uint32_t S[LT * LPS];      // (rows of LPS entries: see link_stage)
-  __shared__ uint16_t anc[LT * LPS];
+  // (r04d, like k_acc_link_tile: ancestors are byte offsets, a cell whose path has ended points to a self-pointing SINK
+  // entry -- a round reads and hands on without per-cell state tests; targets from byte tables; 32-bit staging)
+  __shared__ __attribute__((aligned(4))) uint8_t sd[SDH * SDW];
+  __shared__ uint32_t S[LT * LPS + 2];      // (rows of LPS entries: see LPS)
+  __shared__ uint16_t anc[LT * LPS + 2];
+  constexpr uint32_t SINK2 = (uint32_t)(LT * LPS * 2);
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * LT, y0 = (int)(t / tilesX) * LT;
-  stage_dirs<LLW, NTHR>(dirs, w, h, x0, y0, nodata, sd);
+  stage_dirs_rows(dirs, w, h, x0, y0, nodata, sd);
+  if (threadIdx.x == 0) anc[LT * LPS] = (uint16_t)SINK2;
   __syncthreads();
   // what the border cells receive from outside, one border cell per thread (all lookups in flight together)
   unsigned long long inflow = 0;
@@ -663,7 +699,7 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
     if (slot < 4 * LT - 4) {
       const int bx = slot < LT ? slot : slot < 2 * LT ? slot - LT : slot < 3 * LT - 2 ? 0 : LT - 1;
       const int by = slot < LT ? 0 : slot < 2 * LT ? LT - 1 : slot < 3 * LT - 2 ? slot - 2 * LT + 1 : slot - (3 * LT - 2) + 1;
-      const int o = (by + 1) * LLW + bx + 1;
+      const int o = (by + 1) * SDW + SDO + bx;
       if (sd[o] != nodata) {
         bcell = by * LPS + bx;
         unsigned long long wv[8];
@@ -671,12 +707,13 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
 #pragma unroll
         for (int m = 1; m <= 8; m++) {
           const int nx = bx + d8dx(m), ny = by + d8dy(m);
-          const uint8_t dn = sd[o + d8dy(m) * LLW + d8dx(m)];
+          const uint8_t dn = sd[o + d8dy(m) * SDW + d8dx(m)];
           use[m - 1] = !(nx >= 0 && nx < LT && ny >= 0 && ny < LT) && dn != nodata && dn == (m <= 4 ? m + 4 : m - 4);
           wv[m - 1] = 0;
           if (use[m - 1]) {
-            const int gx = x0 + nx, gy = y0 + ny;
-            wv[m - 1] = nw[((size_t)(gy / LT) * tilesX + (size_t)(gx / LT)) * 256 + (size_t)border_slot(gx % LT, gy % LT)];
+            const uint32_t gx = (uint32_t)(x0 + nx), gy = (uint32_t)(y0 + ny);   // (a cell with data: inside the raster)
+            static_assert(LT == 64, "shifts and masks below");
+            wv[m - 1] = nw[((size_t)(gy >> 6) * tilesX + (size_t)(gx >> 6)) * 256 + (size_t)border_slot((int)(gx & 63u), (int)(gy & 63u))];
           }
         }
 #pragma unroll
@@ -690,21 +727,33 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
     }
   }
   const int lx = threadIdx.x & (LT - 1), ly0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave uniform: row arithmetic on the scalar unit)
-  uint16_t a[LT / 4];      // the 2^k-th ancestor of the thread's cells (ANC_NONE: the path is shorter)
-  uint32_t datamask = 0, act = 0;
-#pragma unroll 4
-  for (int j = 0; j < LT / 4; j++) {   // every cell without branches (see link_stage)
-    const int ly = ly0 + 4 * j, o = (ly + 1) * LLW + lx + 1;
-    const uint8_t d = sd[o];
-    const bool data = d != nodata, flows = data && d >= 1 && d <= 8;
-    const int dd = flows ? d : 0;
-    const int tx = lx + d8dx(dd), ty = ly + d8dy(dd);
-    const bool in_tile = flows && tx >= 0 && tx < LT && ty >= 0 && ty < LT && sd[(ty + 1) * LLW + tx + 1] != nodata;
-    a[j] = in_tile ? (uint16_t)(ty * LPS + tx) : ANC_NONE;
-    datamask |= (data ? 1u : 0u) << j;
-    act |= (in_tile ? 1u : 0u) << j;
-    S[ly * LPS + lx] = data ? 1u : 0u;
-    anc[ly * LPS + lx] = a[j];
+  constexpr int RPT = LT / 4;
+  char *const ancb = reinterpret_cast<char *>(anc), *const Sb = reinterpret_cast<char *>(S);
+  const uint32_t self0 = (uint32_t)((ly0 * LPS + lx) * 2);   // row j of the thread: self0 + j * 4 * LPS * 2 (anc), twice that (S)
+  uint32_t a[RPT];         // the 2^k-th ancestor of the thread's cells (byte offset into anc; SINK2: the path is shorter)
+  uint32_t datamask = 0;
+  {
+    const uint32_t cmcol = lx == 0 ? 1u : lx == LT - 1 ? 2u : 0u;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {   // every cell without branches
+      const int ly = ly0 + 4 * j;
+      const int o = (ly + 1) * SDW + SDO + lx;
+      const uint32_t d = sd[o];
+      const uint32_t e = (d - 1u) & 7u, sel = e | 0x0c0c0c00u;
+      const bool data = d != nodata, flows = data & (d - 1u < 8u);
+      const uint32_t so = d8_byte(D8_SD_HI, D8_SD_LO, sel), lo = d8_byte(D8_LP_HI, D8_LP_LO, sel), fl = d8_byte(D8_FL_HI, D8_FL_LO, sel);
+      const bool into_data = sd[o + (int)so - (SDW + 1)] != nodata;
+      uint32_t cm = cmcol;
+      if (j == 0 && ly0 == 0) cm |= 4u;
+      if (j == RPT - 1 && ly0 == 3) cm |= 8u;
+      const bool in_tile = flows & into_data & ((fl & cm) == 0u);
+      const uint32_t self = self0 + (uint32_t)(j * 4 * LPS * 2);
+      const uint32_t up = self + 2u * lo - (uint32_t)(2 * (LPS + 1));
+      a[j] = in_tile ? up : SINK2;
+      datamask |= (data ? 1u : 0u) << j;
+      *reinterpret_cast<uint32_t *>(Sb + 2u * self) = data ? 1u : 0u;
+      *reinterpret_cast<uint16_t *>(ancb + self) = (uint16_t)a[j];
+    }
   }
   __syncthreads();
   if (bcell >= 0 && inflow) S[bcell] += (uint32_t)inflow;   // (one thread per border cell)
@@ -713,46 +762,46 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
     return;
   }
   int it = 0;
+  uint32_t gact = (1u << (RPT / 4)) - 1u;   // (scalar) groups of four rows with a cell still on its path
+#pragma unroll 1
   for (; it < 13; it++) {
-    uint32_t sv[LT / 4];
-    uint16_t aa[LT / 4];
+    uint32_t sv[RPT], aa[RPT];
 #pragma unroll
-    for (int g = 0; g < LT / 16; g++) {   // groups of four rows: one scalar test skips a group that is done
-      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
+    for (int g = 0; g < RPT / 4; g++) {   // groups of four rows: one scalar test skips a group that is done
+      if (!(gact >> g & 1u)) continue;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int j = 4 * g + e;
-        const bool on = act >> j & 1u;
-        sv[j] = S[(ly0 + 4 * j) * LPS + lx];
-        aa[j] = anc[on ? a[j] : (ly0 + 4 * j) * LPS + lx];   // (a finished cell reads its own slot: no branch around the LDS read)
+        sv[j] = *reinterpret_cast<const uint32_t *>(Sb + 2u * (self0 + (uint32_t)(j * 4 * LPS * 2)));
+        aa[j] = *reinterpret_cast<const uint16_t *>(ancb + a[j]);   // (a finished cell reads the sink's entry: the sink)
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < LT / 16; g++) {
-      if (__ballot((act >> (4 * g)) & 15u) == 0ull) continue;
+    for (int g = 0; g < RPT / 4; g++) {
+      if (!(gact >> g & 1u)) continue;
+      bool on = false;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int j = 4 * g + e;
-        if (act >> j & 1u) {
-          atomicAdd(&S[a[j]], sv[j]);
-          anc[(ly0 + 4 * j) * LPS + lx] = aa[j];
-          a[j] = aa[j];
-          if (aa[j] == ANC_NONE) act &= ~(1u << j);
-        }
+        if (a[j] != SINK2) atomicAdd(reinterpret_cast<uint32_t *>(Sb + 2u * a[j]), sv[j]);
+        *reinterpret_cast<uint16_t *>(ancb + self0 + (uint32_t)(j * 4 * LPS * 2)) = (uint16_t)aa[j];
+        a[j] = aa[j];
+        on |= aa[j] != SINK2;
       }
+      if (__builtin_amdgcn_ballot_w64(on) == 0ull) gact &= ~(1u << g);
     }
-    if (!__syncthreads_or(act != 0)) break;
+    if (!__syncthreads_or(gact != 0u)) break;
   }
   if (it >= 13) {   // 2^12 steps and still on a path: a direction loop inside the tile
     if (threadIdx.x == 0) slow_tiles[atomicAdd(slow_count, 1u)] = t;
     return;
   }
-#pragma unroll 4
-  for (int j = 0; j < LT / 4; j++) {
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
     const int ly = ly0 + 4 * j, gx = x0 + lx, gy = y0 + ly;
     if (gx >= w || gy >= h) continue;
-    const uint32_t v = S[ly * LPS + lx];
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(Sb + 2u * (self0 + (uint32_t)(j * 4 * LPS * 2)));
     area[(size_t)gy * w + gx] = (datamask >> j & 1u) ? (A)v : (A)-1;   // area.noData() == -1, d8_methods.hpp:64,:72-75
   }
 }

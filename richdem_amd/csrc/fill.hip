@@ -1945,23 +1945,41 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
   {
     constexpr int NQ = DLH * (DW / 4), QPT = (NQ + NTHR - 1) / NTHR;
     Quad<T> zq[QPT];
-    bool okq[QPT];
+    if (y0 >= 1 && y0 + DH < h && x0 + DW <= w) {   // (block-uniform) every row and quad of the window lies in the raster: no tests
 #pragma unroll
-    for (int r = 0; r < QPT; r++) {
-      const int i = threadIdx.x + r * NTHR;
-      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
-      const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
-      okq[r] = i < NQ && gy >= 0 && gy < h && gx < w;
-      if (okq[r]) zq[r] = load_quad<T, VEC>(z + (size_t)gy * w, gx, w, T());
-    }
+      for (int r = 0; r < QPT; r++) {
+        const int i = threadIdx.x + r * NTHR;
+        const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+        if (i < NQ) zq[r] = load_quad<T, VEC>(z + (size_t)(y0 - 1 + ly) * w, x0 + 4 * q, w, T());
+      }
 #pragma unroll
-    for (int r = 0; r < QPT; r++) {
-      const int i = threadIdx.x + r * NTHR;
-      if (i >= NQ) continue;
-      const int ly = i / (DW / 4), q = i - ly * (DW / 4);
-      const int o = ly * DLW + 1 + 4 * q;
+      for (int r = 0; r < QPT; r++) {
+        const int i = threadIdx.x + r * NTHR;
+        if (i >= NQ) continue;
+        const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+        const int o = ly * DLW + 1 + 4 * q;
 #pragma unroll
-      for (int e = 0; e < 4; e++) sk[o + e] = (okq[r] && x0 + 4 * q + e < w) ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
+        for (int e = 0; e < 4; e++) sk[o + e] = Key32<T>::to(zq[r].v[e]);
+      }
+    } else {
+      bool okq[QPT];
+#pragma unroll
+      for (int r = 0; r < QPT; r++) {
+        const int i = threadIdx.x + r * NTHR;
+        const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+        const int gx = x0 + 4 * q, gy = y0 - 1 + ly;
+        okq[r] = i < NQ && gy >= 0 && gy < h && gx < w;
+        if (okq[r]) zq[r] = load_quad<T, VEC>(z + (size_t)gy * w, gx, w, T());
+      }
+#pragma unroll
+      for (int r = 0; r < QPT; r++) {
+        const int i = threadIdx.x + r * NTHR;
+        if (i >= NQ) continue;
+        const int ly = i / (DW / 4), q = i - ly * (DW / 4);
+        const int o = ly * DLW + 1 + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; e++) sk[o + e] = (okq[r] && x0 + 4 * q + e < w) ? Key32<T>::to(zq[r].v[e]) : 0xFFFFFFFFu;
+      }
     }
     for (int i = threadIdx.x; i < 2 * DLH; i += NTHR) {   // halo columns
       const int ly = i >> 1, lxh = (i & 1) ? DLW - 1 : 0;
@@ -2093,7 +2111,7 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
           p[j] = rv[e];
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lp) + selfb0 + (uint32_t)(j * LPD * 2)) = (uint16_t)rv[e];
         }
-        if (__ballot(moving) == 0ull) gact &= ~(1u << g);
+        if (__builtin_amdgcn_ballot_w64(moving) == 0ull) gact &= ~(1u << g);   // (the builtin: __ballot() costs two VALU instructions)
       }
     }
   }
@@ -2547,35 +2565,44 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
     // ---- stage 2: keys and components of the tile and its ring into LDS ---------------------------------------------
     {
       uint32_t cq[2][4];
-      bool in[2][4];
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const int i = tid + r * NTHR;
-        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
-        const int gx = x0 + 4 * q, gy = y0 + ly;
-#pragma unroll
-        for (int e = 0; e < 4; e++) in[r][e] = gy < h && gx + e < w;
-      }
+      // (a quad outside the raster was loaded from the tile's first cell: its labels are labels of this descent tile, the
+      // lookups need no guard -- and a label is < cnt <= NT_CAP when the table is used)
       if (tabled) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) cq[r][e] = ntab[in[r][e] ? (uint32_t)lq[r].v[e] & (NT_CAP - 1) : 0u];
+          for (int e = 0; e < 4; e++) cq[r][e] = ntab[lq[r].v[e]];
       } else {   // more nodes than the table holds (white noise): gathered
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) cq[r][e] = curN[tbC + (in[r][e] ? (uint32_t)lq[r].v[e] : 0u)];
+          for (int e = 0; e < 4; e++) cq[r][e] = curN[tbC + (uint32_t)lq[r].v[e]];
       }
+      if (x0 + TW <= w && y0 + TH <= h) {   // (block-uniform) the whole tile lies in the raster: no tests
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const int i = tid + r * NTHR;
-        const int ly = i / (TW / 4), q = i - ly * (TW / 4);
-        const int o = (ly + 1) * LW + 1 + 4 * q;
+        for (int r = 0; r < 2; r++) {
+          const int i = tid + r * NTHR;
+          const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+          const int o = (ly + 1) * LW + 1 + 4 * q;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          sk[o + e] = in[r][e] ? Key32<T>::to(zq[r].v[e]) : 0u;
-          sc[o + e] = in[r][e] ? cq[r][e] : (B | CLOSED);
+          for (int e = 0; e < 4; e++) {
+            sk[o + e] = Key32<T>::to(zq[r].v[e]);
+            sc[o + e] = cq[r][e];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int i = tid + r * NTHR;
+          const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+          const int gx = x0 + 4 * q, gy = y0 + ly;
+          const int o = (ly + 1) * LW + 1 + 4 * q;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const bool in = gy < h && gx + e < w;
+            sk[o + e] = in ? Key32<T>::to(zq[r].v[e]) : 0u;
+            sc[o + e] = in ? cq[r][e] : (B | CLOSED);
+          }
         }
       }
       if (isring) {
@@ -2603,6 +2630,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
         for (int e = 0; e < 3; e++) c1[e] = sc[o + e];
       }
       unsigned long long bal[ROWS];
+      bool bnd[ROWS];
       // (k_scan's "the tile still holds an open boundary" flag feeds the raster rounds, which this path does not have)
       const int rows_in = min(h - y0 - yb, ROWS);   // rows of this band inside the raster
       const bool colin = gxl < w;
@@ -2617,7 +2645,8 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
         const uint32_t C = c1[1];
         uint32_t df = (c1[2] ^ C) | (c2[1] ^ C);
         if (TOPO == 8) df |= (c2[0] ^ C) | (c2[2] ^ C);
-        bal[j] = __ballot(df != 0 && colin && j < rows_in);
+        bnd[j] = df != 0 && colin && j < rows_in;
+        bal[j] = __builtin_amdgcn_ballot_w64(bnd[j]);   // (the builtin: __ballot() costs two VALU instructions)
 #pragma unroll
         for (int e = 0; e < 3; e++) c1[e] = c2[e];
       }
@@ -2631,8 +2660,9 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
         base = __shfl(base, 0, 64);
 #pragma unroll
         for (int j = 0; j < ROWS; j++) {
-          if (bal[j] >> lane & 1ull)
-            list[base + __popcll(bal[j] & ((1ull << lane) - 1ull))] = (uint16_t)((yb + j + 1) * LW + lx + 1);
+          if (bnd[j])
+            list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u))] =
+                (uint16_t)((yb + j + 1) * LW + lx + 1);
           base += (uint32_t)__popcll(bal[j]);
         }
       }
