@@ -122,7 +122,7 @@ def main():
             per_fill = sum(r[4] * r[1] for r in rows if r[0].split("<")[0].replace("rdgpu::", "") in fill_kernels) / nfill
             json.dump({"size": 40000, "GB_per_launch": per, "GB_per_fill": round(per_fill, 2), "engine_sha": engine_sha(),
                        "git_sha": os.environ.get("RDGPU_GIT_SHA"),
-                       "source": f"profiles/{tag}_fill40k_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
+                       "source": f"profiles/{tag}_{what}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
         # the bench line above was printed before these passes ran: give it this round's traffic figure
         d = json.loads(line)
         if d.get("roofline") and d["roofline"].get("kernel") in per:
