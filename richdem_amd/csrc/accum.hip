@@ -393,18 +393,18 @@ __global__ __launch_bounds__(NTHR, 6) void k_acc_link_tile(const uint8_t *__rest
         if (!(gact >> g & 1u)) continue;
         uint32_t qv[4], rv[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]);
+        for (int e = 0; e < 4; e++) { qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]); asm("" : "+v"(qv[e])); }
 #pragma unroll
-        for (int e = 0; e < 4; e++) rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]);
-        bool moving = false;
+        for (int e = 0; e < 4; e++) { rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]); asm("" : "+v"(rv[e])); }   // (opaque 32-bit values: else the compare is narrowed to 16 bits and every value masked again for its use as an address)
+        unsigned long long moving = 0;   // (ballots of the plain compares: v_cmp's lane masks, OR-ed on the scalar unit)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int j = 4 * g + e;
-          moving |= rv[e] != qv[e];   // (equal: qv points to itself -- an exit or the sink -- and the cell is finished)
+          moving |= __builtin_amdgcn_ballot_w64(rv[e] != qv[e]);   // (equal: qv points to itself -- an exit or the sink -- and the cell is finished)
           p[j] = rv[e];
           *reinterpret_cast<uint16_t *>(lpb + self0 + (uint32_t)(j * 4 * LPS * 2)) = (uint16_t)rv[e];
         }
-        if (__builtin_amdgcn_ballot_w64(moving) == 0ull) gact &= ~(1u << g);
+        if (moving == 0ull) gact &= ~(1u << g);
       }
       if (!__syncthreads_or(gact != 0u)) break;
     }
@@ -774,22 +774,23 @@ __global__ __launch_bounds__(NTHR, 5) void k_acc_link_final_sums(const uint8_t *
         const int j = 4 * g + e;
         sv[j] = *reinterpret_cast<const uint32_t *>(Sb + 2u * (self0 + (uint32_t)(j * 4 * LPS * 2)));
         aa[j] = *reinterpret_cast<const uint16_t *>(ancb + a[j]);   // (a finished cell reads the sink's entry: the sink)
+        asm("" : "+v"(aa[j]));
       }
     }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < RPT / 4; g++) {
       if (!(gact >> g & 1u)) continue;
-      bool on = false;
+      unsigned long long on = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int j = 4 * g + e;
         if (a[j] != SINK2) atomicAdd(reinterpret_cast<uint32_t *>(Sb + 2u * a[j]), sv[j]);
         *reinterpret_cast<uint16_t *>(ancb + self0 + (uint32_t)(j * 4 * LPS * 2)) = (uint16_t)aa[j];
         a[j] = aa[j];
-        on |= aa[j] != SINK2;
+        on |= __builtin_amdgcn_ballot_w64(aa[j] != SINK2);
       }
-      if (__builtin_amdgcn_ballot_w64(on) == 0ull) gact &= ~(1u << g);
+      if (on == 0ull) gact &= ~(1u << g);
     }
     if (!__syncthreads_or(gact != 0u)) break;
   }

@@ -2100,18 +2100,18 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
         if (!(gact >> g & 1u)) continue;
         uint32_t qv[4], rv[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]);
+        for (int e = 0; e < 4; e++) { qv[e] = *reinterpret_cast<const uint16_t *>(lpb + p[4 * g + e]); asm("" : "+v"(qv[e])); }
 #pragma unroll
-        for (int e = 0; e < 4; e++) rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]);
-        bool moving = false;
+        for (int e = 0; e < 4; e++) { rv[e] = *reinterpret_cast<const uint16_t *>(lpb + qv[e]); asm("" : "+v"(rv[e])); }   // (opaque 32-bit values: else the compare is narrowed to 16 bits and every value is masked again for its use as an address)
+        unsigned long long moving = 0;   // (ballots of the plain compares: lane masks straight from v_cmp, OR-ed on the scalar unit)
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int j = 4 * g + e;
-          moving |= rv[e] != qv[e];   // (equal: qv is a root, the cell is finished)
+          moving |= __builtin_amdgcn_ballot_w64(rv[e] != qv[e]);   // (equal: qv is a root, the cell is finished)
           p[j] = rv[e];
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lp) + selfb0 + (uint32_t)(j * LPD * 2)) = (uint16_t)rv[e];
         }
-        if (__builtin_amdgcn_ballot_w64(moving) == 0ull) gact &= ~(1u << g);   // (the builtin: __ballot() costs two VALU instructions)
+        if (moving == 0ull) gact &= ~(1u << g);
       }
     }
   }
