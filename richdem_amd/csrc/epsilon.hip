@@ -287,8 +287,8 @@ __global__ __launch_bounds__(NT) void k_eps_check(const T *__restrict__ z, const
       if (feeds) {
         nsrc++;
         const K kc = sd[o];
-        if (sizeof(K) == 4) {
-          // 32-bit keys: one bit per possible key (512 MB), indexed by the key itself -- the sources of a tile lie within
+        if (sizeof(K) == 4 && tie_mask == 0ull) {
+          // 32-bit keys, large rasters (tie_mask == 0): one bit per possible key (512 MB), indexed by the key itself -- the sources of a tile lie within
           // a few metres of each other, so their bits share cache lines (a scattering hash table cost 39 ms at S3,
           // a random DRAM access per source; this costs a few)
           uint32_t *bits = reinterpret_cast<uint32_t *>(tie_table);
@@ -547,6 +547,7 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
   unsigned long long tie_slots = 1024;
   while (ties_on && tie_slots < n / 4) tie_slots *= 2;
   K *tie_table = nullptr;
+  bool bitmap = false;   // the tie detector's set is the 2^32-bit map (f32, large rasters): k_eps_check is told by tie_mask == 0
   unsigned long long *tc = ws.buf<unsigned long long>("eps.tiecounts", 2 * TIE_STRIPES);
   std::vector<unsigned long long> htc_v(2 * TIE_STRIPES);
   unsigned long long htc[2] = {0, 0};
@@ -554,10 +555,11 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     g_stats.attempts++;
     g_stats.slack = (uint64_t)X;
     if (ties_on) {
-      if (sizeof(K) == 4) {   // the bitmap over all 2^32 keys
+      if (sizeof(K) == 4 && n >= (1ull << 26)) {   // the bitmap over all 2^32 keys (a small raster takes the hashed set: no 512 MB for a 200 x 200 DEM)
         tie_slots = (1ull << 32) / 32;
         tie_table = ws.buf<K>("eps.tiebits", tie_slots);
         RD_HIP(hipMemsetAsync(tie_table, 0, tie_slots * sizeof(K), s));
+        bitmap = true;
       } else {
         tie_table = ws.buf<K>("eps.tietable", tie_slots);
         RD_HIP(hipMemsetAsync(tie_table, 0xFF, tie_slots * sizeof(K), s));
@@ -571,14 +573,14 @@ static void run(T *d_z, T nodata, const T *d_W, int w, int h, hipStream_t s) {
     relax_until_quiet<EpsField<T>, TOPO>(EpsField<T>{d_z, nodata, d_W}, D, tflags, tlist, ctr, w, h, "eps.relax", s);
     for (;;) {   // (the proof pass; run again only if the tie detector's set turned out too small for this DEM)
       RD_LAUNCH("eps.check", (k_eps_check<T, TOPO>), dim3(xcd_grid(ntiles)), dim3(NT), 0, s, (const T *)d_z, d_W, nodata, (const K *)D, w,
-                h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2), tie_table, tie_slots - 1, tc);
+                h, tilesX, ntiles, ctr + BATCH, (unsigned long long *)(ctr + BATCH + 2), tie_table, bitmap ? 0ull : tie_slots - 1, tc);
       RD_HIP(hipMemcpyAsync(hw, ctr + BATCH, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       if (ties_on) RD_HIP(hipMemcpyAsync(htc_v.data(), tc, 2 * TIE_STRIPES * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       RD_HIP(hipStreamSynchronize(s));
       htc[0] = htc[1] = 0;
       if (ties_on)
         for (uint32_t i = 0; i < TIE_STRIPES; i++) { htc[0] += htc_v[2 * i]; htc[1] += htc_v[2 * i + 1]; }
-      if (!(ties_on && sizeof(K) == 8 && hw[0] == 0 && htc[0] * 2 > tie_slots)) break;
+      if (!(ties_on && !bitmap && hw[0] == 0 && htc[0] * 2 > tie_slots)) break;
       while (tie_slots < 4 * htc[0]) tie_slots *= 2;   // more than half full: a larger set, the same D
       tie_table = ws.buf<K>("eps.tietable", tie_slots);
       RD_HIP(hipMemsetAsync(tie_table, 0xFF, tie_slots * sizeof(K), s));

@@ -2180,12 +2180,14 @@ __global__ __launch_bounds__(NTHR) void k_descent16(const T *__restrict__ z, Fus
       const uint16_t rv = *reinterpret_cast<const uint16_t *>(sl + p[j]);
       if ((gx < w) & (gy < h)) fo.lab16[(size_t)gy * w + gx] = rv;   // (< 4096: not every cell of a tile can be a root)
     }
-    // the tile's first and last column, the SLOTS of the compact records: two wavefronts, one row per lane, coalesced
-    // (cells past the raster's end are written too and never read)
+    // the tile's first and last column, the SLOTS of the compact records: two wavefronts, one row per lane, coalesced.
+    // A cell past the raster's end gets slot 0: the pair pass does read such a record (a ring cell outside the raster is
+    // loaded from a clamped position and discarded afterwards), and follows its slot into the node table.
     if (fo.edgeS && threadIdx.x < 2 * DH) {
       const int side = threadIdx.x >> 6, lye = threadIdx.x & (DH - 1), lxe = side ? DW - 1 : 0;
       const uint16_t v = lp[lye * LPD + lxe];
-      fo.edgeS[((size_t)t * 2 + side) * DH + lye] = *reinterpret_cast<const uint16_t *>(sl + v);
+      const bool in = x0 + lxe < w && y0 + lye < h;
+      fo.edgeS[((size_t)t * 2 + side) * DH + lye] = in ? *reinterpret_cast<const uint16_t *>(sl + v) : (uint16_t)0;
     }
   }
 }
@@ -2528,6 +2530,9 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
         const size_t row = ok ? (size_t)gy * w : 0;
         lq[r] = load_quad<uint16_t, false>(lab16 + row, ok ? gx : 0, w, (uint16_t)0);
         zq[r] = load_quad<T, false>(z + row, ok ? gx : 0, w, T());
+        if (!ok)   // (the raster's first cells stand in: THEIR labels belong to another descent tile; slot 0 exists in every tile)
+#pragma unroll
+          for (int e = 0; e < 4; e++) lq[r].v[e] = 0;
       }
     }
   };
@@ -2565,8 +2570,8 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
     // ---- stage 2: keys and components of the tile and its ring into LDS ---------------------------------------------
     {
       uint32_t cq[2][4];
-      // (a quad outside the raster was loaded from the tile's first cell: its labels are labels of this descent tile, the
-      // lookups need no guard -- and a label is < cnt <= NT_CAP when the table is used)
+      // (a quad outside the raster holds labels of this descent tile -- its first quad's, or zeros: the lookups need no
+      // guard -- and a label is < cnt <= NT_CAP when the table is used)
       if (tabled) {
 #pragma unroll
         for (int r = 0; r < 2; r++)

@@ -533,3 +533,18 @@ def test_row_blocks_on_either_local_phase(rd, orc, monkeypatch, topo):
                 got = rd.FillDepressions(dem, topology=topo, shards=shards)
                 assert got.tobytes() == exp.tobytes(), (dem.shape, dem.dtype, shards, fused)
     monkeypatch.delenv("RDGPU_SHARD_FUSED")
+
+
+def test_rasters_narrower_than_a_tile(rd, orc):
+    """One tile column whose last columns lie past the raster's end: the pair pass loads a ring cell outside the raster from
+    a clamped position -- the tile's own LAST column's edge record -- and follows its slot into the node table before the
+    value is discarded; the record of a cell past the end must hold a valid slot (r04: a fuzz case, 178 x 62 in two row
+    blocks, faulted on the garbage left there)."""
+    rng = np.random.default_rng(23)
+    for h, w, dt in ((178, 62, np.uint16), (128, 58, np.float32), (200, 63, np.int32), (70, 1, np.float32), (300, 33, np.uint8)):
+        z = np.floor((fractal_dem(w, h, seed=int(rng.integers(1 << 20))).astype(np.float64) + 500) * 0.1)
+        dem = np.clip(z, 0, 250).astype(dt) if dt == np.uint8 else z.astype(dt)
+        exp = orc.port.fill(dem, 8)
+        assert rd.FillDepressions(dem).tobytes() == exp.tobytes(), (h, w, dt)
+        for shards in (2, 4):
+            assert rd.FillDepressions(dem, shards=shards).tobytes() == exp.tobytes(), (h, w, dt, shards)

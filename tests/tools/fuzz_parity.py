@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--trace", action="store_true", help="name every check on stderr as it completes (to locate a crash)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -101,6 +102,8 @@ def main():
         def chk(name, ok):
             nonlocal cases
             cases += 1
+            if args.trace:
+                print(cases, name, tag, file=sys.stderr, flush=True)
             if not ok:
                 bad.append(f"{name} {tag}")
 
