@@ -305,4 +305,51 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t ntiles) {
 }
 inline uint32_t xcd_grid(uint32_t ntiles) { return ((ntiles + 7u) / 8u) * 8u; }
 
+// Stage the (TH_ + 2 H_) x (TW_ + 2 H_) window around the tile whose first cell is (x0, y0) into LDS rows of LW_ elements
+// (the tile's first column at element H_ of a row) -- for a window that lies INSIDE the raster, which the caller tests with
+// window_inside(): four elements per load for the tile's columns (element-aligned: any raster width), the 2 H_ halo
+// columns cell by cell, every load of the thread issued before the first store.  The stencil kernels staged cell by cell
+// with a division and two clamps per cell (r01-r04c): a quarter of their instructions, and they are bound by instruction
+// issue (profiles/r04e_path40k_sq_summary.csv).  Tiles on the raster's border keep that path.
+__device__ __forceinline__ bool window_inside(int x0, int y0, int w, int h, int tw, int th, int halo) {
+  return x0 >= halo && y0 >= halo && x0 + tw + halo <= w && y0 + th + halo <= h;
+}
+template <class T, int TW_, int TH_, int H_, int LW_, int NT_>
+__device__ __forceinline__ void stage_window_inside(const T *__restrict__ src, int w, int x0, int y0, T *dst) {
+  constexpr int ROWS = TH_ + 2 * H_, QPR = TW_ / 4, NQ = ROWS * QPR, QPT = (NQ + NT_ - 1) / NT_;
+  constexpr int NHC = ROWS * 2 * H_, HPT = (NHC + NT_ - 1) / NT_;
+  static_assert(TW_ % 4 == 0, "four elements per load");
+  struct Q4 { T v[4]; };
+  const T *const base = src + ((size_t)(y0 - H_) * w + (size_t)(x0 - H_));   // the window's first cell (block-uniform)
+  Q4 q[QPT];
+  T hv[HPT];
+#pragma unroll
+  for (int r = 0; r < QPT; r++) {
+    const int i = (int)threadIdx.x + r * NT_;
+    const int ly = i / QPR, qq = i - ly * QPR;
+    if (i < NQ) __builtin_memcpy(&q[r], base + (uint32_t)(ly * w + H_ + 4 * qq), sizeof(Q4));
+  }
+#pragma unroll
+  for (int r = 0; r < HPT; r++) {
+    const int i = (int)threadIdx.x + r * NT_;
+    const int ly = i / (2 * H_), c = i - ly * (2 * H_);
+    if (i < NHC) hv[r] = base[(uint32_t)(ly * w + (c < H_ ? c : TW_ + c))];
+  }
+#pragma unroll
+  for (int r = 0; r < QPT; r++) {
+    const int i = (int)threadIdx.x + r * NT_;
+    const int ly = i / QPR, qq = i - ly * QPR;
+    if (i < NQ) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) dst[ly * LW_ + H_ + 4 * qq + e] = q[r].v[e];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < HPT; r++) {
+    const int i = (int)threadIdx.x + r * NT_;
+    const int ly = i / (2 * H_), c = i - ly * (2 * H_);
+    if (i < NHC) dst[ly * LW_ + (c < H_ ? c : TW_ + c)] = hv[r];
+  }
+}
+
 }  // namespace rdgpu

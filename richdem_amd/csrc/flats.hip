@@ -67,7 +67,10 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
-  {
+  if (window_inside(x0, y0, w, h, SW, KLH, 1)) {
+    stage_window_inside<T, SW, KLH, 1, SLW, NTHR>(z, w, x0, y0, sz);
+    stage_window_inside<uint8_t, SW, KLH, 1, SLW, NTHR>(dirs, w, x0, y0, sdir);
+  } else {
     constexpr int IPT = (KLLH * SLW + NTHR - 1) / NTHR;
     T zv[IPT];
     uint8_t dv[IPT];
@@ -158,12 +161,14 @@ __device__ __forceinline__ uint8_t d8_dir_cell(const T *sz, int zx, int zy, int 
   }
   T m = e;
   int dir = 0;
+  bool diag = false;   // the choice so far is a diagonal (see k_flowdirs)
 #pragma unroll
   for (int n = 1; n <= 8; n++) {   // :63-71
     const T v = sz[(zy + fdy(n)) * FZW + zx + fdx(n)];
-    const bool take = (v < m) | ((v == m) & (dir > 0) & ((dir & 1) == 0) & ((n & 1) == 1));
+    const bool take = (n & 1) ? ((v < m) | ((v == m) & diag)) : (v < m);
     m = take ? v : m;
     dir = take ? n : dir;
+    diag = (n & 1) ? (diag & !take) : (diag | take);
   }
   return (uint8_t)dir;
 }
@@ -176,7 +181,9 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
-  {
+  if (window_inside(x0, y0, w, h, SW, KLH, 2)) {
+    stage_window_inside<T, SW, KLH, 2, FZW, NTHR>(z, w, x0, y0, sz);
+  } else {
     constexpr int IPT = (FZH * FZW + NTHR - 1) / NTHR;
     T zv[IPT];
 #pragma unroll
@@ -213,12 +220,14 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       const bool in = gx < w && gy >= 0 && gy < h;
       const bool edge = gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1;
       T m = e;
+      bool diag = false;   // the choice so far is a diagonal (see k_flowdirs)
 #pragma unroll
       for (int n = 1; n <= 8; n++) {   // :63-71 (an edge cell's result is replaced below: its window may lie outside)
         const T v = nbv[n];
-        const bool take = (v < m) | ((v == m) & (dir > 0) & ((dir & 1) == 0) & ((n & 1) == 1));
+        const bool take = (n & 1) ? ((v < m) | ((v == m) & diag)) : (v < m);
         m = take ? v : m;
         dir = take ? n : dir;
+        diag = (n & 1) ? (diag & !take) : (diag | take);
       }
       if (edge)   // :37-54
         dir = (gx == 0 && gy == 0) ? 2 : (gx == 0 && gy == h - 1) ? 8 : (gx == w - 1 && gy == 0) ? 4 : (gx == w - 1 && gy == h - 1) ? 6
@@ -1691,7 +1700,44 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
-  {
+  if (window_inside(x0, y0, w, h, SW, KLH, 1)) {
+    // the window lies inside the raster: four cells per load (see stage_window_inside), the two level fields combined on the way
+    stage_window_inside<T, SW, KLH, 1, SLW, NTHR>(z, w, x0, y0, sz);
+    constexpr int QPR = SW / 4, NQ = KLLH * QPR, QPT = (NQ + NTHR - 1) / NTHR, NHC = KLLH * 2;
+    struct Q4 { int32_t v[4]; };
+    const int32_t *const tb = TW + ((size_t)(y0 - 1) * w + (size_t)(x0 - 1)), *const ab = AW ? AW + ((size_t)(y0 - 1) * w + (size_t)(x0 - 1)) : nullptr;
+    Q4 tq[QPT], aq[QPT];
+    int32_t th = DINF, ah = DINF;
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      const int ly = i / QPR, qq = i - ly * QPR;
+      if (i < NQ) {
+        __builtin_memcpy(&tq[r], tb + (uint32_t)(ly * w + 1 + 4 * qq), sizeof(Q4));
+        if (ab) __builtin_memcpy(&aq[r], ab + (uint32_t)(ly * w + 1 + 4 * qq), sizeof(Q4));
+      }
+    }
+    static_assert(NHC <= NTHR, "one halo cell per thread");
+    if ((int)threadIdx.x < NHC) {
+      const int ly = (int)threadIdx.x >> 1, c = (int)threadIdx.x & 1;
+      th = tb[(uint32_t)(ly * w + (c ? SW + 1 : 0))];
+      if (ab) ah = ab[(uint32_t)(ly * w + (c ? SW + 1 : 0))];
+    }
+    auto mask = [&](int32_t tv_, int32_t av_) -> int32_t { return tv_ >= DINF ? NOTFLAT : tv_ == 1 ? LOWEDGE : 2 * tv_ - (av_ < DINF ? av_ : 0); };
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      const int ly = i / QPR, qq = i - ly * QPR;
+      if (i < NQ) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) sm[ly * SLW + 1 + 4 * qq + e] = mask(tq[r].v[e], ab ? aq[r].v[e] : DINF);
+      }
+    }
+    if ((int)threadIdx.x < NHC) {
+      const int ly = (int)threadIdx.x >> 1, c = (int)threadIdx.x & 1;
+      sm[ly * SLW + (c ? SW + 1 : 0)] = mask(th, ah);
+    }
+  } else {
     constexpr int IPT = (KLLH * SLW + NTHR - 1) / NTHR;
     T zv[IPT];
     int32_t tv[IPT], av[IPT];

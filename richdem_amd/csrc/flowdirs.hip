@@ -23,7 +23,9 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * TW, y0 = (int)(t / tilesX) * TH;
-  {
+  if (window_inside(x0, y0, w, h, TW, TH, 1)) {
+    stage_window_inside<T, TW, TH, 1, LW, NTHR>(z, w, x0, y0, sz);
+  } else {
     constexpr int IPT = (LH * LW + NTHR - 1) / NTHR;
     T zv[IPT];
 #pragma unroll
@@ -68,13 +70,17 @@ __global__ __launch_bounds__(NTHR) void k_flowdirs(const T *__restrict__ z, T no
         else if (gy == 0) dir = 3;
         else dir = 7;
       } else {  // d8_flowdirs.hpp:63-71
+        // (take = v < m, or v == m while the choice so far is a DIAGONAL and n is a cardinal; "is a diagonal" is carried
+        // as a flag -- a lane mask on the scalar unit -- instead of being decoded from dir at every cardinal)
         T m = e;
+        bool diag = false;
 #pragma unroll
         for (int n = 1; n <= 8; n++) {
           const T v = nbv[n];
-          const bool take = (v < m) | ((v == m) & (dir > 0) & ((dir & 1) == 0) & ((n & 1) == 1));
+          const bool take = (n & 1) ? ((v < m) | ((v == m) & diag)) : (v < m);
           m = take ? v : m;
           dir = take ? n : dir;
+          diag = (n & 1) ? (diag & !take) : (diag | take);
         }
       }
     } else {  // MODE_FM, OCallaghan1984.hpp:42-74: edges never flow, NoData neighbours are skipped
