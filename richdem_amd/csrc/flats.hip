@@ -98,16 +98,21 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
   const int gx = x0 + lx;
   T z0[3], z1[3], z2[3];
   uint8_t d0[3], d1[3], d2[3];
+  bool v0[3], v1[3], v2[3], n0[3], n1[3], n2[3];
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     z0[e] = sz[yb * SLW + lx + e]; z1[e] = sz[(yb + 1) * SLW + lx + e];
     d0[e] = sdir[yb * SLW + lx + e]; d1[e] = sdir[(yb + 1) * SLW + lx + e];
+    v0[e] = d0[e] != 255; n0[e] = d0[e] == 0; v1[e] = d1[e] != 255; n1[e] = d1[e] == 0;
   }
 #pragma unroll
   for (int j = 0; j < KLH / 4; j++) {
     const int ly = yb + j, gy = y0 + ly;
 #pragma unroll
-    for (int e = 0; e < 3; e++) { z2[e] = sz[(ly + 2) * SLW + lx + e]; d2[e] = sdir[(ly + 2) * SLW + lx + e]; }
+    for (int e = 0; e < 3; e++) {
+      z2[e] = sz[(ly + 2) * SLW + lx + e]; d2[e] = sdir[(ly + 2) * SLW + lx + e];
+      v2[e] = d2[e] != 255; n2[e] = d2[e] == 0;
+    }
     uint8_t f = 0;
     const uint8_t d = d1[1];
     if (d != 255) {
@@ -119,22 +124,24 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
       // three questions about the 8 neighbours, accumulated without branches (the per-neighbour early-outs compiled
       // into ~14 exec-mask branches and ~130 scalar mask operations per cell): is one of them higher (:409-411), is
       // one an equal NO_FLOW cell (:406-408), is one an equal cell WITH a direction (a low edge of this cell's flat)
-      int higher = 0, eq_noflow = 0, eq_flow = 0;
-      auto nb = [&](T zn, uint8_t dn) {
-        const int valid = dn != 255, eq = zn == e;
-        higher |= valid & (int)(e < zn);
-        eq_noflow |= valid & eq & (int)(dn == 0);
-        eq_flow |= valid & eq & (int)(dn != 0);
+      // (lane masks: the compares are the only vector instructions, the logic runs on the scalar unit; whether a
+      // neighbour is valid / NO_FLOW is found once per staged cell -- v?[], n?[] slide down with the window)
+      bool higher = false, eq_noflow = false, eq_flow = false;
+      auto nb = [&](T zn, bool valid, bool nf) {
+        const bool eq = zn == e;
+        higher |= valid & (e < zn);
+        eq_noflow |= valid & eq & nf;
+        eq_flow |= valid & eq & !nf;
       };
-      nb(z0[0], d0[0]); nb(z0[1], d0[1]); nb(z0[2], d0[2]);
-      nb(z1[0], d1[0]); nb(z1[2], d1[2]);
-      nb(z2[0], d2[0]); nb(z2[1], d2[1]); nb(z2[2], d2[2]);
+      nb(z0[0], v0[0], n0[0]); nb(z0[1], v0[1], n0[1]); nb(z0[2], v0[2], n0[2]);
+      nb(z1[0], v1[0], n1[0]); nb(z1[2], v1[2], n1[2]);
+      nb(z2[0], v2[0], n2[0]); nb(z2[1], v2[1], n2[1]); nb(z2[2], v2[2], n2[2]);
       if (noflow ? higher : eq_noflow) f |= noflow ? F_HIGH : F_LOW;
       if (noflow && eq_flow) f |= F_NEAR;
     }
     if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
 #pragma unroll
-    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; }
+    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; v0[e] = v1[e]; v1[e] = v2[e]; n0[e] = n1[e]; n1[e] = n2[e]; }
   }
 }
 
@@ -250,38 +257,45 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
   const int gx = x0 + lx;
   T z0[3], z1[3], z2[3];
   uint8_t d0[3], d1[3], d2[3];
+  bool v0[3], v1[3], v2[3], n0[3], n1[3], n2[3];
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     z0[e] = sz[(yb + 1) * FZW + lx + 1 + e]; z1[e] = sz[(yb + 2) * FZW + lx + 1 + e];
     d0[e] = sdir[yb * SLW + lx + e]; d1[e] = sdir[(yb + 1) * SLW + lx + e];
+    v0[e] = d0[e] != 255; n0[e] = d0[e] == 0; v1[e] = d1[e] != 255; n1[e] = d1[e] == 0;
   }
 #pragma unroll
   for (int j = 0; j < KLH / 4; j++) {
     const int ly = yb + j, gy = y0 + ly;
 #pragma unroll
-    for (int e = 0; e < 3; e++) { z2[e] = sz[(ly + 3) * FZW + lx + 1 + e]; d2[e] = sdir[(ly + 2) * SLW + lx + e]; }
+    for (int e = 0; e < 3; e++) {
+      z2[e] = sz[(ly + 3) * FZW + lx + 1 + e]; d2[e] = sdir[(ly + 2) * SLW + lx + e];
+      v2[e] = d2[e] != 255; n2[e] = d2[e] == 0;
+    }
     uint8_t f = 0;
     const uint8_t d = d1[1];
     if (d != 255) {
       const bool noflow = d == 0;
       if (noflow) f = F_NOFLOW;
       const T e = z1[1];
-      int higher = 0, eq_noflow = 0, eq_flow = 0;
-      auto nb = [&](T zn, uint8_t dn) {
-        const int valid = dn != 255, eq = zn == e;
-        higher |= valid & (int)(e < zn);
-        eq_noflow |= valid & eq & (int)(dn == 0);
-        eq_flow |= valid & eq & (int)(dn != 0);
+      // (lane masks: the compares are the only vector instructions, the logic runs on the scalar unit; whether a
+      // neighbour is valid / NO_FLOW is found once per staged cell -- v?[], n?[] slide down with the window)
+      bool higher = false, eq_noflow = false, eq_flow = false;
+      auto nb = [&](T zn, bool valid, bool nf) {
+        const bool eq = zn == e;
+        higher |= valid & (e < zn);
+        eq_noflow |= valid & eq & nf;
+        eq_flow |= valid & eq & !nf;
       };
-      nb(z0[0], d0[0]); nb(z0[1], d0[1]); nb(z0[2], d0[2]);
-      nb(z1[0], d1[0]); nb(z1[2], d1[2]);
-      nb(z2[0], d2[0]); nb(z2[1], d2[1]); nb(z2[2], d2[2]);
+      nb(z0[0], v0[0], n0[0]); nb(z0[1], v0[1], n0[1]); nb(z0[2], v0[2], n0[2]);
+      nb(z1[0], v1[0], n1[0]); nb(z1[2], v1[2], n1[2]);
+      nb(z2[0], v2[0], n2[0]); nb(z2[1], v2[1], n2[1]); nb(z2[2], v2[2], n2[2]);
       if (noflow ? higher : eq_noflow) f |= noflow ? F_HIGH : F_LOW;
       if (noflow && eq_flow) f |= F_NEAR;
     }
     if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
 #pragma unroll
-    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; }
+    for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; v0[e] = v1[e]; v1[e] = v2[e]; n0[e] = n1[e]; n1[e] = n2[e]; }
   }
 }
 
