@@ -382,6 +382,17 @@ constexpr int CW = 64, CH = 32;
 // k_ccl_border2 -- read back from the raster those columns cost a 128-byte line per row and array (25.6 GB at S3).
 // A row outside the raster holds the label CCL_NOCELL.
 constexpr uint32_t CCL_NOCELL = 0xFFFFFFFFu;
+// an element of at most 32 bits as the 32-bit lane value a DPP move carries, and back
+template <class T>
+__device__ __forceinline__ uint32_t lane_bits(T v) {
+  if constexpr (sizeof(T) == 4) { uint32_t u; __builtin_memcpy(&u, &v, 4); return u; }
+  else return (uint32_t)v;
+}
+template <class T>
+__device__ __forceinline__ T lane_from_bits(uint32_t u) {
+  if constexpr (sizeof(T) == 4) { T v; __builtin_memcpy(&v, &u, 4); return v; }
+  else return (T)u;
+}
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint32_t *__restrict__ L, int w, int h,
                                                    uint32_t tilesX, uint32_t ntiles, T *__restrict__ colZ, uint32_t *__restrict__ colL) {
@@ -424,6 +435,39 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
   // 8-bit mask of in-tile, in-raster neighbours of equal elevation (bit k-1 for neighbour k)
   uint32_t msk[ROWS];
   int any = 0;
+  bool windowed = false;
+  if constexpr (sizeof(T) <= 4) if (x0 + CW <= w && y0 + CH <= h) {
+    windowed = true;
+    // the tile lies inside the raster (block-uniform): the 3 x 3 window slides down the column, the columns beside it come
+    // from the neighbouring lanes (DPP), the tile's borders are two constant masks -- 8 compares per cell instead of 8
+    // clamped lookups with six bounds tests each (they were half of this kernel's instructions)
+    auto left_of = [](T v) -> T {    // lane l receives lane l - 1's value
+      return lane_from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(0, (int)lane_bits(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    };
+    auto right_of = [](T v) -> T {   // lane l receives lane l + 1's value
+      return lane_from_bits<T>((uint32_t)__builtin_amdgcn_update_dpp(0, (int)lane_bits(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    };
+    const uint32_t colmask = lx == 0 ? ~0x83u : lx == CW - 1 ? ~0x38u : ~0u;   // no W / NW / SW, no NE / E / SE
+    const int ly0 = band * ROWS;
+    T b0 = ly0 > 0 ? sz[(ly0 - 1) * CW + lx] : T(), b1 = sz[ly0 * CW + lx];
+    T a0 = left_of(b0), c0 = right_of(b0), a1 = left_of(b1), c1 = right_of(b1);
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const int ly = ly0 + j;
+      const T b2 = ly + 1 < CH ? sz[(ly + 1) * CW + lx] : T();
+      const T a2 = left_of(b2), c2 = right_of(b2);
+      const T e = b1;
+      uint32_t m = (a1 == e ? 1u : 0u) | (a0 == e ? 2u : 0u) | (b0 == e ? 4u : 0u) | (c0 == e ? 8u : 0u) | (c1 == e ? 16u : 0u) |
+                   (c2 == e ? 32u : 0u) | (b2 == e ? 64u : 0u) | (a2 == e ? 128u : 0u);
+      m &= colmask;
+      if (ly == 0) m &= ~0x0Eu;          // (scalar) no NW / N / NE
+      if (ly == CH - 1) m &= ~0xE0u;     // no SE / S / SW
+      msk[j] = m;
+      any |= m != 0;
+      a0 = a1; b0 = b1; c0 = c1; a1 = a2; b1 = b2; c1 = c2;
+    }
+  }
+  if (!windowed)
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     const int ly = band * ROWS + j, gy = y0 + ly;
