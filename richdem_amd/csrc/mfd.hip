@@ -454,6 +454,102 @@ __global__ __launch_bounds__(NTHR) void k_rdy_fill(uint8_t *f, uint64_t n, const
   }
 }
 
+// The same step with the round's by-products consumed where they arise (r04f).  In k_mfd_round a cell completed "on the
+// side" waits for the next launch, and a launch lasts as long as its longest inline chain: at S3 where every cell drains,
+// 2614 launches of 2.8 ms.  Here a wavefront keeps a STACK of such cells in LDS: a lane whose chain has ended takes the
+// next cell from it in the same trip of the loop, so a launch ends when everything reachable from its list is done --
+// except what a full stack spills to the next launch's list.  All lanes of a wavefront run the loop together (ballots
+// decide), the stack pointer is wave-uniform, LDS operations of one wavefront execute in order: no barriers.
+constexpr int WCAP = 1536;   // entries of a wavefront's stack (4 x 6 KB of LDS per block)
+constexpr uint32_t NOCELL = 0xFFFFFFFFu;
+template <class ACC>
+__global__ __launch_bounds__(NTHR) void k_mfd_stack(ACC a, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    uint32_t *pending, double *acc, uint32_t *next_list,
+                                                    uint32_t *next_count, int w, int h) {
+  __shared__ uint32_t stack[NTHR / 64][WCAP];
+  volatile uint32_t *const st = stack[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  uint32_t sp = 0;   // (wave-uniform)
+  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
+  uint32_t c = i < nlist ? list[i] : NOCELL;
+  double v = c != NOCELL ? acc[c] : 0.0;   // completed in an earlier launch (or a source): final
+  for (;;) {
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(c == NOCELL);
+    if (idle == ~0ull && sp == 0) break;
+    if (idle != 0ull && sp != 0) {   // idle lanes take the top of the stack
+      const uint32_t k = min((uint32_t)__popcll(idle), sp);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      if (c == NOCELL && rank < k) {
+        c = st[sp - 1u - rank];
+        v = atomicAdd(&acc[c], 0.0);       // its final total, read at the memory side
+      }
+      sp -= k;
+    }
+    uint32_t oth[8];
+    bool isoth[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) { oth[n] = 0; isoth[n] = false; }
+    uint32_t no = 0;
+    if (c != NOCELL) {
+      const int x = (int)(c % (uint32_t)w), y = (int)(c / (uint32_t)w);
+      uint32_t cont = NOCELL;
+      if (!(x == 0 || y == 0 || x == w - 1 || y == h - 1)) {   // edge cells never pass flow on (FM_*: :49-50)
+        float p[8];
+        bool nd[8];
+#pragma unroll
+        for (int n = 1; n <= 8; n++) p[n - 1] = a.share(c, n);
+#pragma unroll
+        for (int n = 1; n <= 8; n++)   // flow_accumulation_generic.hpp:81-86
+          nd[n - 1] = (p[n - 1] > 0) ? a.nodata((uint64_t)(y + mdy(n)) * w + (x + mdx(n))) : true;
+        double prev = 0;
+#pragma unroll
+        for (int n = 1; n <= 8; n++)
+          if (!nd[n - 1]) prev += atomicAdd(&acc[(uint64_t)(y + mdy(n)) * w + (x + mdx(n))], (double)p[n - 1] * v);   // :87
+        // every add has returned (= was performed at the memory side) before any counter is decremented
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
+        uint32_t old[8];
+#pragma unroll
+        for (int n = 1; n <= 8; n++)
+          if (!nd[n - 1])
+            old[n - 1] = __hip_atomic_fetch_sub(&pending[(uint64_t)(y + mdy(n)) * w + (x + mdx(n))], 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int n = 1; n <= 8; n++) {
+          if (nd[n - 1] || old[n - 1] != 1) continue;
+          const uint32_t r = (uint32_t)(y + mdy(n)) * (uint32_t)w + (uint32_t)(x + mdx(n));   // r is complete
+          if (cont == NOCELL) cont = r;                       // continue inline with the first one,
+          else { oth[n - 1] = r; isoth[n - 1] = true; no++; }  // the others go on the stack
+        }
+      }
+      c = cont;
+      if (c != NOCELL) v = atomicAdd(&acc[c], 0.0);           // final total, read at the memory side
+    }
+    if (__builtin_amdgcn_ballot_w64(no != 0u) != 0ull) {   // push the step's by-products: one prefix over the lanes
+      uint32_t incl = no;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      uint32_t pos = incl - no;
+      if (sp + total <= (uint32_t)WCAP) {
+#pragma unroll
+        for (int n = 0; n < 8; n++)
+          if (isoth[n]) st[sp + pos++] = oth[n];
+        sp += total;
+      } else {   // the stack cannot take them: the next launch's list
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next_count, total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int n = 0; n < 8; n++)
+          if (isoth[n]) next_list[base + pos++] = oth[n];
+      }
+    }
+  }
+}
+
 static uint32_t g_mfd_rounds = 0;
 
 template <class ACC>
@@ -477,10 +573,21 @@ static void mfd_accumulate(ACC a, int w, int h, double *d_acc, hipStream_t s) {
   if (nl) RD_LAUNCH("mfd.ready_fill", k_rdy_fill, dim3(nblk), dim3(NTHR), 0, s, ready, n, (const uint32_t *)counts, list);
   uint32_t *list2 = ws.buf<uint32_t>("mfd.list2", n);
   uint32_t *ctr = counts + nblk;
+  // Long lists go through k_mfd_round (their by-products are processed next launch, densely packed: a wavefront that
+  // works off its own by-products runs at a few active lanes -- S3's filled DEM, 223 launches: 256 ms, one stacked launch
+  // 492); once a list is short the launches are what costs (S3 where every cell drains: 2614 launches, 7.2 s) and
+  // k_mfd_stack finishes everything that is left.  RDGPU_MFD_STACK_BELOW sets the list length of the switch (0: never).
+  const char *se = getenv("RDGPU_MFD_STACK_BELOW");
+  const uint32_t stack_below = se ? (uint32_t)strtoul(se, nullptr, 10) : (1u << 22);
   while (nl) {
+    const bool stacked = nl < stack_below;
     RD_HIP(hipMemsetAsync(ctr, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("mfd.round", (k_mfd_round<ACC>), dim3((nl + NTHR - 1) / NTHR), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl,
-              pending, d_acc, list2, ctr, w, h);
+    if (stacked)
+      RD_LAUNCH("mfd.round", (k_mfd_stack<ACC>), dim3((nl + NTHR - 1) / NTHR), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl,
+                pending, d_acc, list2, ctr, w, h);
+    else
+      RD_LAUNCH("mfd.round", (k_mfd_round<ACC>), dim3((nl + NTHR - 1) / NTHR), dim3(NTHR), 0, s, a, (const uint32_t *)list, nl,
+                pending, d_acc, list2, ctr, w, h);
     RD_HIP(hipMemcpyAsync(hw, ctr, 4, hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
     nl = hw[0];

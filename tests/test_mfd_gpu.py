@@ -54,7 +54,12 @@ def test_fm_tarboton_proportions(rd, orc):
         assert (ulp_diff_f32(got, exp) <= 1).all(), name
 
 
-def test_fa_tarboton_and_generic_accumulation(rd, orc):
+@pytest.mark.parametrize("stack_below", [None, "0", "4000000000"])
+def test_fa_tarboton_and_generic_accumulation(rd, orc, monkeypatch, stack_below):
+    """stack_below: the list length under which the launches work off their own by-products from a stack in LDS
+    (csrc/mfd.hip, r04f; default 2^22) -- never (one launch per generation), always, and the default"""
+    if stack_below is not None:
+        monkeypatch.setenv("RDGPU_MFD_STACK_BELOW", stack_below)
     for name, dem in dems(orc):
         nd = dem.dtype.type(250 if dem.dtype == np.uint8 else -9999)
         exp = orc.port.fa_tarboton(dem, nd)
