@@ -386,7 +386,12 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
   __syncthreads();
   K d[ROWS], d0[ROWS];
 #pragma unroll
-  for (int j = 0; j < ROWS; j++) d0[j] = d[j] = sd[(band * ROWS + j + 1) * RW + lx + 1];
+  for (int j = 0; j < ROWS; j++) {
+    d0[j] = d[j] = sd[(band * ROWS + j + 1) * RW + lx + 1];
+    // a cell that is not relaxed gets its own value as its floor: every candidate max(floor, ...) is then >= d and the
+    // updates below need no "is it free" test (this kernel is bound by VALU issue: 4.9e10 instructions per fill at S3)
+    if (!(free_ & (1u << j))) zk[j] = d[j];
+  }
   auto ring = [&](int ly /* -1..RCH */, int cx /* -1..CW */) -> K { return sd[(ly + 1) * RW + cx + 1]; };
   K sideL[ROWS], sideR[ROWS];   // what lanes 0 / 63 see in the halo columns (D8: vertical 3-minima; D4: the one cell)
 #pragma unroll
@@ -422,11 +427,9 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
   for (; it < IT_CAP; it++) {
     // Gauss-Seidel along the strip (vertical neighbours: both topologies)
 #pragma unroll
-    for (int j = 1; j < ROWS; j++)
-      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j - 1])));
+    for (int j = 1; j < ROWS; j++) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j - 1])));
 #pragma unroll
-    for (int j = ROWS - 2; j >= 0; j--)
-      if (free_ & (1u << j)) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j + 1])));
+    for (int j = ROWS - 2; j >= 0; j--) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j + 1])));
     xrow[it & 1][band][0][lx] = d[0];
     xrow[it & 1][band][1][lx] = d[ROWS - 1];
     if (!__syncthreads_or(changed)) break;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
 #pragma unroll
       for (int j = 0; j < ROWS; j++) {
         const K cand = kmax(zk[j], step_up<P>(mn[j]));
-        if ((free_ & (1u << j)) && cand < d[j]) { d[j] = cand; moved = 1; }
+        if (cand < d[j]) { d[j] = cand; moved = 1; }
       }
       changed |= moved;
       if (!__any(moved)) break;   // the remaining steps of this trip would compute the same values
