@@ -405,6 +405,9 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
       sideR[j] = lx == CW - 1 ? ring(ly, CW) : KINF;
     }
   }
+  K sideLR[ROWS];
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) sideLR[j] = kmin(sideL[j], sideR[j]);
   const K halo_up = band == 0 ? ring(-1, lx) : KINF, halo_dn = band == RBANDS - 1 ? ring(RCH, lx) : KINF;
   // D8 corner contributions of the rows above / below the band come through the neighbouring lanes' 3-minima, which
   // include `up` / `dn` of THOSE lanes; lanes 0 and 63 add the ring corners through sideL / sideR (rows ly-1..ly+1).
@@ -417,8 +420,10 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
       const K col = TOPO == 8 ? kmin(own[j], d[j]) : d[j];   // what the side lanes need from this column
-      const K side = kmin(dpp_left(col, sideL[j]), dpp_right(col, sideR[j]));
-      out[j] = kmin(own[j], side);
+      // (the shifts fill with the minimum's identity, so that the compiler folds one of them into a v_min_u32_dpp and needs no move per shift; what lanes 0
+      // and 63 see beyond the tile, sideLR, is one more minimum -- one instruction less per cell and step)
+      const K side = kmin(dpp_left(col, (K) ~(K)0), dpp_right(col, (K) ~(K)0));
+      out[j] = kmin(kmin(own[j], side), sideLR[j]);
     }
   };
 
