@@ -414,12 +414,16 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
 
   // smallest value among the neighbours of cell j (D8: 8, D4: 4), given the rows above / below the band
   auto neigh_min = [&](const K up, const K dn, K out[ROWS]) {
-    K own[ROWS];   // vertical neighbours in the own column
-#pragma unroll
-    for (int j = 0; j < ROWS; j++) own[j] = kmin(j ? d[j - 1] : up, j + 1 < ROWS ? d[j + 1] : dn);
+    K own[ROWS];   // vertical neighbours in the own column; D8: the cell itself too (what the side lanes need from this
+                   // column, and harmless in the cell's own minimum: a candidate from d itself is d + 1, never below d)
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
-      const K col = TOPO == 8 ? kmin(own[j], d[j]) : d[j];   // what the side lanes need from this column
+      own[j] = kmin(j ? d[j - 1] : up, j + 1 < ROWS ? d[j + 1] : dn);
+      if (TOPO == 8) own[j] = kmin(own[j], d[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const K col = TOPO == 8 ? own[j] : d[j];
       // (the shifts fill with the minimum's identity, so that the compiler folds one of them into a v_min_u32_dpp and needs no move per shift; what lanes 0
       // and 63 see beyond the tile, sideLR, is one more minimum -- one instruction less per cell and step)
       const K side = kmin(dpp_left(col, (K) ~(K)0), dpp_right(col, (K) ~(K)0));
@@ -432,9 +436,9 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
   for (; it < IT_CAP; it++) {
     // Gauss-Seidel along the strip (vertical neighbours: both topologies)
 #pragma unroll
-    for (int j = 1; j < ROWS; j++) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j - 1])));
+    for (int j = 1; j < ROWS; j++) d[j] = kmin(d[j], kmax(zk[j], d[j - 1] + 1));   // (unsaturated steps: see the write-back)
 #pragma unroll
-    for (int j = ROWS - 2; j >= 0; j--) d[j] = kmin(d[j], kmax(zk[j], step_up<P>(d[j + 1])));
+    for (int j = ROWS - 2; j >= 0; j--) d[j] = kmin(d[j], kmax(zk[j], d[j + 1] + 1));
     xrow[it & 1][band][0][lx] = d[0];
     xrow[it & 1][band][1][lx] = d[ROWS - 1];
     if (!__syncthreads_or(changed)) break;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
       neigh_min(up, dn, mn);
 #pragma unroll
       for (int j = 0; j < ROWS; j++) {
-        const K cand = kmax(zk[j], step_up<P>(mn[j]));
+        const K cand = kmax(zk[j], mn[j] + 1);
         if (cand < d[j]) { d[j] = cand; moved = 1; }
       }
       changed |= moved;
@@ -462,9 +466,14 @@ __global__ __launch_bounds__(NT) void k_eps_relax(const P p, typename P::K *D,
   int top = 0, bot = 0, lef = 0, rig = 0;
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
-    if (!(free_ & (1u << j)) || d[j] >= d0[j]) continue;
+    // The steps above are plain + 1 (one instruction instead of step_up's two, in a loop bound by instruction issue).  They
+    // differ from step_up only past the key of +infinity -- a value counted up from a cell of elevation +inf -- and those
+    // values, POSINF < d < "not reached", all stand for POSINF: saturated here, before anything is compared or stored.
+    // ("Not reached" + 1 is still above every key and never below a d.)
+    const K dj = (d[j] > P::POSINF && d[j] < KINF) ? P::POSINF : d[j];
+    if (!(free_ & (1u << j)) || dj >= d0[j]) continue;
     const int ly = band * ROWS + j;
-    __hip_atomic_store(&D[(size_t)(y0 + ly) * w + gx], d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&D[(size_t)(y0 + ly) * w + gx], dj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     top |= ly == 0; bot |= ly == RCH - 1; lef |= lx == 0; rig |= lx == CW - 1;
   }
   top = __syncthreads_or(top); bot = __syncthreads_or(bot); lef = __syncthreads_or(lef); rig = __syncthreads_or(rig);
