@@ -233,3 +233,21 @@ def test_epsilon_device_entry_and_errors(rd):
     a = rd.rdarray(z.copy(), no_data=ND)
     out = rd.FillDepressions(a, epsilon=True)
     assert "FillDepressions(dem, epsilon=True)" in out.metadata["PROCESSING_HISTORY"] and np.array_equal(np.asarray(out), t.cpu().numpy())
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_epsilon_behind_walls_of_infinity(rd, orc, dt):
+    """nextafter(+inf) == +inf: cells whose only way out leads over cells of elevation +inf end at +inf however many steps
+    they are from the wall (the relaxation counts its steps unsaturated and saturates when it stores, csrc/epsilon.hip);
+    the largest finite values step up to +inf too."""
+    rng = np.random.default_rng(5)
+    h, w = 70, 90
+    z = (rng.permutation(h * w).reshape(h, w) * 0.25 + 10).astype(dt)
+    z[10:40, 20] = z[10:40, 60] = z[10, 20:61] = z[39, 20:61] = np.inf          # a walled yard, 28 x 39 cells inside
+    z[50:60, 5:15] = np.finfo(dt).max                                           # a plateau of the largest finite value ...
+    z[53:57, 8:12] = 1.0                                                        # ... around a pit
+    got = rd.FillDepressions(z, epsilon=True, nodata=dt(-9999))
+    exp = orc.port.fill_epsilon(z, dt(-9999), 8)
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    assert np.isinf(got[11:39, 21:60]).all() and np.isinf(got[53:57, 8:12]).all()
+    assert np.array_equal(got[0], z[0]) and np.array_equal(got[:, 0], z[:, 0])
