@@ -111,6 +111,9 @@ def main():
             topo = int(rng.choice([8, 4]))
             filled = rd.FillDepressions(dem, topology="D8" if topo == 8 else "D4")
             chk(f"fill{topo}", filled.tobytes() == P.fill(dem, topo).tobytes())
+            if np.issubdtype(dt, np.floating) and np.unique(dem).size == dem.size:   # (the epsilon fill: defined by the DEM only without ties)
+                chk(f"fill_epsilon{topo}", rd.FillDepressions(dem, epsilon=True, topology="D8" if topo == 8 else "D4", nodata=nd).tobytes()
+                    == P.fill_epsilon(dem, nd, topo).tobytes())
             if dt in (np.uint32,):
                 continue
             src = filled if rng.random() < 0.7 else dem
