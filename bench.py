@@ -15,7 +15,8 @@ line on rank 0.  Besides `value` (the fill) the line carries
                  directions + flat resolution, d8_flow_accum, ResolveFlatsEpsilon, FA_D8 on the epsilon-resolved
                  DEM -- each with ms, Mcells/s, SURVEY 8d algorithmic bytes and the fraction of 8 TB/s
   end_to_end_host  rdgpu_fill_f32 on a host array (the drop-in boundary: H2D + fill + D2H), never `value`
-  cpu_baseline   the compiled reference on a bounded window of the same DEM on this box's host
+  cpu_baseline   the compiled reference on this box's host: on the WHOLE bench DEM (a child process started after the timed
+                 fills, running beside the stages: `--cpu-full`), with the bounded-window figure as the secondary key
 """
 from __future__ import annotations
 
@@ -35,9 +36,11 @@ STAGE_BYTES = {"d8_flow_directions": 5, "directions_plus_flat_resolution": 6, "d
                "dinf_flow_directions": 8, "fa_tarboton": 20}   # D-infinity: f32 in + f32 angle out; f32 dem + f64 weights in + f64 out
 
 
-def cpu_baseline(Z, sample: int):
-    """Times the reference's FillDepressions<D8> (or the C port) on a bounded window of the SAME DEM,
-    on this box's host cores (1 thread: the reference fill has no OpenMP).  Reported baseline only."""
+def cpu_baseline(Z, sample: int, full=None):
+    """Times the reference's FillDepressions<D8> (or the C port) on this box's host cores (1 thread: the reference fill
+    has no OpenMP).  Reported baseline only.  `full` (start_full_reference's handle): the compiled reference on the WHOLE
+    bench DEM, started in a child process while the GPU stages ran -- when it delivers, THAT is `value` (the metric's own
+    configuration) and the bounded window becomes the secondary key `window`."""
     import numpy as np
 
     import oracle  # checker, used here only for the reported CPU baseline
@@ -61,26 +64,115 @@ def cpu_baseline(Z, sample: int):
         "kind": kind,
         "sample": f"{s}x{s} top-left window of the bench DEM, {what}, {dt:.2f} s",
     }
-    # The whole 40000 x 40000 DEM through the reference: NOT measured in this run (it takes minutes of one host core) --
-    # quoted from earlier builder runs and labelled as such.
-    full = {"note": "quoted, not measured in this run: the compiled reference on the full 40000 x 40000 bench DEM"}
+    got = finish_full_reference(full) if full is not None else None
+    if got is not None and "seconds" in got:
+        n = got["size"]
+        res["window"] = {"value": res["value"], "sample": res["sample"],
+                         "note": "ran beside the full-size child process (one more busy core)"}
+        res["value"] = round(n * n / 1e6 / got["seconds"], 3)
+        res["kind"] = got["kind"]
+        res["sample"] = (f"{n}x{n}: the WHOLE bench DEM (the metric's own configuration), {got['what']}, {got['seconds']:.1f} s of one "
+                         f"host core, measured in this run in a child process beside the GPU stages")
+        res["full_size"] = {k: got[k] for k in ("seconds", "cells_raised", "output_equals_gpu_fill", "bands_compared") if k in got}
+        return res
+    # The whole 40000 x 40000 DEM through the reference was not measured in this run (switched off, or the child failed /
+    # ran out of time): quoted from earlier builder runs and labelled as such.
+    full_q = {"note": "quoted, not measured in this run: the compiled reference on the full 40000 x 40000 bench DEM"}
+    if got is not None:
+        full_q["child"] = got
     try:
         with open(os.path.join(ROOT, "profiles", "r02_parity40k.json")) as f:
             p = json.load(f)
-        full["gpu_box_host_r02"] = {k: p[k] for k in ("ref_fill_s", "ref_fill_Mcells_s", "ref_flat_resolution_s",
-                                                       "ref_d8_flow_accum_s") if k in p}
-        full["gpu_box_host_r02"]["source"] = "profiles/r02_parity40k.json (tests/tools/parity40k.py on a GPU box's host, round 2)"
+        full_q["gpu_box_host_r02"] = {k: p[k] for k in ("ref_fill_s", "ref_fill_Mcells_s", "ref_flat_resolution_s",
+                                                         "ref_d8_flow_accum_s") if k in p}
+        full_q["gpu_box_host_r02"]["source"] = "profiles/r02_parity40k.json (tests/tools/parity40k.py on a GPU box's host, round 2)"
     except (OSError, ValueError):
         pass
     try:
         g = np.load(os.path.join(ROOT, "tests", "golden", "ref_s3_digests.npz"))
-        full["build_container_r03"] = {k.split("/")[1] + "_s": float(g[k]) for k in g.files if k.startswith("ref_seconds/")}
-        full["build_container_r03"]["source"] = ("tests/golden/ref_s3_digests.npz (make_golden.py --s3-digests: the run that produced the "
-                                                 "full-size parity digests; 8-core build container, a slower host)")
+        full_q["build_container_r03"] = {k.split("/")[1] + "_s": float(g[k]) for k in g.files if k.startswith("ref_seconds/")}
+        full_q["build_container_r03"]["source"] = ("tests/golden/ref_s3_digests.npz (make_golden.py --s3-digests: the run that produced the "
+                                                   "full-size parity digests; 8-core build container, a slower host)")
     except (OSError, ValueError):
         pass
-    res["full_size"] = full
+    res["full_size"] = full_q
     return res
+
+
+# ---- the reference on the WHOLE bench DEM, in a child process beside the GPU stages (cpu_baseline leg) ---------------------
+def start_full_reference(Z, W, timeout_s: float):
+    """Writes the (unfilled) bench DEM to a scratch file and starts `bench.py --cpu-full-child`, which runs the compiled
+    reference's PriorityFlood_Zhou2016 on all of it (minutes of ONE host core, ~13 GB of host memory) and leaves its time
+    and the band digests of its output.  Called AFTER the timed fills; the GPU stages run meanwhile.  Returns a handle for
+    finish_full_reference, or None when the compiled reference is not on this box."""
+    import subprocess
+    import tempfile
+
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from digest import band_digests_torch   # (test infrastructure: the same digests the S3 parity tests use)
+
+    n = Z.shape[0]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > 2 * Z.numel() * 4 \
+        else tempfile.gettempdir()
+    raw = os.path.join(base, f"rdgpu_bench_dem_{os.getpid()}.f32")
+    res = raw + ".json"
+    Z.cpu().numpy().tofile(raw)
+    gpu_digests = band_digests_torch(W)              # the GPU fill's output, for the child's answer to be checked against
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-full-child", raw, str(n), res],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return {"proc": child, "raw": raw, "res": res, "size": n, "gpu_digests": gpu_digests, "deadline": time.time() + timeout_s}
+
+
+def finish_full_reference(h):
+    """Waits for the child (up to the handle's deadline), removes the scratch files, compares the digests."""
+    import subprocess
+
+    try:
+        try:
+            h["proc"].wait(timeout=max(1.0, h["deadline"] - time.time()))
+        except subprocess.TimeoutExpired:
+            h["proc"].kill()                           # (the exact process started above)
+            h["proc"].wait()
+            return {"error": "the full-size reference did not finish inside --cpu-full-timeout"}
+        if h["proc"].returncode != 0 or not os.path.exists(h["res"]):
+            return {"error": f"the full-size reference child exited with {h['proc'].returncode}"}
+        with open(h["res"]) as f:
+            got = json.load(f)
+        import numpy as np
+
+        ref_d = np.array(got.pop("digests"), dtype=np.uint64)
+        got["bands_compared"] = int(ref_d.size)
+        got["output_equals_gpu_fill"] = bool(ref_d.size == h["gpu_digests"].size and (ref_d == h["gpu_digests"]).all())
+        got["size"] = h["size"]
+        return got
+    finally:
+        for p in (h["raw"], h["res"]):
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+
+
+def cpu_full_child(raw: str, n: int, res: str) -> None:
+    """`bench.py --cpu-full-child <raw f32 file> <n> <result json>`: the child of start_full_reference."""
+    import numpy as np
+
+    import oracle  # checker: the reported CPU baseline
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from digest import band_digests_np
+
+    dem = np.fromfile(raw, dtype=np.float32).reshape(n, n)
+    t0 = time.perf_counter()
+    out = oracle.ref.fill(dem, 8)
+    dt = time.perf_counter() - t0
+    got = {"seconds": dt, "kind": "reference", "what": "PriorityFlood_Zhou2016 (unmodified reference headers, oracle/_ref)",
+           "cells_raised": int((out != dem).sum()), "digests": [int(d) for d in band_digests_np(out)]}
+    with open(res + ".tmp", "w") as f:
+        json.dump(got, f)
+    os.replace(res + ".tmp", res)
 
 
 def _best(fn, reps, sync):
@@ -185,15 +277,21 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         rd.release_workspace()
         torch.cuda.empty_cache()
         pdirs = torch.empty(W.shape, dtype=torch.uint8, device="cuda")
-        os.environ["RDGPU_PFD_TIE_PASSES"] = "1"                                   # workspace growth (~100 GB of sort and tree buffers):
-        rd.pf_flowdirs_dev(Z, nodata, pdirs)                                       # one pass of the tie order, not timed
-        del os.environ["RDGPU_PFD_TIE_PASSES"]
+        prev = os.environ.get("RDGPU_PFD_TIE_PASSES")                              # (a value the user exported is put back)
+        try:
+            os.environ["RDGPU_PFD_TIE_PASSES"] = "1"                               # workspace growth (~100 GB of sort and tree buffers):
+            rd.pf_flowdirs_dev(Z, nodata, pdirs)                                   # one pass of the tie order, not timed
+        finally:
+            if prev is None:
+                os.environ.pop("RDGPU_PFD_TIE_PASSES", None)
+            else:
+                os.environ["RDGPU_PFD_TIE_PASSES"] = prev
         t_pf = _best(lambda: rd.pf_flowdirs_dev(Z, nodata, pdirs), 1, sync)
         out["priority_flood_flowdirs"] = stage_entry(t_pf, n_cells, STAGE_BYTES["priority_flood_flowdirs"])
         ps = rd.pf_flowdirs_stats()
         out["priority_flood_flowdirs"].update({"input": "the unfilled bench DEM", "levels": ps["levels"],
                                                "cells_with_an_equal_elevation_twin": ps["twins"],
-                                               "tie_order_passes": ps["tie_passes"],
+                                               "tie_order_passes": ps["tie_passes"], "timed_runs": 1,
                                                "cells_with_an_unsettled_tie_order": ps["unresolved"]})
         out["priority_flood_flowdirs"]["cells_differing_from_reference"] = _differing(torch, pdirs, "flowdirs")
     return out
@@ -233,6 +331,8 @@ def host_path(rd, torch, Z, reps: int = 2) -> dict:
 
 
 def main():
+    if len(sys.argv) == 5 and sys.argv[1] == "--cpu-full-child":
+        return cpu_full_child(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -240,6 +340,10 @@ def main():
     ap.add_argument("--size", type=int, default=40000, help="DEM is size x size cells")
     ap.add_argument("--cpu-sample", type=int, default=14000, help="window edge for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cpu-full", type=int, default=-1,
+                    help="1: also run the compiled reference on the WHOLE DEM in a child process beside the GPU stages and report it "
+                         "as cpu_baseline.value (minutes of one host core); 0: window only; default: on at the metric's size 40000")
+    ap.add_argument("--cpu-full-timeout", type=float, default=900.0, help="seconds the child gets before it is given up")
     ap.add_argument("--no-stages", action="store_true", help="skip the directions / flat resolution / accumulation stages")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer end-to-end measurement")
     ap.add_argument("--no-draining-mfd", action="store_true",
@@ -325,6 +429,10 @@ def main():
     prof = rd.profile_totals()
     del scratch
 
+    full = None
+    if args.cpu_sample > 0 and (args.cpu_full == 1 or (args.cpu_full < 0 and n == 40000)):
+        full = start_full_reference(Z, W, args.cpu_full_timeout)   # (after every timed fill; the stages below run beside it)
+
     ms_step = dt * 1e3 / args.steps
     value = cells / 1e6 / (dt / args.steps)
     roofline = fill_roofline(prof, stats, cells, prof_steps, dt / args.steps,
@@ -366,7 +474,7 @@ def main():
         torch.cuda.empty_cache()
         out["end_to_end_host"] = host_path(rd, torch, Z)
     if args.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(Z, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(Z, args.cpu_sample, full)
     emit(out)
 
 

@@ -19,9 +19,12 @@
  * resolution, ResolveFlatsEpsilon and FA_D8 / FM_D8 (these compare elevations in their own type); the D-infinity / MFD
  * families take i8 ... f64.  The row-block shard entry points of the fill take the 8 / 16 / 32-bit types.
  *
- * Threading: every entry point takes a process-wide lock, so calls from several host threads (e.g. Python threads with
- * the GIL released by the wrapper) are safe and run one after the other; when the calling thread changes, the device is
- * synchronised first, because all calls share one grow-only workspace per device.
+ * Threading: every entry point runs under the lock OF THE DEVICE that is current when it is entered (not a process-wide
+ * lock): calls from several host threads on ONE device (e.g. Python threads with the GIL released by the wrapper) are
+ * safe and run one after the other -- when the calling thread changes, that device is synchronised first, because its
+ * calls share one grow-only workspace -- while threads on DIFFERENT devices run side by side.  The single-process
+ * multi-device entry points (rdgpu_*_multi_*, and the plain host entries when RDGPU_DEVICES routes them there) run one
+ * orchestrator at a time per process and must not be called from inside one another.
  * Streams: the `_dev_` entry points enqueue on the stream they are given and use that shared per-device workspace for
  * their scratch.  Issue all `_dev_` calls of a process on ONE stream per device, or synchronise between calls issued on
  * different streams -- two calls in flight on two streams would overwrite each other's scratch.  (The handle-based shard
@@ -84,10 +87,22 @@ int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, voi
  * level L that one cell of elevation L floods in one run of its pit queue.  Identical to the reference on DEMs without
  * equal elevations and on the reference's goldens (tests/depressions/testdem1.{1,2}.out); when several cells of
  * elevation L touch the same pocket the reference's grouping follows std::priority_queue's pop order, this one the
- * lowest cell index. */
+ * lowest cell index.  Where that can happen is DETECTED on the device: pockets sharing any possible flooding cell form a
+ * cluster, a cluster holding a pocket with two or more possible flooding cells is tie-flagged; outside the flagged clusters
+ * the output does not depend on the pop order (rdgpu_fill_max_dep_get_stats; rdgpu_fill_max_dep_ties_dev_<T> also writes
+ * the flagged cells as a uint8 mask -- the parity tests assert that every cell differing from the reference lies in it). */
+typedef struct rdgpu_max_dep_stats {
+  uint64_t pockets;           /* connected components of the cells the plain fill would raise */
+  uint64_t tie_pockets;       /* ... that two or more cells of their spill elevation can flood: the heap's order decides */
+  uint64_t tie_cluster_cells; /* cells of the pockets in tie-flagged clusters (0: the result is the reference's) */
+  uint64_t pocket_cells;      /* cells the plain fill would raise */
+} rdgpu_max_dep_stats;
+int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out);   /* of the calling thread's last max_dep fill */
 #define RDGPU_DECL_MAXDEP(SUF, T)                                                                       \
   int rdgpu_fill_max_dep_##SUF(T *dem, int width, int height, int topology, uint64_t max_dep_size);     \
-  int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int width, int height, int topology, uint64_t max_dep_size, void *hip_stream);
+  int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int width, int height, int topology, uint64_t max_dep_size, void *hip_stream); \
+  int rdgpu_fill_max_dep_ties_dev_##SUF(T *d_dem, int width, int height, int topology, uint64_t max_dep_size,              \
+                                        uint8_t *d_tie_mask, void *hip_stream);
 RDGPU_DECL_MAXDEP(u8, uint8_t)
 RDGPU_DECL_MAXDEP(i16, int16_t)
 RDGPU_DECL_MAXDEP(u16, uint16_t)
@@ -160,13 +175,18 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
  * cells 0).  Identical to the reference, equal elevations included: the reference's queue breaks ties by insertion order
  * (GridCellZk_low_pq, common/grid_cell.hpp:101-122) and that order is reproduced as a fixed point -- one exact
  * flood of the raster's unique ranks per pass, until the ranks reproduce themselves (2 passes on float terrain, the
- * breadth-first depth of the largest plateau on integer DEMs; RDGPU_PFD_TIE_PASSES caps them, the stats say whether the
- * order had settled).  One fill per nesting level of the depressions per pass: exact first, not tuned. */
+ * breadth-first depth of the largest plateau on integer DEMs).  The passes are BOUNDED: RDGPU_PFD_TIE_SECONDS (default 120,
+ * checked between passes) and RDGPU_PFD_TIE_PASSES (default 1000); when a bound stops them the result is still an exact
+ * flood of a stable order, stats.unresolved != 0 says how many ranks were still moving (the C++ shim logs one line to
+ * stderr, the Python layer raises a RuntimeWarning).  RDGPU_PFD_RANKS=0 is the FAST path for callers who do not need the
+ * reference's tie order: one flood, ties decided by neighbour number (seconds instead of tens of seconds at 40000^2);
+ * stats.unresolved then counts the cells where a tie decided.  One fill per nesting level of the depressions per pass. */
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
   uint32_t twins;       /* cells whose elevation occurs more than once in the raster: 0 => the result is the reference's */
   uint64_t unresolved;  /* twins != 0: cells whose place in the tie order was still moving when the passes ran out (0: the
-                           result is the reference's); RDGPU_PFD_RANKS=0: directions decided by neighbour number */
+                           result is the reference's; = twins when no re-rank pass ran at all, RDGPU_PFD_TIE_PASSES=0);
+                           RDGPU_PFD_RANKS=0: directions decided by neighbour number */
   uint32_t tie_passes;  /* passes of the tie order's fixed point (floods beyond the first) */
   uint32_t reserved;
 } rdgpu_pf_flowdirs_stats;

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -282,6 +283,11 @@ void PriorityFloodFlowdirs_Barnes2014(const E &elevations, F &flowdirs) {
   if (elevations.width() == 0 || elevations.height() == 0) return;
   detail::check(detail::c_pf_flowdirs(elevations.data(), elevations.noData(), elevations.width(), elevations.height(), flowdirs.data()),
                 "PriorityFloodFlowdirs_Barnes2014");
+  rdgpu_pf_flowdirs_stats st;
+  if (rdgpu_pf_flowdirs_get_stats(&st) == 0 && st.unresolved != 0)   // (the reference's RDLOG_WARN channel is stderr too)
+    std::fprintf(stderr, "W PriorityFloodFlowdirs_Barnes2014: the order of %llu of %u equal-elevation cells had not settled when the "
+                         "tie-order passes were stopped (RDGPU_PFD_TIE_PASSES / RDGPU_PFD_TIE_SECONDS); directions are the "
+                         "reference's only where those ties do not decide\n", (unsigned long long)st.unresolved, st.twins);
 }
 
 // richdem::d8_flow_directions(const Array2D<T>&, Array2D<U>&)   flowmet/d8_flowdirs.hpp:96-123

@@ -6,6 +6,7 @@ the same buffer); HBM-resident torch tensors go through ``rdgpu_<op>_dev_<dtype>
 from __future__ import annotations
 
 import ctypes
+import os
 import warnings
 
 import numpy as np
@@ -132,6 +133,11 @@ def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bo
     h, w = out.shape
     check(getattr(lib(), f"rdgpu_fill_max_dep_{s}")(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology),
                                                     ctypes.c_uint64(int(max_dep_size))), "rdgpu_fill_max_dep")
+    st = max_dep_stats()   # (64-bit element types run on dense value ranks through the same engine: equal values, equal ranks)
+    if st["tie_pockets"]:
+        warnings.warn(f"fill_max_dep: {st['tie_pockets']} of {st['pockets']} pockets can be flooded by two or more cells of their "
+                      f"spill elevation; in their clusters ({st['tie_cluster_cells']} of {st['pocket_cells']} pocket cells) the "
+                      "reference's grouping follows its heap's pop order, this engine's the lowest cell index", RuntimeWarning)
     return None if in_place else out
 
 
@@ -193,9 +199,16 @@ def pf_flowdirs(dem: np.ndarray, nodata=-9999) -> np.ndarray:
     if st["unresolved"]:
         import warnings
 
-        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell and the order of {st['unresolved']} "
-                      "of them among their equals was still moving when the passes ran out (RDGPU_PFD_TIE_PASSES): the result is "
-                      "the reference's only where those ties do not decide", RuntimeWarning)
+        if os.environ.get("RDGPU_PFD_RANKS", "1")[:1] == "0":
+            why = (f"ties at {st['unresolved']} cells were decided by neighbour number (RDGPU_PFD_RANKS=0, the fast path without the "
+                   "reference's insertion order)")
+        elif st["tie_passes"] == 0:
+            why = "no tie-order pass ran (RDGPU_PFD_TIE_PASSES=0): equal cells were taken in a first-guess order"
+        else:
+            why = (f"the order of {st['unresolved']} of them among their equals was still moving when the tie-order passes were stopped "
+                   f"after {st['tie_passes']} (RDGPU_PFD_TIE_PASSES / RDGPU_PFD_TIE_SECONDS)")
+        warnings.warn(f"pf_flowdirs: {st['twins']} cells share their elevation with another cell and {why}: the result is the "
+                      "reference's only where those ties do not decide", RuntimeWarning)
     return out
 
 
@@ -572,6 +585,33 @@ def fa_tarboton_dev(dem, nodata, accum) -> None:
     s = _torch_elev_suffix(dem)
     check(getattr(lib(), f"rdgpu_fa_tarboton_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
                                                        ctypes.c_void_p(accum.data_ptr()), _stream_ptr()), "rdgpu_fa_tarboton_dev")
+
+
+class _MaxDepStats(ctypes.Structure):
+    _fields_ = [("pockets", ctypes.c_uint64), ("tie_pockets", ctypes.c_uint64), ("tie_cluster_cells", ctypes.c_uint64),
+                ("pocket_cells", ctypes.c_uint64)]
+
+
+def max_dep_stats() -> dict:
+    """Tie census of the calling thread's last max_dep fill: pockets, pockets that several cells of their spill elevation
+    can flood (there the reference's heap order decides the grouping), and the cells of the clusters they touch."""
+    st = _MaxDepStats()
+    check(lib().rdgpu_fill_max_dep_get_stats(ctypes.byref(st)), "rdgpu_fill_max_dep_get_stats")
+    return {k: int(getattr(st, k)) for k, _ in _MaxDepStats._fields_}
+
+
+def fill_max_dep_ties_dev(dem, max_dep_size: int, tie_mask, topology="D8") -> None:
+    """fill_max_dep_dev + the cells of tie-flagged pocket clusters as a uint8 CUDA tensor (1 = the reference's heap order can
+    decide this cell, 0 = order free)."""
+    import torch
+
+    h, w = _dev2d(dem, "fill_max_dep_ties_dev")
+    if tie_mask.dtype != torch.uint8 or tuple(tie_mask.shape) != (h, w) or not tie_mask.is_contiguous() or not tie_mask.is_cuda:
+        raise RdgpuError("fill_max_dep_ties_dev: tie_mask must be a contiguous uint8 CUDA tensor of the DEM's shape")
+    s = _torch_elev_suffix(dem)
+    check(getattr(lib(), f"rdgpu_fill_max_dep_ties_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), w, h, _topo(topology),
+                                                             ctypes.c_uint64(int(max_dep_size)), ctypes.c_void_p(tie_mask.data_ptr()),
+                                                             _stream_ptr()), "rdgpu_fill_max_dep_ties_dev")
 
 
 def fill_max_dep_dev(dem, max_dep_size: int, topology="D8") -> None:

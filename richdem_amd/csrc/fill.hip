@@ -1809,8 +1809,91 @@ __global__ __launch_bounds__(NTHR) void k_md_apply(T *z, const uint32_t *__restr
   }
 }
 
+// ---- tie detector (r05) -------------------------------------------------------------------------------------------------
+// With equal elevations a pocket can have SEVERAL cells able to flood it (un-raised cells of elevation exactly L next to it);
+// which of them the reference's std::priority_queue pops first decides which pockets end up in one run, hence whether the
+// run passes the size limit.  Everything else about the result is order free.  So: ncand[pocket] = the number of distinct
+// candidate cells; pockets that share ANY candidate cell are joined into a CLUSTER (par2, a coarser union-find than the
+// runs, which only join through the chosen spawner); a cluster holding a pocket with two or more candidates is tie-flagged.
+// Inside an unflagged cluster every pocket has exactly one possible flooding cell, so its runs -- and with them the output
+// on all of the cluster's cells -- do not depend on the pop order: a difference from the reference on such a cell would be a
+// bug, not a tie (tests/test_s3_f2_gpu.py asserts that there is none).
 template <class T, int TOPO>
-static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStream_t s) {
+__global__ __launch_bounds__(NTHR) void k_md_ties(const T *__restrict__ z, const uint32_t *__restrict__ lab,
+                                                  const uint32_t *__restrict__ acc, uint32_t *par, uint32_t *par2, uint32_t *ncand,
+                                                  int w, int h, uint32_t B) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t c = (uint64_t)blockIdx.x * NTHR + threadIdx.x; c < n; c += stride) {
+    const uint32_t b = lab[c];
+    const uint32_t kz = Key32<T>::to(z[c]);
+    if (b != B && acc[b] > kz) continue;   // raised cells are flooded, they do not flood
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    uint32_t seen[8];
+    int ns = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (TOPO == 4 && (k & 1)) continue;
+      const int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+      const int xx = x + dx[k], yy = y + dy[k];
+      if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;
+      const size_t q = (size_t)yy * w + xx;
+      const uint32_t bq = lab[q];
+      if (bq == B) continue;
+      const uint32_t L = acc[bq];
+      if (L != kz || !(L > Key32<T>::to(z[q]))) continue;   // a raised neighbour filled to exactly this cell's elevation
+      const uint32_t r = md_find(par, bq);                  // its pocket
+      bool dup = false;
+      for (int i = 0; i < ns; i++) dup |= seen[i] == r;
+      if (!dup) seen[ns++] = r;
+    }
+    for (int i = 0; i < ns; i++) {
+      atomicAdd(&ncand[seen[i]], 1u);
+      if (i) md_unite(par2, seen[0], seen[i]);
+    }
+  }
+}
+// pockets (roots of par with a candidate), tie pockets (two or more candidates); flags the clusters of the latter
+__global__ __launch_bounds__(NTHR) void k_md_flag(uint32_t *par, uint32_t *par2, const uint32_t *__restrict__ ncand, uint32_t *flag,
+                                                  unsigned long long *counts, uint32_t B) {
+  const uint32_t b = blockIdx.x * NTHR + threadIdx.x;
+  const uint32_t nc = b < B ? ncand[b] : 0u;   // (only pocket roots were counted into)
+  if (nc >= 2) flag[md_find(par2, b)] = 1u;
+  const unsigned long long p1 = __ballot(nc >= 1), p2 = __ballot(nc >= 2);
+  if ((threadIdx.x & 63) == 0) {
+    if (p1) atomicAdd(&counts[0], (unsigned long long)__popcll(p1));
+    if (p2) atomicAdd(&counts[1], (unsigned long long)__popcll(p2));
+  }
+}
+// per cell: lies in a pocket of a tie-flagged cluster (mask optional); counts those cells and the pocket cells
+template <class T>
+__global__ __launch_bounds__(NTHR) void k_md_tie_mask(const T *__restrict__ z, const uint32_t *__restrict__ lab,
+                                                      const uint32_t *__restrict__ acc, uint32_t *par2, const uint32_t *__restrict__ flag,
+                                                      uint8_t *mask, unsigned long long *counts, uint64_t n, uint32_t B) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  unsigned long long nt = 0, np = 0;
+  for (uint64_t c0 = (uint64_t)blockIdx.x * NTHR; c0 < n; c0 += stride) {
+    const uint64_t c = c0 + threadIdx.x;
+    bool pocket = false, tie = false;
+    if (c < n) {
+      const uint32_t b = lab[c];
+      pocket = b != B && acc[b] > Key32<T>::to(z[c]);
+      tie = pocket && flag[md_find(par2, b)] != 0;
+      if (mask) mask[c] = tie ? 1 : 0;
+    }
+    nt += (unsigned long long)__popcll(__ballot(tie));
+    np += (unsigned long long)__popcll(__ballot(pocket));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (nt) atomicAdd(&counts[2], nt);
+    if (np) atomicAdd(&counts[3], np);
+  }
+}
+static thread_local rdgpu_max_dep_stats g_md_stats;
+
+template <class T, int TOPO>
+static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStream_t s, uint8_t *d_tie_mask = nullptr) {
+  g_md_stats = rdgpu_max_dep_stats{0, 0, 0, 0};
+  if (d_tie_mask) RD_HIP(hipMemsetAsync(d_tie_mask, 0, (size_t)w * h, s));
   FillBuffers fb;
   BufAlloc ws_alloc{false, nullptr};
   fill_local_phase<T, TOPO>(d_z, w, h, 0, 0, ws_alloc, fb, s);
@@ -1824,6 +1907,23 @@ static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStr
   RD_LAUNCH("maxdep.init", k_md_init, dim3(bgrid), dim3(NTHR), 0, s, par, cnt, spawn, size, B);
   RD_LAUNCH("maxdep.pockets", (k_md_pockets<T, TOPO>), dim3(256u * 16u), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
             (const uint32_t *)fb.acc, par, cnt, w, h, B);
+  {   // the tie detector: before the runs join pockets in `par`
+    uint32_t *par2 = ws.buf<uint32_t>("maxdep.par2", B), *ncand = ws.buf<uint32_t>("maxdep.ncand", B), *flag = ws.buf<uint32_t>("maxdep.flag", B);
+    unsigned long long *counts = ws.buf<unsigned long long>("maxdep.counts", 4);
+    RD_HIP(hipMemcpyAsync(par2, par, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    RD_HIP(hipMemsetAsync(ncand, 0, (size_t)B * sizeof(uint32_t), s));
+    RD_HIP(hipMemsetAsync(flag, 0, (size_t)B * sizeof(uint32_t), s));
+    RD_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), s));
+    RD_LAUNCH("maxdep.ties", (k_md_ties<T, TOPO>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
+              (const uint32_t *)fb.acc, par, par2, ncand, w, h, B);
+    RD_LAUNCH("maxdep.flag", k_md_flag, dim3(bgrid), dim3(NTHR), 0, s, par, par2, (const uint32_t *)ncand, flag, counts, B);
+    RD_LAUNCH("maxdep.tie_mask", (k_md_tie_mask<T>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
+              (const uint32_t *)fb.acc, par2, (const uint32_t *)flag, d_tie_mask, counts, n, B);
+    unsigned long long hc[4];
+    RD_HIP(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    g_md_stats = rdgpu_max_dep_stats{hc[0], hc[1], hc[2], hc[3]};
+  }
   RD_LAUNCH("maxdep.spawn", (k_md_spawn<T, TOPO, 0>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
             (const uint32_t *)fb.acc, par, spawn, w, h, B);
   RD_LAUNCH("maxdep.runs", (k_md_spawn<T, TOPO, 1>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
@@ -1834,10 +1934,10 @@ static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStr
 }
 
 template <class T>
-static void fill_max_dep_device(T *d_z, int w, int h, int topology, uint64_t max_dep, hipStream_t s) {
+static void fill_max_dep_device(T *d_z, int w, int h, int topology, uint64_t max_dep, hipStream_t s, uint8_t *d_tie_mask = nullptr) {
   check_fill_args(d_z, w, h, topology);
-  if (topology == 8) fill_max_dep_device_t<T, 8>(d_z, w, h, max_dep, s);
-  else fill_max_dep_device_t<T, 4>(d_z, w, h, max_dep, s);
+  if (topology == 8) fill_max_dep_device_t<T, 8>(d_z, w, h, max_dep, s, d_tie_mask);
+  else fill_max_dep_device_t<T, 4>(d_z, w, h, max_dep, s, d_tie_mask);
 }
 
 template <class T>
@@ -3231,9 +3331,20 @@ static rdgpu_fill_shard *shard_begin(T *d_dem, int w, int h, int topology, int o
       // left for the exchange or for finish
       done = topology == 8 ? fill_fused<T, 8>(d_dem, w, h, s) : fill_fused<T, 4>(d_dem, w, h, s);
       if (done) { sh->fb = FillBuffers(); sh->fb.trivial = true; }
-    } else if (!(sf && sf[0] == '0'))
+    } else if (!(sf && sf[0] == '0')) {
+      const size_t owned_before = sh->owned.size();
       done = topology == 8 ? fill_fused<T, 8>(d_dem, w, h, s, nullptr, nullptr, nullptr, &sh->fb, &alloc, sh->open_top, sh->open_bottom)
                            : fill_fused<T, 4>(d_dem, w, h, s, nullptr, nullptr, nullptr, &sh->fb, &alloc, sh->open_top, sh->open_bottom);
+      if (!done) {
+        // the attempt gave up (node table or pair list too small: white noise): what it allocated for itself goes back before
+        // the classic phase allocates its own tables, or the shard would hold both until shard_free; the
+        // half-filled FillBuffers is reset as well
+        RD_HIP(hipStreamSynchronize(s));
+        for (size_t i = owned_before; i < sh->owned.size(); i++) (void)hipFree(sh->owned[i]);
+        sh->owned.resize(owned_before);
+        sh->fb = FillBuffers();
+      }
+    }
     if (!done) {
       if (topology == 8) fill_local_phase<T, 8>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
       else fill_local_phase<T, 4>(d_dem, w, h, sh->open_top, sh->open_bottom, alloc, sh->fb, s);
@@ -3488,6 +3599,10 @@ using namespace rdgpu;
   extern "C" int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int w, int h, int topology, uint64_t max_dep_size, void *stream) { \
     return guarded([&] { fill_max_dep_device<T>(d_dem, w, h, topology, max_dep_size, (hipStream_t)stream); }); \
   }                                                                                               \
+  extern "C" int rdgpu_fill_max_dep_ties_dev_##SUF(T *d_dem, int w, int h, int topology, uint64_t max_dep_size,            \
+                                                   uint8_t *d_tie_mask, void *stream) {                                  \
+    return guarded([&] { fill_max_dep_device<T>(d_dem, w, h, topology, max_dep_size, (hipStream_t)stream, d_tie_mask); }); \
+  }                                                                                               \
   extern "C" int rdgpu_pit_mask_##SUF(const T *dem, T nodata, int w, int h, int topology, uint8_t *mask) { \
     return guarded([&] { pit_mask_host<T>(dem, nodata, w, h, topology, mask); });                 \
   }                                                                                               \
@@ -3576,6 +3691,12 @@ extern "C" int rdgpu_fill_graph_solve_dev(int nshards, int width, int topology, 
 
 extern "C" int rdgpu_fill_shard_free(rdgpu_fill_shard *sh) {
   shard_free(sh);
+  return RDGPU_OK;
+}
+
+extern "C" int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out) {
+  if (!out) return RDGPU_ERR_ARG;
+  *out = g_md_stats;
   return RDGPU_OK;
 }
 

@@ -583,15 +583,25 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       RD_LAUNCH("pfd.rank_scatter", k_rank_scatter, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)sidx, rk, n);
       const rdgpu_pf_flowdirs_stats mine = g_stats;
       const char *tp = getenv("RDGPU_PFD_TIE_PASSES");   // passes of the tie order's fixed point (0: raster order, r04's first version)
+      // Each pass settles one more "generation" of tie decisions: 2 - 4 on float terrain, but one breadth-first RING of the
+      // largest plateau on integer DEMs -- min(w, h) / 2 passes for an ocean.  Bounded twice: by wall time
+      // (RDGPU_PFD_TIE_SECONDS, default 120 s, checked between passes: small rasters finish, a 40000^2 ocean does not run for
+      // hours) and by a count (RDGPU_PFD_TIE_PASSES, default 1000);
+      // when a bound stops the iteration the result is an exact flood of SOME stable order, `unresolved` says how many
+      // ranks were still moving and the host wrappers warn.
       const uint32_t max_passes = (w <= 2 || h <= 2) ? 0u : tp ? (uint32_t)strtoul(tp, nullptr, 10) : 1000u;   // (no interior cell: no tie to order)
+      const char *tsec = getenv("RDGPU_PFD_TIE_SECONDS");
+      const double max_seconds = tsec ? atof(tsec) : 120.0;
+      const auto t_tie0 = std::chrono::steady_clock::now();
       uint32_t passes = 0, levels_total = 0;
-      unsigned long long moved = 0;
+      unsigned long long moved = (w <= 2 || h <= 2) ? 0ull : (unsigned long long)g_stats.twins;   // no re-rank pass ran: every twin's place is undecided
       g_rank_pass = true;
       try {
         for (;;) {
           pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
           levels_total += g_stats.levels;
           if (passes >= max_passes) break;
+          if (passes && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tie0).count() > max_seconds) break;
           passes++;
           // ---- the discovery times under this pass's flood, and the ranks of (z, discovery time) -----------------------
           uint32_t *zkey = keys;   // (keys still holds every cell's key: k_rank_keys' output, untouched by the sort)
@@ -706,7 +716,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       g_stats.twins = mine.twins;
       g_stats.levels = levels_total;
       g_stats.tie_passes = passes;
-      g_stats.unresolved = moved;   // ranks still moving when the passes ran out (0: the reference's order)
+      g_stats.unresolved = moved;   // ranks still moving when the passes ran out (0: the reference's order; no pass at all: the twins)
       RD_LAUNCH("pfd.nodata_dirs", (k_nodata_dirs<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, d_dirs, w, h);
       return;
     }

@@ -847,10 +847,10 @@ def d8_flow_accum_blocks(dirs, area, world: int, nodata: int = 255) -> int:
             sh = GpuAccumShard()
             shards.append(sh)
             sh.begin(blk, nodata, above(s), below(s))
-        rounds = 1
+        rounds = 1                        # (the one-exchange attempt above was an exchange: d8_flow_accum_sharded's `extra`)
         while True:
             outs = [sh.outbox() for sh in shards]
-            rounds += 1
+            rounds += 1                   # counted like accum_exchange_loop: the gather that finds nothing crossing is one too
             if not any(bool((o != 0).any().item()) for o in outs):
                 break
             for s, sh in enumerate(shards):

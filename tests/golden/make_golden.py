@@ -283,11 +283,35 @@ def s3_f2(which, size=40000, seed=3):
          "bands": band_digests_np(out), "blocks": _block_digests(out), "sample": out.ravel()[pos]}
     if which in ("epsilon", "maxdep"):
         g["cells_changed"] = np.int64((out != z).sum())
+    if which == "maxdep":
+        # r05: the reference's RAISED cells of the whole raster as a bit mask (200 MB, scratch/ -- not committed); the blocks the
+        # GPU test reports as differing are cut out of it by `--s3-f2-maxdep-blocks` and committed, so that the test can assert
+        # that EVERY differing cell lies in a tie-flagged cluster of pockets (a raised cell holds its pocket's fill level, so the
+        # mask and the plain fill reproduce the reference's output exactly)
+        os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
+        raised = out != z
+        assert np.array_equal(out[raised], R.fill(z, 8)[raised])          # raised cells sit at the plain fill's level
+        np.save(os.path.join(ROOT, "scratch", f"ref_s3_maxdep_raised_{n}.npy"), np.packbits(raised, axis=1))
     if which == "watersheds":
         g["labels"] = np.int64(out.max())
     path = os.path.join(HERE, f"ref_s3_f2_{which}.npz" if n == 40000 else f"ref_s3_f2_{which}_{n}.npz")
     np.savez_compressed(path, **g)
     print("wrote", path, round(secs, 1), "s", os.path.getsize(path), "bytes", flush=True)
+
+
+def s3_f2_maxdep_blocks(blocks, size=40000):
+    """Cuts the 1000 x 1000 blocks `blocks` (flat indices by * 40 + bx, as the GPU test reports them) out of the reference's
+    raised-cell mask left in scratch/ by `--s3-f2 maxdep` and commits them: tests/golden/ref_s3_f2_maxdep_blocks.npz."""
+    packed = np.load(os.path.join(ROOT, "scratch", f"ref_s3_maxdep_raised_{size}.npy"), mmap_mode="r")
+    nb = -(-size // 1000)
+    g = {"size": np.int64(size), "block_ids": np.array(sorted(blocks), np.int64)}
+    for b in sorted(blocks):
+        by, bx = divmod(int(b), nb)
+        rows = np.unpackbits(np.asarray(packed[by * 1000:(by + 1) * 1000]), axis=1)[:, :size]
+        g[f"raised/{b}"] = np.packbits(rows[:, bx * 1000:(bx + 1) * 1000], axis=1)
+    path = os.path.join(HERE, "ref_s3_f2_maxdep_blocks.npz" if size == 40000 else f"ref_s3_f2_maxdep_blocks_{size}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
 def s2_dinf(size=10000, seed=2):
@@ -336,6 +360,9 @@ if __name__ == "__main__":
     elif "--s2-dinf" in sys.argv:
         sys.path.insert(0, HERE)
         s2_dinf(int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 10000)
+    elif "--s3-f2-maxdep-blocks" in sys.argv:
+        size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000
+        s3_f2_maxdep_blocks([int(b) for b in sys.argv[sys.argv.index("--s3-f2-maxdep-blocks") + 1].split(",")], size)
     elif "--s3-f2" in sys.argv:
         sys.path.insert(0, HERE)
         size = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 40000

@@ -2,6 +2,7 @@
 reference's own goldens (tests/depressions/testdem1.{1,2}.out, tests/tests.cpp:273-287), the committed outputs of the
 compiled reference on tie-free DEMs, and random DEMs against the C restatement."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -74,6 +75,59 @@ def test_max_dep_integer_dems(rd, orc):
             differ += not np.array_equal(got, exp)
         assert np.array_equal(rd.fill_max_dep(z, 0), z) and np.array_equal(rd.fill_max_dep(z, 10 ** 8), W)
     print(f"max_dep integer DEMs: {differ} of {total} cases differ from the C restatement (ties)")
+
+
+def test_max_dep_tie_detector(rd, orc):
+    """r05: WHERE the heap's order can decide is detected on the device -- pockets that two or more cells of their spill
+    elevation can flood, and the clusters of pockets sharing a possible flooding cell with them (csrc/fill.hip k_md_ties).
+    Outside the flagged clusters the output is a function of the DEM alone, so BOTH CPU implementations (the compiled
+    reference on libstdc++'s heap, the C restatement on its own heap -- they disagree with each other on about half of these
+    rasters) must agree with the engine on every unflagged cell.  Tie-free rasters flag nothing."""
+    import torch
+
+    rng = np.random.default_rng(23)
+    checked = differing = flagged_cells = pocket_cells = 0
+    backends = [orc.port] + ([orc.ref] if orc.ref.available else [])
+    for i in range(60):
+        h, w = (int(v) for v in rng.integers(4, 120, 2))
+        if i % 3 == 0:
+            z = rng.integers(0, 4 + i, (h, w)).astype(np.int32)
+        elif i % 3 == 1:
+            z = np.floor(rng.random((h, w)) * (6 + i)).astype(np.float32)
+        else:
+            z = rng.integers(0, 3 + i // 2, (h, w)).astype(np.uint8)
+        for topo, nm in ((8, "D8"), (4, "D4")):
+            for md in (1, 4, 25):
+                t = torch.from_numpy(z).cuda()
+                mask = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+                rd.fill_max_dep_ties_dev(t, md, mask, nm)
+                torch.cuda.synchronize()
+                got, m = t.cpu().numpy(), mask.cpu().numpy().astype(bool)
+                st = rd.max_dep_stats()
+                assert st["tie_cluster_cells"] == int(m.sum()) and st["pocket_cells"] == int((orc.port.fill(z, topo) > z).sum()), st
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    assert np.array_equal(got, rd.fill_max_dep(z, md, nm))      # (the host entry warns about the same pockets)
+                for be in backends:
+                    exp = be.fill_max_dep(z, md, topo)
+                    d = got != exp
+                    assert not (d & ~m).any(), (i, nm, md, int((d & ~m).sum()), st)
+                    differing += int(d.any())
+                    checked += 1
+                flagged_cells += int(m.sum())
+                pocket_cells += st["pocket_cells"]
+    assert differing > 0          # (the sweep does contain rasters where the heaps disagree: the assertion above had work to do)
+    print(f"max_dep tie detector: {differing} of {checked} comparisons differ from a CPU heap, always inside flagged clusters "
+          f"({flagged_cells} of {pocket_cells} pocket cells flagged)")
+    for seed in range(6):         # tie-free: nothing flagged, equal to the restatement
+        z = (rng.permutation(90 * 70).reshape(70, 90) * 0.5).astype(np.float32)
+        t = torch.from_numpy(z).cuda()
+        mask = torch.empty(z.shape, dtype=torch.uint8, device="cuda")
+        rd.fill_max_dep_ties_dev(t, 12, mask)
+        torch.cuda.synchronize()
+        st = rd.max_dep_stats()
+        assert st["tie_pockets"] == 0 and st["tie_cluster_cells"] == 0 and not mask.any().item(), st
+        assert np.array_equal(t.cpu().numpy(), orc.port.fill_max_dep(z, 12, 8))
 
 
 def test_max_dep_sizes_and_types(rd, orc):

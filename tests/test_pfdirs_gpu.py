@@ -129,6 +129,8 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         raster_order = rd.pf_flowdirs(dem, nodata=np.int32(-9999))
+    st0 = rd.pf_flowdirs_stats()
+    assert st0["tie_passes"] == 0 and st0["unresolved"] == st0["twins"] > 0, st0    # no re-rank pass ran: every twin is undecided
     order = np.argsort(dem.ravel(), kind="stable")
     ranks = np.empty(dem.size, np.int32)
     ranks[order] = np.arange(dem.size, dtype=np.int32)
@@ -136,6 +138,15 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
     monkeypatch.delenv("RDGPU_PFD_TIE_PASSES")
     assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.int32(-9999)), exp)     # (any first order converges: here raster order)
     monkeypatch.delenv("RDGPU_PFD_TIE_INIT")
+    # the passes are bounded (count and wall time): a stopped iteration says so -- stats and a RuntimeWarning
+    flat = np.zeros((33, 47), np.int16)
+    for var, val in (("RDGPU_PFD_TIE_PASSES", "2"), ("RDGPU_PFD_TIE_SECONDS", "0")):
+        monkeypatch.setenv(var, val)
+        with pytest.warns(RuntimeWarning, match="tie-order passes were stopped"):
+            rd.pf_flowdirs(flat, nodata=np.int16(-9999))
+        st1 = rd.pf_flowdirs_stats()
+        assert 1 <= st1["tie_passes"] <= 2 and st1["unresolved"] > 0, (var, st1)
+        monkeypatch.delenv(var)
     monkeypatch.setenv("RDGPU_PFD_RANKS", "0")               # r03: ties decided inside the levels, by neighbour number
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

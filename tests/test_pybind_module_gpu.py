@@ -90,3 +90,24 @@ def test_resolve_flats_epsilon(R, orc):
     a = dem.copy()
     R.rdResolveFlatsEpsilon(wrap(R, a, -9999))
     assert np.array_equal(a, orc.port.resolve_flats_epsilon(dem, np.float32(-9999)))
+
+
+def test_epsilon_fill_warns_with_the_tie_count(R, orc):
+    """rd.FillDepressions(epsilon=True) through `_richdem`: on an integer-valued DEM the reference's surface follows its heap's
+    pop order; the binding says how many gradient sources shared an elevation (a RuntimeWarning with the device's count),
+    and stays silent -- and equal to the restatement -- on a tie-free DEM."""
+    import warnings
+
+    import richdem_amd as rd
+
+    z = np.floor(fractal_dem(180, 140, seed=12) * 0.05).astype(np.float32)
+    with pytest.warns(RuntimeWarning, match=r"\d+ gradient sources share their elevation"):
+        R.rdPFepsilonD8(wrap(R, z.copy(), -9999))
+    assert rd.epsilon_stats()["tie_sources"] > 0
+    rng = np.random.default_rng(4)
+    free = (rng.permutation(120 * 90).reshape(90, 120) * 0.25).astype(np.float32)
+    a = free.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        R.rdPFepsilonD8(wrap(R, a, -9999))
+    assert np.array_equal(a, orc.port.fill_epsilon(free, np.float32(-9999), 8))

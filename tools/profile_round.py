@@ -57,6 +57,17 @@ def kernel_shas():
     return " ".join(out)
 
 
+def git_sha():
+    """the commit the tree was at when it was sent to the GPU box (tools/gpurun.sh writes .gitsha; the box has no .git)"""
+    if os.environ.get("RDGPU_GIT_SHA"):
+        return os.environ["RDGPU_GIT_SHA"]
+    try:
+        with open(os.path.join(ROOT, ".gitsha")) as f:
+            return f.read().strip()
+    except OSError:
+        return "unknown"
+
+
 def main():
     tag = sys.argv[1]
     steps = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "3"
@@ -93,7 +104,7 @@ def main():
         rows.append((k, n, fg, wg, fg + wg))
     with open(os.path.join(OUT, f"{tag}_{what}_pmc_summary.csv"), "w") as f:
         f.write(f"# {tag} PMC summary: fill, 40000x40000 f32, 1 step (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)\n")
-        f.write(f"# git {os.environ.get('RDGPU_GIT_SHA')}  kernel sources sha1: {kernel_shas()}\n")
+        f.write(f"# git {git_sha()}  kernel sources sha1: {kernel_shas()}\n")
         f.write("# counters are KiB; WRITE_SIZE x1, FETCH_SIZE x2 (gfx950 half-count; calibration: k_synth writes 6.4e9 B, k_count_pits reads 6.4e9 B)\n")
         f.write("kernel,launches,fetch_GB_per_launch(x2),write_GB_per_launch,total_GB_per_launch\n")
         for r in rows:
@@ -121,7 +132,7 @@ def main():
             nfill = max(1, sum(r[1] for r in rows if r[0].split("<")[0] in ("rdgpu::k_descent", "rdgpu::k_descent16")))
             per_fill = sum(r[4] * r[1] for r in rows if r[0].split("<")[0].replace("rdgpu::", "") in fill_kernels) / nfill
             json.dump({"size": 40000, "GB_per_launch": per, "GB_per_fill": round(per_fill, 2), "engine_sha": engine_sha(),
-                       "git_sha": os.environ.get("RDGPU_GIT_SHA"),
+                       "git_sha": git_sha(),
                        "source": f"profiles/{tag}_{what}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per MI355X_MICROARCH.md)"}, f)
         # the bench line above was printed before these passes ran: give it this round's traffic figure
         d = json.loads(line)
@@ -143,6 +154,7 @@ def main():
         with open(os.path.join(OUT, f"{tag}_{what}_sq_summary.csv"), "w") as f:
             f.write(f"# {tag} SQ counters, fill 40000x40000 f32, 1 step (rocprofv3 --kernel-trace --pmc SQ_*; quad-cycle units; "
                     "fractions of SQ_WAVE_CYCLES)\n")
+            f.write(f"# git {git_sha()}  kernel sources sha1: {kernel_shas()}\n")
             f.write("kernel,launches,wave_cycles,wait_any,wait_inst_any,active_inst_any,active_valu,active_lds,insts_valu,insts_lds\n")
             for k in sorted(cols["SQ_WAVE_CYCLES"]):
                 wc = cols["SQ_WAVE_CYCLES"][k][1]

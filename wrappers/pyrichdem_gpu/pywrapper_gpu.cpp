@@ -5,7 +5,7 @@
 // builds a module with the same name and the same binding surface -- Array2D_<type>, Array3D_float, the rd*/FA_*/
 // FM_* functions -- over the C++ shim (include/rdgpu/richdem_gpu.hpp -> librdgpu.so), so the reference's own
 // `richdem/__init__.py` runs FillDepressions / FlowAccumulation / FlowProportions / FlowAccumFromProps /
-// ResolveFlats on the GPU unchanged.  What lies outside SURVEY.md section 8 (epsilon fill, breaching, terrain
+// ResolveFlats on the GPU unchanged (the epsilon fill included).  What lies outside SURVEY.md section 8 (breaching, terrain
 // attributes, the random Rho8/Rho4 family, terrain generation, the depression hierarchy) is bound too, and raises
 // std::runtime_error("... outside the scope of the MI355X engine"): the surface is complete, the failure loud.
 //
@@ -51,6 +51,19 @@ void def_out_of_scope(py::module_ &m, const char *name) {
 
 using release = py::call_guard<py::gil_scoped_release>;
 
+// rd.FillDepressions(epsilon=True) on a DEM with equal elevations among its gradient sources (every integer-valued DEM):
+// the reference's surface follows std::priority_queue's pop order there, the engine's is the order-free lower bound.  The
+// device counts those sources; the caller is told how many (a RuntimeWarning, raised with the GIL held).
+void warn_epsilon_ties() {
+  rdgpu_epsilon_stats st;
+  if (rdgpu_fill_epsilon_get_stats(&st) != 0 || st.tie_sources == 0) return;
+  const std::string msg = "FillDepressions(epsilon=True): " + std::to_string(st.tie_sources) +
+                          " gradient sources share their elevation with another one; the reference's Priority-Flood+Epsilon "
+                          "resolves such ties by std::priority_queue's pop order, the MI355X engine returns the order-free "
+                          "surface (a cell-wise lower bound of the reference's)";
+  if (PyErr_WarnEx(PyExc_RuntimeWarning, msg.c_str(), 1) < 0) throw py::error_already_set();
+}
+
 struct DepressionRecord {
   static constexpr std::uint32_t NONE = 0xFFFFFFFFu;
   std::uint32_t pit_cell = NONE, out_cell = NONE, parent = NONE, odep = NONE, geolink = NONE;
@@ -70,10 +83,15 @@ void bind_functions(py::module_ &m) {
   m.def("rdFillDepressionsD4", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Barnes2014<Topology::D4>(dem); }, release(),
         "Fill all depressions, D4 (PriorityFlood_Barnes2014<D4>'s result).");
   // pywrapper.hpp:34-35 (floating-point element types; the others raise as the reference's specialisations do)
-  m.def("rdPFepsilonD8", [](Array2D<T> &dem) { rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D8>(dem); }, release(),
-        "Fill all depressions with epsilon.");
-  m.def("rdPFepsilonD4", [](Array2D<T> &dem) { rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D4>(dem); }, release(),
-        "Fill all depressions with epsilon.");
+  // (the engine runs with the GIL released; the tie census of the call is turned into a Python RuntimeWarning afterwards)
+  m.def("rdPFepsilonD8", [](Array2D<T> &dem) {
+    { py::gil_scoped_release nogil; rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D8>(dem); }
+    warn_epsilon_ties();
+  }, "Fill all depressions with epsilon.");
+  m.def("rdPFepsilonD4", [](Array2D<T> &dem) {
+    { py::gil_scoped_release nogil; rdgpu::PriorityFloodEpsilon_Barnes2014<Topology::D4>(dem); }
+    warn_epsilon_ties();
+  }, "Fill all depressions with epsilon.");
   m.def("rdResolveFlatsEpsilon", [](Array2D<T> &dem) { rdgpu::ResolveFlatsEpsilon(dem); }, release(),
         "Raise the cells of drainable flats by the smallest representable steps (ResolveFlatsEpsilon).");
 
