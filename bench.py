@@ -227,8 +227,12 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         area.fill_(1.0)
         t_fa = min(t_fa, _best(lambda: rd.fa_d8_dev(E, nodata, area), 1, sync))
     out["fa_d8"] = stage_entry(t_fa, n_cells, 20)
-    out["fa_d8"]["input"] = "fill -> ResolveFlatsEpsilon output, unit weights"
+    out["fa_d8"]["input"] = "fill -> ResolveFlatsEpsilon output, an array of ones as weights (the engine reads it once to find out)"
     out["fa_d8"]["max_accum"] = float(area.max().item())
+    # the same when the CALLER says the weights are ones (rdgpu_fa_d8_unit_dev_<T>: what rd.FlowAccumulation(weights=None) and
+    # rd_flow_accumulation's accum(dem, 1) amount to): 12 algorithmic bytes per cell -- the DEM in, the accumulation out
+    t_fu = _best(lambda: rd.fa_d8_dev(E, nodata, area, unit_weights=True), reps, sync)
+    out["fa_d8"]["unit_weights_declared"] = {**stage_entry(t_fu, n_cells, 12), "max_accum": float(area.max().item())}
     # D-infinity (north_star names it beside D8): the angle raster (dinf_flow_directions) and FA_Tarboton on the epsilon-resolved
     # DEM, where every cell drains
     ang = torch.empty(W.shape, dtype=torch.float32, device="cuda")

@@ -88,13 +88,15 @@ int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, voi
  * equal elevations and on the reference's goldens (tests/depressions/testdem1.{1,2}.out); when several cells of
  * elevation L touch the same pocket the reference's grouping follows std::priority_queue's pop order, this one the
  * lowest cell index.  Where that can happen is DETECTED on the device: pockets sharing any possible flooding cell form a
- * cluster, a cluster holding a pocket with two or more possible flooding cells is tie-flagged; outside the flagged clusters
+ * cluster, a cluster holding a pocket with two or more possible flooding cells is tie-flagged, and inside it the order
+ * matters only for pockets within the size limit of clusters beyond it; on all other cells
  * the output does not depend on the pop order (rdgpu_fill_max_dep_get_stats; rdgpu_fill_max_dep_ties_dev_<T> also writes
  * the flagged cells as a uint8 mask -- the parity tests assert that every cell differing from the reference lies in it). */
 typedef struct rdgpu_max_dep_stats {
   uint64_t pockets;           /* connected components of the cells the plain fill would raise */
   uint64_t tie_pockets;       /* ... that two or more cells of their spill elevation can flood: the heap's order decides */
-  uint64_t tie_cluster_cells; /* cells of the pockets in tie-flagged clusters (0: the result is the reference's) */
+  uint64_t tie_cluster_cells; /* cells whose fate the heap's order can decide: pockets no larger than the limit, in tie-flagged
+                                 clusters larger than the limit (0: the result is the reference's whatever its heap does) */
   uint64_t pocket_cells;      /* cells the plain fill would raise */
 } rdgpu_max_dep_stats;
 int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out);   /* of the calling thread's last max_dep fill */
@@ -587,6 +589,17 @@ int rdgpu_fa_d8_dev_f64(const double *d_dem, double nodata, int width, int heigh
 int rdgpu_fa_d8_dev_i8(const int8_t *d_dem, int8_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_i64(const int64_t *d_dem, int64_t nodata, int width, int height, double *d_accum, void *hip_stream);
 int rdgpu_fa_d8_dev_u64(const uint64_t *d_dem, uint64_t nodata, int width, int height, double *d_accum, void *hip_stream);
+/* FA_D8 when the CALLER KNOWS that every cell generates a flow of 1 -- it built the accumulation array itself, as
+ * apps/rd_flow_accumulation.cpp:13 (Array2D<double> accum(dem, 1)) and rd.FlowAccumulation(weights=None) do: accum is
+ * OUTPUT ONLY.  The plain entries above have to read the weights once to find that out (12.8 GB at 40000^2) and, on the
+ * host path, upload them (12.8 GB over PCIe); these do neither.  Same result as the plain entry on an array of ones. */
+#define RDGPU_DECL_FA_UNIT(SUF, T)                                                                              \
+  int rdgpu_fa_d8_unit_##SUF(const T *dem, T nodata, int width, int height, double *accum_out);                 \
+  int rdgpu_fa_d8_unit_dev_##SUF(const T *d_dem, T nodata, int width, int height, double *d_accum_out, void *hip_stream);
+RDGPU_DECL_FA_UNIT(u8, uint8_t) RDGPU_DECL_FA_UNIT(i8, int8_t) RDGPU_DECL_FA_UNIT(i16, int16_t) RDGPU_DECL_FA_UNIT(u16, uint16_t)
+RDGPU_DECL_FA_UNIT(i32, int32_t) RDGPU_DECL_FA_UNIT(u32, uint32_t) RDGPU_DECL_FA_UNIT(f32, float) RDGPU_DECL_FA_UNIT(f64, double)
+RDGPU_DECL_FA_UNIT(i64, int64_t) RDGPU_DECL_FA_UNIT(u64, uint64_t)
+#undef RDGPU_DECL_FA_UNIT
 
 /* ---- D-infinity (Tarboton 1997) and the generic FlowAccumulation ---------------------------------
  * rdgpu_dinf_flowdirs_<T>   replaces richdem::dinf_flow_directions (include/richdem/flowmet/dinf_flowdirs.hpp

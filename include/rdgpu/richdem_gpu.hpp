@@ -60,6 +60,7 @@ int c_fill(T *, int, int, int) { unsupported("FillDepressions"); }
   inline int c_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_d8_flowdirs_##SUF(p, nd, w, h, o); } \
   inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
   inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
+  inline int c_fa_d8_unit(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_unit_##SUF(p, nd, w, h, a); } \
   inline int c_fa_dinf(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_tarboton_##SUF(p, nd, w, h, a); } \
   inline int c_fa_mfd(const T *p, T nd, int w, int h, int m, double x, double *a) { return rdgpu_fa_mfd_##SUF(p, nd, w, h, m, x, a); } \
   inline int c_rfe(T *p, T nd, int w, int h) { return rdgpu_resolve_flats_epsilon_##SUF(p, nd, w, h); } \
@@ -80,6 +81,7 @@ RDGPU_SHIM_STENCIL(i8, int8_t)
   inline int c_flowdirs(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_d8_flowdirs_##SUF(p, nd, w, h, o); } \
   inline int c_flatres(const T *p, T nd, int w, int h, uint8_t *o) { return rdgpu_flat_resolution_d8_##SUF(p, nd, w, h, o); } \
   inline int c_fa_d8(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_##SUF(p, nd, w, h, a); } \
+  inline int c_fa_d8_unit(const T *p, T nd, int w, int h, double *a) { return rdgpu_fa_d8_unit_##SUF(p, nd, w, h, a); } \
   inline int c_rfe(T *p, T nd, int w, int h) { return rdgpu_resolve_flats_epsilon_##SUF(p, nd, w, h); } \
   inline int c_fm_d8(const T *p, T nd, int w, int h, float *o) { return rdgpu_fm_d8_##SUF(p, nd, w, h, o); }
 RDGPU_SHIM_STENCIL64(i64, int64_t)
@@ -91,6 +93,8 @@ template <class T>
 int c_flatres(const T *, T, int, int, uint8_t *) { unsupported("barnes_flat_resolution_d8"); }
 template <class T>
 int c_fa_d8(const T *, T, int, int, double *) { unsupported("FA_D8"); }
+template <class T>
+int c_fa_d8_unit(const T *, T, int, int, double *) { unsupported("FA_D8"); }
 template <class T>
 int c_fa_dinf(const T *, T, int, int, double *) { unsupported("FA_Tarboton"); }
 template <class T>
@@ -391,6 +395,24 @@ void FA_Tarboton(const E &elevations, G &accum) {
 }
 template <class E, class G>
 void FA_Dinfinity(const E &elevations, G &accum) { FA_Tarboton(elevations, accum); }
+
+// FA_D8 for a caller that built `accum` as an array of ones itself (apps/rd_flow_accumulation.cpp:13: Array2D<double>
+// accum(dem, 1)) and says so: rdgpu::FA_D8(dem, accum, rdgpu::unit_weights).  accum is then output only -- nothing is read
+// from it, nothing uploaded (rdgpu_fa_d8_unit_<T>); the result equals FA_D8 on an array of ones.
+struct unit_weights_t {};
+constexpr unit_weights_t unit_weights{};
+template <class E, class G>
+void FA_D8(const E &elevations, G &accum, unit_weights_t) {
+  using T = detail::elem_t<E>;
+  accum.setNoData((detail::elem_t<G>)-1);
+  if (accum.width() != elevations.width() || accum.height() != elevations.height())
+    throw std::runtime_error("Accumulation array must have same dimensions as proportions array!");
+  if (elevations.width() == 0 || elevations.height() == 0) return;
+  detail::with_double_accum(accum, [&](double *a) {
+    detail::check(detail::c_fa_d8_unit((const T *)elevations.data(), elevations.noData(), elevations.width(), elevations.height(), a),
+                  "FA_D8");
+  });
+}
 
 // richdem::FA_Holmgren / FA_Quinn / FA_Freeman / FA_D4   methods/flow_accumulation.hpp:18-20, :28
 namespace detail {

@@ -416,7 +416,14 @@ def FlowAccumulation(dem: np.ndarray, method: str = "D8", nodata=-9999, weights:
     if not isinstance(dem, np.ndarray) or dem.ndim != 2:
         raise RdgpuError("FlowAccumulation: expected a 2-D numpy array")
     if weights is None:
-        acc = np.ones(dem.shape, np.float64)       # __init__.py:560-563: every cell generates 1
+        kind, _, _ = _method("FlowAccumulation", method, exponent)
+        if kind == "d8":                           # every cell generates 1 (__init__.py:560-563) and THIS code knows it:
+            d, s = _elev(dem, "FlowAccumulation", mfd=False)   # the unit-weights entry neither reads nor uploads an array of ones
+            acc = np.empty(d.shape, np.float64)
+            check(getattr(lib(), f"rdgpu_fa_d8_unit_{s}")(d.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), d.shape[1], d.shape[0],
+                                                          acc.ctypes.data_as(ctypes.c_void_p)), "rdgpu_fa_d8_unit")
+            return acc
+        acc = np.ones(dem.shape, np.float64)
     else:
         if weights.shape != dem.shape:             # flow_accumulation_generic.hpp:42-43
             raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
@@ -512,15 +519,16 @@ def d8_flow_accum_dev(dirs, area, nodata: int = 255) -> None:
           "rdgpu_d8_flow_accum_dev")
 
 
-def fa_d8_dev(dem, nodata, accum) -> None:
-    """accum (float64 CUDA tensor, pre-loaded with per-cell weights) <- FA_D8 accumulation."""
+def fa_d8_dev(dem, nodata, accum, unit_weights: bool = False) -> None:
+    """accum (float64 CUDA tensor, pre-loaded with per-cell weights) <- FA_D8 accumulation.  unit_weights=True: the caller
+    guarantees that every weight is 1 (accum is then output only; the engine does not read the weights to find out)."""
     import torch
 
     h, w = _dev2d(dem, "fa_d8_dev")
     if _dev2d(accum, "fa_d8_dev", torch.float64) != (h, w):
         raise RdgpuError("Accumulation array must have same dimensions as proportions array!")
     s = _torch_elev_suffix(dem)
-    check(getattr(lib(), f"rdgpu_fa_d8_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
+    check(getattr(lib(), f"rdgpu_fa_d8_unit_dev_{s}" if unit_weights else f"rdgpu_fa_d8_dev_{s}")(ctypes.c_void_p(dem.data_ptr()), _scalar(s, nodata), w, h,
                                                  ctypes.c_void_p(accum.data_ptr()), _stream_ptr()), "rdgpu_fa_d8_dev")
 
 

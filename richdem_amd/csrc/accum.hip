@@ -1025,6 +1025,11 @@ __global__ __launch_bounds__(NTHR) void k_acc_not_all_ones(const double *__restr
 template <class A>
 void d8_flow_accum_device(const uint8_t *d_dirs, uint8_t nodata, int w, int h, A *d_area, hipStream_t s);
 
+__global__ __launch_bounds__(NTHR) void k_acc_ones(double *acc, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NTHR;
+  for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < n; i += stride) acc[i] = 1.0;
+}
+
 // Weighted accumulation over FM_D8 directions (255 = NoData), in place in d_acc.
 // Every weight 1 -- what FA_D8 is called with unless the caller has weights (the Python wrapper's and the apps'
 // accum.setAll(1)): the directions come from a DEM, so they are loop-free and the sums are d8_flow_accum's cell counts,
@@ -1077,14 +1082,24 @@ void flow_accum_f64_device(const uint8_t *d_dirs, int w, int h, double *d_acc, h
   RD_LAUNCH("accum.nodata_f64", k_acc_nodata_f64, dim3(sgrid(n)), dim3(NTHR), 0, s, d_dirs, d_acc, n);
 }
 
+// unit_weights: the caller GUARANTEES that every cell generates a flow of 1 (it built the array itself: the apps'
+// Array2D<double> accum(dem, 1), rd.FlowAccumulation(weights=None)) -- d_acc is then output only and the weights are
+// neither read (k_acc_not_all_ones: 12.8 GB at S3) nor, on the host path, uploaded (12.8 GB over PCIe)
 template <class T>
-void fa_d8_device(const T *d_z, T nodata, int w, int h, double *d_acc, hipStream_t s) {
+void fa_d8_device(const T *d_z, T nodata, int w, int h, double *d_acc, hipStream_t s, bool unit_weights = false) {
   if (!d_z || !d_acc) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_d8: null pointer");
   check_dims(w, h, "rdgpu_fa_d8");
   Workspace &ws = Workspace::get();
   uint8_t *dirs = ws.buf<uint8_t>("accum.fmdirs", (size_t)w * h);
   // the one read of the weights runs on the side stream while the directions are made on the caller's
   int unit = -1;
+  if (unit_weights && unit_check_enabled()) {
+    flowdirs_device<T>(d_z, nodata, w, h, dirs, MODE_FM, s);
+    d8_flow_accum_device<double>(dirs, (uint8_t)255, w, h, d_acc, s);
+    return;
+  }
+  if (unit_weights)   // RDGPU_ACCUM_UNIT=0 (A/B and tests): the weighted engine on an array of ones made here
+    RD_LAUNCH("accum.ones", k_acc_ones, dim3(sgrid((uint64_t)w * h)), dim3(NTHR), 0, s, d_acc, (uint64_t)w * h);
   if (unit_check_enabled()) {
     Workspace::SideLane &lane = ws.side_lane(0);
     RD_HIP(hipEventRecord(lane.fork, s));
@@ -1112,15 +1127,15 @@ static void d8_flow_accum_host(const uint8_t *dirs, uint8_t nodata, int w, int h
 }
 
 template <class T>
-static void fa_d8_host(const T *dem, T nodata, int w, int h, double *accum) {
+static void fa_d8_host(const T *dem, T nodata, int w, int h, double *accum, bool unit_weights = false) {
   if (!dem || !accum) throw Error(RDGPU_ERR_ARG, "rdgpu_fa_d8: null pointer");
   check_dims(w, h, "rdgpu_fa_d8");
   const size_t n = (size_t)w * h;
   T *d = Workspace::get().buf<T>("host.dem", n);
   double *da = Workspace::get().buf<double>("host.area", n);
   RD_HIP(hipMemcpy(d, dem, n * sizeof(T), hipMemcpyHostToDevice));
-  RD_HIP(hipMemcpy(da, accum, n * sizeof(double), hipMemcpyHostToDevice));
-  fa_d8_device<T>(d, nodata, w, h, da, nullptr);
+  if (!unit_weights) RD_HIP(hipMemcpy(da, accum, n * sizeof(double), hipMemcpyHostToDevice));
+  fa_d8_device<T>(d, nodata, w, h, da, nullptr, unit_weights);
   RD_HIP(hipStreamSynchronize(nullptr));
   RD_HIP(hipMemcpy(accum, da, n * sizeof(double), hipMemcpyDeviceToHost));
 }
@@ -1581,6 +1596,12 @@ static void fm_d8_host(const T *dem, T nodata, int w, int h, float *props9) {
   }                                                                                                          \
   extern "C" int rdgpu_fa_d8_dev_##SUF(const T *d_dem, T nodata, int w, int h, double *d_accum, void *stream) { \
     return guarded([&] { fa_d8_device<T>(d_dem, nodata, w, h, d_accum, (hipStream_t)stream); });             \
+  }                                                                                                          \
+  extern "C" int rdgpu_fa_d8_unit_##SUF(const T *dem, T nodata, int w, int h, double *accum_out) {           \
+    return guarded([&] { fa_d8_host<T>(dem, nodata, w, h, accum_out, true); });                              \
+  }                                                                                                          \
+  extern "C" int rdgpu_fa_d8_unit_dev_##SUF(const T *d_dem, T nodata, int w, int h, double *d_accum_out, void *stream) { \
+    return guarded([&] { fa_d8_device<T>(d_dem, nodata, w, h, d_accum_out, (hipStream_t)stream, true); });   \
   }
 RD_FA_API(u8, uint8_t)
 RD_FA_API(i16, int16_t)

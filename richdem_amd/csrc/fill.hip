@@ -1816,8 +1816,10 @@ __global__ __launch_bounds__(NTHR) void k_md_apply(T *z, const uint32_t *__restr
 // candidate cells; pockets that share ANY candidate cell are joined into a CLUSTER (par2, a coarser union-find than the
 // runs, which only join through the chosen spawner); a cluster holding a pocket with two or more candidates is tie-flagged.
 // Inside an unflagged cluster every pocket has exactly one possible flooding cell, so its runs -- and with them the output
-// on all of the cluster's cells -- do not depend on the pop order: a difference from the reference on such a cell would be a
-// bug, not a tie (tests/test_s3_f2_gpu.py asserts that there is none).
+// on all of the cluster's cells -- do not depend on the pop order.  Inside a flagged one the order matters only where the
+// size limit can fall either way (k_md_tie_mask): S3, limit 100: 3420 of 4.18 million pockets have two candidates, most of
+// them lakes far above the limit.  A difference from the reference on an unmasked cell would be a bug, not a tie
+// (tests/test_s3_f2_gpu.py and tests/test_maxdep_gpu.py assert that there is none).
 template <class T, int TOPO>
 __global__ __launch_bounds__(NTHR) void k_md_ties(const T *__restrict__ z, const uint32_t *__restrict__ lab,
                                                   const uint32_t *__restrict__ acc, uint32_t *par, uint32_t *par2, uint32_t *ncand,
@@ -1864,10 +1866,25 @@ __global__ __launch_bounds__(NTHR) void k_md_flag(uint32_t *par, uint32_t *par2,
     if (p2) atomicAdd(&counts[1], (unsigned long long)__popcll(p2));
   }
 }
-// per cell: lies in a pocket of a tie-flagged cluster (mask optional); counts those cells and the pocket cells
+// cells per pocket (sizeP, at the pocket's root in par) and per cluster (size2, at the cluster's root in par2)
+__global__ __launch_bounds__(NTHR) void k_md_tie_sizes(uint32_t *par, uint32_t *par2, const uint32_t *__restrict__ cnt, uint32_t *sizeP,
+                                                       uint32_t *size2, uint32_t B) {
+  const uint32_t b = blockIdx.x * NTHR + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t c = cnt[b];
+  if (!c) return;
+  atomicAdd(&sizeP[md_find(par, b)], c);
+  atomicAdd(&size2[md_find(par2, b)], c);
+}
+// per cell: can the heap's order decide whether this cell is raised?  It lies in a pocket of a tie-flagged cluster, AND the
+// size limit can fall either way: a pocket larger than the limit is never raised (any run holding it is larger still), a
+// cluster that fits the limit as a whole is always raised (every run is part of it) -- whatever the order.  (mask optional;
+// counts those cells and the pocket cells)
 template <class T>
 __global__ __launch_bounds__(NTHR) void k_md_tie_mask(const T *__restrict__ z, const uint32_t *__restrict__ lab,
-                                                      const uint32_t *__restrict__ acc, uint32_t *par2, const uint32_t *__restrict__ flag,
+                                                      const uint32_t *__restrict__ acc, uint32_t *par, uint32_t *par2,
+                                                      const uint32_t *__restrict__ flag, const uint32_t *__restrict__ sizeP,
+                                                      const uint32_t *__restrict__ size2, uint64_t max_dep,
                                                       uint8_t *mask, unsigned long long *counts, uint64_t n, uint32_t B) {
   const uint64_t stride = (uint64_t)gridDim.x * NTHR;
   unsigned long long nt = 0, np = 0;
@@ -1877,7 +1894,10 @@ __global__ __launch_bounds__(NTHR) void k_md_tie_mask(const T *__restrict__ z, c
     if (c < n) {
       const uint32_t b = lab[c];
       pocket = b != B && acc[b] > Key32<T>::to(z[c]);
-      tie = pocket && flag[md_find(par2, b)] != 0;
+      if (pocket) {
+        const uint32_t c2 = md_find(par2, b);
+        tie = flag[c2] != 0 && (uint64_t)size2[c2] > max_dep && (uint64_t)sizeP[md_find(par, b)] <= max_dep;
+      }
       if (mask) mask[c] = tie ? 1 : 0;
     }
     nt += (unsigned long long)__popcll(__ballot(tie));
@@ -1917,8 +1937,13 @@ static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStr
     RD_LAUNCH("maxdep.ties", (k_md_ties<T, TOPO>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
               (const uint32_t *)fb.acc, par, par2, ncand, w, h, B);
     RD_LAUNCH("maxdep.flag", k_md_flag, dim3(bgrid), dim3(NTHR), 0, s, par, par2, (const uint32_t *)ncand, flag, counts, B);
+    uint32_t *sizeP = ws.buf<uint32_t>("maxdep.sizeP", B), *size2 = ws.buf<uint32_t>("maxdep.size2", B);
+    RD_HIP(hipMemsetAsync(sizeP, 0, (size_t)B * sizeof(uint32_t), s));
+    RD_HIP(hipMemsetAsync(size2, 0, (size_t)B * sizeof(uint32_t), s));
+    RD_LAUNCH("maxdep.tie_sizes", k_md_tie_sizes, dim3(bgrid), dim3(NTHR), 0, s, par, par2, (const uint32_t *)cnt, sizeP, size2, B);
     RD_LAUNCH("maxdep.tie_mask", (k_md_tie_mask<T>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
-              (const uint32_t *)fb.acc, par2, (const uint32_t *)flag, d_tie_mask, counts, n, B);
+              (const uint32_t *)fb.acc, par, par2, (const uint32_t *)flag, (const uint32_t *)sizeP, (const uint32_t *)size2, max_dep,
+              d_tie_mask, counts, n, B);
     unsigned long long hc[4];
     RD_HIP(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
@@ -2759,7 +2784,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
       uint32_t total = 0;
 #pragma unroll
       for (int j = 0; j < ROWS; j++) total += (uint32_t)__popcll(bal[j]);
-      if (total) {
+      if (total && !(precheck & 16)) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&nlist, total);
         base = __shfl(base, 0, 64);
@@ -2775,7 +2800,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
     __syncthreads();
     load_b(tid);
     // ---- phase 2: the pairs (k_scan<EMIT>'s) -----------------------------------------------------------------------
-    const uint32_t nl = nlist;
+    const uint32_t nl = (precheck & 4) ? 0u : nlist;
     constexpr int NF = TOPO == 8 ? 4 : 2;
     const int foff[4] = {1, TOPO == 8 ? LW + 1 : LW, LW, LW - 1};
     for (uint32_t i = tid; i < nl; i += NTHR) {
@@ -2784,6 +2809,13 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
       uint32_t nD[NF], nH[NF];
 #pragma unroll
       for (int e = 0; e < NF; e++) { nD[e] = sc[o + foff[e]]; nH[e] = sk[o + foff[e]]; }
+      if (precheck & 64) {   // (timing probe: the gathers alone)
+        uint32_t sink = C ^ kc;
+#pragma unroll
+        for (int e = 0; e < NF; e++) sink ^= nD[e] ^ nH[e];
+        if (sink == 0x12345u) nlist = 1;
+        continue;
+      }
       uint32_t pd[2] = {C, C}, pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
       for (int e = 0; e < NF; e++) {
@@ -2798,6 +2830,10 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
               pair_spill_local(eo, best, seg, &seg_fill, C < D ? C : D, C < D ? D : C, hn);
           }
         }
+      }
+      if (precheck & 32) {   // (timing probe: gathers + the neighbours' sorting into two components, no table)
+        if ((pd[0] ^ pd[1] ^ pk[0] ^ pk[1]) == 0x12345u) nlist = 1;
+        continue;
       }
       uint32_t ps[2], pq[2], lo[2], hi[2];
       unsigned long long pv[2];
@@ -2831,7 +2867,7 @@ __global__ __launch_bounds__(NTHR) void k_pairs16(const T *__restrict__ z, const
       if (occ) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
     }
     __syncthreads();
-    const uint32_t tot = pt_n;
+    const uint32_t tot = (precheck & 8) ? 0u : pt_n;
     if (tid == 0) {
       uint32_t ob = seg_fill;   // (spills are over: nothing else touches the counter until the next tile's pairs)
       if (ob + tot > eo.seglimit) { *eo.overflow = 1; ob = 0xFFFFFFFFu; }
@@ -3072,7 +3108,15 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   const bool dedup = !(env_dedup && env_dedup[0] == '0');
   const char *env_pc = getenv("RDGPU_FILL_PRECHECK");
   const char *env_st = getenv("RDGPU_FILL_PAIRS_STRIDED");
-  const int precheck = (!(env_pc && env_pc[0] == '0') ? 1 : 0) | (!(env_st && env_st[0] == '0') ? 2 : 0);
+  // RDGPU_FILL_PAIRS_ABLATE (timing probes only -- the fill's RESULT IS WRONG with any bit set): 4 = no pair loop (phase 2),
+  // 8 = no proposals and no records (phase 3), 16 = no boundary list (phase 1), 32 = the pair loop without its table trips,
+  // 64 = the pair loop's gathers alone: what each part costs, tools/probes/pairs_ablate.sh.  r05 at S3 (profiles/r05e_*):
+  // staging + detection 2.5 ms, list 0.4, gathers 0.45, sorting the neighbours 1.0, table 1.8, proposals + records 0.5 = 6.1.
+  // Built on that and measured SLOWER or equal, not kept: the pair pass on local component ids with a direct triangular pair
+  // table (9.5 ms: its LDS atomics and the id lookups cost more than the hash they replace), one table trip per cell with
+  // the cells of a second component on a wavefront's own list (6.1-6.2), a two-slot fast path (6.2).
+  const char *env_ab = getenv("RDGPU_FILL_PAIRS_ABLATE");
+  const int precheck = (!(env_pc && env_pc[0] == '0') ? 1 : 0) | (!(env_st && env_st[0] == '0') ? 2 : 0) | (env_ab ? (atoi(env_ab) & 124) : 0);
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
     RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
@@ -3127,10 +3171,12 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
     RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
     RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
               dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, dflags, 14 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
+    if (first && getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair pass: %u records, overflow %u, %u tiles on the slow road\n", hw[4], hw[5], hw[12]);
     if (hw[0] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: hook chain unfinished\n"); return false; }
     const uint32_t next = hw[2];
+    if (first && (precheck & 124)) break;   // RDGPU_FILL_PAIRS_ABLATE (timing probes): the pair pass ran, its output is not used
     if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
     if (first && hw[5] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair list overflow (B %u cap %llu nseg %u segcap %u nwork %u)\n", B, (unsigned long long)cap, nseg, segcap, nwork1); return false; }   // the pair list overflowed: the DEM is untouched, the classic path takes over
     nroots = next;

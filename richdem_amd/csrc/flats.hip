@@ -129,7 +129,8 @@ __global__ __launch_bounds__(NTHR) void k_flat_classify(const T *__restrict__ z,
       bool higher = false, eq_noflow = false, eq_flow = false;
       auto nb = [&](T zn, bool valid, bool nf) {
         const bool eq = zn == e;
-        higher |= valid & (e < zn);
+        higher |= valid & !eq;   // (only asked of a NO_FLOW centre, and a valid neighbour of one is never LOWER -- the cell would
+                                 // drain there: "not equal" is "higher", one compare per neighbour instead of two)
         eq_noflow |= valid & eq & nf;
         eq_flow |= valid & eq & !nf;
       };
@@ -180,7 +181,12 @@ __device__ __forceinline__ uint8_t d8_dir_cell(const T *sz, int zx, int zy, int 
   return (uint8_t)dir;
 }
 
-template <class T>
+// NEARDIRS (r05): a NO_FLOW cell NEXT TO a low edge of its own flat gets its FINAL direction here.  d8_masked_FlowDir
+// (:42-65) sends it to a low edge -- mask 2, below every NO_FLOW cell's -- and which one only depends on WHICH neighbours
+// are equal-elevation cells with a direction: the first of them in neighbour order, replaced by the first odd-numbered one
+// after it if it is a diagonal (the same tie rule as everywhere).  That is known here and nowhere later without the
+// elevations, so the pass after the searches (k_flat_dirs_q) reads no DEM at all.
+template <class T, bool NEARDIRS = false>
 __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z, T nodata, uint8_t *__restrict__ dirs,
                                                         uint8_t *__restrict__ flags, int w, int h, uint32_t tilesX, uint32_t ntiles) {
   __shared__ T sz[FZH * FZW];
@@ -283,7 +289,8 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       bool higher = false, eq_noflow = false, eq_flow = false;
       auto nb = [&](T zn, bool valid, bool nf) {
         const bool eq = zn == e;
-        higher |= valid & (e < zn);
+        higher |= valid & !eq;   // (only asked of a NO_FLOW centre, and a valid neighbour of one is never LOWER -- the cell would
+                                 // drain there: "not equal" is "higher", one compare per neighbour instead of two)
         eq_noflow |= valid & eq & nf;
         eq_flow |= valid & eq & !nf;
       };
@@ -292,6 +299,21 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       nb(z2[0], v2[0], n2[0]); nb(z2[1], v2[1], n2[1]); nb(z2[2], v2[2], n2[2]);
       if (noflow ? higher : eq_noflow) f |= noflow ? F_HIGH : F_LOW;
       if (noflow && eq_flow) f |= F_NEAR;
+      if (NEARDIRS && noflow && eq_flow) {
+        // neighbours 1..8 in the 234/105/876 numbering; le: an equal-elevation cell with a direction (a low edge of this flat)
+        auto lowedge = [&](T zn, bool valid, bool nf) -> bool { return valid && zn == e && !nf; };
+        const bool le[9] = {false,
+                            lowedge(z1[0], v1[0], n1[0]), lowedge(z0[0], v0[0], n0[0]), lowedge(z0[1], v0[1], n0[1]),
+                            lowedge(z0[2], v0[2], n0[2]), lowedge(z1[2], v1[2], n1[2]), lowedge(z2[2], v2[2], n2[2]),
+                            lowedge(z2[1], v2[1], n2[1]), lowedge(z2[0], v2[0], n2[0])};
+        int nd = 0;
+#pragma unroll
+        for (int k = 1; k <= 8; k++) {
+          const bool take = le[k] && (nd == 0 || ((nd & 1) == 0 && (k & 1) == 1));
+          nd = take ? k : nd;
+        }
+        if (gx < w && gy < h) dirs[(size_t)gy * w + gx] = (uint8_t)nd;   // (a NO_FLOW cell is interior: its window is complete)
+      }
     }
     if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
 #pragma unroll
@@ -1860,6 +1882,124 @@ __global__ __launch_bounds__(NTHR) void k_flat_dirs_levels(const T *__restrict__
   }
 }
 
+// The same directions WITHOUT the DEM, from 4 bits per cell (r05; the default of the directions-only entry).  What
+// d8_masked_FlowDir compares are masks of adjacent cells of one flat, and
+//   * two adjacent NO_FLOW cells always lie in one flat (equal elevation: a higher one would have a direction), are reached
+//     by the towards search together or not at all, likewise by the away search, and their levels differ by at most one in
+//     either field (breadth-first levels of adjacent vertices): |mask(n) - mask(c)| = |2 dT - dA| <= 3, so the masks
+//     MODULO 8 order a cell's neighbourhood exactly;
+//   * a neighbour WITH a direction only counts as a low edge of the cell's own flat, and a cell that has one (towards level
+//     2, exactly the F_NEAR cells) got its final direction in k_dirs_classify<NEARDIRS> already;
+//   * a cell takes part iff its towards level lies in [2, DINF): low edges hold 1, everything else DINF.
+// So the window is staged as ONE BYTE per cell -- bits 0-2 the mask modulo 8, bit 3 "does not take part", bit 4 "has its
+// direction" -- four cells per LDS store, and a neighbour costs a subtraction, two ANDs, an OR and two compares: no
+// elevations read or compared (k_flat_dirs_levels: 20.4 GB fetched, 4.5 ms at S3).  Measured and dropped on the way
+// (profiles/r05b_flats_bytes_ab.json): byte planes written by the searches beside their 32-bit levels, so that this pass
+// reads 3 bytes per cell -- the stores slowed every visit and the start levels (36.1 against 32.6 ms for the stage): the
+// stage is bound by instruction issue and dependent visits, not by these bytes.
+constexpr int QLW = SW + 8;   // bytes per staged row: the tile's first column at byte 4 (its quads are aligned words), the halo at 3 and 68
+__device__ __forceinline__ uint32_t flat_q(int32_t tv, int32_t av) {
+  const uint32_t m = (uint32_t)(2 * tv - (av < DINF ? av : 0));
+  const bool part = (uint32_t)(tv - 2) < (uint32_t)(DINF - 2);
+  return part ? ((m & 7u) | (tv == 2 ? 16u : 0u)) : 8u;
+}
+__global__ __launch_bounds__(NTHR) void k_flat_dirs_q(const int32_t *__restrict__ TW, const int32_t *__restrict__ AW, uint8_t *dirs,
+                                                      int w, int h, uint32_t tilesX, uint32_t ntiles) {
+  __shared__ __attribute__((aligned(4))) uint8_t sq[KLLH * QLW];
+  const uint32_t t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int x0 = (int)(t % tilesX) * SW, y0 = (int)(t / tilesX) * KLH;
+  if (window_inside(x0, y0, w, h, SW, KLH, 1)) {
+    constexpr int QPR = SW / 4, NQ = KLLH * QPR, QPT = (NQ + NTHR - 1) / NTHR, NHC = KLLH * 2;
+    struct Q4 { int32_t v[4]; };
+    const int32_t *const tb = TW + ((size_t)(y0 - 1) * w + (size_t)(x0 - 1)), *const ab = AW ? AW + ((size_t)(y0 - 1) * w + (size_t)(x0 - 1)) : nullptr;
+    Q4 tq[QPT], aq[QPT];
+    int32_t th = DINF, ah = DINF;
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      const int ly = i / QPR, qq = i - ly * QPR;
+      if (i < NQ) {
+        __builtin_memcpy(&tq[r], tb + (uint32_t)(ly * w + 1 + 4 * qq), sizeof(Q4));
+        if (ab) __builtin_memcpy(&aq[r], ab + (uint32_t)(ly * w + 1 + 4 * qq), sizeof(Q4));
+      }
+    }
+    static_assert(NHC <= NTHR, "one halo cell per thread");
+    if ((int)threadIdx.x < NHC) {
+      const int ly = (int)threadIdx.x >> 1, c = (int)threadIdx.x & 1;
+      th = tb[(uint32_t)(ly * w + (c ? SW + 1 : 0))];
+      if (ab) ah = ab[(uint32_t)(ly * w + (c ? SW + 1 : 0))];
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      const int ly = i / QPR, qq = i - ly * QPR;
+      if (i < NQ) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) word |= flat_q(tq[r].v[e], ab ? aq[r].v[e] : DINF) << (8 * e);
+        *reinterpret_cast<uint32_t *>(&sq[ly * QLW + 4 + 4 * qq]) = word;
+      }
+    }
+    if ((int)threadIdx.x < NHC) {
+      const int ly = (int)threadIdx.x >> 1, c = (int)threadIdx.x & 1;
+      sq[ly * QLW + (c ? SW + 4 : 3)] = (uint8_t)flat_q(th, ah);
+    }
+  } else {
+    constexpr int IPT = (KLLH * SLW + NTHR - 1) / NTHR;
+    int32_t tv[IPT], av[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {   // all loads of the thread in flight together (clamped addresses)
+      const int i = min((int)threadIdx.x + r * NTHR, KLLH * SLW - 1);
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = min(max(x0 - 1 + lx, 0), w - 1), gy = min(max(y0 - 1 + ly, 0), h - 1);
+      const size_t g = (size_t)gy * w + gx;
+      tv[r] = TW[g];
+      av[r] = AW ? AW[g] : DINF;
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+      const int i = (int)threadIdx.x + r * NTHR;
+      if (i >= KLLH * SLW) continue;
+      const int ly = i / SLW, lx = i - ly * SLW;
+      const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+      const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+      sq[ly * QLW + 3 + lx] = in ? (uint8_t)flat_q(tv[r], av[r]) : (uint8_t)8;
+    }
+  }
+  __syncthreads();
+  // a wavefront owns a band of 8 consecutive rows, a lane one column; the 3 x 3 windows slide down in registers
+  const int lx = threadIdx.x & (SW - 1), yb = (int)(threadIdx.x >> 6) * (KLH / 4);
+  const int gx = x0 + lx;
+  uint32_t c0[3], c1[3], c2[3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) { c0[e] = sq[yb * QLW + 3 + lx + e]; c1[e] = sq[(yb + 1) * QLW + 3 + lx + e]; }
+#pragma unroll
+  for (int j = 0; j < KLH / 4; j++) {
+    const int gy = y0 + yb + j;
+#pragma unroll
+    for (int e = 0; e < 3; e++) c2[e] = sq[(yb + j + 2) * QLW + 3 + lx + e];
+    const uint32_t cc = c1[1];
+    // interior only (:108-109); a NO_FLOW cell of a drainable flat that has no direction yet
+    if (gx > 0 && gy > 0 && gx < w - 1 && gy < h - 1 && (cc & 24u) == 0u) {
+      const uint32_t cn[9] = {c1[1], c1[0], c0[0], c0[1], c0[2], c1[2], c2[2], c2[1], c2[0]};   // neighbours 1..8: 234/105/876
+      const uint32_t qc = (cc & 7u) - 4u;   // rb = mask(n) - mask(c) + 4 in 1 .. 7 for a neighbour that takes part, >= 8 otherwise
+      uint32_t m = 4u;
+      int dir = 0;
+#pragma unroll
+      for (int k = 1; k <= 8; k++) {
+        const uint32_t v = cn[k], rb = ((v - qc) & 7u) | (v & 8u);
+        const bool take = rb < m || (rb == m && dir > 0 && (dir & 1) == 0 && (k & 1) == 1);
+        m = take ? rb : m;
+        dir = take ? k : dir;
+      }
+      dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) { c0[e] = c1[e]; c1[e] = c2[e]; }
+  }
+}
+
 static inline uint32_t stencil_tiles(int w, int h, uint32_t *tilesX) {
   *tilesX = (uint32_t)((w + SW - 1) / SW);
   return *tilesX * (uint32_t)((h + SH - 1) / SH);
@@ -2521,10 +2661,18 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   Workspace &ws = Workspace::get();
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
+  // r05: the last pass from 4 bits per cell, without the DEM (k_flat_dirs_q; the cells next to a low edge get their direction
+  // in the classification); RDGPU_FLAT_Q=0: k_flat_dirs_levels over the level planes and the DEM (r02-r04): A/B and tests
+  const char *envq = getenv("RDGPU_FLAT_Q");
+  const bool qpass = fused_classify && !(envq && envq[0] == '0');
   if (fused_classify) {
     const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
-    RD_LAUNCH("flats.dirs_classify", (k_dirs_classify<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, nodata, d_dirs, flags, w, h,
-              tilesX, ntiles);
+    if (qpass)
+      RD_LAUNCH("flats.dirs_classify", (k_dirs_classify<T, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, nodata, d_dirs, flags,
+                w, h, tilesX, ntiles);
+    else
+      RD_LAUNCH("flats.dirs_classify", (k_dirs_classify<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, nodata, d_dirs, flags, w, h,
+                tilesX, ntiles);
   } else {
     launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   }
@@ -2578,8 +2726,12 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
     g_fstats.towards_levels = run_relax_towards(d_dirs, flags, TWd, w, h, s);
   }
   const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
-  RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
-            (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
+  if (qpass)
+    RD_LAUNCH("flats.dirs_q", k_flat_dirs_q, dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const int32_t *)TWd, (const int32_t *)A, d_dirs,
+              w, h, tilesX, ntiles);
+  else
+    RD_LAUNCH("flats.dirs_levels", (k_flat_dirs_levels<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, (const int32_t *)TWd,
+              (const int32_t *)A, d_dirs, w, h, tilesX, ntiles);
 }
 
 template <class T>

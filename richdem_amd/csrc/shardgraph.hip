@@ -162,16 +162,34 @@ static void fill_sharded_host(T *dem, int w, int h, int topology, int nshards, B
 }
 
 // The same protocol over SEVERAL devices driven by this one process (the role of the reference's
-// programs/parallel_priority_flood producer + consumers, main.cpp:276-330, :401-547): row block s lives on devices[s], is
-// uploaded over that device's own PCIe link and filled locally there, the cut rows and spillover graphs meet in the
-// middle, the solved levels go back, and every device raises and returns its block.
+// programs/parallel_priority_flood producer + consumers, main.cpp:276-330, :401-547, :700-800, and of its exchange layer
+// include/richdem/common/communication.hpp): row block s lives on devices[s], is uploaded over that device's own PCIe link
+// and filled locally there, the cut rows and spillover graphs meet on devices[0], the solved levels go back, and every
+// device raises and returns its block.
 // One HOST THREAD PER DEVICE: the local phase synchronises with its device several times per Boruvka round, so issuing
 // the blocks from one thread would run them one after another (r02).  A worker holds its device's API lock for its
 // phase (common.hpp: locks are per device), so the devices run side by side and a second caller on one of them waits.
 // A device may be listed more than once: its blocks are then handled in order by that device's worker (what the
-// one-GPU tests do -- they exercise the threads, the staging and the joined solve, not the concurrency).
-// The joined graph is solved on devices[0] with the raster's own Boruvka kernels (rdgpu_fill_graph_solve_dev, 0.7 ms at
-// S3 / 8 blocks; RDGPU_MULTI_HOST_SOLVE=1: the host Priority-Flood above, 106 ms -- kept for A/B and the tests).
+// one-GPU tests do -- they exercise the threads, the events, the peer copies and the joined solve, not the concurrency).
+//
+// THE EXCHANGE NEVER TOUCHES THE HOST (r05): every block exports its cut-row keys and edge triples into a buffer on ITS
+// device (rdgpu_fill_shard_export_dev) and records an event; devices[0]'s stream waits for the events, pulls the exports
+// into the joined layout with hipMemcpyPeerAsync (xGMI where peer access is available -- enabled here -- else the runtime's
+// staging), solves the joined graph with the raster's own Boruvka kernels (rdgpu_fill_graph_solve_dev, 0.7 ms at S3 / 8
+// blocks), pushes each block's 2 * width levels to its device and records one event that the blocks' streams wait for
+// before rdgpu_fill_shard_finish_dev.  Only the edge COUNTS (one word per block) are read by the host, to size the joined
+// buffer.  RDGPU_MULTI_HOST_STAGED=1: the r02-r04 exchange through host vectors and blocking copies (A/B and tests);
+// RDGPU_MULTI_HOST_SOLVE=1 (implies it): the joined graph solved by the host Priority-Flood above.
+static void enable_peer(int a, int b) {
+  if (a == b) return;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) return;   // (the peer copies then stage through the runtime)
+  DeviceGuard g(a);
+  const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+  else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+}
+
 template <class T, class Begin>
 static void fill_multi_host(T *dem, int w, int h, int topology, const int *devices, int ndev, Begin begin) {
   if (!dem || w <= 0 || h <= 0 || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: bad arguments");
@@ -184,22 +202,38 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
   std::vector<rdgpu_fill_shard *> sh(ndev, nullptr);
   std::vector<T *> blk(ndev, nullptr);
   std::vector<hipStream_t> st(ndev, nullptr);
+  std::vector<hipEvent_t> ev(ndev, nullptr);       // block s: its export is in its device buffer
+  hipEvent_t ev_levels = nullptr;                  // devices[0]: every block's levels are on its device
+  hipStream_t s0 = nullptr;                        // devices[0]: the exchange and the joined solve
+  std::vector<uint32_t *> d_exp(ndev, nullptr), d_lev(ndev, nullptr);
+  std::vector<uint32_t> counts(ndev, 0);
   std::vector<int> r0(ndev + 1);
   for (int s = 0; s <= ndev; s++) r0[s] = (int)((int64_t)h * s / ndev);
   const size_t per = (size_t)2 * w;
-  std::vector<uint32_t> keys((size_t)ndev * per, 0), levels((size_t)ndev * per, 0);
+  const char *hsolve = getenv("RDGPU_MULTI_HOST_SOLVE"), *hstaged = getenv("RDGPU_MULTI_HOST_STAGED");
+  const bool host_solve = hsolve && hsolve[0] == '1';
+  const bool staged = host_solve || (hstaged && hstaged[0] == '1') || ndev == 1;
+  std::vector<uint32_t> keys, levels;
   std::vector<std::vector<uint32_t>> edges(ndev);
+  if (staged) { keys.assign((size_t)ndev * per, 0); levels.assign((size_t)ndev * per, 0); }
   auto cleanup = [&]() noexcept {   // error path only: best effort
     for (int s = 0; s < ndev; s++) {
       if (hipSetDevice(devices[s]) != hipSuccess) continue;
       if (sh[s]) rdgpu_fill_shard_free(sh[s]);
       if (st[s]) { (void)hipStreamSynchronize(st[s]); (void)hipStreamDestroy(st[s]); }
+      if (ev[s]) (void)hipEventDestroy(ev[s]);
+    }
+    if (hipSetDevice(devices[0]) == hipSuccess) {
+      if (s0) { (void)hipStreamSynchronize(s0); (void)hipStreamDestroy(s0); }
+      if (ev_levels) (void)hipEventDestroy(ev_levels);
     }
   };
   int home = 0;
   RD_HIP(hipGetDevice(&home));
   try {
-    // 1. every device: upload its blocks (own PCIe link, own stream), local phase, cut rows + spillover graph back
+    if (!staged)
+      for (int s = 1; s < ndev; s++) { enable_peer(devices[0], devices[s]); enable_peer(devices[s], devices[0]); }
+    // 1. every device: upload its blocks (own PCIe link, own stream), local phase; the export stays on the device
     per_device(devices, ndev, [&](int, const std::vector<int> &mine) {
       for (int s : mine) {
         const size_t cells = (size_t)(r0[s + 1] - r0[s]) * w;
@@ -212,19 +246,49 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
         if (rc) throw Error(rc, rdgpu_last_error());
         uint32_t ne = 0;
         rdgpu_fill_shard_edge_count(sh[s], &ne);
-        edges[s].resize((size_t)ne * 3);
-        const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
-                                                ne ? edges[s].data() : nullptr);
-        if (rc2) throw Error(rc2, rdgpu_last_error());
+        counts[s] = ne;
+        if (staged) {
+          edges[s].resize((size_t)ne * 3);
+          const int rc2 = rdgpu_fill_shard_export(sh[s], &keys[(size_t)s * per], &keys[(size_t)s * per + w],
+                                                  ne ? edges[s].data() : nullptr);
+          if (rc2) throw Error(rc2, rdgpu_last_error());
+        } else {
+          // [2 * w keys | 3 * ne edge words] and the block's levels, in buffers of this device
+          d_exp[s] = Workspace::get().buf<uint32_t>(("multi.export." + std::to_string(s)).c_str(), per + (size_t)std::max(ne, 1u) * 3);
+          d_lev[s] = Workspace::get().buf<uint32_t>(("multi.levels." + std::to_string(s)).c_str(), per);
+          const int rc2 = rdgpu_fill_shard_export_dev(sh[s], d_exp[s], ne ? d_exp[s] + per : nullptr, ne);
+          if (rc2) throw Error(rc2, rdgpu_last_error());
+          RD_HIP(hipEventCreateWithFlags(&ev[s], hipEventDisableTiming));
+          RD_HIP(hipEventRecord(ev[s], st[s]));
+        }
       }
     });
-    // 2. the joined graph
-    const char *hs = getenv("RDGPU_MULTI_HOST_SOLVE");
-    if (ndev > 1 && !(hs && hs[0] == '1')) {
+    if (!staged) {
+      // 2. the exchange and the joined solve on devices[0]: events and peer copies, no host buffer
       DeviceGuard g(devices[0]);
       uint32_t cap = 1;
-      std::vector<uint32_t> counts(ndev);
-      for (int s = 0; s < ndev; s++) { counts[s] = (uint32_t)(edges[s].size() / 3); cap = std::max(cap, counts[s]); }
+      for (int s = 0; s < ndev; s++) cap = std::max(cap, counts[s]);
+      Workspace &ws = Workspace::get();
+      uint32_t *d_keys = ws.buf<uint32_t>("multi.keys", (size_t)ndev * per), *d_edges = ws.buf<uint32_t>("multi.edges", (size_t)ndev * cap * 3);
+      uint32_t *d_counts = ws.buf<uint32_t>("multi.counts", ndev), *d_levels = ws.buf<uint32_t>("multi.levels", (size_t)ndev * per);
+      RD_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+      RD_HIP(hipMemcpyAsync(d_counts, counts.data(), (size_t)ndev * 4, hipMemcpyHostToDevice, s0));   // (the one host word per block)
+      for (int s = 0; s < ndev; s++) {
+        RD_HIP(hipStreamWaitEvent(s0, ev[s], 0));
+        RD_HIP(hipMemcpyPeerAsync(d_keys + (size_t)s * per, devices[0], d_exp[s], devices[s], per * 4, s0));
+        if (counts[s])
+          RD_HIP(hipMemcpyPeerAsync(d_edges + (size_t)s * cap * 3, devices[0], d_exp[s] + per, devices[s], (size_t)counts[s] * 12, s0));
+      }
+      const int rc = rdgpu_fill_graph_solve_dev(ndev, w, topology, d_keys, d_edges, d_counts, cap, d_levels, (void *)s0);
+      if (rc) throw Error(rc, rdgpu_last_error());
+      for (int s = 0; s < ndev; s++)
+        RD_HIP(hipMemcpyPeerAsync(d_lev[s], devices[s], d_levels + (size_t)s * per, devices[0], per * 4, s0));
+      RD_HIP(hipEventCreateWithFlags(&ev_levels, hipEventDisableTiming));
+      RD_HIP(hipEventRecord(ev_levels, s0));
+    } else if (ndev > 1 && !host_solve) {
+      DeviceGuard g(devices[0]);
+      uint32_t cap = 1;
+      for (int s = 0; s < ndev; s++) cap = std::max(cap, counts[s]);
       std::vector<uint32_t> padded((size_t)ndev * cap * 3, 0);
       for (int s = 0; s < ndev; s++) std::copy(edges[s].begin(), edges[s].end(), padded.begin() + (size_t)s * cap * 3);
       Workspace &ws = Workspace::get();
@@ -251,7 +315,13 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
       for (int s : mine) {
         rdgpu_fill_shard *p = sh[s];
         sh[s] = nullptr;
-        const int rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);   // synchronises the block's stream
+        int rc;
+        if (staged) {
+          rc = rdgpu_fill_shard_finish(p, &levels[(size_t)s * per]);   // synchronises the block's stream
+        } else {
+          RD_HIP(hipStreamWaitEvent(st[s], ev_levels, 0));              // the levels have arrived on this device
+          rc = rdgpu_fill_shard_finish_dev(p, d_lev[s]);                // synchronises the block's stream
+        }
         if (rc) throw Error(rc, rdgpu_last_error());
         RD_HIP(hipMemcpyAsync(dem + (size_t)r0[s] * w, blk[s], (size_t)(r0[s + 1] - r0[s]) * w * sizeof(T), hipMemcpyDeviceToHost, st[s]));
       }
@@ -259,8 +329,17 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
         RD_HIP(hipStreamSynchronize(st[s]));   // a failed copy must not return RDGPU_OK with a partly updated DEM
         RD_HIP(hipStreamDestroy(st[s]));
         st[s] = nullptr;
+        if (ev[s]) { RD_HIP(hipEventDestroy(ev[s])); ev[s] = nullptr; }
       }
     });
+    if (s0) {
+      DeviceGuard g(devices[0]);
+      RD_HIP(hipStreamSynchronize(s0));
+      RD_HIP(hipStreamDestroy(s0));
+      s0 = nullptr;
+      RD_HIP(hipEventDestroy(ev_levels));
+      ev_levels = nullptr;
+    }
   } catch (...) {
     cleanup();
     (void)hipSetDevice(home);

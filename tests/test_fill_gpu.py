@@ -425,6 +425,22 @@ def test_multi_device_entry_on_one_gpu(rd, orc, monkeypatch):
     check(lib().rdgpu_fill_multi_f32(a.ctypes.data_as(ctypes.c_void_p), 700, 530, 8, arr, 4), "rdgpu_fill_multi_f32")
     assert np.array_equal(a, exp)
     monkeypatch.delenv("RDGPU_MULTI_HOST_SOLVE")
+    # r05: the default exchange stays on the devices (exports in device buffers, events, hipMemcpyPeerAsync into the joined
+    # layout on devices[0], the levels pushed back the same way); RDGPU_MULTI_HOST_STAGED=1 is the r02-r04 exchange through
+    # host vectors -- same bits, also on a noise raster whose blocks carry thousands of edge records and on D4
+    rng = np.random.default_rng(77)
+    noise = rng.random((530, 700)).astype(np.float32)
+    for dem, topo in ((z, 8), (noise, 8), (noise, 4)):
+        want = orc.port.fill(dem, topo)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("RDGPU_MULTI_HOST_STAGED", env)
+            a = dem.copy()
+            arr = (ctypes.c_int * 6)(0, 0, 0, 0, 0, 0)
+            check(lib().rdgpu_fill_multi_f32(a.ctypes.data_as(ctypes.c_void_p), 700, 530, topo, arr, 6), "rdgpu_fill_multi_f32")
+            assert np.array_equal(a, want), (topo, env)
+            if env:
+                monkeypatch.delenv("RDGPU_MULTI_HOST_STAGED")
     monkeypatch.setenv("RDGPU_DEVICES", "0,0,0")
     assert np.array_equal(rd.FillDepressions(z), exp)
     monkeypatch.delenv("RDGPU_DEVICES")

@@ -143,7 +143,8 @@ def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000", "RDGPU_FLAT_AWAY_BESIDE=0", "RDGPU_FLAT_ASYNC_BLOCKS=3",
-                                    "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1", "RDGPU_FLAT_ASYNC_FAIL=1"])
+                                    "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1", "RDGPU_FLAT_ASYNC_FAIL=1",
+                                    "RDGPU_FLAT_Q=0"])
 def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     """The bitmap search in rounds to the end, with its asynchronous tail from the first batch on (k_relax_bits_async),
     with the away search after instead of beside the towards tail, on three resident blocks; ResolveFlatsEpsilon with the
@@ -163,6 +164,47 @@ def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     monkeypatch.delenv(k)
     assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
     assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
+
+
+def test_directions_from_masks_modulo_8(rd, orc, monkeypatch):
+    """r05: the directions-only entry derives the directions from the two level planes alone, as masks modulo 8 (adjacent
+    cells of a flat differ by at most one level in either field), cells next to a low edge getting theirs in the
+    classification pass; RDGPU_FLAT_Q=0 is the r02-r04 pass that also reads and compares the DEM.
+    Both equal the oracle: plateaus whose levels run far past 4 and past 256, a flat with an island of higher ground (high
+    edges inside), flats without an outlet (no direction), NoData beside flats, flats wider than a tile and crossing the tile
+    borders at every offset, under both search schedules."""
+    rng = np.random.default_rng(91)
+    cases = {}
+    cases["terraces"] = orc.port.fill(fractal_dem_int(900, 700, 81, 0.01))
+    lake = np.full((300, 520), 50, np.int32)
+    lake[0, :] = lake[-1, :] = lake[:, 0] = lake[:, -1] = 90
+    lake[150, 0] = 10                                           # one outlet: levels up to ~520
+    lake[100:140, 200:260] = 70                                 # an island: high edges in the middle of the flat
+    cases["lake with an island, one outlet"] = lake
+    pit = np.full((130, 170), 40, np.int32)
+    pit[0, :] = pit[-1, :] = pit[:, 0] = pit[:, -1] = 60
+    cases["a flat without an outlet"] = pit
+    nod = orc.port.fill(fractal_dem_int(500, 400, 82, 0.02))
+    nod[rng.random(nod.shape) < 0.03] = -9999
+    nod[200:230, 100:300] = -9999
+    cases["NoData beside flats"] = nod
+    for dx in (0, 1, 31, 63):
+        a = np.full((200, 260), 20, np.int32)
+        a[:, :dx + 3] = 100 - np.arange(dx + 3)[None, :]
+        a[:, -5:] = 5
+        cases[f"flat crossing tiles, offset {dx}"] = a
+    fl = np.floor(orc.port.fill(fractal_dem(800, 600, seed=83)) * np.float32(0.02)).astype(np.float32)
+    cases["float terraces"] = fl
+    for name, dem in cases.items():
+        nd = dem.dtype.type(-9999)
+        exp = orc.port.flat_resolution(dem, nd)
+        for sw in (None, "RDGPU_FLAT_Q=0", "RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000"):
+            if sw:
+                monkeypatch.setenv(*sw.split("="))
+            got = rd.barnes_flat_resolution_d8(dem, nd)
+            if sw:
+                monkeypatch.delenv(sw.split("=")[0])
+            assert np.array_equal(got, exp), (name, sw, int((got != exp).sum()))
 
 
 def test_device_entries_on_a_side_stream_of_the_caller(rd, orc):

@@ -119,6 +119,20 @@ def test_fa_d8_unit_weights_take_the_counting_path_with_the_same_result(rd, orc,
         slow = rd.FlowAccumulation(dem, "D8", nodata=-9999)
         monkeypatch.delenv("RDGPU_ACCUM_UNIT")
         assert np.array_equal(fast, exp) and np.array_equal(slow, exp)
+    # r05: weights=None goes through rdgpu_fa_d8_unit_<T> (the caller KNOWS the weights are ones: nothing read, nothing uploaded);
+    # an explicit array of ones through the plain entry (detected on the device), and the HBM-resident pair -- same doubles
+    import torch
+
+    dem = orc.port.fill(z)
+    exp = orc.port.fa_d8(dem, np.float32(-9999))
+    assert np.array_equal(rd.FlowAccumulation(dem, "D8", nodata=-9999, weights=np.ones(dem.shape)), exp)
+    t = torch.from_numpy(dem).cuda()
+    a1 = torch.ones(dem.shape, dtype=torch.float64, device="cuda")
+    a2 = torch.full(dem.shape, -7.0, dtype=torch.float64, device="cuda")        # (output only: whatever it held is ignored)
+    rd.fa_d8_dev(t, -9999.0, a1)
+    rd.fa_d8_dev(t, -9999.0, a2, unit_weights=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(a1.cpu().numpy(), exp) and np.array_equal(a2.cpu().numpy(), exp)
     one_off = np.ones(z.shape)
     one_off[450, 350] = 1.0 + 2.0 ** -40    # a single weight that is not 1: the weighted path, exactly representable sums
     assert np.array_equal(rd.FlowAccumulation(z, "D8", nodata=-9999, weights=one_off), orc.port.fa_d8(z, np.float32(-9999), one_off))

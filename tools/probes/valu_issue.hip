@@ -96,6 +96,77 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t *out, uint32_t seed) {
       BODY8(OP)
 #undef OP
     }
+    // ---- second batch (r05): which of the everyday integer / float instructions run at the ~2.4-cycle rate of v_add_u32 / v_fma_f32
+#define TWO(K, INS)                                                              \
+    else if (KIND == K) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < UNROLL / NACC; u++)                  \
+        _Pragma("unroll") for (int j = 0; j < NACC; j++) asm volatile(INS " %0, %0, %1" : "+v"(a[j]) : "v"(b)); \
+    }
+#define THREE(K, INS)                                                            \
+    else if (KIND == K) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < UNROLL / NACC; u++)                  \
+        _Pragma("unroll") for (int j = 0; j < NACC; j++) asm volatile(INS " %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "v"(c)); \
+    }
+    TWO(14, "v_and_b32") TWO(15, "v_or_b32") TWO(16, "v_xor_b32") TWO(17, "v_lshlrev_b32") TWO(20, "v_max_u32")
+    TWO(21, "v_mul_u32_u24") TWO(25, "v_sub_u32") TWO(26, "v_min_f32") TWO(27, "v_max_f32") TWO(37, "v_add_f32") TWO(38, "v_mul_f32")
+    TWO(41, "v_min_u16") TWO(42, "v_add_u16") TWO(44, "v_lshrrev_b32") TWO(46, "v_min_i32") TWO(47, "v_mul_lo_u32")
+    THREE(22, "v_mad_u32_u24") THREE(23, "v_add3_u32") THREE(24, "v_lshl_add_u32") THREE(28, "v_min3_f32") THREE(30, "v_bfe_u32")
+    THREE(32, "v_add_lshl_u32") THREE(33, "v_or3_b32") THREE(40, "v_alignbit_b32") THREE(48, "v_xad_u32") THREE(49, "v_med3_u32")
+    THREE(50, "v_lshl_or_b32") THREE(51, "v_max3_u32")
+    else if (KIND == 18) {   // compare into VCC alone
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("v_cmp_lt_u32 vcc, %0, %1" ::"v"(a[j]), "v"(b) : "vcc");
+    } else if (KIND == 29) {
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a[j]), "v"(b) : "vcc");
+    } else if (KIND == 19) {   // select alone (VCC as it is)
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b) : "vcc");
+    } else if (KIND == 31) {
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("v_mov_b32 %0, %1" : "=v"(a[j]) : "v"(b));
+    } else if (KIND == 36) {
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[j]) : "v"(b));
+    } else if (KIND == 35) {   // LDS stores
+#pragma unroll
+      for (int j = 0; j < NACC; j++) a[j] &= 0x3FFCu;
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) asm volatile("ds_write_b32 %0, %1" ::"v"(a[j]), "v"(b) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)");
+    } else if (KIND == 52 || KIND == 53 || KIND == 54 || KIND == 55) {
+      // the SCALAR unit: 52 = s_add_u32 alone, 53 = s_and_b64 (lane-mask logic) alone, 54 = one s_add_u32 after every v_add_u32
+      // (does scalar work ride along with vector work of the same wave?), 55 = one s_and_b64 after every v_min_u32
+      uint32_t sa[NACC];
+      unsigned long long sm[NACC];
+#pragma unroll
+      for (int j = 0; j < NACC; j++) { sa[j] = __builtin_amdgcn_readfirstlane(a[j]); sm[j] = __builtin_amdgcn_ballot_w64(a[j] > (uint32_t)j); asm volatile("" : "+s"(sa[j]), "+s"(sm[j])); }
+#pragma unroll
+      for (int u = 0; u < UNROLL / NACC; u++)
+#pragma unroll
+        for (int j = 0; j < NACC; j++) {
+          if (KIND == 54) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b));
+          if (KIND == 55) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b));
+          if (KIND == 52 || KIND == 54) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sa[j])::"scc");
+          else asm volatile("s_and_b64 %0, %0, exec" : "+s"(sm[j])::"scc");
+        }
+#pragma unroll
+      for (int j = 0; j < NACC; j++) { a[j] ^= sa[j] ^ (uint32_t)sm[j]; }
+    }
+#undef TWO
+#undef THREE
   }
   uint32_t s = 0;
 #pragma unroll
@@ -152,5 +223,45 @@ int main() {
   run<5>("v_pk_add_f32 (2 flops per lane)", 1, d, cus, ghz);
   run<8>("ds_read_u16", 1, d, cus, ghz);
   run<9>("ds_read_b32", 1, d, cus, ghz);
+  printf("-- second batch\n");
+  run<31>("v_mov_b32", 1, d, cus, ghz);
+  run<14>("v_and_b32", 1, d, cus, ghz);
+  run<15>("v_or_b32", 1, d, cus, ghz);
+  run<16>("v_xor_b32", 1, d, cus, ghz);
+  run<33>("v_or3_b32", 1, d, cus, ghz);
+  run<50>("v_lshl_or_b32", 1, d, cus, ghz);
+  run<17>("v_lshlrev_b32", 1, d, cus, ghz);
+  run<44>("v_lshrrev_b32", 1, d, cus, ghz);
+  run<30>("v_bfe_u32", 1, d, cus, ghz);
+  run<40>("v_alignbit_b32", 1, d, cus, ghz);
+  run<25>("v_sub_u32", 1, d, cus, ghz);
+  run<23>("v_add3_u32", 1, d, cus, ghz);
+  run<24>("v_lshl_add_u32", 1, d, cus, ghz);
+  run<32>("v_add_lshl_u32", 1, d, cus, ghz);
+  run<48>("v_xad_u32", 1, d, cus, ghz);
+  run<21>("v_mul_u32_u24", 1, d, cus, ghz);
+  run<22>("v_mad_u32_u24", 1, d, cus, ghz);
+  run<47>("v_mul_lo_u32", 1, d, cus, ghz);
+  run<20>("v_max_u32", 1, d, cus, ghz);
+  run<46>("v_min_i32", 1, d, cus, ghz);
+  run<51>("v_max3_u32", 1, d, cus, ghz);
+  run<49>("v_med3_u32", 1, d, cus, ghz);
+  run<41>("v_min_u16", 1, d, cus, ghz);
+  run<42>("v_add_u16", 1, d, cus, ghz);
+  run<18>("v_cmp_lt_u32 -> vcc", 1, d, cus, ghz);
+  run<19>("v_cndmask_b32 (vcc)", 1, d, cus, ghz);
+  run<36>("v_mbcnt_lo_u32_b32", 1, d, cus, ghz);
+  run<37>("v_add_f32", 1, d, cus, ghz);
+  run<38>("v_mul_f32", 1, d, cus, ghz);
+  run<26>("v_min_f32", 1, d, cus, ghz);
+  run<27>("v_max_f32", 1, d, cus, ghz);
+  run<28>("v_min3_f32", 1, d, cus, ghz);
+  run<29>("v_cmp_lt_f32 -> vcc", 1, d, cus, ghz);
+  run<35>("ds_write_b32", 1, d, cus, ghz);
+  printf("-- the scalar unit (cycles per instruction COUNTED: all scalar ones, or the vector ones of a mixed stream)\n");
+  run<52>("s_add_u32 alone", 1, d, cus, ghz);
+  run<53>("s_and_b64 alone", 1, d, cus, ghz);
+  run<54>("v_add_u32 + s_add_u32 pairs (per pair)", 1, d, cus, ghz);
+  run<55>("v_min_u32 + s_and_b64 pairs (per pair)", 1, d, cus, ghz);
   return 0;
 }
