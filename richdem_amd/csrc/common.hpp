@@ -74,9 +74,18 @@ inline std::mutex &orchestrator_mutex() {
   static std::mutex m;
   return m;
 }
+inline bool &orchestrating() {   // this thread is inside a multi-device entry: another one from here would wait for itself
+  static thread_local bool inside = false;
+  return inside;
+}
 template <class F>
 int unlocked(F &&fn) {
+  if (orchestrating()) {   // (the lock below is not recursive -- say so instead of deadlocking)
+    set_last_error("rdgpu_*_multi_*: a multi-device entry was called from inside another one on the same thread");
+    return RDGPU_ERR_ARG;
+  }
   std::lock_guard<std::mutex> one_orchestrator(orchestrator_mutex());
+  struct Flag { Flag() { orchestrating() = true; } ~Flag() { orchestrating() = false; } } flag;
   try {
     fn();
     return RDGPU_OK;
