@@ -156,6 +156,17 @@ struct DeviceGuard {   // the worker's device: current + locked for the scope
   }
 };
 
+// direct copies between two devices of this process (xGMI) where the platform allows them; without it a peer copy is staged
+// by the runtime
+inline void enable_peer_access(int a, int b) {
+  if (a == b) return;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); return; }
+  DeviceGuard g(a);
+  (void)hipDeviceEnablePeerAccess(b, 0);   // (hipErrorPeerAccessAlreadyEnabled is fine)
+  (void)hipGetLastError();
+}
+
 // runs job(device, its shard indices) for every distinct device, each in a thread of its own; rethrows the first failure
 template <class Job>
 inline void per_device(const int *devices, int ndev, Job job) {

@@ -81,6 +81,49 @@ static bool link_solve(int S, int w, const std::vector<unsigned long long> &boxe
   return alive == 0;
 }
 
+// ---- the same forest on the GPU (r05: the exchange of the multi-device accumulation stays on the devices) -------------------
+// gathered boxes / links in the layout above, on devices[0].  inflow[v] = what v's own neighbours across the cut sent +
+// the inflow of every node whose chain of links passes through v: subtree sums of a forest, by pointer doubling --
+// S_(k+1)(v) = S_k(v) + sum of S_k(u) over the u whose 2^k-th successor is v (every node upstream at distance [2^k, 2^(k+1))
+// arrives through exactly one such u).  2 * width * blocks nodes (640 000 at S3 / 8), <= 40 rounds; a chain that has not
+// ended then is a loop across the cuts (reported, as by link_solve).
+constexpr uint32_t LK_NONE = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void k_ml_init(const unsigned long long *__restrict__ boxes, const int32_t *__restrict__ links, int S,
+                                                 int w, unsigned long long *sum, uint32_t *succ, uint32_t *bad) {
+  const uint32_t n = (uint32_t)S * 2u * (uint32_t)w, i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const int s = (int)(i / (2u * (uint32_t)w)), r = (int)(i / (uint32_t)w) & 1, x = (int)(i % (uint32_t)w);
+  auto at = [&](int s_, int r_, int x_) { return ((uint32_t)s_ * 2u + (uint32_t)r_) * (uint32_t)w + (uint32_t)x_; };
+  unsigned long long v = 0;
+  if (r == 0 && s > 0) v = boxes[at(s - 1, 1, x)] & LOW56;          // my first row receives what the block above sent down
+  if (r == 1 && s + 1 < S) v = boxes[at(s + 1, 0, x)] & LOW56;      // my last row: what the block below sent up
+  sum[i] = v;
+  const int32_t lk = links[i];
+  uint32_t d = LK_NONE;
+  if (lk != -1) {
+    const bool down = lk < 0;
+    const int col = (int)((uint32_t)lk & 0x7FFFFFFFu), t = down ? s + 1 : s - 1;
+    if (t < 0 || t >= S || col >= w) *bad = 1u;
+    else d = at(t, down ? 0 : 1, col);
+  }
+  succ[i] = d;
+}
+__global__ __launch_bounds__(256) void k_ml_round(const unsigned long long *__restrict__ sum_in, unsigned long long *sum_out,
+                                                  const uint32_t *__restrict__ succ_in, uint32_t *succ_out, uint32_t n, uint32_t *alive) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t d = succ_in[i];
+  if (d != LK_NONE) {
+    const unsigned long long v = sum_in[i];
+    if (v) atomicAdd(&sum_out[d], v);
+    const uint32_t dd = succ_in[d];
+    succ_out[i] = dd;
+    if (dd != LK_NONE) *alive = 1u;
+  } else {
+    succ_out[i] = LK_NONE;
+  }
+}
+
 template <class A>
 static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w, int h, A *area, const int *devices, int ndev) {
   if (!dirs || !area || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_d8_flow_accum_multi: null pointer");
@@ -99,6 +142,16 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
   std::vector<uint8_t *> d_ext(S, nullptr);
   std::vector<unsigned long long> boxes((size_t)S * 2 * w), inflow, pending(S, 0);
   std::vector<int32_t> links((size_t)S * 2 * w);
+  // r05: boxes and links go from their devices to devices[0] by peer copies behind events, the forest is solved there on the
+  // GPU and every block's inflows are pushed back -- the host sees one word per block (does it hold a loop).
+  // RDGPU_MULTI_HOST_STAGED=1: through the host vectors above and the host Kahn order (r02-r04): A/B and tests.
+  const char *hstaged = getenv("RDGPU_MULTI_HOST_STAGED");
+  const bool staged = (hstaged && hstaged[0] == '1') || S == 1;
+  std::vector<hipEvent_t> ev(S, nullptr);
+  std::vector<unsigned long long *> d_boxv(S, nullptr);
+  std::vector<int32_t *> d_linkv(S, nullptr);
+  hipEvent_t ev_in = nullptr;
+  hipStream_t s0 = nullptr;
   int home = 0;
   RD_HIP(hipGetDevice(&home));
   auto cleanup = [&]() noexcept {
@@ -107,6 +160,11 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
       if (sh[s]) { rdgpu_accum_shard_free(sh[s]); sh[s] = nullptr; }
       if (st[s] && owns[s]) { (void)hipStreamSynchronize(st[s]); (void)hipStreamDestroy(st[s]); }
       st[s] = nullptr;
+      if (ev[s]) { (void)hipEventDestroy(ev[s]); ev[s] = nullptr; }
+    }
+    if (hipSetDevice(devices[0]) == hipSuccess) {
+      if (s0) { (void)hipStreamSynchronize(s0); (void)hipStreamDestroy(s0); s0 = nullptr; }
+      if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
     }
     (void)hipSetDevice(home);
   };
@@ -136,21 +194,68 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
         if (rc) throw Error(rc, rdgpu_last_error());
         rc = rdgpu_accum_shard_links(sh[s], d_links, d_box + 2 * w);
         if (rc) throw Error(rc, rdgpu_last_error());
-        RD_HIP(hipMemcpyAsync(&boxes[(size_t)s * 2 * w], d_box, (size_t)2 * w * 8, hipMemcpyDeviceToHost, st[s]));
         RD_HIP(hipMemcpyAsync(&pending[s], d_box + 2 * w, 8, hipMemcpyDeviceToHost, st[s]));
-        RD_HIP(hipMemcpyAsync(&links[(size_t)s * 2 * w], d_links, (size_t)2 * w * 4, hipMemcpyDeviceToHost, st[s]));
+        if (staged) {
+          RD_HIP(hipMemcpyAsync(&boxes[(size_t)s * 2 * w], d_box, (size_t)2 * w * 8, hipMemcpyDeviceToHost, st[s]));
+          RD_HIP(hipMemcpyAsync(&links[(size_t)s * 2 * w], d_links, (size_t)2 * w * 4, hipMemcpyDeviceToHost, st[s]));
+        } else {
+          d_boxv[s] = d_box;
+          d_linkv[s] = d_links;
+          RD_HIP(hipEventCreateWithFlags(&ev[s], hipEventDisableTiming));
+          RD_HIP(hipEventRecord(ev[s], st[s]));
+        }
       }
       RD_HIP(hipStreamSynchronize(st[mine[0]]));
     });
     for (int s = 0; s < S; s++) loops |= pending[s] != 0;
-    if (!loops) loops = !link_solve(S, w, boxes, links, inflow);
+    if (!loops && staged) loops = !link_solve(S, w, boxes, links, inflow);
+    if (!loops && !staged) {
+      DeviceGuard g(devices[0]);
+      Workspace &ws = Workspace::get();
+      const uint32_t nn = (uint32_t)S * 2u * (uint32_t)w, grid = (nn + 255u) / 256u;
+      unsigned long long *d_boxes = ws.buf<unsigned long long>("multi.l.boxes", nn), *sumA = ws.buf<unsigned long long>("multi.l.sumA", nn),
+                         *sumB = ws.buf<unsigned long long>("multi.l.sumB", nn);
+      int32_t *d_links_all = ws.buf<int32_t>("multi.l.links", nn);
+      uint32_t *succA = ws.buf<uint32_t>("multi.l.succA", nn), *succB = ws.buf<uint32_t>("multi.l.succB", nn), *flags = ws.buf<uint32_t>("multi.l.flags", 2);
+      uint32_t *hw = ws.host_words();
+      for (int s = 1; s < S; s++) { enable_peer_access(devices[0], devices[s]); enable_peer_access(devices[s], devices[0]); }
+      RD_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+      for (int s = 0; s < S; s++) {
+        RD_HIP(hipStreamWaitEvent(s0, ev[s], 0));
+        RD_HIP(hipMemcpyPeerAsync(d_boxes + (size_t)s * 2 * w, devices[0], d_boxv[s], devices[s], (size_t)2 * w * 8, s0));
+        RD_HIP(hipMemcpyPeerAsync(d_links_all + (size_t)s * 2 * w, devices[0], d_linkv[s], devices[s], (size_t)2 * w * 4, s0));
+      }
+      RD_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s0));
+      RD_LAUNCH("multi.link_init", k_ml_init, dim3(grid), dim3(256), 0, s0, (const unsigned long long *)d_boxes, (const int32_t *)d_links_all, S, w,
+                sumA, succA, flags + 1);
+      for (int round = 0;; round++) {
+        RD_HIP(hipMemcpyAsync(sumB, sumA, (size_t)nn * 8, hipMemcpyDeviceToDevice, s0));
+        RD_HIP(hipMemsetAsync(flags, 0, sizeof(uint32_t), s0));
+        RD_LAUNCH("multi.link_round", k_ml_round, dim3(grid), dim3(256), 0, s0, (const unsigned long long *)sumA, sumB, (const uint32_t *)succA,
+                  succB, nn, flags);
+        std::swap(sumA, sumB);
+        std::swap(succA, succB);
+        RD_HIP(hipMemcpyAsync(hw, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
+        RD_HIP(hipStreamSynchronize(s0));
+        if (hw[1]) throw Error(RDGPU_ERR_HIP, "rdgpu_d8_flow_accum_multi: link out of range (internal error)");
+        if (!hw[0]) break;
+        if (round >= 40) { loops = true; break; }   // a chain of links longer than any forest over these nodes: a loop across the cuts
+      }
+      if (!loops) {
+        for (int s = 0; s < S; s++)   // every block's inflows onto its device (its outbox buffer is free again)
+          RD_HIP(hipMemcpyPeerAsync(d_boxv[s], devices[s], sumA + (size_t)s * 2 * w, devices[0], (size_t)2 * w * 8, s0));
+        RD_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        RD_HIP(hipEventRecord(ev_in, s0));
+      }
+    }
     if (!loops) {
       per_device(devices, S, [&](int, const std::vector<int> &mine) {
         Workspace &ws = Workspace::get();
         for (int s : mine) {
           const int rows = r0[s + 1] - r0[s];
           unsigned long long *d_in = ws.buf<unsigned long long>(("multi.box." + std::to_string(s)).c_str(), (size_t)2 * w + 1);
-          RD_HIP(hipMemcpyAsync(d_in, &inflow[(size_t)s * 2 * w], (size_t)2 * w * 8, hipMemcpyHostToDevice, st[s]));
+          if (staged) RD_HIP(hipMemcpyAsync(d_in, &inflow[(size_t)s * 2 * w], (size_t)2 * w * 8, hipMemcpyHostToDevice, st[s]));
+          else RD_HIP(hipStreamWaitEvent(st[s], ev_in, 0));   // (the inflows arrived in this very buffer)
           int rc = rdgpu_accum_shard_add_paths(sh[s], s > 0 ? d_in : nullptr, s + 1 < S ? d_in + w : nullptr);
           if (rc) throw Error(rc, rdgpu_last_error());
           A *d_area = ws.buf<A>(("multi.area." + std::to_string(s)).c_str(), (size_t)rows * w);

@@ -180,16 +180,6 @@ static void fill_sharded_host(T *dem, int w, int h, int topology, int nshards, B
 // before rdgpu_fill_shard_finish_dev.  Only the edge COUNTS (one word per block) are read by the host, to size the joined
 // buffer.  RDGPU_MULTI_HOST_STAGED=1: the r02-r04 exchange through host vectors and blocking copies (A/B and tests);
 // RDGPU_MULTI_HOST_SOLVE=1 (implies it): the joined graph solved by the host Priority-Flood above.
-static void enable_peer(int a, int b) {
-  if (a == b) return;
-  int can = 0;
-  if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) return;   // (the peer copies then stage through the runtime)
-  DeviceGuard g(a);
-  const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-  else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-}
-
 template <class T, class Begin>
 static void fill_multi_host(T *dem, int w, int h, int topology, const int *devices, int ndev, Begin begin) {
   if (!dem || w <= 0 || h <= 0 || !devices) throw Error(RDGPU_ERR_ARG, "rdgpu_fill_multi: bad arguments");
@@ -232,7 +222,7 @@ static void fill_multi_host(T *dem, int w, int h, int topology, const int *devic
   RD_HIP(hipGetDevice(&home));
   try {
     if (!staged)
-      for (int s = 1; s < ndev; s++) { enable_peer(devices[0], devices[s]); enable_peer(devices[s], devices[0]); }
+      for (int s = 1; s < ndev; s++) { enable_peer_access(devices[0], devices[s]); enable_peer_access(devices[s], devices[0]); }
     // 1. every device: upload its blocks (own PCIe link, own stream), local phase; the export stays on the device
     per_device(devices, ndev, [&](int, const std::vector<int> &mine) {
       for (int s : mine) {

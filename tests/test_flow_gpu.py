@@ -337,6 +337,28 @@ def test_multi_device_accumulation_entry_on_one_gpu(rd, orc, monkeypatch):
             check(getattr(lib(), f"rdgpu_d8_flow_accum_multi_{suf}")(dirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), w, h,
                                                                       out.ctypes.data_as(ctypes.c_void_p), arr, len(devs)), "multi")
             assert np.array_equal(out, exp), (suf, len(devs))
+    # r05: the default exchange stays on the devices (boxes and links pulled by hipMemcpyPeerAsync behind events, the forest
+    # over the cut-row cells solved on devices[0] by pointer doubling, the inflows pushed back); RDGPU_MULTI_HOST_STAGED=1 is
+    # the r02-r04 exchange through host vectors and the host's Kahn order: the same doubles, also on rivers that cross many cuts
+    snake = np.zeros((400, 90), np.uint8)
+    snake[:, :] = 7                                                # south ...
+    snake[:, 1::2] = 3                                             # ... and north in alternate columns
+    snake[-1, 0:-1:2] = 5                                          # turn east at the bottom / top: one path through every cut, 90 times
+    snake[0, 1:-1:2] = 5
+    snake[0, -1] = 3 if (snake.shape[1] - 1) % 2 else 7
+    for ddirs in (dirs, snake):
+        hh, ww = ddirs.shape
+        want = orc.port.d8_flow_accum(ddirs, 255, np.float64)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("RDGPU_MULTI_HOST_STAGED", env)
+            out = np.empty((hh, ww), np.float64)
+            arr = (ctypes.c_int * 9)(*([0] * 9))
+            check(lib().rdgpu_d8_flow_accum_multi_f64(ddirs.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint8(255), ww, hh,
+                                                      out.ctypes.data_as(ctypes.c_void_p), arr, 9), "multi")
+            if env:
+                monkeypatch.delenv("RDGPU_MULTI_HOST_STAGED")
+            assert np.array_equal(out, want), (ddirs.shape, env, float(out.max()), float(want.max()))
     # raw directions with loops: reported by the blocks / the link solve, then one device
     rng = np.random.default_rng(5)
     loops = rng.integers(0, 9, (260, 300)).astype(np.uint8)
