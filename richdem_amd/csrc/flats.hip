@@ -419,7 +419,8 @@ template <class T>
 __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint32_t *__restrict__ L, int w, int h,
                                                    uint32_t tilesX, uint32_t ntiles, T *__restrict__ colZ, uint32_t *__restrict__ colL) {
   __shared__ T sz[CH * CW];
-  __shared__ uint16_t lab[CH * CW];
+  __shared__ uint32_t lab[CH * CW];            // union-find parents over the tile's cells (a run's first cell stands for the run)
+  __shared__ unsigned long long smask[CH];     // per row: the lanes that start a run
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int x0 = (int)(t % tilesX) * CW, y0 = (int)(t / tilesX) * CH;
@@ -433,7 +434,6 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
     T v = T();
     if (gx < w && gy < h) v = z[(size_t)gy * w + gx];
     sz[ly * CW + lx] = v;
-    lab[ly * CW + lx] = (uint16_t)(ly * CW + lx);
   }
   __syncthreads();
   // A tile of ONE elevation (open water: 30 % of S3's tiles, 61 % of its NO_FLOW cells) is one component.
@@ -507,29 +507,71 @@ __global__ __launch_bounds__(NTHR) void k_ccl_tile(const T *__restrict__ z, uint
     msk[j] = m;
     any |= m != 0;
   }
-  if (__syncthreads_or(any)) {
-    for (int it = 0; it < CW * CH; it++) {
-      int changed = 0;
+  // r05: components from ROW RUNS.  (r01-r04: min-label propagation with pointer jumping, one barrier per sweep, a few dozen
+  // sweeps on a lake's shore -- 16.7 ms at S3, the critical path of ResolveFlatsEpsilon.)  A row's runs of equal cells come
+  // straight from a ballot (a cell without an equal W neighbour starts one): every cell knows its run's first cell at once.
+  // Runs of consecutive rows are joined by a lock-free union-find over the runs' first cells, with the unions cut down
+  // to the few that matter: a run's first cell looks at its equal NW and N neighbours, and ANY cell at its equal NE
+  // neighbour only if that cell starts a run of the row above -- every other adjacency is implied (an upper cell that does
+  // not start a run shares its run with the cell left of it, which the lane to the left or the run's first cell covers).
+  // Open water: one union per row.  Then one find per cell.
+  uint32_t lab0[ROWS];
+  unsigned long long sm_[ROWS];
+  const unsigned long long le = ~0ull >> (63 - lx);   // lanes <= this one
 #pragma unroll
-      for (int j = 0; j < ROWS; j++) {
-        const uint32_t m = msk[j];
-        if (m) {
-          const int li = (band * ROWS + j) * CW + lx;
-          uint16_t best = lab[li];
-#pragma unroll
-          for (int k = 1; k <= 8; k++)
-            if (m & (1u << (k - 1))) {
-              const uint16_t v = lab[li + fdy(k) * CW + fdx(k)];
-              best = v < best ? v : best;
-            }
-          // jump: follow the label chain one step (labels always decrease, so this is safe under races)
-          const uint16_t bb = lab[best];
-          best = bb < best ? bb : best;
-          if (best < lab[li]) { lab[li] = best; changed = 1; }
-        }
+  for (int j = 0; j < ROWS; j++) {
+    const int ly = band * ROWS + j;
+    const unsigned long long st_ = __builtin_amdgcn_ballot_w64(!(msk[j] & 1u));   // (lane 0 always: its W bit is masked off)
+    sm_[j] = st_;
+    lab0[j] = (uint32_t)(ly * CW + (63 - __clzll((long long)(st_ & le))));
+    lab[ly * CW + lx] = lab0[j];
+    if (lx == 0) smask[ly] = st_;
+  }
+  const int any_b = __syncthreads_or(any);   // (block-uniform: does any cell of the tile have an equal neighbour)
+  if (any_b) {
+    auto lfind = [&](uint32_t x) {   // (parents only ever decrease; other wavefronts lower them meanwhile: relaxed atomic loads)
+      uint32_t p_ = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (p_ != x) { x = p_; p_ = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      return x;
+    };
+    auto lunite = [&](uint32_t a_, uint32_t b_) {
+      for (;;) {
+        a_ = lfind(a_);
+        b_ = lfind(b_);
+        if (a_ == b_) return;
+        if (a_ < b_) { const uint32_t t_ = a_; a_ = b_; b_ = t_; }   // the larger root goes under the smaller: acyclic under any interleaving
+        const uint32_t old_ = atomicMin(&lab[a_], b_);
+        if (old_ == a_) return;
+        a_ = old_;
       }
-      if (!__syncthreads_or(changed)) break;
+    };
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const int ly = band * ROWS + j;
+      const uint32_t m = msk[j];
+      if (!(m & 0x0Eu)) continue;                                       // no equal cell in the row above (row 0: masked off)
+      const unsigned long long su = j ? sm_[j - 1] : smask[ly - 1];    // the row above: its run starts
+      auto run_of = [&](int ux) { return (uint32_t)((ly - 1) * CW + (63 - __clzll((long long)(su & (~0ull >> (63 - ux)))))); };
+      if ((m & 8u) && (su >> (lx + 1) & 1ull)) lunite(lab0[j], (uint32_t)((ly - 1) * CW + lx + 1));
+      if (!(m & 1u)) {
+        if (m & 4u) lunite(lab0[j], run_of(lx));
+        if (m & 2u) lunite(lab0[j], run_of(lx - 1));
+      }
     }
+  }
+  __syncthreads();
+  if (any_b) {   // every cell: its run's root; written back for the column records below
+    uint32_t root[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      uint32_t x = lab0[j], p_ = lab[x];
+      while (p_ != x) { x = p_; p_ = lab[x]; }
+      root[j] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) lab[(band * ROWS + j) * CW + lx] = root[j];
+    __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
