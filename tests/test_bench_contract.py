@@ -65,3 +65,31 @@ def test_bench_stdout_is_reserved_for_the_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode != 0 and r.stdout == "" and "WORLD_SIZE=1" in r.stderr
+
+
+def test_full_size_reference_child_leg(tmp_path):
+    """bench.py's cpu_baseline at the metric's own configuration: the compiled reference on the WHOLE DEM runs in a child
+    process (`bench.py --cpu-full-child <raw f32> <n> <json>`) beside the GPU stages and hands back its time, the number of
+    cells it raised and the band digests of its output -- which the parent compares with the GPU fill's.  Here: the child on
+    a small raster; its digests equal those of the C restatement's fill (the digests are the S3 parity tests' own)."""
+    import numpy as np
+    import pytest
+
+    import oracle
+    from richdem_amd.synth import fractal_dem
+
+    oracle.build()
+    if not oracle.ref.available:
+        pytest.skip("oracle/_ref/libref.so (the compiled reference) is not on this machine")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from digest import band_digests_np
+
+    n = 1200
+    z = fractal_dem(n, n, seed=3)
+    raw, res = str(tmp_path / "dem.f32"), str(tmp_path / "out.json")
+    z.tofile(raw)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-full-child", raw, str(n), res])
+    got = json.load(open(res))
+    exp = oracle.port.fill(z, 8)
+    assert got["kind"] == "reference" and got["seconds"] > 0 and got["cells_raised"] == int((exp != z).sum())
+    assert np.array_equal(np.array(got["digests"], dtype=np.uint64), band_digests_np(exp))
