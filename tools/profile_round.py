@@ -145,24 +145,35 @@ def main():
     if "--sq" in sys.argv:
         names_sq = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                     "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
+        # r05: scalar instructions too (a scalar instruction costs a SIMD ~5 cycles, tools/probes/valu_issue.hip): a second pass,
+        # so that the first keeps its eight counters
+        names_sq2 = ["SQ_INSTS_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES"]
         d = os.path.join(OUT, f"{tag}_sq")
         shutil.rmtree(d, ignore_errors=True)
         cmd = (["rocprofv3", "--kernel-trace", "--pmc"] + names_sq + ["--output-format", "csv", "-d", d, "-o", "run", "--"]
                + bench[:2] + prof_tail)
         print("sq rc", run(cmd, os.path.join(OUT, f"{tag}_sq.log")))
         cols = {n: counters(d, n) for n in names_sq}
+        d2 = os.path.join(OUT, f"{tag}_sq2")
+        shutil.rmtree(d2, ignore_errors=True)
+        cmd2 = (["rocprofv3", "--kernel-trace", "--pmc"] + names_sq2 + ["--output-format", "csv", "-d", d2, "-o", "run", "--"]
+                + bench[:2] + prof_tail)
+        print("sq2 rc", run(cmd2, os.path.join(OUT, f"{tag}_sq2.log")))
+        cols2 = {n: counters(d2, n) for n in names_sq2}
+        shutil.rmtree(d2, ignore_errors=True)
         with open(os.path.join(OUT, f"{tag}_{what}_sq_summary.csv"), "w") as f:
             f.write(f"# {tag} SQ counters, fill 40000x40000 f32, 1 step (rocprofv3 --kernel-trace --pmc SQ_*; quad-cycle units; "
                     "fractions of SQ_WAVE_CYCLES)\n")
             f.write(f"# git {git_sha()}  kernel sources sha1: {kernel_shas()}\n")
-            f.write("kernel,launches,wave_cycles,wait_any,wait_inst_any,active_inst_any,active_valu,active_lds,insts_valu,insts_lds\n")
+            f.write("kernel,launches,wave_cycles,wait_any,wait_inst_any,active_inst_any,active_valu,active_lds,insts_valu,insts_lds,insts_salu,insts_smem\n")
             for k in sorted(cols["SQ_WAVE_CYCLES"]):
                 wc = cols["SQ_WAVE_CYCLES"][k][1]
                 if not k.startswith("rdgpu::") or wc <= 0:
                     continue
                 frac = [cols[n][k][1] / wc for n in names_sq[1:6]]
                 f.write(f"{k},{cols['SQ_WAVE_CYCLES'][k][0]},{wc:.4g}," + ",".join(f"{x:.3f}" for x in frac)
-                        + f",{cols['SQ_INSTS_VALU'][k][1]:.4g},{cols['SQ_INSTS_LDS'][k][1]:.4g}\n")
+                        + f",{cols['SQ_INSTS_VALU'][k][1]:.4g},{cols['SQ_INSTS_LDS'][k][1]:.4g}"
+                        + f",{cols2['SQ_INSTS_SALU'][k][1]:.4g},{cols2['SQ_INSTS_SMEM'][k][1]:.4g}\n")
     print(line.strip())
 
 
