@@ -306,17 +306,44 @@ __global__ __launch_bounds__(NT) void k_tie_parents(const uint8_t *__restrict__ 
 // one round of "nearest ancestor of greater rank" by pointer jumping: every ancestor strictly between c and g[c] has a
 // smaller rank than c, so while g[c] is smaller too, g[g[c]] -- whatever another lane has made of it meanwhile -- is the
 // next candidate
+// (r05) A cell that has found its ancestor marks the pointer (bit 31: cell indices stay below 2^31, T_ROOT carries the bit
+// anyway): from then on a round costs it one load instead of three, one of them a gather.  k_tie_g_done strips the marks.
+constexpr uint32_t G_DONE = 0x80000000u;
 __global__ __launch_bounds__(NT) void k_tie_greater(const uint32_t *__restrict__ rk, uint32_t *g, uint64_t n, uint32_t *changed) {
   const uint64_t stride = (uint64_t)gridDim.x * NT;
   bool ch = false;
   for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
     uint32_t a = g[c];
+    if (a & G_DONE) continue;   // the root, or found in an earlier round
     const uint32_t r = rk[c];
-    int hops = 0;
-    while (a != T_ROOT && rk[a] < r && hops < 8) { a = __hip_atomic_load(&g[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hops++; }
-    if (hops) { __hip_atomic_store(&g[c], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ch |= (a != T_ROOT && rk[a] < r); }
+    bool done = false;
+    for (int hops = 0; hops < 8; hops++) {
+      if (rk[a] >= r) { done = true; break; }
+      const uint32_t na = __hip_atomic_load(&g[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (na == T_ROOT) { a = T_ROOT; done = true; break; }
+      a = na & ~G_DONE;
+    }
+    __hip_atomic_store(&g[c], done ? (a | G_DONE) : a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ch |= !done;
   }
   if (__any(ch) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+__global__ __launch_bounds__(NT) void k_tie_g_done(uint32_t *g, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t a = g[c];
+    if (a != T_ROOT) g[c] = a & ~G_DONE;
+  }
+}
+
+// r05: where the search starts.  A cell the PLAIN FILL of the rank raster does not raise has no ancestor of greater rank at all
+// -- un-raised cells pop in increasing rank, and a wet ancestor lies below the cell that flooded its pocket, which popped
+// before c, hence below c -- yet these cells (half of S3) have the longest chains to walk: to the raster's border.  They start
+// at the root; the others at their parent.  (k_tie_greater: 239 rounds, 5.3 s of the function's 18 at S3 before this.)
+__global__ __launch_bounds__(NT) void k_tie_g_init(const uint32_t *__restrict__ par, const uint32_t *__restrict__ rk,
+                                                   const uint32_t *__restrict__ F0, uint32_t *g, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) g[c] = F0[c] == rk[c] ? T_ROOT : par[c];
 }
 
 // depth in T' by pointer doubling (ping-pong): anc / dist -> anc2 / dist2
@@ -610,7 +637,16 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           uint32_t *flag = ws.buf<uint32_t>("pfd.t.flag", 4);
           uint32_t *hw = ws.host_words();
           RD_LAUNCH("pfd.tie.parents", k_tie_parents, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, par, w, h);
-          RD_HIP(hipMemcpyAsync(g, par, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          const char *gi = getenv("RDGPU_PFD_GREATER_INIT");   // =0: every search starts at the parent (r04): A/B and tests
+          if (gi && gi[0] == '0') {
+            RD_HIP(hipMemcpyAsync(g, par, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          } else {   // one plain fill of the rank raster (the pool is free here) says which cells have no greater ancestor
+            uint32_t *F0 = pool4(0, 0);
+            RD_HIP(hipMemcpyAsync(F0, rk, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            check_rc(Calls<uint32_t>::fill(F0, w, h, (void *)s));
+            RD_LAUNCH("pfd.tie.g_init", k_tie_g_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)par, (const uint32_t *)rk, (const uint32_t *)F0,
+                      g, n);
+          }
           for (int round = 0;; round++) {   // nearest ancestor of greater elevation
             RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
             RD_LAUNCH("pfd.tie.greater", k_tie_greater, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)rk, g, n, flag);
@@ -619,6 +655,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
             if (hw[0] == 0) break;
             if (round > 10000) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the record tree did not settle (internal error)");
           }
+          RD_LAUNCH("pfd.tie.g_done", k_tie_g_done, dim3(sgrid(n)), dim3(NT), 0, s, g, n);
           // ---- depth in T' (pointer doubling), cells bucketed by depth: pool thirds 0 / 1 ping-pong, 2 holds the cells ----
           uint32_t *ancA = pool4(0, 0), *dstA = pool4(0, 1), *ancB = pool4(1, 0), *dstB = pool4(1, 1), *cellsA = pool4(2, 0);
           RD_LAUNCH("pfd.tie.init", k_tie_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, ancA, dstA, size, cellsA, n);
