@@ -186,7 +186,26 @@ __device__ __forceinline__ uint8_t d8_dir_cell(const T *sz, int zx, int zy, int 
 // are equal-elevation cells with a direction: the first of them in neighbour order, replaced by the first odd-numbered one
 // after it if it is a diagonal (the same tie rule as everywhere).  That is known here and nowhere later without the
 // elevations, so the pass after the searches (k_flat_dirs_q) reads no DEM at all.
-template <class T, bool NEARDIRS = false>
+// FindFlats' pseudo direction of a staged cell (flats/find_flats.hpp:29-69; see k_find_flats): 0 = flat, 1 = not, 255 = NoData
+template <class T>
+__device__ __forceinline__ uint8_t find_flats_cell(const T *sz, int zx, int zy, int gx, int gy, int w, int h, T nodata) {
+  if (gx < 0 || gy < 0 || gx >= w || gy >= h) return 255;
+  const T e = sz[zy * FZW + zx];
+  if (e == nodata) return 255;
+  if (gx == 0 || gy == 0 || gx == w - 1 || gy == h - 1) return 1;
+  uint8_t f = 0;
+#pragma unroll
+  for (int n = 1; n <= 8; n++) {
+    const T v = sz[(zy + fdy(n)) * FZW + zx + fdx(n)];
+    if (v < e || v == nodata) f = 1;
+  }
+  return f;
+}
+
+// FINDFLATS (r05, ResolveFlatsEpsilon's lean path): the "directions" are FindFlats' pseudo raster and are NOT written -- nothing
+// but this classification reads them there: k_find_flats + k_flat_classify (two passes over the DEM, the pseudo raster
+// written and read back) in one.
+template <class T, bool NEARDIRS = false, bool FINDFLATS = false>
 __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z, T nodata, uint8_t *__restrict__ dirs,
                                                         uint8_t *__restrict__ flags, int w, int h, uint32_t tilesX, uint32_t ntiles) {
   __shared__ T sz[FZH * FZW];
@@ -245,16 +264,23 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       if (edge)   // :37-54
         dir = (gx == 0 && gy == 0) ? 2 : (gx == 0 && gy == h - 1) ? 8 : (gx == w - 1 && gy == 0) ? 4 : (gx == w - 1 && gy == h - 1) ? 6
               : gx == 0 ? 1 : gx == w - 1 ? 5 : gy == 0 ? 3 : 7;
+      if (FINDFLATS) {   // find_flats.hpp:48-63: an edge cell is no flat; a lower neighbour or a NoData neighbour makes a cell no flat
+        bool notflat = edge;
+#pragma unroll
+        for (int n = 1; n <= 8; n++) notflat |= (nbv[n] < e) | (nbv[n] == nodata);
+        dir = notflat ? 1 : 0;
+      }
       if (e == nodata) dir = 255;
       if (!in) dir = 255;
       sdir[ry * SLW + lane + 1] = (uint8_t)dir;
-      if (in && ry >= 1 && ry <= KLH) dirs[(size_t)gy * w + gx] = (uint8_t)dir;
+      if (!FINDFLATS && in && ry >= 1 && ry <= KLH) dirs[(size_t)gy * w + gx] = (uint8_t)dir;
 #pragma unroll
       for (int e2 = 0; e2 < 3; e2++) { r0[e2] = r1[e2]; r1[e2] = r2[e2]; }
     }
     if (threadIdx.x < 2 * KLLH) {
       const int ly = (int)threadIdx.x % KLLH, lx = threadIdx.x < KLLH ? 0 : SLW - 1;
-      sdir[ly * SLW + lx] = d8_dir_cell<T>(sz, lx + 1, ly + 1, x0 - 1 + lx, y0 - 1 + ly, w, h, nodata);
+      sdir[ly * SLW + lx] = FINDFLATS ? find_flats_cell<T>(sz, lx + 1, ly + 1, x0 - 1 + lx, y0 - 1 + ly, w, h, nodata)
+                                      : d8_dir_cell<T>(sz, lx + 1, ly + 1, x0 - 1 + lx, y0 - 1 + ly, w, h, nodata);
     }
   }
   __syncthreads();
@@ -2539,7 +2565,7 @@ static bool use_bits_engine() {
 // Returns device pointers (workspace) to M, L, fh through the out parameters.
 template <class T>
 static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int h, int32_t **outM, uint32_t **outL,
-                                 int32_t **outFh, hipStream_t s, const int32_t **outA = nullptr) {
+                                 int32_t **outFh, hipStream_t s, const int32_t **outA = nullptr, T ff_nodata = T()) {
   const uint64_t n = (uint64_t)w * h;
   Workspace &ws = Workspace::get();
   int32_t *M = ws.buf<int32_t>("flats.mask", n);
@@ -2551,7 +2577,14 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
 
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
-  launch_classify<T>(d_z, d_dirs, w, h, flags, s);
+  if (d_dirs) {
+    launch_classify<T>(d_z, d_dirs, w, h, flags, s);
+  } else {   // (ResolveFlatsEpsilon's lean path: FindFlats and the classification in one pass; nodata travels in *outA's place)
+    if (!lean) throw Error(RDGPU_ERR_ARG, "resolve_flats_device: the fused FindFlats classification needs the lean path");
+    const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
+    RD_LAUNCH("flats.findflats_classify", (k_dirs_classify<T, false, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, ff_nodata,
+              (uint8_t *)nullptr, flags, w, h, tilesX, ntiles);
+  }
   uint32_t *low = nullptr, *highall = nullptr;
   uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
   if (!lean) {
@@ -3406,8 +3439,13 @@ void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s)
   if (!d_z) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: null pointer");
   if (w <= 0 || h <= 0) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: width and height must be positive");
   if ((uint64_t)w * (uint64_t)h > 0x7FFF0000ull) throw Error(RDGPU_ERR_ARG, "rdgpu_resolve_flats_epsilon: raster too large");
-  uint8_t *flats = Workspace::get().buf<uint8_t>("flats.findflats", (size_t)w * h);
-  {
+  // r05: on the lean path (the default) FindFlats is part of the classification pass; RDGPU_RFE_FUSED_FINDFLATS=0 or the other
+  // paths: k_find_flats writes the pseudo direction raster first
+  const char *envf = getenv("RDGPU_RFE_FUSED_FINDFLATS");
+  const bool fused_ff = use_bits_engine() && lean_labels() && !(envf && envf[0] == '0');
+  uint8_t *flats = nullptr;
+  if (!fused_ff) {
+    flats = Workspace::get().buf<uint8_t>("flats.findflats", (size_t)w * h);
     uint32_t tilesX;
     const uint32_t ntiles = stencil_tiles(w, h, &tilesX);
     RD_LAUNCH("flats.find_flats", (k_find_flats<T>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, (const T *)d_z, nodata, flats, w, h,
@@ -3416,7 +3454,7 @@ void resolve_flats_epsilon_device(T *d_z, T nodata, int w, int h, hipStream_t s)
   int32_t *M, *fh;
   uint32_t *L;
   const int32_t *A = nullptr;
-  resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s, &A);
+  resolve_flats_device<T>(d_z, flats, w, h, &M, &L, &fh, s, &A, nodata);
   if (L) {
     if (reinterpret_cast<uintptr_t>(d_z) % 16 == 0)
       RD_LAUNCH("flats.epsilon", (k_flat_epsilon4<T>), dim3(sgrid((uint64_t)w * h / 4 + 3)), dim3(NTHR), 0, s, d_z, (const int32_t *)M, A,
