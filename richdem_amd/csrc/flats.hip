@@ -284,6 +284,11 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
     }
   }
   __syncthreads();
+  // (r05, measured twice: classifying on the VECTOR unit -- x = bits(n) ^ bits(c), masks from the direction bytes with adds and
+  // shifts, min / OR over the eight -- removes the ~100 scalar instructions per row that the lane-mask form below leaves
+  // (8.3e9 scalar against 8.2e9 vector instructions per launch at S3, profiles/r05m_path40k_sq_summary.csv) and is NOT
+  // faster: 5.95 ms against 5.2-5.5, profiles/r05n_flats_ab.txt.  The scalar unit issues beside the vector unit, from other
+  // wavefronts; the sum of the two is not what bounds the kernel.)
   // the flags: k_flat_classify's window over (elevations, directions)
   const int lx = threadIdx.x & (SW - 1), yb = (int)(threadIdx.x >> 6) * (KLH / 4);
   const int gx = x0 + lx;
