@@ -291,7 +291,8 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
 // exchanged and the ghost rows lowered until no cut row changes any more (towards field first, then away), the deepest
 // away level per flat is agreed on through one small union-find over the cut rows (on devices[0]), and every block
 // writes the directions of its own rows.  Driver = richdem_amd/sharded.py::flat_exchange, here for the devices of one
-// process: the relaxations synchronise with their device per batch of rounds, hence a host thread per device.
+// process: the relaxations synchronise with their device per batch of rounds, hence a host thread per device.  (r05) What the
+// blocks exchange -- cut rows, heights, solved levels -- is copied from device to device.
 // ------------------------------------------------------------------------------------------------------------------
 #define RD_FS_BEGIN(SUF, T)                                                                                        \
   static int fs_begin_typed(const T *d, T nd, int w, int rows, int gt, int gb, hipStream_t st, rdgpu_flat_shard **o) { \
@@ -300,6 +301,16 @@ static void d8_flow_accum_multi_host(const uint8_t *dirs, uint8_t nodata, int w,
 RD_FS_BEGIN(u8, uint8_t) RD_FS_BEGIN(i8, int8_t) RD_FS_BEGIN(i16, int16_t) RD_FS_BEGIN(u16, uint16_t) RD_FS_BEGIN(i32, int32_t)
 RD_FS_BEGIN(u32, uint32_t) RD_FS_BEGIN(f32, float) RD_FS_BEGIN(f64, double) RD_FS_BEGIN(i64, int64_t) RD_FS_BEGIN(u64, uint64_t)
 #undef RD_FS_BEGIN
+
+// r05: a block's received cut rows against the ones it received the round before (and kept for the next comparison)
+__global__ __launch_bounds__(256) void k_cut_changed(const int32_t *__restrict__ in, int32_t *prev, uint32_t lo, uint32_t hi, int first,
+                                                     uint32_t *flag) {
+  const uint32_t i = lo + blockIdx.x * 256u + threadIdx.x;
+  if (i >= hi) return;
+  const int32_t v = in[i];
+  if (first || prev[i] != v) *flag = 1u;
+  prev[i] = v;
+}
 
 template <class T>
 static void flat_resolution_multi_host(const T *dem, T nodata, int w, int h, uint8_t *dirs, const int *devices, int ndev) {
@@ -316,6 +327,8 @@ static void flat_resolution_multi_host(const T *dem, T nodata, int w, int h, uin
   std::vector<rdgpu_flat_shard *> sh(S, nullptr);
   std::vector<T *> d_ext(S, nullptr);
   std::vector<int32_t> cut((size_t)S * 2 * w), prev, heights((size_t)S * 8 * w), solved((size_t)S * 4 * w);
+  const char *hstaged = getenv("RDGPU_MULTI_HOST_STAGED");
+  const bool staged = (hstaged && hstaged[0] == '1') || S == 1;
   int home = 0;
   RD_HIP(hipGetDevice(&home));
   auto cleanup = [&]() noexcept {
@@ -338,55 +351,91 @@ static void flat_resolution_multi_host(const T *dem, T nodata, int w, int h, uin
         if (rc) throw Error(rc, rdgpu_last_error());
       }
     });
+    // r05: the cut rows, the heights and the solved levels go from device to device (peer copies); the host sees one word per
+    // block and round ("did a row I received change").  RDGPU_MULTI_HOST_STAGED=1: through the host vectors (r03-r04).
+    std::vector<int32_t *> d_cut(S, nullptr);
+    std::vector<char> changed(S, 0);
+    if (!staged)
+      for (int s = 0; s < S; s++)
+        for (int t = std::max(0, s - 1); t <= std::min(S - 1, s + 1); t++)
+          if (t != s) enable_peer_access(devices[s], devices[t]);
     for (int phase = 0; phase < 2; phase++) {   // towards the low edges first: it also tells which flats have an outlet
       prev.clear();
-      for (;;) {
+      for (int round = 0;; round++) {
         per_device(devices, S, [&](int, const std::vector<int> &mine) {
           Workspace &ws = Workspace::get();
           for (int s : mine) {
             int rc = rdgpu_flat_shard_relax(sh[s], phase);
             if (rc) throw Error(rc, rdgpu_last_error());
             int32_t *d_b = ws.buf<int32_t>(name("cut", s).c_str(), (size_t)2 * w);
+            d_cut[s] = d_b;
             rc = rdgpu_flat_shard_boundary(sh[s], phase, d_b);
             if (rc) throw Error(rc, rdgpu_last_error());
             RD_HIP(hipStreamSynchronize(nullptr));
-            RD_HIP(hipMemcpy(&cut[(size_t)s * 2 * w], d_b, (size_t)2 * w * 4, hipMemcpyDeviceToHost));
+            if (staged) RD_HIP(hipMemcpy(&cut[(size_t)s * 2 * w], d_b, (size_t)2 * w * 4, hipMemcpyDeviceToHost));
           }
         });
-        if (!prev.empty() && prev == cut) break;   // no cut row changed anywhere: the field is final
+        if (staged && !prev.empty() && prev == cut) break;   // no cut row changed anywhere: the field is final
         per_device(devices, S, [&](int, const std::vector<int> &mine) {
           Workspace &ws = Workspace::get();
           for (int s : mine) {
             int32_t *d_in = ws.buf<int32_t>(name("cutin", s).c_str(), (size_t)2 * w);
             // the last own row of the block above, the first own row of the block below
-            if (s > 0) RD_HIP(hipMemcpy(d_in, &cut[((size_t)(s - 1) * 2 + 1) * w], (size_t)w * 4, hipMemcpyHostToDevice));
-            if (s + 1 < S) RD_HIP(hipMemcpy(d_in + w, &cut[((size_t)(s + 1) * 2) * w], (size_t)w * 4, hipMemcpyHostToDevice));
+            if (staged) {
+              if (s > 0) RD_HIP(hipMemcpy(d_in, &cut[((size_t)(s - 1) * 2 + 1) * w], (size_t)w * 4, hipMemcpyHostToDevice));
+              if (s + 1 < S) RD_HIP(hipMemcpy(d_in + w, &cut[((size_t)(s + 1) * 2) * w], (size_t)w * 4, hipMemcpyHostToDevice));
+            } else {
+              if (s > 0) RD_HIP(hipMemcpyPeer(d_in, devices[s], d_cut[s - 1] + w, devices[s - 1], (size_t)w * 4));
+              if (s + 1 < S) RD_HIP(hipMemcpyPeer(d_in + w, devices[s], d_cut[s + 1], devices[s + 1], (size_t)w * 4));
+              int32_t *d_prev = ws.buf<int32_t>(name("cutprev", s).c_str(), (size_t)2 * w);
+              uint32_t *flag = ws.buf<uint32_t>(name("cutflag", s).c_str(), 1);
+              const uint32_t lo = s > 0 ? 0u : (uint32_t)w, hi = s + 1 < S ? 2u * (uint32_t)w : (uint32_t)w;
+              uint32_t hv = 0;
+              RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), nullptr));
+              if (hi > lo)
+                RD_LAUNCH("multi.cut_changed", k_cut_changed, dim3((hi - lo + 255u) / 256u), dim3(256), 0, nullptr, (const int32_t *)d_in, d_prev,
+                          lo, hi, round == 0 ? 1 : 0, flag);
+              RD_HIP(hipMemcpy(&hv, flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+              changed[s] = hv != 0;
+              if (!changed[s]) continue;   // the same rows as last round: injecting them again changes nothing
+            }
             const int rc = rdgpu_flat_shard_inject(sh[s], phase, s > 0 ? d_in : nullptr, s + 1 < S ? d_in + w : nullptr);
             if (rc) throw Error(rc, rdgpu_last_error());
           }
         });
-        prev = cut;
+        if (staged) prev = cut;
+        else if (std::none_of(changed.begin(), changed.end(), [](char c) { return c != 0; })) break;   // no received row changed anywhere
       }
     }
+    std::vector<int32_t *> d_hv(S, nullptr);
     per_device(devices, S, [&](int, const std::vector<int> &mine) {
       Workspace &ws = Workspace::get();
       for (int s : mine) {
         int32_t *d_h = ws.buf<int32_t>(name("heights", s).c_str(), (size_t)8 * w);
+        d_hv[s] = d_h;
         const int rc = rdgpu_flat_shard_heights(sh[s], d_h);
         if (rc) throw Error(rc, rdgpu_last_error());
         RD_HIP(hipStreamSynchronize(nullptr));
-        RD_HIP(hipMemcpy(&heights[(size_t)s * 8 * w], d_h, (size_t)8 * w * 4, hipMemcpyDeviceToHost));
+        if (staged) RD_HIP(hipMemcpy(&heights[(size_t)s * 8 * w], d_h, (size_t)8 * w * 4, hipMemcpyDeviceToHost));
       }
     });
+    int32_t *d_solved_all = nullptr;
     {
       DeviceGuard g(devices[0]);
       Workspace &ws = Workspace::get();
       int32_t *d_g = ws.buf<int32_t>("multi.heights_all", heights.size()), *d_o = ws.buf<int32_t>("multi.solved_all", solved.size());
-      RD_HIP(hipMemcpy(d_g, heights.data(), heights.size() * 4, hipMemcpyHostToDevice));
+      if (staged) RD_HIP(hipMemcpy(d_g, heights.data(), heights.size() * 4, hipMemcpyHostToDevice));
+      else
+        for (int s = 0; s < S; s++) {
+          enable_peer_access(devices[0], devices[s]);
+          enable_peer_access(devices[s], devices[0]);
+          RD_HIP(hipMemcpyPeer(d_g + (size_t)s * 8 * w, devices[0], d_hv[s], devices[s], (size_t)8 * w * 4));
+        }
       const int rc = rdgpu_flat_graph_solve_dev(d_g, S, w, d_o, nullptr);
       if (rc) throw Error(rc, rdgpu_last_error());
       RD_HIP(hipStreamSynchronize(nullptr));
-      RD_HIP(hipMemcpy(solved.data(), d_o, solved.size() * 4, hipMemcpyDeviceToHost));
+      if (staged) RD_HIP(hipMemcpy(solved.data(), d_o, solved.size() * 4, hipMemcpyDeviceToHost));
+      d_solved_all = d_o;
     }
     per_device(devices, S, [&](int, const std::vector<int> &mine) {
       Workspace &ws = Workspace::get();
@@ -394,7 +443,8 @@ static void flat_resolution_multi_host(const T *dem, T nodata, int w, int h, uin
         const int rows = r0[s + 1] - r0[s];
         int32_t *d_s = ws.buf<int32_t>(name("solved", s).c_str(), (size_t)4 * w);
         uint8_t *d_d = ws.buf<uint8_t>(name("dirs", s).c_str(), (size_t)rows * w);
-        RD_HIP(hipMemcpy(d_s, &solved[(size_t)s * 4 * w], (size_t)4 * w * 4, hipMemcpyHostToDevice));
+        if (staged) RD_HIP(hipMemcpy(d_s, &solved[(size_t)s * 4 * w], (size_t)4 * w * 4, hipMemcpyHostToDevice));
+        else RD_HIP(hipMemcpyPeer(d_s, devices[s], d_solved_all + (size_t)s * 4 * w, devices[0], (size_t)4 * w * 4));
         const int rc = rdgpu_flat_shard_finish(sh[s], d_s, d_d);   // (does not release the handle)
         if (rc) throw Error(rc, rdgpu_last_error());
         RD_HIP(hipStreamSynchronize(nullptr));

@@ -111,9 +111,10 @@ def test_errors(rd):
 
 def test_multi_device_flat_resolution_entry_on_one_gpu(rd, orc, monkeypatch):
     """rdgpu_flat_resolution_d8_multi_<T> (one process, a list of devices): with device 0 listed several times the row
-    blocks go through exactly the multi-device code -- a worker thread per device, two ghost rows per cut, the cut-row
-    exchanges through the host, the flat-height solve on devices[0] -- and the directions equal the single-device call
-    (and the oracle) on every cell; RDGPU_DEVICES routes the plain host entry the same way."""
+    blocks go through exactly the multi-device code -- a worker thread per device, two ghost rows per cut, the cut rows,
+    heights and solved levels copied from device to device (r05; RDGPU_MULTI_HOST_STAGED=1: through the host, r03-r04), the
+    flat-height solve on devices[0] -- and the directions equal the single-device call (and the oracle) on every cell;
+    RDGPU_DEVICES routes the plain host entry the same way."""
     import ctypes
 
     from richdem_amd._lib import check, lib
@@ -128,6 +129,14 @@ def test_multi_device_flat_resolution_entry_on_one_gpu(rd, orc, monkeypatch):
         check(lib().rdgpu_flat_resolution_d8_multi_f32(z.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(-9999), w, h,
                                                        out.ctypes.data_as(ctypes.c_void_p), arr, len(devs)), "multi")
         assert np.array_equal(out, exp), len(devs)
+    monkeypatch.setenv("RDGPU_MULTI_HOST_STAGED", "1")
+    for devs in ([0] * 5,):
+        out = np.empty((h, w), np.uint8)
+        arr = (ctypes.c_int * len(devs))(*devs)
+        check(lib().rdgpu_flat_resolution_d8_multi_f32(z.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(-9999), w, h,
+                                                       out.ctypes.data_as(ctypes.c_void_p), arr, len(devs)), "multi staged")
+        assert np.array_equal(out, exp), ("staged", len(devs))
+    monkeypatch.delenv("RDGPU_MULTI_HOST_STAGED")
     q = z.astype(np.int32)
     out = np.empty((h, w), np.uint8)
     arr = (ctypes.c_int * 3)(0, 0, 0)
