@@ -346,6 +346,42 @@ __global__ __launch_bounds__(NT) void k_tie_g_init(const uint32_t *__restrict__ 
   for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) g[c] = F0[c] == rk[c] ? T_ROOT : par[c];
 }
 
+// r05 (tree iteration, see pf_flowdirs_device): when the tree of directions is NOT the exact flood of the ranks, "the plain fill
+// leaves c alone" says nothing about c's ancestors in it.  M(c) = the greatest rank among c's proper ancestors, by pointer
+// doubling IN PLACE on one packed word per cell (high: the maximum over the ancestors up to and including `a`; low: a) -- an
+// 8-byte load is one consistent (maximum, pointer) pair whatever other lanes have done to it meanwhile.
+__global__ __launch_bounds__(NT) void k_tie_maxanc_init(const uint32_t *__restrict__ par, const uint32_t *__restrict__ rk,
+                                                        unsigned long long *st, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t p = par[c];
+    st[c] = ((unsigned long long)(p == T_ROOT ? 0u : rk[p]) << 32) | p;
+  }
+}
+__global__ __launch_bounds__(NT) void k_tie_maxanc(unsigned long long *st, uint64_t n, uint32_t *changed) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  bool ch = false;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    unsigned long long v = st[c];
+    uint32_t a = (uint32_t)v, m = (uint32_t)(v >> 32);
+    if (a == T_ROOT) continue;
+    for (int hops = 0; hops < 4 && a != T_ROOT; hops++) {
+      const unsigned long long u = __hip_atomic_load(&st[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m = max(m, (uint32_t)(u >> 32));
+      a = (uint32_t)u;
+    }
+    __hip_atomic_store(&st[c], ((unsigned long long)m << 32) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ch |= a != T_ROOT;
+  }
+  if (__any(ch) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+__global__ __launch_bounds__(NT) void k_tie_g_init_maxanc(const uint32_t *__restrict__ par, const uint32_t *__restrict__ rk,
+                                                          const unsigned long long *__restrict__ st, uint32_t *g, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride)
+    g[c] = (uint32_t)(st[c] >> 32) < rk[c] ? T_ROOT : par[c];   // (a border cell: no ancestor, maximum 0 -- and its parent is the root anyway)
+}
+
 // depth in T' by pointer doubling (ping-pong): anc / dist -> anc2 / dist2
 __global__ __launch_bounds__(NT) void k_tie_depth(const uint32_t *__restrict__ anc, const uint32_t *__restrict__ dist, uint32_t *anc2,
                                                   uint32_t *dist2, uint64_t n, uint32_t *changed) {
@@ -448,6 +484,41 @@ __global__ __launch_bounds__(NT) void k_tie_tau(const uint8_t *__restrict__ dirs
     tau[c] = t;
     cells[c] = (uint32_t)c;
   }
+}
+// r05, the tree iteration's step: the flood pushes a cell when the FIRST of its neighbours is popped, so under the pop ranks R the
+// tree of directions must be D(c) = the neighbour of least R.  Rewrites the directions of the interior cells to that (counting
+// the cells that change) and forms the discovery times from it: k_tie_tau with the parents read off R.
+__global__ __launch_bounds__(NT) void k_tie_tau_argmin(uint8_t *dirs, const uint32_t *__restrict__ R, unsigned long long *tau, uint32_t *cells,
+                                                       int w, int h, unsigned long long *changed) {
+  const uint64_t n = (uint64_t)w * h, stride = (uint64_t)gridDim.x * NT;
+  const unsigned long long nb = 2ull * w + 2ull * h;
+  uint32_t m = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const int x = (int)(c % (uint64_t)w), y = (int)(c / (uint64_t)w);
+    unsigned long long t;
+    if (y == 0) t = 2ull * x;
+    else if (y == h - 1) t = 2ull * x + 1;
+    else if (x == 0) t = 2ull * w + 2ull * (y - 1);
+    else if (x == w - 1) t = 2ull * w + 2ull * (y - 1) + 1;
+    else {
+      uint32_t best = 0xFFFFFFFFu;
+      int bd = 1;
+#pragma unroll
+      for (int d = 1; d <= 8; d++) {   // (pop ranks are distinct: no tie to break)
+        const uint32_t r = R[(size_t)(y + ndy(d)) * w + (x + ndx(d))];
+        if (r < best) { best = r; bd = d; }
+      }
+      m += dirs[c] != (uint8_t)bd;
+      dirs[c] = (uint8_t)bd;
+      const int inv = ((bd + 3) & 7) + 1;                                   // the closing cell pushed c in direction inverse(bd)
+      const int pos = (inv & 1) ? (inv - 1) >> 1 : 4 + ((inv - 2) >> 1);   // d8_order = 1,3,5,7,2,4,6,8
+      t = nb + ((unsigned long long)best + 1ull) * 8ull + (unsigned long long)pos;
+    }
+    tau[c] = t;
+    cells[c] = (uint32_t)c;
+  }
+  for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&changed[(blockIdx.x & 63) * 2 + 1], (unsigned long long)m);
 }
 // first tie key, before any flood: a cell on a slope is most likely closed by its LOWEST neighbour, so equal cells are
 // ordered by (that neighbour's key, position among its pushes) -- closer to the insertion order than the cell index, one
@@ -622,13 +693,42 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       const auto t_tie0 = std::chrono::steady_clock::now();
       uint32_t passes = 0, levels_total = 0;
       unsigned long long moved = (w <= 2 || h <= 2) ? 0ull : (unsigned long long)g_stats.twins;   // no re-rank pass ran: every twin's place is undecided
+      unsigned long long dchanged = 0;
+      // r05, THE TREE ITERATION (RDGPU_PFD_TREE_ITER=1; off by default, see the end of this comment).  Only the first pass floods by
+      // levels.  For ANY tree of directions D and distinct ranks r the
+      // machinery below yields R = the order in which a priority queue walks D (pop the least rank, push its children), and the
+      // real flood pushes a cell when the first of its neighbours pops: if D(c) = argmin over c's neighbours of R -- checked and
+      // enforced by k_tie_tau_argmin -- queue walk and flood have the same frontier after every pop, by induction the same
+      // order, and D IS the flood's tree for r.  So the state (D, r) is iterated: R from (D, r); D' = argmin R; the discovery
+      // times from (D', R) and r' from them; "no direction changed and no rank moved" certifies the reference's result.  It
+      // converges from the front like the passes did: while the first m pops are the reference's, every cell next to one of
+      // them gets its true parent and its true discovery time, so pop m + 1 is right in the next iteration (D' stays a forest:
+      // a cell's old parent pops before it, so the least R among its neighbours is below its own).  Once the ranks rest, one
+      // level flood brings the lagging tree up to date and the next iteration is the check; a level flood is also run when a
+      // bound stops the iteration (the result is then an exact flood of some stable order, as before) and every
+      // RDGPU_PFD_TREE_REFLOOD iterations (default 12).  MEASURED (profiles/r05o_pfd_tree_iteration.txt): the ranks settle
+      // exactly as fast as with a flood per pass (1.48e9, 101 590, 6, 0 moved at S3) with half the floods (918 levels instead
+      // of 1836), but an iteration without the exact tree's shortcut for k_tie_greater costs 2.5 s, not 1.6: 15.9 s against
+      // 15.1 s at S3 -- no gain on float terrain, so the default stays a level flood per pass.  On rasters whose plateaus need
+      // one pass per breadth-first ring both schemes need the same count, and an iteration is a third cheaper than a pass.
+      const char *tie_env = getenv("RDGPU_PFD_TREE_ITER");
+      const bool tree_iter = tie_env && tie_env[0] == '1';
+      const char *rf_env = getenv("RDGPU_PFD_TREE_REFLOOD");
+      const uint32_t reflood = rf_env ? (uint32_t)strtoul(rf_env, nullptr, 10) : 12u;
+      bool exact = false;          // d_dirs is the exact flood of rk
+      uint32_t since_flood = 0;
       g_rank_pass = true;
       try {
         for (;;) {
-          pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
-          levels_total += g_stats.levels;
-          if (passes >= max_passes) break;
-          if (passes && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tie0).count() > max_seconds) break;
+          const bool stop = passes >= max_passes ||
+                            (passes && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tie0).count() > max_seconds);
+          if (!exact && (passes == 0 || !tree_iter || stop || since_flood >= reflood)) {
+            pf_flowdirs_device<uint32_t>(rk, 0xFFFFFFFFu, w, h, d_dirs, s);   // (no rank is 2^32 - 1: n < 2^31)
+            levels_total += g_stats.levels;
+            exact = true;
+            since_flood = 0;
+          }
+          if (stop) break;
           passes++;
           // ---- the discovery times under this pass's flood, and the ranks of (z, discovery time) -----------------------
           uint32_t *zkey = keys;   // (keys still holds every cell's key: k_rank_keys' output, untouched by the sort)
@@ -640,7 +740,20 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           const char *gi = getenv("RDGPU_PFD_GREATER_INIT");   // =0: every search starts at the parent (r04): A/B and tests
           if (gi && gi[0] == '0') {
             RD_HIP(hipMemcpyAsync(g, par, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-          } else {   // one plain fill of the rank raster (the pool is free here) says which cells have no greater ancestor
+          } else if (!exact) {   // any tree: the greatest rank among a cell's ancestors says whether it has a greater one
+            unsigned long long *st = pool8(0);
+            RD_LAUNCH("pfd.tie.maxanc_init", k_tie_maxanc_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)par, (const uint32_t *)rk, st, n);
+            for (int round = 0;; round++) {
+              RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+              RD_LAUNCH("pfd.tie.maxanc", k_tie_maxanc, dim3(sgrid(n)), dim3(NT), 0, s, st, n, flag);
+              RD_HIP(hipMemcpyAsync(hw, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+              RD_HIP(hipStreamSynchronize(s));
+              if (hw[0] == 0) break;
+              if (round > 64) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the tree of directions holds a loop (internal error)");
+            }
+            RD_LAUNCH("pfd.tie.g_init", k_tie_g_init_maxanc, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)par, (const uint32_t *)rk,
+                      (const unsigned long long *)st, g, n);
+          } else {   // the exact flood's tree: one plain fill of the rank raster (the pool is free here) says which cells have no greater ancestor
             uint32_t *F0 = pool4(0, 0);
             RD_HIP(hipMemcpyAsync(F0, rk, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
             check_rc(Calls<uint32_t>::fill(F0, w, h, (void *)s));
@@ -722,8 +835,12 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           // ---- discovery times -> order by (elevation, discovery time): sort by the time, then stably by the key ----------
           unsigned long long *tau = sk64, *stau = k64;
           uint32_t *c0 = ucells, *c1 = scells;
-          RD_LAUNCH("pfd.tie.tau", k_tie_tau, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, (const uint32_t *)par, (const uint32_t *)R,
-                    tau, c0, w, h);
+          RD_HIP(hipMemsetAsync(counters, 0, 128 * sizeof(unsigned long long), s));
+          if (tree_iter)
+            RD_LAUNCH("pfd.tie.tau_argmin", k_tie_tau_argmin, dim3(sgrid(n)), dim3(NT), 0, s, d_dirs, (const uint32_t *)R, tau, c0, w, h, counters);
+          else
+            RD_LAUNCH("pfd.tie.tau", k_tie_tau, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, (const uint32_t *)par, (const uint32_t *)R,
+                      tau, c0, w, h);
           tb = 0;
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, tau, stau, c0, c1, (int)n, 0, 36, s));
           tmp = ws.buf("pfd.rtmp", tb);
@@ -735,15 +852,22 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           tmp = ws.buf("pfd.rtmp", tb);
           RD_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, zk, zks, c1, c0, (int)n, 0, 32, s));
           uint32_t *rk_new = par;   // (the parents are dead)
-          RD_HIP(hipMemsetAsync(counters, 0, 128 * sizeof(unsigned long long), s));
           RD_LAUNCH("pfd.tie.new_ranks", k_tie_new_ranks, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)c0, (const uint32_t *)rk, rk_new, n,
                     counters);
           RD_LAUNCH("pfd.sum", k_sum_counters, dim3(1), dim3(128), 0, s, counters, sums);
-          RD_HIP(hipMemcpyAsync(&moved, sums, sizeof moved, hipMemcpyDeviceToHost, s));
+          unsigned long long mv[2] = {0, 0};   // ranks that moved, directions that changed
+          RD_HIP(hipMemcpyAsync(mv, sums, sizeof mv, hipMemcpyDeviceToHost, s));
           RD_HIP(hipStreamSynchronize(s));
-          if (getenv("RDGPU_PFD_TRACE")) fprintf(stderr, "pfd tie pass %u: %llu ranks moved, record tree depth %u\n", passes, moved, maxd);
-          if (moved == 0) break;   // the order reproduces itself: it is the reference's
-          RD_HIP(hipMemcpyAsync(rk, rk_new, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          moved = mv[0];
+          dchanged = tree_iter ? mv[1] : 0ull;
+          if (getenv("RDGPU_PFD_TRACE"))
+            fprintf(stderr, "pfd tie pass %u: %llu ranks moved, %llu directions changed (tree %s), record tree depth %u\n", passes, moved, dchanged,
+                    exact ? "from the level flood" : "iterated", maxd);
+          if (moved == 0 && dchanged == 0) break;   // tree and order reproduce themselves: they are the reference's
+          if (moved) RD_HIP(hipMemcpyAsync(rk, rk_new, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          exact = false;
+          since_flood++;
+          if (moved == 0) since_flood = reflood;   // the order is (very likely) final and only the tree lags: one level flood, then the check
         }
       } catch (...) {
         g_rank_pass = false;
@@ -753,7 +877,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       g_stats.twins = mine.twins;
       g_stats.levels = levels_total;
       g_stats.tie_passes = passes;
-      g_stats.unresolved = moved;   // ranks still moving when the passes ran out (0: the reference's order; no pass at all: the twins)
+      g_stats.unresolved = moved ? moved : dchanged;   // ranks (or, with the order at rest, directions) still moving when the passes ran out (0: the reference's order; no pass at all: the twins)
       RD_LAUNCH("pfd.nodata_dirs", (k_nodata_dirs<T>), dim3(sgrid(n)), dim3(NT), 0, s, d_z, nodata, d_dirs, w, h);
       return;
     }

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-from proto_tie_order import flowdirs_with_ties  # noqa: E402
+from proto_tie_order import flowdirs_tree_iteration, flowdirs_with_ties  # noqa: E402
 
 
 def test_fixed_point_of_the_discovery_order_is_the_stable_queues_order(orc):
@@ -25,6 +25,12 @@ def test_fixed_point_of_the_discovery_order_is_the_stable_queues_order(orc):
         got[(z == -9999) & interior] = 0                       # NoData cells carry no direction (:545-548)
         assert np.array_equal(got, ref), (floods, int((got != ref).sum()))
         assert floods >= 2
+        # r05, the tree iteration: ONE flood, then (tree of directions, ranks) iterated -- pop order of the queue's walk over the
+        # tree, every cell re-pointed at its first-popped neighbour, discovery times, ranks -- to the same directions
+        got2, its = flowdirs_tree_iteration(z, lambda rk: orc.port.pf_flowdirs(rk, np.int32(-7777)))
+        got2 = got2.copy()
+        got2[(z == -9999) & interior] = 0
+        assert np.array_equal(got2, ref), (its, int((got2 != ref).sum()))
     # the ranks alone, equal cells in raster order, are NOT the reference's order (what the iteration is for)
     z = cases[0]
     order = np.argsort(z.ravel(), kind="stable")

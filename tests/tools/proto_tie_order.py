@@ -96,6 +96,42 @@ def flowdirs_with_ties(z, tie_free_flood, maxit=1000):
     raise AssertionError("the tie order did not settle")
 
 
+def flowdirs_tree_iteration(z, tie_free_flood, maxit=1000):
+    """The same directions with ONE flood (r05, csrc/pfdirs.hip "the tree iteration"): the state (tree of directions D,
+    ranks r) is iterated -- R = the order in which a priority queue walks D under r (pop_ranks), D'(c) = the neighbour of
+    least R (the flood pushes a cell when the first of its neighbours pops), discovery times from (D', R), r' from them --
+    until neither a direction nor a rank changes.  Returns (directions, iterations)."""
+    h, w = z.shape
+    n = h * w
+    bidx, nb = border_push_index(w, h)
+    zr = z.ravel()
+    order = np.lexsort((np.arange(n, dtype=np.int64), zr))
+    rk = np.empty(n, np.int32)
+    rk[order] = np.arange(n, dtype=np.int32)
+    dirs = tie_free_flood(rk.reshape(h, w)).copy()
+    for it in range(1, maxit + 1):
+        par, R = pop_ranks(rk.reshape(h, w), dirs)
+        R2 = R.reshape(h, w)
+        new = dirs.copy()
+        tau = np.empty(n, np.int64)
+        for y in range(h):
+            for x in range(w):
+                c = y * w + x
+                if x == 0 or y == 0 or x == w - 1 or y == h - 1:
+                    tau[c] = bidx[y, x]
+                    continue
+                best = min(range(1, 9), key=lambda d: R2[y + DY[d], x + DX[d]])
+                new[y, x] = best
+                tau[c] = nb + R2[y + DY[best], x + DX[best]] * 8 + D8_ORDER.index(INV[best])
+        order = np.lexsort((tau, zr))
+        rk2 = np.empty(n, np.int32)
+        rk2[order] = np.arange(n, dtype=np.int32)
+        if np.array_equal(new, dirs) and np.array_equal(rk2, rk):
+            return dirs, it
+        dirs, rk = new, rk2
+    raise AssertionError("the tree iteration did not settle")
+
+
 if __name__ == "__main__":
     import os
     import sys
@@ -113,3 +149,5 @@ if __name__ == "__main__":
         ref = B.pf_flowdirs(z, z.dtype.type(-9999))
         got, it = flowdirs_with_ties(z, lambda rk: B.pf_flowdirs(rk, np.int32(-9999)))
         print(name, "floods", it, "cells differing from the reference", int((got != ref).sum()), "of", z.size, flush=True)
+        got2, it2 = flowdirs_tree_iteration(z, lambda rk: B.pf_flowdirs(rk, np.int32(-9999)))
+        print(name, "tree iteration: 1 flood +", it2, "iterations, cells differing", int((got2 != ref).sum()), flush=True)
