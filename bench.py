@@ -206,7 +206,8 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
         _best(lambda: rd.d8_flow_directions_dev(W, nodata, dirs, flats=True), reps, sync), n_cells, 6)
     fs = rd.flat_stats()
     out["directions_plus_flat_resolution"].update({"noflow_cells": fs["noflow"], "rounds_towards": fs["towards"],
-                                                   "rounds_away": fs["away"]})
+                                                   "rounds_away": fs["away"], "tail_visits": fs["tail_visits"],
+                                                   "tail_live_tiles": fs["tail_live_tiles"]})
     area = torch.empty(W.shape, dtype=torch.float64, device="cuda")
     rd.d8_flow_accum_dev(dirs, area)
     out["d8_flow_accum"] = stage_entry(_best(lambda: rd.d8_flow_accum_dev(dirs, area), reps, sync), n_cells, 9)

@@ -420,6 +420,18 @@ typedef struct rdgpu_flat_stats {
   uint32_t towards_levels; /* tile-relaxation rounds, towards-lower gradient                 */
 } rdgpu_flat_stats;
 int rdgpu_flat_get_stats(rdgpu_flat_stats *out);
+/* The asynchronous tails of the two level searches of the last flat resolution on this thread (csrc/flats.hip,
+ * k_relax_bits_async; no reference counterpart -- the reference's searches are serial queues, flats/flat_resolution.hpp:152-298):
+ * tile visits by the resident wavefronts, tiles that were live when the rounds handed over (summed over the launches),
+ * launches, launches that gave up and were finished in rounds. */
+typedef struct rdgpu_flat_async_stats {
+  uint64_t visits;
+  uint32_t launches;
+  uint32_t failures;
+  uint32_t live_tiles;
+  uint32_t reserved;
+} rdgpu_flat_async_stats;
+int rdgpu_flat_get_async_stats(rdgpu_flat_async_stats *out);
 
 /* ResolveFlatsEpsilon(Array2D<T>&) (flats/flats.hpp:21-28; rd.ResolveFlats): the DEM is altered in place so
  * that every flat with an outlet drains -- each interior cell of such a flat is raised by flat_mask increments

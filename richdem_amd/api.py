@@ -545,11 +545,19 @@ class _FlatStats(ctypes.Structure):
                 ("away", ctypes.c_uint32), ("towards", ctypes.c_uint32)]
 
 
+class _FlatAsyncStats(ctypes.Structure):
+    _fields_ = [("visits", ctypes.c_uint64), ("launches", ctypes.c_uint32), ("failures", ctypes.c_uint32),
+                ("live_tiles", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
 def flat_stats() -> dict:
-    """rdgpu_flat_get_stats of the last flat resolution on this process."""
+    """rdgpu_flat_get_stats + rdgpu_flat_get_async_stats of the last flat resolution on this thread."""
     st = _FlatStats()
     check(lib().rdgpu_flat_get_stats(ctypes.byref(st)), "rdgpu_flat_get_stats")
-    return {"low_edges": st.low, "high_edges": st.high, "noflow": st.noflow, "away": st.away, "towards": st.towards}
+    a = _FlatAsyncStats()
+    check(lib().rdgpu_flat_get_async_stats(ctypes.byref(a)), "rdgpu_flat_get_async_stats")
+    return {"low_edges": st.low, "high_edges": st.high, "noflow": st.noflow, "away": st.away, "towards": st.towards,
+            "tail_visits": a.visits, "tail_live_tiles": a.live_tiles, "tail_launches": a.launches, "tail_failures": a.failures}
 
 
 def release_workspace() -> None:

@@ -2315,8 +2315,8 @@ static uint32_t async_threshold() {
   return env ? (uint32_t)strtoul(env, nullptr, 10) : 20000u;
 }
 
-struct AsyncInfo { uint32_t visits, launches, failures; };
-static thread_local AsyncInfo g_async_info = {0, 0, 0};
+struct AsyncInfo { uint64_t visits; uint32_t launches, failures, live_tiles; };   // (of the last flat resolution: rdgpu_flat_get_async_stats)
+static thread_local AsyncInfo g_async_info = {0, 0, 0, 0};
 
 // What relax_rounds_bits / the static search hand to the code around them when the search reaches its tail: mark() before
 // the resident launch is enqueued (the place for an event the side work waits on), go() after it (the resident
@@ -2328,6 +2328,7 @@ struct Beside {
 
 struct AsyncRun {
   AsyncQ Q;
+  const uint32_t *live = nullptr;   // the length of the tile list the queues were filled from
   uint32_t blocks = 0;
   int cus = 0, rate_khz = 0;
 };
@@ -2352,6 +2353,7 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
   // twenty seconds of wall_clock64 ticks (an attribute that reads 0 is taken as the usual 100 MHz)
   const unsigned long long budget = (unsigned long long)std::max(r.rate_khz, 100000) * 1000ull * 20ull;
   uint32_t *last = b.ctr + (BITS_BATCH - 1);   // (its own counter word: the rounds' words may not have been read back yet)
+  r.live = last;
   RD_HIP(hipMemsetAsync(last, 0, sizeof(uint32_t), s));
   RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
             last);
@@ -2380,7 +2382,9 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
 // finishes the search in rounds from "every tile active" (the fixed point does not depend on the schedule).
 static bool async_check(const AsyncRun &r, const char *name, hipStream_t s) {
   std::vector<uint32_t> all(AQ_WORDS);
+  uint32_t live = 0;
   RD_HIP(hipMemcpyAsync(all.data(), r.Q.ctl, AQ_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  if (r.live) RD_HIP(hipMemcpyAsync(&live, r.live, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   uint64_t enq = 0, done = 0, queued = 0, pushes = 0;
   for (int qi = 0; qi < AQ_NQ; qi++) {
@@ -2395,6 +2399,7 @@ static bool async_check(const AsyncRun &r, const char *name, hipStream_t s) {
     return false;
   }
   g_async_info.visits += all[AQ_G_VISITS];
+  g_async_info.live_tiles += live;
   g_async_info.launches++;
   if (getenv("RDGPU_FLAT_TRACE"))
     fprintf(stderr, "%s asynchronous tail: %u visits, %llu pushes, %u wavefronts on %d CUs, ticks (%d kHz): in visits %llu, longest wavefront %u\n",
@@ -2580,6 +2585,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
   const bool lean = outA && use_bits_engine() && lean_labels();
   if (!lean) RD_HIP(hipMemsetAsync(M, 0, n * sizeof(int32_t), s));  // flat_mask.setAll(0), :469 (lean: the towards search writes every cell)
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
+  g_async_info = AsyncInfo{0, 0, 0, 0};
 
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   if (d_dirs) {
@@ -2740,6 +2746,7 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   const uint64_t n = (uint64_t)w * h;
   Workspace &ws = Workspace::get();
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
+  g_async_info = AsyncInfo{0, 0, 0, 0};
   uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   // r05: the last pass from 4 bits per cell, without the DEM (k_flat_dirs_q; the cells next to a low edge get their direction
   // in the classification); RDGPU_FLAT_Q=0: k_flat_dirs_levels over the level planes and the DEM (r02-r04): A/B and tests
@@ -3605,5 +3612,10 @@ extern "C" void rdgpu_flat_shard_free(rdgpu_flat_shard *f) { fs_free(f); }
 extern "C" int rdgpu_flat_get_stats(rdgpu_flat_stats *out) {
   if (!out) return RDGPU_ERR_ARG;
   *out = g_fstats;
+  return RDGPU_OK;
+}
+extern "C" int rdgpu_flat_get_async_stats(rdgpu_flat_async_stats *out) {
+  if (!out) return RDGPU_ERR_ARG;
+  *out = rdgpu_flat_async_stats{g_async_info.visits, g_async_info.launches, g_async_info.failures, g_async_info.live_tiles, 0};
   return RDGPU_OK;
 }

@@ -160,6 +160,11 @@ def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     eeps = orc.port.resolve_flats_epsilon(ffl, np.float32(-9999))
     monkeypatch.setenv(k, v)
     assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
+    st = rd.flat_stats()                                # rdgpu_flat_get_async_stats: what the resident wavefronts did
+    if switch == "RDGPU_FLAT_ASYNC=100000":             # both searches hand over after the first batch of rounds
+        assert 1 <= st["tail_launches"] <= 2 and st["tail_failures"] == 0 and st["tail_visits"] >= st["tail_live_tiles"] > 0, st
+    if switch == "RDGPU_FLAT_ASYNC=0":
+        assert st["tail_launches"] == 0 and st["tail_visits"] == 0, st
     assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
     monkeypatch.delenv(k)
     assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
