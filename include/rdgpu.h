@@ -175,21 +175,22 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
 /* PriorityFloodFlowdirs_Barnes2014(elevations, flowdirs) -- depressions/Barnes2014.hpp:483-555: D8 directions of the flood
  * that does not raise the DEM; every cell points at the neighbour that was flooded first (border cells off the raster, NoData
  * cells 0).  Identical to the reference, equal elevations included: the reference's queue breaks ties by insertion order
- * (GridCellZk_low_pq, common/grid_cell.hpp:101-122) and that order is reproduced as a fixed point -- one exact
- * flood of the raster's unique ranks per pass, until the ranks reproduce themselves (2 passes on float terrain, the
- * breadth-first depth of the largest plateau on integer DEMs).  The passes are BOUNDED: RDGPU_PFD_TIE_SECONDS (default 120,
+ * (GridCellZk_low_pq, common/grid_cell.hpp:101-122) and that order is reproduced as a fixed point -- an exact
+ * flood of the raster's unique ranks, then passes over (tree of directions, ranks) until both reproduce themselves, a second
+ * flood once the ranks rest (3 - 4 passes on float terrain, the breadth-first depth of the largest plateau on integer DEMs;
+ * RDGPU_PFD_TREE_ITER=0: a flood in every pass).  The passes are BOUNDED: RDGPU_PFD_TIE_SECONDS (default 120,
  * checked between passes) and RDGPU_PFD_TIE_PASSES (default 1000); when a bound stops them the result is still an exact
  * flood of a stable order, stats.unresolved != 0 says how many ranks were still moving (the C++ shim logs one line to
  * stderr, the Python layer raises a RuntimeWarning).  RDGPU_PFD_RANKS=0 is the FAST path for callers who do not need the
  * reference's tie order: one flood, ties decided by neighbour number (seconds instead of tens of seconds at 40000^2);
- * stats.unresolved then counts the cells where a tie decided.  One fill per nesting level of the depressions per pass. */
+ * stats.unresolved then counts the cells where a tie decided.  One fill per nesting level of the depressions per flood. */
 typedef struct rdgpu_pf_flowdirs_stats {
   uint32_t levels;      /* fills run */
   uint32_t twins;       /* cells whose elevation occurs more than once in the raster: 0 => the result is the reference's */
   uint64_t unresolved;  /* twins != 0: cells whose place in the tie order was still moving when the passes ran out (0: the
                            result is the reference's; = twins when no re-rank pass ran at all, RDGPU_PFD_TIE_PASSES=0);
                            RDGPU_PFD_RANKS=0: directions decided by neighbour number */
-  uint32_t tie_passes;  /* passes of the tie order's fixed point (floods beyond the first) */
+  uint32_t tie_passes;  /* passes of the tie order's fixed point (rank computations; not every pass floods) */
   uint32_t reserved;
 } rdgpu_pf_flowdirs_stats;
 int rdgpu_pf_flowdirs_get_stats(rdgpu_pf_flowdirs_stats *out);

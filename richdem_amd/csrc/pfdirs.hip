@@ -21,7 +21,7 @@
 // DEM -- and it is reproduced: a raster with twins is flooded on its UNIQUE RANKS of (elevation, tie key), and the tie key
 // is iterated to the fixed point "discovery time under the flood it induces" (k_tie_* below): equal to the compiled
 // reference on its own tie-heavy vectors and, digest for digest, on the 40000 x 40000 bench DEM (1.58e9 cells with a twin;
-// 4 floods, 19 s).  `twins`, `tie_passes`, `unresolved` (ranks still moving when RDGPU_PFD_TIE_PASSES ran out: 0 = exact)
+// r04: 4 floods, 19 s; r05: 2 floods + the tree iteration in pf_flowdirs_device, 10.9 s).  `twins`, `tie_passes`, `unresolved` (ranks still moving when RDGPU_PFD_TIE_PASSES ran out: 0 = exact)
 // in rdgpu_pf_flowdirs_get_stats.  RDGPU_PFD_RANKS=0: ties decided inside the levels by neighbour number (r03).
 // tests/tools/proto_pf_flowdirs.py is the tie-free algorithm in numpy, checked against the oracle.
 #include "common.hpp"
@@ -694,7 +694,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       uint32_t passes = 0, levels_total = 0;
       unsigned long long moved = (w <= 2 || h <= 2) ? 0ull : (unsigned long long)g_stats.twins;   // no re-rank pass ran: every twin's place is undecided
       unsigned long long dchanged = 0;
-      // r05, THE TREE ITERATION (RDGPU_PFD_TREE_ITER=1; off by default, see the end of this comment).  Only the first pass floods by
+      // r05, THE TREE ITERATION (the default; RDGPU_PFD_TREE_ITER=0: a level flood per pass, r04).  Only the first pass floods by
       // levels.  For ANY tree of directions D and distinct ranks r the
       // machinery below yields R = the order in which a priority queue walks D (pop the least rank, push its children), and the
       // real flood pushes a cell when the first of its neighbours pops: if D(c) = argmin over c's neighbours of R -- checked and
@@ -703,16 +703,17 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       // times from (D', R) and r' from them; "no direction changed and no rank moved" certifies the reference's result.  It
       // converges from the front like the passes did: while the first m pops are the reference's, every cell next to one of
       // them gets its true parent and its true discovery time, so pop m + 1 is right in the next iteration (D' stays a forest:
-      // a cell's old parent pops before it, so the least R among its neighbours is below its own).  Once the ranks rest, one
-      // level flood brings the lagging tree up to date and the next iteration is the check; a level flood is also run when a
-      // bound stops the iteration (the result is then an exact flood of some stable order, as before) and every
-      // RDGPU_PFD_TREE_REFLOOD iterations (default 12).  MEASURED (profiles/r05o_pfd_tree_iteration.txt): the ranks settle
-      // exactly as fast as with a flood per pass (1.48e9, 101 590, 6, 0 moved at S3) with half the floods (918 levels instead
-      // of 1836), but an iteration without the exact tree's shortcut for k_tie_greater costs 2.5 s, not 1.6: 15.9 s against
-      // 15.1 s at S3 -- no gain on float terrain, so the default stays a level flood per pass.  On rasters whose plateaus need
-      // one pass per breadth-first ring both schemes need the same count, and an iteration is a third cheaper than a pass.
+      // a cell's old parent pops before it, so the least R among its neighbours is below its own).  The ranks settle as fast as
+      // with a flood per pass (S3: 1.48e9, 101 590, 6, 0 moved), the tree lags behind them (3484, 1845, 802, ... directions
+      // still changing, halving per iteration): once (almost) no rank moves -- <= max(64, n / 2^24), RDGPU_PFD_TREE_REFLOOD_MOVED --
+      // ONE level flood brings the tree up to date and the next iteration is the check.  A level flood is also run when a bound
+      // stops the iteration (the result is then an exact flood of some stable order, as before) and every
+      // RDGPU_PFD_TREE_REFLOOD iterations (default 12); at worst every iteration floods: the r04 scheme.  S3
+      // (profiles/r05q_pfd_tree_ab.txt): 918 - 1377 levels instead of 1836, 15.1 -> 12.4 s with the flood at "no rank moved".
       const char *tie_env = getenv("RDGPU_PFD_TREE_ITER");
-      const bool tree_iter = tie_env && tie_env[0] == '1';
+      const bool tree_iter = !(tie_env && tie_env[0] == '0');
+      const char *rm_env = getenv("RDGPU_PFD_TREE_REFLOOD_MOVED");
+      const unsigned long long reflood_moved = rm_env ? strtoull(rm_env, nullptr, 10) : std::max<unsigned long long>(64ull, n >> 24);
       const char *rf_env = getenv("RDGPU_PFD_TREE_REFLOOD");
       const uint32_t reflood = rf_env ? (uint32_t)strtoul(rf_env, nullptr, 10) : 12u;
       bool exact = false;          // d_dirs is the exact flood of rk
@@ -867,7 +868,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           if (moved) RD_HIP(hipMemcpyAsync(rk, rk_new, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
           exact = false;
           since_flood++;
-          if (moved == 0) since_flood = reflood;   // the order is (very likely) final and only the tree lags: one level flood, then the check
+          if (moved <= reflood_moved) since_flood = reflood;   // the order is (all but) final and only the tree lags: one level flood, then the check
         }
       } catch (...) {
         g_rank_pass = false;

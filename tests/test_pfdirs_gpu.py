@@ -118,20 +118,30 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
         exp = orc.port.pf_flowdirs(dem, nd)
         assert st["unresolved"] == 0, (name, st)
         assert np.array_equal(got, exp), (name, int((got != exp).sum()), dem.size, st)
-    # r05, the tree iteration (RDGPU_PFD_TREE_ITER=1): one level flood, then (tree of directions, ranks) iterated to "every cell
-    # points at its first-popped neighbour and the order reproduces itself" -- the same directions, fewer floods
-    monkeypatch.setenv("RDGPU_PFD_TREE_ITER", "1")
+    # r05, the tree iteration is the default: one level flood, then (tree of directions, ranks) iterated to "every cell points at
+    # its first-popped neighbour and the order reproduces itself", a level flood again once the ranks rest.  The same
+    # directions from a level flood per pass (RDGPU_PFD_TREE_ITER=0, r04), from refloods at other moments, and without them
+    monkeypatch.setenv("RDGPU_PFD_TREE_ITER", "0")
     for name, dem in cases.items():
         nd = dem.dtype.type(-9999) if dem.dtype.kind in "if" and dem.dtype.itemsize > 1 else dem.dtype.type(255)
         got = rd.pf_flowdirs(dem, nodata=nd)
         st = rd.pf_flowdirs_stats()
         assert st["unresolved"] == 0, (name, st)
         assert np.array_equal(got, orc.port.pf_flowdirs(dem, nd)), ("tree iteration", name, st)
-    monkeypatch.setenv("RDGPU_PFD_TREE_REFLOOD", "3")        # a fresh level flood every third iteration
-    got = rd.pf_flowdirs(cases["plateaus"], nodata=np.int32(-9999))
-    assert np.array_equal(got, orc.port.pf_flowdirs(cases["plateaus"], np.int32(-9999)))
-    monkeypatch.delenv("RDGPU_PFD_TREE_REFLOOD")
     monkeypatch.delenv("RDGPU_PFD_TREE_ITER")
+    for var, val in (("RDGPU_PFD_TREE_REFLOOD", "3"),          # a fresh level flood every third iteration
+                     ("RDGPU_PFD_TREE_REFLOOD_MOVED", "100000000"),   # ... after every iteration (the threshold always holds)
+                     ("RDGPU_PFD_TREE_REFLOOD", "1000000")):   # ... only once the ranks rest: the tree alone iterated to its fixed point
+        monkeypatch.setenv(var, val)
+        if val == "1000000":
+            monkeypatch.setenv("RDGPU_PFD_TREE_REFLOOD_MOVED", "0")
+        for name in ("plateaus", "6 levels", "float32 terrain (local ties)"):
+            dem = cases[name]
+            got = rd.pf_flowdirs(dem, nodata=dem.dtype.type(-9999))
+            st = rd.pf_flowdirs_stats()
+            assert st["unresolved"] == 0 and np.array_equal(got, orc.port.pf_flowdirs(dem, dem.dtype.type(-9999))), (var, val, name, st)
+        monkeypatch.delenv(var)
+    monkeypatch.delenv("RDGPU_PFD_TREE_REFLOOD_MOVED")
     for shape in [(3, 3), (3, 4), (4, 4), (5, 3), (3, 9), (2, 7), (1, 5), (6, 2)]:      # the smallest rasters, all ties
         for dem in (np.zeros(shape, np.int32), rng.integers(0, 2, shape).astype(np.int32)):
             assert np.array_equal(rd.pf_flowdirs(dem, nodata=np.int32(-9999)), orc.port.pf_flowdirs(dem, np.int32(-9999))), (shape, dem)
