@@ -484,8 +484,8 @@ int rdgpu_flat_shard_rounds(const rdgpu_flat_shard *shard, int phase);
 void rdgpu_flat_shard_free(rdgpu_flat_shard *shard);
 
 /* barnes_flat_resolution_d8(alter = false) of ONE raster over SEVERAL devices of this process: row block s (+ two ghost
- * rows per cut) on devices[s], a host thread per device, the cut rows of the two level fields exchanged through the host
- * until none changes, the flat heights agreed on devices[0]; the result equals rdgpu_flat_resolution_d8_<T> on the whole
+ * rows per cut) on devices[s], a host thread per device, the cut rows of the two level fields exchanged from device to
+ * device (peer copies; RDGPU_MULTI_HOST_STAGED=1: through the host) until none changes, the flat heights agreed on devices[0]; the result equals rdgpu_flat_resolution_d8_<T> on the whole
  * raster.  A device may be listed more than once.  rdgpu_flat_resolution_d8_<T> takes this path when RDGPU_DEVICES
  * lists two or more ids.  (Verified on one physical device listed several times.) */
 #define RDGPU_DECL_FLATS_MULTI(SUF, T) \
@@ -556,7 +556,8 @@ int rdgpu_accum_shard_free(rdgpu_accum_shard *shard);
 
 /* d8_flow_accum of ONE raster over SEVERAL devices of this process (the reference's tiled driver
  * programs/parallel_d8_accum/main.cpp:373-464 as a library call): row block s on devices[s] (a host thread per device,
- * its own PCIe link), one exchange of the cut rows' outboxes and links through the host, the same result as
+ * its own PCIe link), one exchange of the cut rows' outboxes and links -- device to device by peer copies, the forest over
+ * the cut rows solved on devices[0]; RDGPU_MULTI_HOST_STAGED=1: through the host --, the same result as
  * rdgpu_d8_flow_accum_<A> on the whole raster.  Direction loops fall back to devices[0] alone.  A device may be listed
  * more than once.  rdgpu_d8_flow_accum_<A> takes this path when RDGPU_DEVICES lists two or more ids.
  * (Verified on one physical device listed several times: this build's test boxes have one GPU.) */
