@@ -26,6 +26,8 @@
 // tests/tools/proto_pf_flowdirs.py is the tie-free algorithm in numpy, checked against the oracle.
 #include "common.hpp"
 
+#include <type_traits>
+
 #include <hipcub/hipcub.hpp>
 
 #include <chrono>
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(NT) void k_refine(const T *__restrict__ z, const T 
 // counters[1]: wet cells.  active[]: per 64 x 64 tile of the fill, "a wet cell in the tile or next to it".
 template <class T>
 __global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F, uint8_t *__restrict__ outlet, uint8_t *active, int w,
-                                                   int h, unsigned long long *counters, const uint32_t *__restrict__ tiles) {
+                                                   int h, unsigned long long *counters, const uint32_t *__restrict__ tiles, T *last_level) {
   // (the same list: everywhere else the raster is walls and outlets already, and for good)
   const uint32_t t = tiles[blockIdx.x];
   const int ftx = (w + FT - 1) / FT;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(NT) void k_next_level(const T *__restrict__ z, T *F
         for (int tx = tx0; tx <= tx1; tx++) active[(size_t)ty * ftx + tx] = 1;
     }
     outlet[c] = o;
+    if (last_level && wet) last_level[c] = f;   // (r05) overwritten level after level: in the end the level of the cell's INNERMOST pocket
     F[c] = wet ? e : wall_value<T>();
   }
   for (int o = 32; o > 0; o >>= 1) nwet += __shfl_down(nwet, o, 64);
@@ -246,6 +249,10 @@ __global__ __launch_bounds__(NT) void k_finish(const T *__restrict__ z, T nodata
 
 static thread_local rdgpu_pf_flowdirs_stats g_stats = {0, 0, 0, 0, 0};
 static thread_local bool g_rank_pass = false;   // the call runs on the unique ranks of another raster (see pf_flowdirs_device)
+// r05: where the flood of a rank raster leaves, per cell, the level of its innermost pocket (null: not wanted).  The header's
+// key(c) = (F_0(c), ..., z(c)) IS the path root -> c of the record tree, so the cell of rank F_(k-1)(c) is c's nearest
+// ancestor of greater rank: after an exact flood the record tree needs no search at all (k_tie_from_levels).
+static thread_local uint32_t *g_last_level = nullptr;
 
 // ---- equal elevations: the flood on UNIQUE RANKS (r04) ----------------------------------------------------------------------
 // What this engine can do exactly is a tie-free raster; so a raster with twins is replaced by a rank permutation -- position
@@ -380,6 +387,21 @@ __global__ __launch_bounds__(NT) void k_tie_g_init_maxanc(const uint32_t *__rest
   const uint64_t stride = (uint64_t)gridDim.x * NT;
   for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride)
     g[c] = (uint32_t)(st[c] >> 32) < rk[c] ? T_ROOT : par[c];   // (a border cell: no ancestor, maximum 0 -- and its parent is the root anyway)
+}
+
+// r05: the record tree straight from an exact flood's levels (see g_last_level): cell of every rank, then parent' = the cell
+// whose rank is the level of c's innermost pocket
+__global__ __launch_bounds__(NT) void k_tie_rank_cells(const uint32_t *__restrict__ rk, uint32_t *cell_of, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) cell_of[rk[c]] = (uint32_t)c;
+}
+__global__ __launch_bounds__(NT) void k_tie_from_levels(const uint32_t *__restrict__ last_level, const uint32_t *__restrict__ cell_of,
+                                                        uint32_t *g, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * NT;
+  for (uint64_t c = (uint64_t)blockIdx.x * NT + threadIdx.x; c < n; c += stride) {
+    const uint32_t l = last_level[c];
+    g[c] = l == T_ROOT ? T_ROOT : cell_of[l];
+  }
 }
 
 // depth in T' by pointer doubling (ping-pong): anc / dist -> anc2 / dist2
@@ -718,6 +740,9 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       const uint32_t reflood = rf_env ? (uint32_t)strtoul(rf_env, nullptr, 10) : 12u;
       bool exact = false;          // d_dirs is the exact flood of rk
       uint32_t since_flood = 0;
+      const char *ll_env = getenv("RDGPU_PFD_LEVEL_TREE");   // =0: the record tree by the ancestor search also after an exact flood (A/B, tests)
+      uint32_t *last_level = (ll_env && ll_env[0] == '0') ? nullptr : ws.buf<uint32_t>("pfd.t.last_level", n);
+      g_last_level = last_level;
       g_rank_pass = true;
       try {
         for (;;) {
@@ -739,7 +764,13 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
           uint32_t *hw = ws.host_words();
           RD_LAUNCH("pfd.tie.parents", k_tie_parents, dim3(sgrid(n)), dim3(NT), 0, s, (const uint8_t *)d_dirs, par, w, h);
           const char *gi = getenv("RDGPU_PFD_GREATER_INIT");   // =0: every search starts at the parent (r04): A/B and tests
-          if (gi && gi[0] == '0') {
+          const bool from_levels = exact && last_level != nullptr;
+          if (from_levels) {   // the exact flood's own levels name every cell's nearest greater ancestor: no search
+            uint32_t *cell_of = pool4(0, 0);
+            RD_LAUNCH("pfd.tie.rank_cells", k_tie_rank_cells, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)rk, cell_of, n);
+            RD_LAUNCH("pfd.tie.from_levels", k_tie_from_levels, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)last_level,
+                      (const uint32_t *)cell_of, g, n);
+          } else if (gi && gi[0] == '0') {
             RD_HIP(hipMemcpyAsync(g, par, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
           } else if (!exact) {   // any tree: the greatest rank among a cell's ancestors says whether it has a greater one
             unsigned long long *st = pool8(0);
@@ -761,7 +792,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
             RD_LAUNCH("pfd.tie.g_init", k_tie_g_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)par, (const uint32_t *)rk, (const uint32_t *)F0,
                       g, n);
           }
-          for (int round = 0;; round++) {   // nearest ancestor of greater elevation
+          for (int round = 0; !from_levels; round++) {   // nearest ancestor of greater elevation
             RD_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
             RD_LAUNCH("pfd.tie.greater", k_tie_greater, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)rk, g, n, flag);
             RD_HIP(hipMemcpyAsync(hw, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -769,7 +800,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
             if (hw[0] == 0) break;
             if (round > 10000) throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the record tree did not settle (internal error)");
           }
-          RD_LAUNCH("pfd.tie.g_done", k_tie_g_done, dim3(sgrid(n)), dim3(NT), 0, s, g, n);
+          if (!from_levels) RD_LAUNCH("pfd.tie.g_done", k_tie_g_done, dim3(sgrid(n)), dim3(NT), 0, s, g, n);
           // ---- depth in T' (pointer doubling), cells bucketed by depth: pool thirds 0 / 1 ping-pong, 2 holds the cells ----
           uint32_t *ancA = pool4(0, 0), *dstA = pool4(0, 1), *ancB = pool4(1, 0), *dstB = pool4(1, 1), *cellsA = pool4(2, 0);
           RD_LAUNCH("pfd.tie.init", k_tie_init, dim3(sgrid(n)), dim3(NT), 0, s, (const uint32_t *)g, ancA, dstA, size, cellsA, n);
@@ -872,9 +903,11 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
         }
       } catch (...) {
         g_rank_pass = false;
+        g_last_level = nullptr;
         throw;
       }
       g_rank_pass = false;
+      g_last_level = nullptr;
       g_stats.twins = mine.twins;
       g_stats.levels = levels_total;
       g_stats.tie_passes = passes;
@@ -884,6 +917,13 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
     }
   }
   RD_LAUNCH("pfd.init", k_init_cand, dim3(sgrid(n)), dim3(NT), 0, s, cand, w, h);
+  T *last_level = nullptr;
+  if constexpr (std::is_same<T, uint32_t>::value) {
+    if (g_rank_pass && g_last_level) {
+      last_level = g_last_level;
+      RD_HIP(hipMemsetAsync(last_level, 0xFF, n * sizeof(uint32_t), s));   // T_ROOT: never wet -- no ancestor of greater rank
+    }
+  }
   if (w > 2 && h > 2) {
     T *F = ws.buf<T>("pfd.level", n);
     uint8_t *outlet = ws.buf<uint8_t>("pfd.outlet", n);
@@ -912,7 +952,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
         RD_LAUNCH("pfd.refine", (k_refine<T>), dim3(ncur), dim3(NT), 0, s, d_z, (const T *)F, cand, w, h, counters, sums + 2,
                   (const uint32_t *)cur_tiles);
         RD_LAUNCH("pfd.next_level", (k_next_level<T>), dim3(ncur), dim3(NT), 0, s, d_z, F, outlet, active, w, h, counters,
-                  (const uint32_t *)cur_tiles);
+                  (const uint32_t *)cur_tiles, last_level);
       }
       RD_HIP(hipMemsetAsync(lcounts, 0, 4 * sizeof(uint32_t), s));
       RD_LAUNCH("pfd.skip_state", k_skip_state, dim3((ftiles + NT - 1) / NT), dim3(NT), 0, s, skip, active, ftiles, ftx, scan_rows, lists,
@@ -928,7 +968,7 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
         t_last = now;
       }
       ncur = hcounts[2];
-      if (host[0] == 0 || host[1] == 0) break;                       // every cell decided / nothing wet any more
+      if ((host[0] == 0 && !last_level) || host[1] == 0) break;      // every cell decided (the levels themselves are wanted: to the last wet cell) / nothing wet any more
       if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
       last_open = host[0];
       last_wet = host[1];
