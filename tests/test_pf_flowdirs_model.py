@@ -23,3 +23,22 @@ def test_nested_fill_levels_give_the_pop_order(orc, case):
     assert np.unique(dem).size == dem.size
     got, levels = pf_flowdirs_model(dem, -9999.0)
     assert np.array_equal(got, orc.port.pf_flowdirs(dem, -9999.0)) and levels >= 1
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_the_levels_name_the_record_tree(orc, case):
+    """r05: after an exact flood csrc/pfdirs.hip builds the record tree (nearest ancestor of greater elevation in the tree of
+    directions) WITHOUT a search: parent'(c) = the cell whose elevation is the level of c's innermost pocket.  The numpy model of
+    the levels against the definition, on the oracle's directions."""
+    from proto_pf_flowdirs import record_parents_by_search, record_parents_from_levels
+    from richdem_amd.synth import fractal_dem
+
+    rng = np.random.default_rng(150 + case)
+    h, w = (int(v) for v in rng.integers(6, 48, 2))
+    if case % 2:
+        dem = rng.permutation(h * w).reshape(h, w).astype(np.float32)
+    else:
+        dem = fractal_dem(w, h, seed=170 + case).astype(np.float64) + rng.random((h, w)) * 1e-6
+    assert np.unique(dem).size == dem.size
+    dirs = orc.port.pf_flowdirs(dem, -9999.0)
+    assert np.array_equal(record_parents_from_levels(dem), record_parents_by_search(dem, dirs))

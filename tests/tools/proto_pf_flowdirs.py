@@ -46,7 +46,7 @@ def restricted_fill(z, domain, outlet):
     return F
 
 
-def pf_flowdirs_model(dem, nodata):
+def pf_flowdirs_model(dem, nodata, want_levels=False):
     z = dem.astype(np.float64)
     h, w = z.shape
     assert np.unique(z).size == z.size, "the model is for DEMs without equal elevations"
@@ -69,6 +69,8 @@ def pf_flowdirs_model(dem, nodata):
             hit[ok] = z[ny[ok], nx[ok]] == Fp[ys[ok], xs[ok]]
             outlet[ys[hit], xs[hit]] = True
         levels.append(restricted_fill(z, wet, outlet))
+    if want_levels:
+        return levels
     dirs = np.zeros((h, w), np.uint8)
     for y in range(h):
         for x in range(w):
@@ -93,6 +95,40 @@ def pf_flowdirs_model(dem, nodata):
     inner = np.zeros((h, w), bool); inner[1:-1, 1:-1] = True
     dirs[inner & (dem == nodata)] = 0
     return dirs, len(levels)
+
+
+def record_parents_from_levels(dem):
+    """parent' of every cell in the record tree (the nearest ancestor of greater elevation in the flood's tree of directions),
+    read off the nested fill levels alone: key(c) = (F_0(c), ..., z(c)) IS the path root -> c of that tree, so parent'(c) is
+    THE cell whose elevation is the level of c's innermost pocket (the last level at which c was still wet); -1: the root.
+    What csrc/pfdirs.hip does after an exact flood (k_next_level keeps that level, k_tie_from_levels looks the cell up)."""
+    z = dem.astype(np.float64)
+    h, w = z.shape
+    levels = pf_flowdirs_model(dem, None, want_levels=True)
+    last = np.full((h, w), np.nan)
+    for F in levels:
+        wet = np.isfinite(F) & (F > z)
+        last[wet] = F[wet]
+    cell_of = {float(v): i for i, v in enumerate(z.ravel())}
+    return np.array([-1 if np.isnan(v) else cell_of[float(v)] for v in last.ravel()], np.int64)
+
+
+def record_parents_by_search(dem, dirs):
+    """the same by definition: walk up the tree of directions to the first ancestor of greater elevation"""
+    z = dem.astype(np.float64).ravel()
+    h, w = dem.shape
+    par = np.full(h * w, -1, np.int64)
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            d = int(dirs[y, x])
+            par[y * w + x] = (y + D8[d][1]) * w + (x + D8[d][0])
+    g = np.full(h * w, -1, np.int64)
+    for c in range(h * w):
+        a = par[c]
+        while a >= 0 and z[a] < z[c]:
+            a = par[a]
+        g[c] = a
+    return g
 
 
 if __name__ == "__main__":
