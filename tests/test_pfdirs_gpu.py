@@ -129,7 +129,8 @@ def test_equal_elevations_equal_the_reference(rd, orc, monkeypatch):
         assert st["unresolved"] == 0, (name, st)
         assert np.array_equal(got, orc.port.pf_flowdirs(dem, nd)), ("tree iteration", name, st)
     monkeypatch.delenv("RDGPU_PFD_TREE_ITER")
-    for var, val in (("RDGPU_PFD_TREE_REFLOOD", "3"),          # a fresh level flood every third iteration
+    for var, val in (("RDGPU_PFD_LEVEL_TREE", "0"),            # the record tree by the ancestor search also after an exact flood
+                     ("RDGPU_PFD_TREE_REFLOOD", "3"),          # a fresh level flood every third iteration
                      ("RDGPU_PFD_TREE_REFLOOD_MOVED", "100000000"),   # ... after every iteration (the threshold always holds)
                      ("RDGPU_PFD_TREE_REFLOOD", "1000000")):   # ... only once the ranks rest: the tree alone iterated to its fixed point
         monkeypatch.setenv(var, val)
