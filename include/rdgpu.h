@@ -2,6 +2,9 @@
  * FillDepressions / pit_mask / d8_flow_directions / barnes_flat_resolution_d8 / ResolveFlatsEpsilon /
  * d8_flow_accum / FA_D8 / FA_Tarboton / FA_Quinn / FA_Holmgren / FA_Freeman / FlowAccumulation(props).
  *
+ * NaN elevations are unsupported input throughout (the reference's heaps and compares give them no defined place either;
+ * a float NoData value must be a number -- NaN never equals itself, so NaN "NoData" cells would count as data).
+ *
  * Plain pointers and sizes only.  Rasters are dense row-major, i = y*width + x,
  * no padding (reference: include/richdem/common/Array2D.hpp:592-595).  All
  * functions return 0 on success and a non-zero code on failure; the message is
@@ -81,6 +84,32 @@ int rdgpu_fill_dev_f64(double *d_dem, int width, int height, int topology, void 
 int rdgpu_fill_dev_i64(int64_t *d_dem, int width, int height, int topology, void *hip_stream);
 int rdgpu_fill_dev_u64(uint64_t *d_dem, int width, int height, int topology, void *hip_stream);
 
+/* HasDepressions<topology>(const Array2D<T>&) (depressions/Barnes2014.hpp:44-103; apps/rd_depressions_has.cpp:14):
+ * *out = 1 when the DEM holds a depression, i.e. when FillDepressions<topology> would raise at least one cell (the
+ * reference runs the flood of PriorityFlood_Original without raising and stops at the first cell discovered from a higher
+ * one, :91-95 -- the same predicate whatever its heap does among equal keys), 0 otherwise.  The DEM is not modified.
+ * PriorityFlood_Original<topology> (:136-198) returns the surface of FillDepressions<topology>: rdgpu_fill_<T>.
+ *
+ * PriorityFlood_Wei2018(Array2D<T>&) (depressions/Wei2018.hpp:154-202): the D8 fill whose seeds are the raster's edge
+ * cells AND every data cell next to a NoData cell (InitPriorityQue, :14-50): NoData cells are never altered and NoData
+ * regions inside the raster are outlets.  Equal to rdgpu_fill_<T> on rasters without NoData (tests/tests.cpp:259-262). */
+#define RDGPU_DECL_VARIANTS(SUF, T)                                                                                  \
+  int rdgpu_has_depressions_##SUF(const T *dem, int width, int height, int topology, int *out);                      \
+  int rdgpu_has_depressions_dev_##SUF(const T *d_dem, int width, int height, int topology, int *out, void *hip_stream); \
+  int rdgpu_fill_wei2018_##SUF(T *dem, T nodata, int width, int height);                                             \
+  int rdgpu_fill_wei2018_dev_##SUF(T *d_dem, T nodata, int width, int height, void *hip_stream);
+RDGPU_DECL_VARIANTS(u8, uint8_t)
+RDGPU_DECL_VARIANTS(i8, int8_t)
+RDGPU_DECL_VARIANTS(i16, int16_t)
+RDGPU_DECL_VARIANTS(u16, uint16_t)
+RDGPU_DECL_VARIANTS(i32, int32_t)
+RDGPU_DECL_VARIANTS(u32, uint32_t)
+RDGPU_DECL_VARIANTS(f32, float)
+RDGPU_DECL_VARIANTS(f64, double)
+RDGPU_DECL_VARIANTS(i64, int64_t)
+RDGPU_DECL_VARIANTS(u64, uint64_t)
+#undef RDGPU_DECL_VARIANTS
+
 /* PriorityFlood_Barnes2014_max_dep<topology>(Array2D<T>&, uint64_t max_dep_size) (depressions/Barnes2014.hpp:844-931;
  * apps/rd_depressions_flood.cpp:16-19 with a non-zero third argument): only depressions of at most max_dep_size
  * cells are filled, the others are left as they are.  "Depression" as the reference counts it: the cells below the
@@ -99,7 +128,8 @@ typedef struct rdgpu_max_dep_stats {
                                  clusters larger than the limit (0: the result is the reference's whatever its heap does) */
   uint64_t pocket_cells;      /* cells the plain fill would raise */
 } rdgpu_max_dep_stats;
-int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out);   /* of the calling thread's last max_dep fill */
+int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out);   /* of the calling thread's last max_dep fill; waits for that
+                                                                  call's stream (the `_dev_` entries themselves do not block) */
 #define RDGPU_DECL_MAXDEP(SUF, T)                                                                       \
   int rdgpu_fill_max_dep_##SUF(T *dem, int width, int height, int topology, uint64_t max_dep_size);     \
   int rdgpu_fill_max_dep_dev_##SUF(T *d_dem, int width, int height, int topology, uint64_t max_dep_size, void *hip_stream); \
@@ -178,10 +208,12 @@ int rdgpu_fill_epsilon_get_stats(rdgpu_epsilon_stats *out);
  * (GridCellZk_low_pq, common/grid_cell.hpp:101-122) and that order is reproduced as a fixed point -- an exact
  * flood of the raster's unique ranks, then passes over (tree of directions, ranks) until both reproduce themselves, a second
  * flood once the ranks rest (3 - 4 passes on float terrain, the breadth-first depth of the largest plateau on integer DEMs;
- * RDGPU_PFD_TREE_ITER=0: a flood in every pass).  The passes are BOUNDED: RDGPU_PFD_TIE_SECONDS (default 120,
- * checked between passes) and RDGPU_PFD_TIE_PASSES (default 1000); when a bound stops them the result is still an exact
- * flood of a stable order, stats.unresolved != 0 says how many ranks were still moving (the C++ shim logs one line to
- * stderr, the Python layer raises a RuntimeWarning).  RDGPU_PFD_RANKS=0 is the FAST path for callers who do not need the
+ * RDGPU_PFD_TREE_ITER=0: a flood in every pass).  The passes are BOUNDED by a count, RDGPU_PFD_TIE_PASSES (default 1000:
+ * deterministic -- the same DEM gives the same raster on every machine); a wall-time bound is opt-in
+ * (RDGPU_PFD_TIE_SECONDS=<seconds>, checked between passes: a result stopped by the clock is NOT reproducible across
+ * machines or host loads).  When a bound stops the passes the call still returns RDGPU_OK, the result is an exact flood of a
+ * stable order and stats.unresolved != 0 says how many ranks were still moving (the C++ shim logs one line to stderr, the
+ * Python layer raises a RuntimeWarning): callers that need the reference's tie order must read the stats.  RDGPU_PFD_RANKS=0 is the FAST path for callers who do not need the
  * reference's tie order: one flood, ties decided by neighbour number (seconds instead of tens of seconds at 40000^2);
  * stats.unresolved then counts the cells where a tie decided.  One fill per nesting level of the depressions per flood. */
 typedef struct rdgpu_pf_flowdirs_stats {

@@ -110,6 +110,19 @@ int c_fm_dinf(const T *, T, int, int, float *) { unsupported("FM_Tarboton"); }
 template <class T>
 int c_fm_mfd(const T *, T, int, int, int, double, float *) { unsupported("FM_Holmgren / FM_Freeman / FM_Quinn / FM_D4"); }
 
+#define RDGPU_SHIM_VARIANTS(SUF, T)                                                                          \
+  inline int c_hasdep(const T *p, int w, int h, int t, int *o) { return rdgpu_has_depressions_##SUF(p, w, h, t, o); } \
+  inline int c_fill_wei(T *p, T nd, int w, int h) { return rdgpu_fill_wei2018_##SUF(p, nd, w, h); }
+RDGPU_SHIM_VARIANTS(u8, uint8_t) RDGPU_SHIM_VARIANTS(i8, int8_t) RDGPU_SHIM_VARIANTS(i16, int16_t)
+RDGPU_SHIM_VARIANTS(u16, uint16_t) RDGPU_SHIM_VARIANTS(i32, int32_t) RDGPU_SHIM_VARIANTS(u32, uint32_t)
+RDGPU_SHIM_VARIANTS(f32, float) RDGPU_SHIM_VARIANTS(f64, double) RDGPU_SHIM_VARIANTS(i64, int64_t)
+RDGPU_SHIM_VARIANTS(u64, uint64_t)
+#undef RDGPU_SHIM_VARIANTS
+template <class T>
+int c_hasdep(const T *, int, int, int, int *) { unsupported("HasDepressions"); }
+template <class T>
+int c_fill_wei(T *, T, int, int) { unsupported("PriorityFlood_Wei2018"); }
+
 #define RDGPU_SHIM_PITMASK(SUF, T) \
   inline int c_pitmask(const T *p, T nd, int w, int h, int topo, uint8_t *m) { return rdgpu_pit_mask_##SUF(p, nd, w, h, topo, m); }
 RDGPU_SHIM_PITMASK(u8, uint8_t)
@@ -215,6 +228,32 @@ void PriorityFlood_Barnes2014(A &dem) {
 template <auto topo, class A>
 void FillDepressions(A &dem) {
   detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()), "FillDepressions");
+}
+
+// richdem::PriorityFlood_Original<topo>(Array2D<T>&)      depressions/Barnes2014.hpp:136-198: the surface of
+// FillDepressions<topo> (every flood of this family returns it, tests/tests.cpp:233-271)
+template <auto topo, class A>
+void PriorityFlood_Original(A &dem) {
+  detail::check(detail::c_fill(dem.data(), dem.width(), dem.height(), detail::topology_code<topo>()), "PriorityFlood_Original");
+}
+
+// richdem::PriorityFlood_Wei2018(Array2D<T>&)             depressions/Wei2018.hpp:154-202: D8; NoData cells are left alone
+// and the data cells next to them are seeds beside the raster's edge cells (InitPriorityQue, :14-50)
+template <class A>
+void PriorityFlood_Wei2018(A &dem) {
+  using T = detail::elem_t<A>;
+  if (dem.width() == 0 || dem.height() == 0) return;
+  detail::check(detail::c_fill_wei((T *)dem.data(), dem.noData(), dem.width(), dem.height()), "PriorityFlood_Wei2018");
+}
+
+// richdem::HasDepressions<topo>(const Array2D<T>&)        depressions/Barnes2014.hpp:44-103 (apps/rd_depressions_has.cpp:14)
+template <auto topo, class A>
+bool HasDepressions(const A &elevations) {
+  if (elevations.width() == 0 || elevations.height() == 0) return false;   // (an empty queue: "No depressions found.")
+  int found = 0;
+  detail::check(detail::c_hasdep(elevations.data(), elevations.width(), elevations.height(), detail::topology_code<topo>(), &found),
+                "HasDepressions");
+  return found != 0;
 }
 
 // richdem::PriorityFlood_Barnes2014_max_dep<topo>(Array2D<T>&, uint64_t max_dep_size)   depressions/Barnes2014.hpp:844-931

@@ -113,6 +113,30 @@ class _Backend:
             self._fn(f"fill_{s}")(_ptr(out), w, h, int(topo))
         return out
 
+    def fill_wei2018(self, dem: np.ndarray, nodata) -> np.ndarray:
+        """PriorityFlood_Wei2018 (depressions/Wei2018.hpp:154-202) with the raster's NoData value set."""
+        out = np.ascontiguousarray(dem).copy()
+        h, w = out.shape
+        s = _suf(out)
+        self._fn(f"fill_wei2018_{s}")(_ptr(out), _CT[s](nodata), w, h)
+        return out
+
+    def fill_original(self, dem: np.ndarray, topo: int = 8) -> np.ndarray:
+        """PriorityFlood_Original<topo> (depressions/Barnes2014.hpp:136-198); the restatement's fill returns the same surface."""
+        out = np.ascontiguousarray(dem).copy()
+        h, w = out.shape
+        s = _suf(out)
+        self._fn(f"fill_original_{s}" if self.prefix == "ref" else f"fill_{s}")(_ptr(out), w, h, int(topo))
+        return out
+
+    def has_depressions(self, dem: np.ndarray, topo: int = 8) -> bool:
+        """HasDepressions<topo> (depressions/Barnes2014.hpp:44-103)."""
+        dem = np.ascontiguousarray(dem)
+        h, w = dem.shape
+        f = getattr(self.lib, f"{self.prefix}_has_depressions_{_suf(dem)}")
+        f.restype = ctypes.c_int
+        return bool(f(_ptr(dem), w, h, int(topo)))
+
     # ---- directions -------------------------------------------------------------------------
     def d8_flowdirs(self, dem: np.ndarray, nodata) -> np.ndarray:
         dem = np.ascontiguousarray(dem)

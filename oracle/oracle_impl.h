@@ -787,6 +787,89 @@ void FN(orc_fill_max_dep)(T *dem, int w, int h, int topo, uint64_t max_dep_size)
   free(closed); free(heap); free(pit); free(dep);
 }
 
+/* HasDepressions<topo>, depressions/Barnes2014.hpp:44-103: the flood of PriorityFlood_Original (:136-198) on the
+ * UNRAISED elevations; the first cell discovered from a strictly higher one ends it with "true" (:91-95). */
+int FN(orc_has_depressions)(const T *dem, int w, int h, int topo) {
+  const int *dx = topo == 4 ? D4X : D8X, *dy = topo == 4 ? D4Y : D8Y;
+  const int nmax = topo == 4 ? 4 : 8;
+  size_t N = (size_t)w * h;
+  int8_t *closed = (int8_t *)calloc(N, 1);                     /* :62 */
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  int found = 0;
+  FN(seed_border)(dem, w, h, closed, &heap, &hn, &hcap);       /* :69-80 */
+  while (hn > 0 && !found) {                                   /* :84-99 */
+    FN(hcell) c = FN(heap_pop)(heap, &hn);
+    for (int n = 1; n <= nmax; n++) {
+      int nx = c.x + dx[n], ny = c.y + dy[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (closed[ni]) continue;
+      closed[ni] = 1;
+      if (dem[ni] < dem[(size_t)c.y * w + c.x]) { found = 1; break; }   /* :91-95 */
+      FN(hcell) o = {dem[ni], nx, ny};
+      FN(heap_push)(&heap, &hn, &hcap, o);
+    }
+  }
+  free(closed); free(heap);
+  return found;
+}
+
+/* PriorityFlood_Wei2018, depressions/Wei2018.hpp:154-202.  What distinguishes it from the other fills is its seeding
+ * (InitPriorityQue, :14-50): NoData cells are flagged up front and never altered, and every data cell next to one is a seed
+ * at its own elevation beside the raster's edge cells.  The flood itself (ProcessPit :124-150 raising cells <= the spill
+ * level, ProcessTraceQue :54-120 deciding which slope cells need the heap at all) produces the Priority-Flood surface over
+ * those seeds; it is restated here as the plain flood of orc_fill (heap + pit queue) with Wei's seeds and flags, which
+ * tests/test_oracle_pinning.py holds against the compiled reference on rasters with NoData holes. */
+void FN(orc_fill_wei2018)(T *dem, T nodata, int w, int h) {
+  size_t N = (size_t)w * h;
+  int8_t *flag = (int8_t *)calloc(N, 1);                       /* :166 */
+  FN(hcell) *heap = NULL; size_t hn = 0, hcap = 0;
+  FN(hcell) *pit = (FN(hcell) *)malloc(N * sizeof(FN(hcell)));
+  size_t ph = 0, pt = 0;
+  for (int y = 0; y < h; y++)                                  /* InitPriorityQue :23-49 */
+    for (int x = 0; x < w; x++) {
+      size_t i = (size_t)y * w + x;
+      if (flag[i]) continue;
+      if (dem[i] == nodata) {
+        flag[i] = 1;
+        for (int n = 1; n <= 8; n++) {
+          int nx = x + D8X[n], ny = y + D8Y[n];
+          if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+          size_t ni = (size_t)ny * w + nx;
+          if (flag[ni] || dem[ni] == nodata) continue;
+          FN(hcell) o = {dem[ni], nx, ny};
+          FN(heap_push)(&heap, &hn, &hcap, o);
+          flag[ni] = 1;
+        }
+      } else if (x == 0 || y == 0 || x == w - 1 || y == h - 1) {
+        FN(hcell) o = {dem[i], x, y};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+        flag[i] = 1;
+      }
+    }
+  while (hn > 0 || ph < pt) {                                  /* :171-197 */
+    FN(hcell) c;
+    if (ph < pt) c = pit[ph++];
+    else c = FN(heap_pop)(heap, &hn);
+    for (int n = 1; n <= 8; n++) {
+      int nx = c.x + D8X[n], ny = c.y + D8Y[n];
+      if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
+      size_t ni = (size_t)ny * w + nx;
+      if (flag[ni]) continue;
+      flag[ni] = 1;
+      if (dem[ni] <= c.z) {                                    /* depression cell, :184-189 / ProcessPit :143-146 */
+        dem[ni] = c.z;
+        FN(hcell) p = {c.z, nx, ny};
+        pit[pt++] = p;
+      } else {                                                 /* slope cell, :190-194 */
+        FN(hcell) o = {dem[ni], nx, ny};
+        FN(heap_push)(&heap, &hn, &hcap, o);
+      }
+    }
+  }
+  free(flag); free(heap); free(pit);
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

@@ -343,6 +343,39 @@ void ref_pf_flowdirs(T *dem, T nodata, int w, int h, uint8_t *dirs) {
   PriorityFloodFlowdirs_Barnes2014(a, fd);
   std::memcpy(dirs, fd.data(), (size_t)w * h);
 }
+// PriorityFlood_Wei2018 with a NoData value (Wei2018.hpp:154-202; InitPriorityQue :14-50 seeds the neighbours of NoData cells),
+// PriorityFlood_Original<topo> (Barnes2014.hpp:136-198), HasDepressions<topo> (:44-103)
+template <class T>
+void ref_fill_wei2018(T *dem, T nodata, int w, int h) {
+  Array2D<T> a(dem, w, h);
+  a.setNoData(nodata);
+  PriorityFlood_Wei2018(a);
+}
+template <class T>
+void ref_fill_original(T *dem, int w, int h, int topo) {
+  Array2D<T> a(dem, w, h);
+  if (topo == 8) PriorityFlood_Original<Topology::D8>(a);
+  else PriorityFlood_Original<Topology::D4>(a);
+}
+template <class T>
+int ref_has_depressions(const T *dem, int w, int h, int topo) {
+  Array2D<T> a(const_cast<T *>(dem), w, h);
+  return (topo == 8 ? HasDepressions<Topology::D8>(a) : HasDepressions<Topology::D4>(a)) ? 1 : 0;
+}
+#define REF_VARIANTS_API(SUF, T)                                                                                              \
+  extern "C" void ref_fill_wei2018_##SUF(T *dem, T nodata, int w, int h) { ref_fill_wei2018<T>(dem, nodata, w, h); }          \
+  extern "C" void ref_fill_original_##SUF(T *dem, int w, int h, int topo) { ref_fill_original<T>(dem, w, h, topo); }          \
+  extern "C" int ref_has_depressions_##SUF(const T *dem, int w, int h, int topo) { return ref_has_depressions<T>(dem, w, h, topo); }
+REF_VARIANTS_API(u8, uint8_t)
+REF_VARIANTS_API(i8, int8_t)
+REF_VARIANTS_API(i16, int16_t)
+REF_VARIANTS_API(u16, uint16_t)
+REF_VARIANTS_API(i32, int32_t)
+REF_VARIANTS_API(u32, uint32_t)
+REF_VARIANTS_API(f32, float)
+REF_VARIANTS_API(f64, double)
+REF_VARIANTS_API(i64, int64_t)
+REF_VARIANTS_API(u64, uint64_t)
 #define REF_F2_API(SUF, T)                                                                                                    \
   extern "C" void ref_watersheds_##SUF(T *dem, T nodata, int w, int h, int topo, int alter, int32_t *labels) {                \
     ref_watersheds<T>(dem, nodata, w, h, topo, alter, labels);                                                                \

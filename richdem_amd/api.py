@@ -117,6 +117,39 @@ def FillDepressions(dem: np.ndarray, epsilon: bool = False, in_place: bool = Fal
     return None if in_place else out
 
 
+def has_depressions(dem: np.ndarray, topology="D8") -> bool:
+    """HasDepressions<topo> (depressions/Barnes2014.hpp:44-103; apps/rd_depressions_has.cpp): True when the fill would
+    raise at least one cell of ``dem``."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("has_depressions: expected a 2-D numpy array")
+    dem = np.ascontiguousarray(dem)
+    h, w = dem.shape
+    if w == 0 or h == 0:
+        return False
+    out = ctypes.c_int(0)
+    check(getattr(lib(), f"rdgpu_has_depressions_{_suffix(dem.dtype)}")(dem.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology),
+                                                                          ctypes.byref(out)), "rdgpu_has_depressions")
+    return bool(out.value)
+
+
+def fill_wei2018(dem: np.ndarray, nodata=-9999, in_place: bool = False):
+    """PriorityFlood_Wei2018 (depressions/Wei2018.hpp:154-202): the D8 fill in which NoData cells stay as they are and the
+    data cells next to them drain like the raster's edge cells (InitPriorityQue, :14-50)."""
+    if not isinstance(dem, np.ndarray) or dem.ndim != 2:
+        raise RdgpuError("fill_wei2018: expected a 2-D numpy array")
+    out = dem if in_place else dem.copy()
+    if not out.flags["C_CONTIGUOUS"]:
+        if in_place:
+            raise RdgpuError("fill_wei2018(in_place=True) needs a C-contiguous array")
+        out = np.ascontiguousarray(out)
+    s = _suffix(out.dtype)
+    h, w = out.shape
+    if w and h:
+        check(getattr(lib(), f"rdgpu_fill_wei2018_{s}")(out.ctypes.data_as(ctypes.c_void_p), _scalar(s, nodata), w, h),
+              "rdgpu_fill_wei2018")
+    return None if in_place else out
+
+
 def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bool = False):
     """PriorityFlood_Barnes2014_max_dep<topo> (depressions/Barnes2014.hpp:844-931; rd_depressions_flood's third
     argument): only depressions of at most ``max_dep_size`` cells are filled."""
@@ -134,7 +167,7 @@ def fill_max_dep(dem: np.ndarray, max_dep_size: int, topology="D8", in_place: bo
     check(getattr(lib(), f"rdgpu_fill_max_dep_{s}")(out.ctypes.data_as(ctypes.c_void_p), w, h, _topo(topology),
                                                     ctypes.c_uint64(int(max_dep_size))), "rdgpu_fill_max_dep")
     st = max_dep_stats()   # (64-bit element types run on dense value ranks through the same engine: equal values, equal ranks)
-    if st["tie_pockets"]:
+    if st["tie_cluster_cells"]:   # (cells whose fate the order can actually decide; pockets with two candidates alone are common)
         warnings.warn(f"fill_max_dep: {st['tie_pockets']} of {st['pockets']} pockets can be flooded by two or more cells of their "
                       f"spill elevation; in their clusters ({st['tie_cluster_cells']} of {st['pocket_cells']} pocket cells) the "
                       "reference's grouping follows its heap's pop order, this engine's the lowest cell index", RuntimeWarning)

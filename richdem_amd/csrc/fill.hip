@@ -1909,10 +1909,14 @@ __global__ __launch_bounds__(NTHR) void k_md_tie_mask(const T *__restrict__ z, c
   }
 }
 static thread_local rdgpu_max_dep_stats g_md_stats;
+static thread_local unsigned long long *g_md_pinned = nullptr;   // the tie detector's counts of the last call, once its stream got there
+static thread_local bool g_md_pending = false;
+static thread_local hipStream_t g_md_stream = nullptr;
 
 template <class T, int TOPO>
 static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStream_t s, uint8_t *d_tie_mask = nullptr) {
   g_md_stats = rdgpu_max_dep_stats{0, 0, 0, 0};
+  g_md_pending = false;
   if (d_tie_mask) RD_HIP(hipMemsetAsync(d_tie_mask, 0, (size_t)w * h, s));
   FillBuffers fb;
   BufAlloc ws_alloc{false, nullptr};
@@ -1944,10 +1948,12 @@ static void fill_max_dep_device_t(T *d_z, int w, int h, uint64_t max_dep, hipStr
     RD_LAUNCH("maxdep.tie_mask", (k_md_tie_mask<T>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
               (const uint32_t *)fb.acc, par, par2, (const uint32_t *)flag, (const uint32_t *)sizeP, (const uint32_t *)size2, max_dep,
               d_tie_mask, counts, n, B);
-    unsigned long long hc[4];
-    RD_HIP(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    g_md_stats = rdgpu_max_dep_stats{hc[0], hc[1], hc[2], hc[3]};
+    // the counts come back LAZILY (the stream-ordered `_dev_` entry must not block the host): copied into a pinned
+    // word block behind the kernels, read by rdgpu_fill_max_dep_get_stats after it has waited for this stream
+    if (!g_md_pinned) RD_HIP(hipHostMalloc((void **)&g_md_pinned, 4 * sizeof(unsigned long long)));
+    RD_HIP(hipMemcpyAsync(g_md_pinned, counts, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    g_md_pending = true;
+    g_md_stream = s;
   }
   RD_LAUNCH("maxdep.spawn", (k_md_spawn<T, TOPO, 0>), dim3(sgrid), dim3(NTHR), 0, s, (const T *)d_z, (const uint32_t *)fb.lab,
             (const uint32_t *)fb.acc, par, spawn, w, h, B);
@@ -3108,14 +3114,18 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   const bool dedup = !(env_dedup && env_dedup[0] == '0');
   const char *env_pc = getenv("RDGPU_FILL_PRECHECK");
   const char *env_st = getenv("RDGPU_FILL_PAIRS_STRIDED");
-  // RDGPU_FILL_PAIRS_ABLATE (timing probes only -- the fill's RESULT IS WRONG with any bit set): 4 = no pair loop (phase 2),
+  // RDGPU_FILL_PAIRS_ABLATE (timing probes only, compiled in with -DRDGPU_PROBES -- the fill's RESULT IS WRONG with any bit set): 4 = no pair loop (phase 2),
   // 8 = no proposals and no records (phase 3), 16 = no boundary list (phase 1), 32 = the pair loop without its table trips,
   // 64 = the pair loop's gathers alone: what each part costs, tools/probes/pairs_ablate.sh.  r05 at S3 (profiles/r05e_*):
   // staging + detection 2.5 ms, list 0.4, gathers 0.45, sorting the neighbours 1.0, table 1.8, proposals + records 0.5 = 6.1.
   // Built on that and measured SLOWER or equal, not kept: the pair pass on local component ids with a direct triangular pair
   // table (9.5 ms: its LDS atomics and the id lookups cost more than the hash they replace), one table trip per cell with
   // the cells of a second component on a wavefront's own list (6.1-6.2), a two-slot fast path (6.2).
+#ifdef RDGPU_PROBES   // (a stray environment variable must not be able to corrupt a production fill)
   const char *env_ab = getenv("RDGPU_FILL_PAIRS_ABLATE");
+#else
+  const char *env_ab = nullptr;
+#endif
   const int precheck = (!(env_pc && env_pc[0] == '0') ? 1 : 0) | (!(env_st && env_st[0] == '0') ? 2 : 0) | (env_ab ? (atoi(env_ab) & 124) : 0);
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);
@@ -3742,6 +3752,11 @@ extern "C" int rdgpu_fill_shard_free(rdgpu_fill_shard *sh) {
 
 extern "C" int rdgpu_fill_max_dep_get_stats(rdgpu_max_dep_stats *out) {
   if (!out) return RDGPU_ERR_ARG;
+  if (g_md_pending) {
+    if (hipStreamSynchronize(g_md_stream) != hipSuccess) { set_last_error("rdgpu_fill_max_dep_get_stats: hipStreamSynchronize failed"); return RDGPU_ERR_HIP; }
+    g_md_stats = rdgpu_max_dep_stats{g_md_pinned[0], g_md_pinned[1], g_md_pinned[2], g_md_pinned[3]};
+    g_md_pending = false;
+  }
   *out = g_md_stats;
   return RDGPU_OK;
 }

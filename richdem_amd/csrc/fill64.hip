@@ -224,6 +224,20 @@ static void pf_flowdirs64_device(const T *d_z, T nodata, int w, int h, uint8_t *
   if (rc) throw Error(rc, rdgpu_last_error());
 }
 
+// PriorityFlood_Wei2018 (depressions/Wei2018.hpp:154-202) compares and copies elevations and tests cells against NoData:
+// the u32 engine (variants.hip) on the ranks, NoData as its rank
+extern "C" int rdgpu_fill_wei2018_dev_u32(uint32_t *, uint32_t, int, int, void *);
+template <class T>
+static void wei2018_64_device(T *d_z, T nodata, int w, int h, hipStream_t s) {
+  check64(d_z, w, h, 8, "rdgpu_fill_wei2018");
+  const uint64_t n = (uint64_t)w * h;
+  const Ranks r = dense_ranks<T>(d_z, n, s);
+  const int rc = rdgpu_fill_wei2018_dev_u32(r.rk, nodata_rank<T>(r, nodata, s), w, h, s);
+  if (rc) throw Error(rc, rdgpu_last_error());
+  RD_LAUNCH("fill64.ranks_back", (k_ranks_back<T>), dim3(sgrid(n)), dim3(NTHR), 0, s, d_z, (const uint32_t *)r.rk,
+            (const uint64_t *)r.uniq, n);
+}
+
 // host-pointer forms: H2D, the device form, D2H of what the call produces
 template <class T, class F>
 static void with_device_copy(T *dem, int w, int h, bool copy_back, F &&fn) {
@@ -359,3 +373,14 @@ RD_F2_64_API(u64, uint64_t)
 RD_PFD64_API(f64, double)
 RD_PFD64_API(i64, int64_t)
 RD_PFD64_API(u64, uint64_t)
+
+#define RD_WEI64_API(SUF, T)                                                                                           \
+  extern "C" int rdgpu_fill_wei2018_dev_##SUF(T *d_dem, T nodata, int w, int h, void *stream) {                        \
+    return guarded([&] { wei2018_64_device<T>(d_dem, nodata, w, h, (hipStream_t)stream); });                           \
+  }                                                                                                                    \
+  extern "C" int rdgpu_fill_wei2018_##SUF(T *dem, T nodata, int w, int h) {                                            \
+    return guarded([&] { with_device_copy<T>(dem, w, h, true, [&](T *d) { wei2018_64_device<T>(d, nodata, w, h, nullptr); }); }); \
+  }
+RD_WEI64_API(f64, double)
+RD_WEI64_API(i64, int64_t)
+RD_WEI64_API(u64, uint64_t)

@@ -704,14 +704,15 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       const rdgpu_pf_flowdirs_stats mine = g_stats;
       const char *tp = getenv("RDGPU_PFD_TIE_PASSES");   // passes of the tie order's fixed point (0: raster order, r04's first version)
       // Each pass settles one more "generation" of tie decisions: 2 - 4 on float terrain, but one breadth-first RING of the
-      // largest plateau on integer DEMs -- min(w, h) / 2 passes for an ocean.  Bounded twice: by wall time
-      // (RDGPU_PFD_TIE_SECONDS, default 120 s, checked between passes: small rasters finish, a 40000^2 ocean does not run for
-      // hours) and by a count (RDGPU_PFD_TIE_PASSES, default 1000);
+      // largest plateau on integer DEMs -- min(w, h) / 2 passes for an ocean.  Bounded by a COUNT (RDGPU_PFD_TIE_PASSES,
+      // default 1000): deterministic, the same DEM gives the same raster on every machine.  A wall-time bound is opt-in
+      // (RDGPU_PFD_TIE_SECONDS=<s>, checked between passes; ADVICE r05: a result cut off by the clock is not reproducible
+      // across machines or loads, so it is never the default);
       // when a bound stops the iteration the result is an exact flood of SOME stable order, `unresolved` says how many
       // ranks were still moving and the host wrappers warn.
       const uint32_t max_passes = (w <= 2 || h <= 2) ? 0u : tp ? (uint32_t)strtoul(tp, nullptr, 10) : 1000u;   // (no interior cell: no tie to order)
       const char *tsec = getenv("RDGPU_PFD_TIE_SECONDS");
-      const double max_seconds = tsec ? atof(tsec) : 120.0;
+      const double max_seconds = tsec ? atof(tsec) : std::numeric_limits<double>::infinity();
       const auto t_tie0 = std::chrono::steady_clock::now();
       uint32_t passes = 0, levels_total = 0;
       unsigned long long moved = (w <= 2 || h <= 2) ? 0ull : (unsigned long long)g_stats.twins;   // no re-rank pass ran: every twin's place is undecided
@@ -969,7 +970,13 @@ void pf_flowdirs_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, h
       }
       ncur = hcounts[2];
       if ((host[0] == 0 && !last_level) || host[1] == 0) break;      // every cell decided (the levels themselves are wanted: to the last wet cell) / nothing wet any more
-      if (host[0] == last_open && host[1] == last_wet) break;        // no progress: equal elevations (see the header)
+      if (host[0] == last_open && host[1] == last_wet) {             // no progress: equal elevations (see the header)
+        //  in a rank pass the levels are tie free, the wet count shrinks strictly and this exit cannot be taken with
+        // wet cells left; if it ever were, last_level -- and the record tree read off it -- would be silently incomplete
+        if (g_rank_pass && last_level && host[1] != 0)
+          throw Error(RDGPU_ERR_HIP, "rdgpu_pf_flowdirs: the level flood of a rank raster stalled with wet cells left (internal error)");
+        break;
+      }
       last_open = host[0];
       last_wet = host[1];
       check_rc(Calls<T>::fill_outlets(F, outlet, skip, sparse ? lists : nullptr, stride, hcounts, w, h, (void *)s));

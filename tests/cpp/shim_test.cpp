@@ -32,6 +32,8 @@ extern "C" {
 void orc_fill_f32(float *, int, int, int);
 void orc_fill_i32(int32_t *, int, int, int);
 void orc_fill_f64(double *, int, int, int);
+void orc_fill_wei2018_f32(float *, float, int, int);
+int orc_has_depressions_f32(const float *, int, int, int);
 void orc_flat_resolution_f32(const float *, float, int, int, uint8_t *);
 void orc_flat_resolution_alter_f32(float *, float, int, int, uint8_t *);
 void orc_d8_flowdirs_f32(const float *, float, int, int, uint8_t *);
@@ -84,6 +86,28 @@ int main() {
     Arr<float> d4 = dem;
     rdgpu::PriorityFlood_Barnes2014<Topo::D4>(d4);
     EXPECT(d4 == c);
+  }
+  // the sweep's other names (reference tests/tests.cpp:233-271): PriorityFlood_Original<topo>, PriorityFlood_Wei2018 with NoData
+  // holes as outlets (Wei2018.hpp:14-50), HasDepressions<topo> (apps/rd_depressions_has.cpp:14)
+  {
+    Arr<float> a = dem, b = dem;
+    rdgpu::PriorityFlood_Original<Topo::D8>(a);
+    rdgpu::FillDepressions<Topo::D8>(b);
+    EXPECT(a == b);
+    Arr<float> hole = dem;
+    for (int y = 90; y < 104; y++)
+      for (int x = 120; x < 180; x++) hole(x, y) = -9999.0f;
+    std::vector<float> e(hole.data(), hole.data() + (size_t)w * h);
+    orc_fill_wei2018_f32(e.data(), -9999.0f, w, h);
+    Arr<float> plain = hole;
+    rdgpu::PriorityFlood_Wei2018(hole);
+    EXPECT(std::memcmp(hole.data(), e.data(), e.size() * 4) == 0);
+    rdgpu::FillDepressions<Topo::D8>(plain);
+    EXPECT(!(plain == hole));
+    EXPECT(rdgpu::HasDepressions<Topo::D8>(dem) == (orc_has_depressions_f32(dem.data(), w, h, 8) != 0));
+    EXPECT(rdgpu::HasDepressions<Topo::D8>(dem));
+    EXPECT(!rdgpu::HasDepressions<Topo::D8>(b));
+    EXPECT(!rdgpu::HasDepressions<Topo::D4>(Arr<float>(5, 4, 1.0f)));
   }
   // wrapping (externally owned) integer memory: the numpy -> Array2D(T*,w,h) path of the Python wrapper
   {

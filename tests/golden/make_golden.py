@@ -10,6 +10,8 @@
                         tests/tests.cpp:273-287) and outputs of the compiled reference's PriorityFloodEpsilon /
                         PriorityFloodWatersheds / PriorityFlood_Barnes2014_max_dep on seeded DEMs WITHOUT equal
                         elevations (with ties those three depend on std::priority_queue's pop order).
+* ref_variants.npz   -- (--variants) PriorityFlood_Wei2018 (NoData holes as outlets), PriorityFlood_Original<D8/D4>,
+                        HasDepressions<D8/D4> of the compiled reference on seeded rasters.
 * ref_generated.npz  -- outputs of the UNMODIFIED reference headers (oracle/_ref/libref.so) on seeded
                         inputs, for the functions the reference has no golden file for
                         (d8_flow_directions, barnes_flat_resolution_d8, FA_D8, fill on float/int DEMs).
@@ -88,6 +90,48 @@ def main():
             gen[f"{name}/{tag}/fa_d8"] = R.fa_d8(src, nd)
     np.savez_compressed(os.path.join(HERE, "ref_generated.npz"), **gen)
     print("wrote", len(fx), "fixture arrays and", len(gen), "generated arrays")
+
+
+def variant_cases():
+    """Seeded rasters for PriorityFlood_Wei2018 / PriorityFlood_Original / HasDepressions: NoData holes inside the raster
+    (Wei2018 drains into them), NoData on the border, none at all, a raster without depressions."""
+    rng = np.random.default_rng(6)
+    cases = {}
+    z = fractal_dem(130, 97, 61).copy()
+    cases["plain_f32"] = (z, np.float32(-9999))
+    holes = z.copy()
+    holes[40:47, 50:61] = -9999
+    holes[80, 20] = -9999
+    holes[10:12, 100:103] = -9999
+    holes[0:5, 0:9] = -9999
+    cases["holes_f32"] = (holes, np.float32(-9999))
+    q = np.floor((fractal_dem(83, 140, 62) + 1200) * 0.05).astype(np.int32)
+    q[rng.random(q.shape) < 0.01] = -1
+    cases["holes_i32"] = (q, np.int32(-1))
+    u = np.floor((fractal_dem(70, 66, 63) + 1200) * 0.02).astype(np.uint8)
+    u[30:33, 30:36] = 0          # NoData = 0, lower than everything, as the reference's precondition has it
+    cases["holes_u8"] = (u, np.uint8(0))
+    d = fractal_dem(64, 71, 64).astype(np.float64) + 1e-9 * np.arange(64 * 71).reshape(71, 64)
+    d[20:24, 5:15] = -9999
+    cases["holes_f64"] = (d, np.float64(-9999))
+    yy, xx = np.mgrid[0:50, 0:60]
+    cases["cone_f32"] = ((np.hypot(yy - 25, xx - 30) * -1.0).astype(np.float32), np.float32(-9999))   # no depression
+    cases["bowl_i16"] = ((np.hypot(yy - 25, xx - 30) * 3).astype(np.int16), np.int16(-9999))           # one big one
+    return cases
+
+
+def variants():
+    oracle.build()
+    R = oracle.ref
+    g = {}
+    for name, (dem, nd) in variant_cases().items():
+        g[f"{name}/dem"], g[f"{name}/nodata"] = dem, nd
+        g[f"{name}/wei2018"] = R.fill_wei2018(dem, nd)
+        for topo in (8, 4):
+            g[f"{name}/original_d{topo}"] = R.fill_original(dem, topo)
+            g[f"{name}/has_depressions_d{topo}"] = np.bool_(R.has_depressions(dem, topo))
+    np.savez_compressed(os.path.join(HERE, "ref_variants.npz"), **g)
+    print("wrote", len(g), "variant arrays")
 
 
 def tie_free(dem, nodata=-9999.0):
@@ -369,6 +413,9 @@ if __name__ == "__main__":
         s3_f2(sys.argv[sys.argv.index("--s3-f2") + 1], size)
     elif "--f2" in sys.argv:
         f2()
+    elif "--variants" in sys.argv:
+        variants()
     else:
         main()
         f2()
+        variants()

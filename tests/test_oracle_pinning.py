@@ -198,3 +198,41 @@ def test_alter_true_on_integer_dems_port_equals_reference(orc, dtype, offset):
     a_dem, a_dirs = orc.port.flat_resolution_alter(dem, nd)
     b_dem, b_dirs = orc.ref.flat_resolution_alter(dem, nd)
     assert a_dem.tobytes() == b_dem.tobytes() and np.array_equal(a_dirs, b_dirs) and (a_dem != dem).any()
+
+
+def _variants():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_variants.npz"))
+
+
+def test_variants_restatement_matches_reference_vectors(orc):
+    """PriorityFlood_Wei2018 (NoData holes are outlets, Wei2018.hpp:14-50), PriorityFlood_Original<D8/D4>
+    (Barnes2014.hpp:136-198), HasDepressions<D8/D4> (:44-103): the restatement against the compiled reference's outputs
+    (tests/golden/make_golden.py --variants)."""
+    g = _variants()
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 7
+    differs = 0
+    for n in names:
+        dem, nd = g[f"{n}/dem"], g[f"{n}/nodata"].item()
+        wei = orc.port.fill_wei2018(dem, nd)
+        assert np.array_equal(wei, g[f"{n}/wei2018"]), n
+        differs += int((wei != g[f"{n}/original_d8"]).sum())
+        for topo in (8, 4):
+            assert np.array_equal(orc.port.fill_original(dem, topo), g[f"{n}/original_d{topo}"]), (n, topo)
+            assert orc.port.has_depressions(dem, topo) == bool(g[f"{n}/has_depressions_d{topo}"]), (n, topo)
+            assert orc.port.has_depressions(dem, topo) == bool((g[f"{n}/original_d{topo}"] != dem).any()), (n, topo)
+    assert differs > 500   # the vectors do exercise what sets Wei2018 apart
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_variants_restatement_matches_live_reference(orc, seed):
+    if not orc.ref.available:
+        pytest.skip("oracle/_ref/libref.so not built here")
+    rng = np.random.default_rng(100 + seed)
+    h, w = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+    dem = rng.integers(0, 12, (h, w)).astype([np.int32, np.float32, np.uint8][seed % 3])
+    nd = dem.dtype.type(0 if seed % 3 == 2 else 3)
+    assert np.array_equal(orc.port.fill_wei2018(dem, nd), orc.ref.fill_wei2018(dem, nd))
+    for topo in (8, 4):
+        assert orc.port.has_depressions(dem, topo) == orc.ref.has_depressions(dem, topo)
+        assert np.array_equal(orc.port.fill(dem, topo), orc.ref.fill_original(dem, topo))

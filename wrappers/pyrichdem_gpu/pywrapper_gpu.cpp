@@ -82,6 +82,17 @@ void bind_functions(py::module_ &m) {
         "Fill all depressions, D8 (PriorityFlood_Zhou2016's result).");
   m.def("rdFillDepressionsD4", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Barnes2014<Topology::D4>(dem); }, release(),
         "Fill all depressions, D4 (PriorityFlood_Barnes2014<D4>'s result).");
+  // not in the reference's module (it binds the default fill only): the other names of the sweep, for scripts that call them
+  m.def("rdPriorityFloodOriginalD8", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Original<Topology::D8>(dem); }, release(),
+        "PriorityFlood_Original<D8> (depressions/Barnes2014.hpp:136-198).");
+  m.def("rdPriorityFloodOriginalD4", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Original<Topology::D4>(dem); }, release(),
+        "PriorityFlood_Original<D4>.");
+  m.def("rdPriorityFloodWei2018", [](Array2D<T> &dem) { rdgpu::PriorityFlood_Wei2018(dem); }, release(),
+        "PriorityFlood_Wei2018 (depressions/Wei2018.hpp:154-202): NoData cells are left alone, their neighbours are seeds.");
+  m.def("rdHasDepressionsD8", [](const Array2D<T> &dem) { return rdgpu::HasDepressions<Topology::D8>(dem); }, release(),
+        "HasDepressions<D8> (depressions/Barnes2014.hpp:44-103).");
+  m.def("rdHasDepressionsD4", [](const Array2D<T> &dem) { return rdgpu::HasDepressions<Topology::D4>(dem); }, release(),
+        "HasDepressions<D4>.");
   // pywrapper.hpp:34-35 (floating-point element types; the others raise as the reference's specialisations do)
   // (the engine runs with the GIL released; the tie census of the call is turned into a Python RuntimeWarning afterwards)
   m.def("rdPFepsilonD8", [](Array2D<T> &dem) {
