@@ -14,7 +14,8 @@ class RdgpuError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "librdgpu.so")
+    # RDGPU_LIB: another build of the same library (tools/probes: librdgpu_probe.so, `make -C richdem_amd/csrc probe`)
+    return os.environ.get("RDGPU_LIB") or os.path.join(_HERE, "librdgpu.so")
 
 
 def build(force: bool = False) -> str:

@@ -1214,6 +1214,15 @@ __device__ __forceinline__ int32_t wave_suffix_min(int32_t v, int lane) {
 // general rows read, level loop incl. flushes, flushes alone, wake test, whole visit; [15] longest visit
 __device__ unsigned long long g_relax_stats[16];
 
+#ifdef RDGPU_PROBES
+// tools/probes/flat_visit_hist.py: per field (towards first) and tile: [0] visits, [1] visits that had work, [2] BFS levels
+// stepped, [3] visits starting BELOW the start level of the tile's previous working visit (that visit ran ahead), [4] that level
+__device__ uint32_t *g_probe_hist = nullptr;
+extern "C" int rdgpu_probe_flat_hist(uint32_t *d_hist) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_probe_hist), &d_hist, sizeof d_hist) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // D accesses of a visit.  CO (the asynchronous search, k_relax_bits_async): other wavefronts of the SAME launch write the
 // ring cells this visit reads and read the cells it writes, across CUs and XCDs whose L1 / L2 are not coherent with each
 // other -- relaxed agent-scope atomics (sc1 loads and write-through stores) on both sides, MI355X_MICROARCH.md's
@@ -1304,6 +1313,20 @@ __device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__rest
     if (lane == 0) expanded[t] = 1;
   }
   if (STATS && lane == 0) { atomicAdd(&g_relax_stats[0], 1ull); if (level >= DINF) atomicAdd(&g_relax_stats[1], 1ull); }
+#ifdef RDGPU_PROBES
+  uint32_t *const ph = g_probe_hist ? g_probe_hist + ((SEED_LEVEL == 2 ? 0u : 5u) * tilesX * tilesY + t) : nullptr;
+  const uint32_t pstride = tilesX * tilesY;
+  uint32_t psteps = 0;
+  if (ph && lane == 0) {
+    atomicAdd(&ph[0], 1u);
+    if (level < DINF) {
+      atomicAdd(&ph[pstride], 1u);
+      const uint32_t last = ph[4 * pstride];
+      if (last != 0 && (uint32_t)level < last) atomicAdd(&ph[3 * pstride], 1u);
+      ph[4 * pstride] = (uint32_t)level;
+    }
+  }
+#endif
   if (level >= DINF) return 0u;   // nothing new reaches this tile
   if (STATS) tk1 = wall_clock64();
   // OPEN WATER: every cell of the tile takes part, so the levels are chessboard distances from the ring (and from what the
@@ -1466,6 +1489,9 @@ __device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__rest
     nlo &= (uint32_t)A; nhi &= (uint32_t)(A >> 32);
     const unsigned long long N = ((unsigned long long)nhi << 32) | nlo;
     if (STATS && lane == 0) atomicAdd(&g_relax_stats[4], 1ull);
+#ifdef RDGPU_PROBES
+    psteps++;
+#endif
     if (__any(N != 0)) {
       const int32_t rel = level - base;
       relmax = rel;
@@ -1494,6 +1520,9 @@ __device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__rest
   base = level;
   }
   if (timed && lane == 0) { atomicAdd(&g_relax_stats[11], wall_clock64() - tk3); atomicAdd(&g_relax_stats[12], tkf); }
+#ifdef RDGPU_PROBES
+  if (ph && lane == 0) atomicAdd(&ph[2 * pstride], psteps);
+#endif
   }
   unsigned long long tk4 = 0;
   if (STATS) tk4 = wall_clock64();
