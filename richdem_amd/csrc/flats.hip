@@ -1072,11 +1072,20 @@ __global__ __launch_bounds__(RNT) void k_flat_relax(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------
 constexpr int BT = 64;   // bitmap tiles are BT x BT
 constexpr int BPLANES = 8;   // level planes: 256 levels per flush
+// r06 (flat_planes.inc): a level field kept as bit planes per 64 x 64 tile instead of one int per cell
+struct PlaneField {
+  unsigned long long *P = nullptr;   // [tile][16][64]
+  int32_t *E = nullptr;              // [tile][4][64]
+  unsigned long long *R = nullptr;   // [tile][64]
+  uint32_t *overflow = nullptr;
+};
 struct BitsScratch {
   unsigned long long *mbits;   // per tile and row: the cells that take part
   uint8_t *tflags, *expanded;  // tile is active next round / has been visited in this field
   uint32_t *tlist, *ctr, *counts;
   uint32_t tilesX, tilesY, ntiles;
+  PlaneField pf;               // P != nullptr: the search runs on planes
+  unsigned long long *near = nullptr;   // (planes, towards field) the seeds' rows: the cells next to a low edge
 };
 
 __device__ __forceinline__ uint32_t dpp_up(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
@@ -1575,6 +1584,8 @@ __device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__rest
   return wake;
 }
 
+#include "flat_planes.inc"
+
 template <int SEED_LEVEL, bool STATS = false>
 __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
                                                      const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ count,
@@ -1669,12 +1680,12 @@ __device__ __forceinline__ bool aq_terminated(const AsyncQ &Q, int lane) {
   return e == d;
 }
 
-template <int SEED_LEVEL>
-__global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned long long *__restrict__ mbits, int32_t *D, AsyncQ Q, int w,
+template <int SEED_LEVEL, bool PL = false>
+__global__ __launch_bounds__(NTHR, PL ? 2 : 4) void k_relax_bits_async(const unsigned long long *__restrict__ mbits, int32_t *D, AsyncQ Q, int w,
                                                            int h, RowWin win, uint32_t tilesX, uint32_t tilesY,
-                                                           unsigned long long tick_budget, int nap) {
+                                                           unsigned long long tick_budget, int nap, PlaneField pf = PlaneField{}) {
   static_assert(AQ_NQ == 64, "one lane per queue in the termination test");
-  __shared__ uint16_t open_rows[NTHR / 64][BT * BT];
+  __shared__ uint16_t open_rows[NTHR / 64][PL ? 2 : BT * BT];   // (the plane visits keep nothing in LDS)
   const int lane = threadIdx.x & 63;
   uint16_t *const orow = open_rows[threadIdx.x >> 6];
   const uint32_t me = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6), nworkers = gridDim.x * (NTHR / 64);
@@ -1730,7 +1741,8 @@ __global__ __launch_bounds__(NTHR, 4) void k_relax_bits_async(const unsigned lon
     idle_polls = 0;
     visits++;
     const unsigned long long tv0 = wall_clock64();
-    const uint32_t wake = relax_visit<SEED_LEVEL, false, true>(mbits, nullptr, D, tile, orow, false, w, h, win, tilesX, tilesY);
+    const uint32_t wake = PL ? relax_visit_p<SEED_LEVEL, true>(mbits, nullptr, pf, tile, w, h, tilesX, tilesY)
+                             : relax_visit<SEED_LEVEL, false, true>(mbits, nullptr, D, tile, orow, false, w, h, win, tilesX, tilesY);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the visit's write-through stores have landed
     busy += wall_clock64() - tv0;
     // Wake the neighbours: an idle one goes into its queue (a queued one will see the stores when it is visited, a running
@@ -2324,7 +2336,7 @@ static uint32_t run_relax_towards(const uint8_t *d_dirs, const uint8_t *flags, i
 
 // ---- the bitmap engine's rounds (same protocol as relax_rounds: batches of rounds, counts read back per batch) ----
 // second = true: the tile flags, lists and counters of a search that runs BESIDE another one (the bitmaps are shared)
-static BitsScratch bits_scratch(int w, int h, bool second = false) {
+static BitsScratch bits_scratch(int w, int h, bool second = false, bool planes = false) {
   Workspace &ws = Workspace::get();
   BitsScratch b;
   b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
@@ -2334,6 +2346,13 @@ static BitsScratch bits_scratch(int w, int h, bool second = false) {
   b.tlist = ws.buf<uint32_t>(second ? "flats.btlist2" : "flats.btlist", b.ntiles);
   b.ctr = ws.buf<uint32_t>(second ? "flats.tctr2" : "flats.tctr", BITS_BATCH);
   b.counts = ws.buf<uint32_t>("flats.bcounts", 3 * 256 + 8);
+  if (planes) {
+    b.pf.P = ws.buf<unsigned long long>(second ? "flats.planes2" : "flats.planes", (size_t)b.ntiles * NPL * BT);
+    b.pf.E = ws.buf<int32_t>(second ? "flats.pedges2" : "flats.pedges", (size_t)b.ntiles * 256);
+    b.pf.R = ws.buf<unsigned long long>(second ? "flats.preached2" : "flats.preached", (size_t)b.ntiles * BT);
+    b.pf.overflow = ws.buf<uint32_t>("flats.poverflow", 4) + (second ? 1 : 0);
+    if (!second) b.near = ws.buf<unsigned long long>("flats.pnear", (size_t)b.ntiles * BT);
+  }
   return b;
 }
 
@@ -2400,8 +2419,12 @@ static AsyncRun async_enqueue(const BitsScratch &b, int32_t *D, int w, int h, co
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_BLOCKS")) r.blocks = std::max(1, atoi(e));
   if (const char *e = getenv("RDGPU_FLAT_ASYNC_NAP")) nap = std::min(255, std::max(1, atoi(e)));
   if (beside && beside->mark) beside->mark();
-  RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(r.blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
-            h, win, b.tilesX, b.tilesY, budget, nap);
+  if (b.pf.P)
+    RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL, true>), dim3(r.blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q,
+              w, h, win, b.tilesX, b.tilesY, budget, nap, b.pf);
+  else
+    RD_LAUNCH(name, (k_relax_bits_async<SEED_LEVEL>), dim3(r.blocks), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, D, Q, w,
+              h, win, b.tilesX, b.tilesY, budget, nap, PlaneField{});
   if (beside && beside->go) beside->go();
   return r;
 }
@@ -2454,7 +2477,10 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
     for (int k = 0; k < batch; k++) {
       RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles,
                 b.tlist, b.ctr + k);
-      if (trace)
+      if (b.pf.P)
+        RD_LAUNCH(name, (k_relax_planes<SEED_LEVEL>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, b.expanded, b.pf,
+                  (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, b.tilesX, b.tilesY);
+      else if (trace)
         RD_LAUNCH(name, (k_relax_bits<SEED_LEVEL, true>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
                   b.expanded, D, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win,
                   b.tilesX, b.tilesY);
@@ -2503,13 +2529,17 @@ static uint32_t relax_rounds_bits(const BitsScratch &b, int32_t *D, int w, int h
 // Towards levels from the low edges, D written in full; write_m: also the bitmap of the cells that take part (shared
 // with the away field); counts3 (optional, host): low edges, high edges, NO_FLOW cells.
 static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m, unsigned long long *counts3, int w, int h,
-                                 hipStream_t s, const Beside *beside = nullptr) {
-  const BitsScratch b = bits_scratch(w, h);
+                                 hipStream_t s, const Beside *beside = nullptr, bool planes = false) {
+  const BitsScratch b = bits_scratch(w, h, false, planes);
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
   uint32_t *cnt = counts3 ? b.counts : nullptr;
   if (cnt) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
-  if (write_m)
+  if (planes) {
+    RD_HIP(hipMemsetAsync(b.pf.overflow, 0, 2 * sizeof(uint32_t), s));   // (both fields' words)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits, b.near,
+              b.tflags, cnt, w, h, b.tilesX, b.tilesY);
+  } else if (write_m)
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
               (const int32_t *)nullptr, D, b.mbits, b.tflags, cnt, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr,
               b.tilesX, b.tilesY);
@@ -2527,11 +2557,14 @@ static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m,
 
 // Away levels from the high edges (with L / fh: only those of flats that have an outlet), D written in full.
 static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int32_t *fh, int32_t *D, bool write_m, int w, int h,
-                              hipStream_t s) {
-  const BitsScratch b = bits_scratch(w, h);
+                              hipStream_t s, bool planes = false) {
+  const BitsScratch b = bits_scratch(w, h, planes, planes);   // (planes: the field's own planes, beside the towards field's)
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
-  if (write_m)
+  if (planes)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits,
+              (unsigned long long *)nullptr, b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+  else if (write_m)
     RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, L, fh, D, b.mbits,
               b.tflags, (uint32_t *)nullptr, w, RowWin{0, h, nullptr, nullptr}, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   else
@@ -2553,14 +2586,18 @@ static bool away_beside() {
   const char *env = getenv("RDGPU_FLAT_AWAY_BESIDE");
   return !(env && env[0] == '0') && async_threshold() > 0 && getenv("RDGPU_FLAT_TRACE") == nullptr;
 }
-static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, int h, hipStream_t s) {
+static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, int h, hipStream_t s, bool planes = false) {
   static_assert(AWAY_STATIC_ROUNDS < BITS_BATCH - 1, "the tail's own counter word is the last one");
   StaticAway sa;
-  sa.b = bits_scratch(w, h, true);
+  sa.b = bits_scratch(w, h, true, planes);
   const BitsScratch &b = sa.b;
   const RowWin win{0, h, nullptr, nullptr};
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
+  if (planes)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits,
+              (unsigned long long *)nullptr, b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
+  else
   RD_LAUNCH("flats.bits_prepare", (k_bits_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, (const uint32_t *)nullptr,
             (const int32_t *)nullptr, A, b.mbits, b.tflags, (uint32_t *)nullptr, w, win, (const int32_t *)nullptr, b.tilesX, b.tilesY);
   RD_HIP(hipMemsetAsync(b.ctr, 0, BITS_BATCH * sizeof(uint32_t), s));
@@ -2570,6 +2607,10 @@ static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, i
     // (the front of this search shrinks fast -- S3: 0.86, 0.78, 0.37, 0.17, 0.09, 0.04, 0.02, 0.01 of the tiles -- and a grid
     // that is too small for a round is not an error: the tiles past it stay active for the next one)
     const uint32_t full = (b.ntiles + 3) / 4, grid = k < 2 ? full : std::max<uint32_t>(256u, full >> (k - 1));
+    if (planes)
+      RD_LAUNCH("flats.relax_away", (k_relax_planes<1>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, b.expanded,
+                b.pf, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, b.tilesX, b.tilesY);
+    else
     RD_LAUNCH("flats.relax_away", (k_relax_bits<1>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits,
               b.expanded, A, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, win, b.tilesX, b.tilesY);
   }
@@ -2754,6 +2795,7 @@ static void resolve_flats_device(const T *d_z, const uint8_t *d_dirs, int w, int
             (const int32_t *)fh, n);
 }
 
+static thread_local bool g_planes_overflowed = false;   // (flat_resolution_device: this call repeats a plane search that overflowed)
 template <class T>
 void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dirs, hipStream_t s) {
   if (!d_z || !d_dirs) throw Error(RDGPU_ERR_ARG, "rdgpu_flat_resolution_d8: null pointer");
@@ -2792,7 +2834,11 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   } else {
     launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   }
-  int32_t *TWd = ws.buf<int32_t>("flats.mask", n), *A = nullptr;
+  // r06: the level fields as bit planes per tile (flat_planes.inc); RDGPU_FLAT_PLANES=0, a level beyond 16 bits (an open flat
+  // wider than 65 000 cells), or any of the A/B switches above: one int per cell (r02-r05)
+  const char *envp = getenv("RDGPU_FLAT_PLANES");
+  const bool planes = qpass && use_bits_engine() && !(envp && envp[0] == '0') && !g_planes_overflowed && !getenv("RDGPU_FLAT_TRACE");
+  int32_t *TWd = planes ? nullptr : ws.buf<int32_t>("flats.mask", n), *A = nullptr;
   if (use_bits_engine()) {
     // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
     unsigned long long c3[3] = {0, 0, 0};
@@ -2808,22 +2854,39 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
     bs.go = [&]() {
       if (!beside || c3[0] == 0 || c3[1] == 0) return;
       RD_HIP(hipStreamWaitEvent(lane->stream, lane->fork, 0));
-      A = ws.buf<int32_t>("flats.away", n);
-      sa = enqueue_away_static(flags, A, w, h, lane->stream);
+      if (!planes) A = ws.buf<int32_t>("flats.away", n);
+      sa = enqueue_away_static(flags, A, w, h, lane->stream, planes);
       RD_HIP(hipEventRecord(lane->join, lane->stream));
       started = true;
     };
-    g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s, &bs);
+    g_fstats.towards_levels = run_bits_towards(flags, TWd, true, c3, w, h, s, &bs, planes);
     if (started) RD_HIP(hipStreamWaitEvent(s, lane->join, 0));
     g_fstats.low_edges = c3[0];
     g_fstats.high_edges = c3[1];
     g_fstats.noflow_cells = c3[2];
     if (c3[0] == 0) return;   // no flats, or none with an outlet (:475-481)
+    bool have_away = started;
     if (c3[1] > 0 && !started) {
-      A = ws.buf<int32_t>("flats.away", n);
-      g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s);
+      if (!planes) A = ws.buf<int32_t>("flats.away", n);
+      g_fstats.away_levels = run_bits_away(flags, nullptr, nullptr, A, false, w, h, s, planes);
+      have_away = true;
     }
     if (started) g_fstats.away_levels = finish_away_static(sa, A, w, h, s);
+    if (planes) {
+      const BitsScratch bt = bits_scratch(w, h, false, true), ba = bits_scratch(w, h, true, true);
+      uint32_t over[2] = {0, 0};
+      RD_HIP(hipMemcpyAsync(over, bt.pf.overflow, sizeof over, hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      if (over[0] | over[1]) {   // a level beyond 16 bits: once more, on ints (dirs holds what the classification wrote: nothing is lost)
+        g_planes_overflowed = true;
+        struct Reset { ~Reset() { g_planes_overflowed = false; } } reset;
+        flat_resolution_device<T>(d_z, nodata, w, h, d_dirs, s);
+        return;
+      }
+      RD_LAUNCH("flats.dirs_q", k_flat_dirs_qp, dim3(xcd_grid((bt.ntiles + 3) / 4)), dim3(NTHR), 0, s, bt.pf, ba.pf,
+                (const unsigned long long *)bt.near, have_away ? 1 : 0, d_dirs, w, h, bt.tilesX, bt.tilesY);
+      return;
+    }
   } else {
     uint32_t *low = nullptr, *highall = nullptr;
     uint32_t nlow = 0, nhigh_all = 0, nnoflow = 0;
