@@ -46,6 +46,8 @@ extern "C" {
 #define RDGPU_ERR_HIP 1         /* a HIP runtime call failed (no GPU, OOM, ...) */
 #define RDGPU_ERR_ARG 2         /* bad dimensions / null pointer / bad topology  */
 #define RDGPU_ERR_UNSUPPORTED 3 /* dtype not supported by this build             */
+#define RDGPU_ERR_CAPACITY 4    /* rdgpu_fill_graph_solve_dev: a count in d_counts exceeds `cap` -- that shard's edges are
+                                   not in d_edges_all; nothing was solved (the caller repeats its exchange with more room) */
 
 /* ---- runtime ---------------------------------------------------------------------------- */
 const char *rdgpu_last_error(void);

@@ -66,7 +66,9 @@ def lib() -> ctypes.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().rdgpu_last_error().decode(errors="replace")
-        raise RdgpuError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")
+        err = RdgpuError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")
+        err.code = rc
+        raise err
 
 
 def fill_stats() -> dict:

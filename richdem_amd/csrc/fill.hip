@@ -3492,6 +3492,12 @@ __device__ __forceinline__ bool graph_edge(const GraphDesc &g, uint64_t idx, uin
   return true;
 }
 
+// a shard's edge count beyond the capacity of the gathered payload: its edges were not sent (sharded.py, one exchange)
+__global__ void k_graph_check_counts(const uint32_t *__restrict__ counts, uint32_t S, uint32_t cap, uint32_t *flag) {
+  for (uint32_t s = threadIdx.x; s < S; s += blockDim.x)
+    if (counts[s] > cap) atomicOr(flag, 1u);
+}
+
 __global__ __launch_bounds__(NTHR) void k_graph_touch(GraphDesc g, uint64_t nslots, uint32_t *closed) {
   const uint64_t stride = (uint64_t)gridDim.x * NTHR;
   for (uint64_t i = (uint64_t)blockIdx.x * NTHR + threadIdx.x; i < nslots; i += stride) {
@@ -3559,10 +3565,12 @@ static void graph_solve_device(int S, int w, int topo, const uint32_t *d_keys_al
   RD_HIP(hipMemsetAsync(closed, 0, ((size_t)B + 1) * 4, s));   // 0 = closed (isolated) until an edge touches it
   RD_LAUNCH("graph.touch", k_graph_touch, dim3(egrid), dim3(NTHR), 0, s, g, nslots, closed);
   RD_HIP(hipMemsetAsync(dflags, 0, 16 * 4, s));
+  if (d_counts) hipLaunchKernelGGL(k_graph_check_counts, dim3(1), dim3(64), 0, s, d_counts, (uint32_t)S, cap, dflags + 3);
   RD_LAUNCH("graph.init_tables", k_init_tables, dim3(cdiv((uint64_t)B + 1, NTHR)), dim3(NTHR), 0, s, cur, acc, link, rootsA,
             dflags + 2, (const uint32_t *)closed, B);
-  RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4, hipMemcpyDeviceToHost, s));
+  RD_HIP(hipMemcpyAsync(hw, dflags + 2, 8, hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
+  if (hw[1] != 0) throw Error(RDGPU_ERR_CAPACITY, "rdgpu_fill_graph_solve_dev: a shard holds more edges than the gathered payload has room for");
   uint32_t nroots = hw[0];
   while (nroots > 0) {
     const uint32_t rgrid = cdiv(nroots, NTHR);

@@ -1078,6 +1078,8 @@ struct PlaneField {
   int32_t *E = nullptr;              // [tile][4][64]
   unsigned long long *R = nullptr;   // [tile][64]
   uint32_t *overflow = nullptr;
+  uint8_t *expanded = nullptr;       // per tile: has been visited (its planes exist)
+  int32_t max_level = 0xFFF0;        // a level from here on raises `overflow` (the planes hold 16 bits)
 };
 struct BitsScratch {
   unsigned long long *mbits;   // per tile and row: the cells that take part
@@ -1741,7 +1743,7 @@ __global__ __launch_bounds__(NTHR, PL ? 2 : 4) void k_relax_bits_async(const uns
     idle_polls = 0;
     visits++;
     const unsigned long long tv0 = wall_clock64();
-    const uint32_t wake = PL ? relax_visit_p<SEED_LEVEL, true>(mbits, nullptr, pf, tile, w, h, tilesX, tilesY)
+    const uint32_t wake = PL ? relax_visit_p<SEED_LEVEL, true>(mbits, pf.expanded, pf, tile, w, h, tilesX, tilesY)
                              : relax_visit<SEED_LEVEL, false, true>(mbits, nullptr, D, tile, orow, false, w, h, win, tilesX, tilesY);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the visit's write-through stores have landed
     busy += wall_clock64() - tv0;
@@ -2351,6 +2353,8 @@ static BitsScratch bits_scratch(int w, int h, bool second = false, bool planes =
     b.pf.E = ws.buf<int32_t>(second ? "flats.pedges2" : "flats.pedges", (size_t)b.ntiles * 256);
     b.pf.R = ws.buf<unsigned long long>(second ? "flats.preached2" : "flats.preached", (size_t)b.ntiles * BT);
     b.pf.overflow = ws.buf<uint32_t>("flats.poverflow", 4) + (second ? 1 : 0);
+    b.pf.expanded = b.expanded;
+    if (const char *e = getenv("RDGPU_FLAT_PLANES_MAX")) b.pf.max_level = std::min(0xFFF0, std::max(8, atoi(e)));   // (tests: the overflow path)
     if (!second) b.near = ws.buf<unsigned long long>("flats.pnear", (size_t)b.ntiles * BT);
   }
   return b;

@@ -20,6 +20,8 @@ import numpy as np
 
 from ._lib import RdgpuError, check, lib
 
+RDGPU_ERR_CAPACITY = 4   # include/rdgpu.h
+
 _TOPO = {"D8": 8, "D4": 4, 8: 8, 4: 4}
 
 
@@ -28,6 +30,16 @@ def row_split(height: int, world: int):
     if height < world:
         raise RdgpuError(f"row_split: {height} rows cannot be split over {world} ranks (every rank needs at least one row)")
     return [(height * s // world, height * (s + 1) // world) for s in range(world)]
+
+
+def _host_staged(group, tensor=None) -> bool:
+    """True when the process group cannot move HBM-resident tensors itself (gloo: the CPU tests, and the multi-process
+    tests that put every rank on one GPU): collectives are then staged through host memory."""
+    import torch.distributed as dist
+
+    if tensor is not None and not getattr(tensor, "is_cuda", False):
+        return False
+    return str(dist.get_backend(group)).lower() != "nccl"
 
 
 def _check_block(block, who: str) -> None:
@@ -151,8 +163,22 @@ def graph_solve_dev(keys_all, edges_all, counts, topology: int):
     return levels
 
 
+def shard_edge_capacity(width: int) -> int:
+    """Edge triples a rank's payload has room for in the one-exchange fill: a function of the raster's width alone, so
+    that every rank sizes the collective alike without asking the others (S3 in 8 blocks: 4.8 * width triples per rank).
+    RDGPU_SHARD_EDGE_CAP overrides it (tests: the overflow path)."""
+    import os
+
+    env = os.environ.get("RDGPU_SHARD_EDGE_CAP")
+    return max(1, int(env)) if env else 8 * int(width) + 4096
+
+
 def _fill_sharded_device(block, topo: int, group, eng) -> None:
-    """Device-resident protocol: local phase, ONE all-gather (RCCL), GPU graph solve, finish."""
+    """Device-resident protocol: local phase, ONE all-gather (RCCL) of a fixed-capacity payload
+    [edge count | 2 * width cut-row keys | capacity * 3 edge words], GPU graph solve, finish -- no host read between
+    them (r06; the reference's Job1 message, programs/parallel_priority_flood/main.cpp:147-173, is one message too).
+    A rank with more edges than the capacity sends its true count: the solve sees it on the device and refuses
+    (RDGPU_ERR_CAPACITY), and the ranks repeat the exchange with the exact size -- two collectives, as r05 always did."""
     import torch
     import torch.distributed as dist
 
@@ -160,20 +186,30 @@ def _fill_sharded_device(block, topo: int, group, eng) -> None:
     dev = block.device
     w = block.shape[1]
     keys, edges = eng.begin_dev(block, rank > 0, rank + 1 < world, topo)
-    cnt = torch.tensor([edges.shape[0]], dtype=torch.int32, device=dev)
-    counts = torch.empty(world, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(counts, cnt, group=group)
-    cap = int(counts.max().item())
-    plen = 2 * w + 3 * cap
-    payload = torch.zeros(plen, dtype=torch.int32, device=dev)
-    payload[: 2 * w] = keys
-    payload[2 * w : 2 * w + 3 * edges.shape[0]] = edges.reshape(-1)
-    gathered = torch.empty(world * plen, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gathered, payload, group=group)
-    g2 = gathered.view(world, plen)
-    keys_all = g2[:, : 2 * w].contiguous()
-    edges_all = g2[:, 2 * w :].contiguous().view(world, cap, 3)
-    levels = graph_solve_dev(keys_all, edges_all, counts, topo)
+    ne = int(edges.shape[0])
+
+    def exchange(cap: int):
+        plen = 1 + 2 * w + 3 * cap
+        payload = torch.zeros(plen, dtype=torch.int32, device=dev)
+        payload[0] = ne
+        payload[1 : 1 + 2 * w] = keys
+        if ne <= cap:
+            payload[1 + 2 * w : 1 + 2 * w + 3 * ne] = edges.reshape(-1)
+        g2 = _all_gather_stack(payload, group)                       # [world, plen]
+        counts = g2[:, 0].contiguous()
+        keys_all = g2[:, 1 : 1 + 2 * w].contiguous()
+        edges_all = g2[:, 1 + 2 * w :].contiguous().view(world, cap, 3)
+        return graph_solve_dev(keys_all, edges_all, counts, topo), counts
+
+    try:
+        levels, _ = exchange(shard_edge_capacity(w))
+    except RdgpuError as e:
+        if getattr(e, "code", None) != RDGPU_ERR_CAPACITY:
+            raise
+        # some rank's graph did not fit (every rank's solve saw the same counts and refused alike): exact size, second exchange
+        cnt = torch.tensor([ne], dtype=torch.int32, device=dev)
+        cap = int(_all_gather_stack(cnt, group).max().item())
+        levels, _ = exchange(cap)
     eng.finish_dev(levels[rank].contiguous())
 
 
@@ -234,8 +270,9 @@ def fill_depressions_sharded(block, topology="D8", group=None, engine=None, comm
     if comm_device is None:
         comm_device = block.device if hasattr(block, "device") else "cpu"
     try:
-        if isinstance(eng, GpuShardEngine) and hasattr(block, "is_cuda") and block.is_cuda:
-            return _fill_sharded_device(block, topo, group, eng)
+        if isinstance(eng, GpuShardEngine) and hasattr(block, "is_cuda") and block.is_cuda and str(comm_device) != "cpu":
+            return _fill_sharded_device(block, topo, group, eng)   # (a gloo group stages the one all-gather through the host)
+        # comm_device="cpu" with GPU blocks: the host exchange of r02 -- export to host, all-gather, HOST graph solve, finish
         keys, edges = eng.begin(block, rank > 0, rank + 1 < world, topo)
         keys_all, edges_all = _all_gather_shards(keys, edges, group, comm_device)
         levels = graph_solve(keys_all, edges_all, topo)
@@ -432,6 +469,11 @@ def _all_gather_stack(mine, group):
 
     world = dist.get_world_size(group)
     flat = mine.contiguous().view(-1)
+    if _host_staged(group, flat):   # (gloo moves host memory only)
+        hflat = flat.cpu()
+        hout = torch.empty(world * hflat.numel(), dtype=hflat.dtype)
+        dist.all_gather_into_tensor(hout, hflat, group=group)
+        return hout.to(flat.device).view((world,) + tuple(mine.shape))
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)
     return out.view((world,) + tuple(mine.shape))

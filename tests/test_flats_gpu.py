@@ -144,7 +144,7 @@ def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
 
 @pytest.mark.parametrize("switch", ["RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000", "RDGPU_FLAT_AWAY_BESIDE=0", "RDGPU_FLAT_ASYNC_BLOCKS=3",
                                     "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1", "RDGPU_FLAT_ASYNC_FAIL=1",
-                                    "RDGPU_FLAT_Q=0"])
+                                    "RDGPU_FLAT_Q=0", "RDGPU_FLAT_PLANES=0", "RDGPU_FLAT_PLANES_MAX=40"])
 def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     """The bitmap search in rounds to the end, with its asynchronous tail from the first batch on (k_relax_bits_async),
     with the away search after instead of beside the towards tail, on three resident blocks; ResolveFlatsEpsilon with the
@@ -169,6 +169,33 @@ def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     monkeypatch.delenv(k)
     assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), edirs)
     assert rd.ResolveFlats(ffl, nodata=np.float32(-9999)).tobytes() == eeps.tobytes()
+
+
+def test_level_planes_long_channels_and_overflow(rd, orc, monkeypatch):
+    """r06 (csrc/flat_planes.inc): the level fields as 16 bit planes per 64 x 64 tile.  A serpentine channel of one elevation
+    -- breadth-first levels in the thousands, crossing every tile many times, several 256-level segments per visit -- and
+    rasters narrower / shorter than a tile; then the same channel with the planes' range cut to 300 levels
+    (RDGPU_FLAT_PLANES_MAX): the search overflows and the int engine takes over, same directions."""
+    h, w = 330, 410
+    dem = np.full((h, w), 50, np.int32)
+    for k, y in enumerate(range(2, h - 2, 4)):       # walls every 4 rows, a gap at alternating ends
+        dem[y, 2:w - 2] = 10
+        x = w - 3 if k % 2 == 0 else 2
+        if y + 4 < h - 2:
+            dem[y:y + 5, x] = 10
+    dem[2, 1] = 5; dem[2, 0] = 1                     # the outlet
+    nd = np.int32(-9999)
+    exp = orc.port.flat_resolution(dem, nd)
+    assert (exp[dem == 10] != 0).all()
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), exp)
+    for shape in ((70, 9), (9, 70), (64, 64), (65, 129), (1, 200), (200, 1), (3, 3)):
+        rng = np.random.default_rng(shape[0] * 7 + shape[1])
+        small = orc.port.fill(rng.integers(0, 4, shape).astype(np.int32))
+        assert np.array_equal(rd.barnes_flat_resolution_d8(small, nd), orc.port.flat_resolution(small, nd)), shape
+    monkeypatch.setenv("RDGPU_FLAT_PLANES_MAX", "300")
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), exp)
+    monkeypatch.setenv("RDGPU_FLAT_ASYNC", "100000")   # ... and when the overflow happens in the asynchronous tail
+    assert np.array_equal(rd.barnes_flat_resolution_d8(dem, nd), exp)
 
 
 def test_directions_from_masks_modulo_8(rd, orc, monkeypatch):

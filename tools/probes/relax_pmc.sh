@@ -9,7 +9,7 @@ import csv,sys,os,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 d=collections.OrderedDict()
 for r in rows:
-    if "k_relax_bits" not in r["Kernel_Name"] and "k_flat_relax" not in r["Kernel_Name"]: continue
+    if not any(k in r["Kernel_Name"] for k in ("k_relax_bits", "k_flat_relax", "k_relax_planes", "k_flat_dirs_q", "k_planes_prepare")): continue
     k=(int(r["Dispatch_Id"]))
     d.setdefault(k,{"name":r["Kernel_Name"][:40],"grid":r.get("Grid_Size")})[r["Counter_Name"]]=float(r["Counter_Value"])
 with open(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/relax_pmc.txt","w") as f:
