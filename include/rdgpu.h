@@ -287,6 +287,8 @@ typedef struct rdgpu_fill_stats {
   uint64_t scan_tiles;  /* tiles visited by fill.scan, summed over the rounds */
   uint32_t tile_cells;  /* cells per scan tile                               */
   uint32_t edge_records; /* component-pair records the first raster pass handed to rounds 2.. (0: raster rounds) */
+  uint32_t host_syncs;   /* stream synchronisations inside the fill (r06: 2 -- after the descent, after the rounds) */
+  uint32_t reserved;
 } rdgpu_fill_stats;
 int rdgpu_fill_get_stats(rdgpu_fill_stats *out);
 

@@ -36,6 +36,8 @@ class rdgpu_fill_stats(ctypes.Structure):
         ("scan_tiles", ctypes.c_uint64),
         ("tile_cells", ctypes.c_uint32),
         ("edge_records", ctypes.c_uint32),
+        ("host_syncs", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -75,7 +77,8 @@ def fill_stats() -> dict:
     st = rdgpu_fill_stats()
     check(lib().rdgpu_fill_get_stats(ctypes.byref(st)), "rdgpu_fill_get_stats")
     return {"cells": st.cells, "basins": st.basins, "rounds": st.rounds, "jump_passes": st.jump_passes,
-            "scan_tiles": st.scan_tiles, "tile_cells": st.tile_cells, "edge_records": st.edge_records}
+            "scan_tiles": st.scan_tiles, "tile_cells": st.tile_cells, "edge_records": st.edge_records,
+            "host_syncs": st.host_syncs}
 
 
 def profile_enable(on: bool = True) -> None:

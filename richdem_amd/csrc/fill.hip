@@ -465,10 +465,13 @@ __global__ __launch_bounds__(NTHR) void k_mark_terminals(const uint32_t *__restr
   if (open_bottom) tid[lab[(size_t)(h - 1) * w + x]] = (uint32_t)(w + x);
 }
 
+// (r06) dyn != nullptr in the round kernels below: the count is read from the device -- the rounds of a fill are enqueued
+// without a host read-back between them, over grids the host sizes from upper bounds (grid-stride loops: a launch
+// whose list turns out empty costs a few microseconds).
 __global__ __launch_bounds__(NTHR) void k_best_reset(const uint32_t *__restrict__ roots, uint32_t nroots,
-                                                     unsigned long long *best) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  if (i < nroots) best[roots[i]] = ~0ull;
+                                                     unsigned long long *best, const uint32_t *__restrict__ dyn = nullptr) {
+  if (dyn) nroots = *dyn;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nroots; i += gridDim.x * NTHR) best[roots[i]] = ~0ull;
 }
 
 // One raster pass of a Boruvka round.  tiles_in == nullptr: all tiles (XCD-banded order); otherwise
@@ -951,18 +954,20 @@ __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ ek, uint32_t n,
                                                      const uint32_t *__restrict__ segcount, uint32_t segcap,
                                                      const uint32_t *__restrict__ cur, unsigned long long *best, uint32_t B,
-                                                     uint32_t *oa, uint32_t *ob, uint32_t *ok, uint32_t *ocount) {
+                                                     uint32_t *oa, uint32_t *ob, uint32_t *ok, uint32_t *ocount,
+                                                     const uint32_t *__restrict__ dyn = nullptr) {
   __shared__ uint32_t wtot[NTHR / 64];
   __shared__ uint32_t bbase, dn;
   __shared__ unsigned long long dt_pair[DEDUP ? DT_SLOTS : 1];
   __shared__ uint32_t dt_key[DEDUP ? DT_SLOTS : 1];
   __shared__ uint16_t dt_list[DEDUP ? DT_SLOTS : 1];
-  const size_t i0 = (size_t)blockIdx.x * (NTHR * EPT);
+  if (dyn) n = *dyn;   // (the dense rounds: the record count the round before left on the device)
+  for (size_t i0 = (size_t)blockIdx.x * (NTHR * EPT); i0 < (size_t)n; i0 += (size_t)gridDim.x * (NTHR * EPT)) {
   size_t lim = n;   // records of this block's range that exist
   if (SEG) {
     const uint32_t seg = (uint32_t)(i0 / segcap);
     lim = (size_t)seg * segcap + segcount[seg];
-    if (i0 >= lim) return;
+    if (i0 >= lim) continue;
   }
   if (DEDUP) {
     for (int i = threadIdx.x; i < DT_SLOTS; i += NTHR) { dt_pair[i] = ~0ull; dt_key[i] = 0xFFFFFFFFu; }
@@ -1058,6 +1063,8 @@ __global__ __launch_bounds__(NTHR) void k_edge_round(const uint32_t *__restrict_
     }
     off += (uint32_t)__popcll(bal[r]);
   }
+  __syncthreads();   // (the next chunk of the block reuses the tables)
+  }
 }
 
 __global__ __launch_bounds__(NTHR) void k_sum_segments(const uint32_t *__restrict__ segcount, uint32_t nseg, uint32_t *total) {
@@ -1084,51 +1091,56 @@ __global__ __launch_bounds__(NTHR) void k_compact_alive(const uint8_t *__restric
 
 __global__ __launch_bounds__(NTHR) void k_hook(const uint32_t *__restrict__ roots, uint32_t nroots,
                                                const unsigned long long *__restrict__ best,
-                                               unsigned long long *link) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  if (i >= nroots) return;
-  const uint32_t r = roots[i];
-  const unsigned long long b = best[r];
-  const uint32_t t = (uint32_t)b;
-  bool keep_root = false;
-  if (b == ~0ull) keep_root = true;  // no neighbouring component (cannot happen on a connected raster)
-  else if (!(t & CLOSED)) {
-    // mutual lowest pass: the pair merges, the smaller id stays root (the pass heights agree
-    // because both sides see the same cell pair).  Closed components never choose, so never mutual.
-    keep_root = ((uint32_t)best[t] == r) && (r < t);
+                                               unsigned long long *link, const uint32_t *__restrict__ dyn = nullptr) {
+  if (dyn) nroots = *dyn;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nroots; i += gridDim.x * NTHR) {
+    const uint32_t r = roots[i];
+    const unsigned long long b = best[r];
+    const uint32_t t = (uint32_t)b;
+    bool keep_root = false;
+    if (b == ~0ull) keep_root = true;  // no neighbouring component (cannot happen on a connected raster)
+    else if (!(t & CLOSED)) {
+      // mutual lowest pass: the pair merges, the smaller id stays root (the pass heights agree
+      // because both sides see the same cell pair).  Closed components never choose, so never mutual.
+      keep_root = ((uint32_t)best[t] == r) && (r < t);
+    }
+    link[r] = keep_root ? (unsigned long long)r : b;
   }
-  link[r] = keep_root ? (unsigned long long)r : b;
 }
 
 // pointer jumping over this round's hook forest, carrying the path maximum in the high word.
 __global__ __launch_bounds__(NTHR) void k_chase_links(const uint32_t *__restrict__ roots, uint32_t nroots,
-                                                      unsigned long long *link, int maxhops, uint32_t *flag) {
-  const uint32_t i = blockIdx.x * NTHR + threadIdx.x;
-  if (i >= nroots) return;
-  const uint32_t r = roots[i];
-  unsigned long long l = __hip_atomic_load(&link[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t p = (uint32_t)l, m = (uint32_t)(l >> 32);
-  if (p == r) return;
-  const uint32_t p0 = p;
-  int hops = 0;
-  bool unfinished = false;
-  for (;;) {
-    if (p & CLOSED) break;   // the outside / a frozen terminal: a root by definition
-    const unsigned long long lp = __hip_atomic_load(&link[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t pp = (uint32_t)lp;
-    if (pp == p) break;
-    const uint32_t mm = (uint32_t)(lp >> 32);
-    p = pp;
-    m = mm > m ? mm : m;
-    if (++hops >= maxhops) { unfinished = true; break; }
+                                                      unsigned long long *link, int maxhops, uint32_t *flag,
+                                                      const uint32_t *__restrict__ dyn = nullptr) {
+  if (dyn) nroots = *dyn;
+  for (uint32_t i = blockIdx.x * NTHR + threadIdx.x; i < nroots; i += gridDim.x * NTHR) {
+    const uint32_t r = roots[i];
+    unsigned long long l = __hip_atomic_load(&link[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t p = (uint32_t)l, m = (uint32_t)(l >> 32);
+    if (p == r) continue;
+    const uint32_t p0 = p;
+    int hops = 0;
+    bool unfinished = false;
+    for (;;) {
+      if (p & CLOSED) break;   // the outside / a frozen terminal: a root by definition
+      const unsigned long long lp = __hip_atomic_load(&link[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t pp = (uint32_t)lp;
+      if (pp == p) break;
+      const uint32_t mm = (uint32_t)(lp >> 32);
+      p = pp;
+      m = mm > m ? mm : m;
+      if (++hops >= maxhops) { unfinished = true; break; }
+    }
+    if (p != p0)
+      __hip_atomic_store(&link[r], ((unsigned long long)m << 32) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (unfinished) *flag = 1;
   }
-  if (p != p0)
-    __hip_atomic_store(&link[r], ((unsigned long long)m << 32) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (unfinished) *flag = 1;
 }
 
 __global__ __launch_bounds__(NTHR) void k_update_basins(uint32_t *cur, uint32_t *acc,
-                                                        const unsigned long long *__restrict__ link, uint32_t B) {
+                                                        const unsigned long long *__restrict__ link, uint32_t B,
+                                                        const uint32_t *__restrict__ dyn = nullptr) {
+  if (dyn && *dyn == 0u) return;   // (a round enqueued after the last: nothing hooked)
   const uint32_t b = blockIdx.x * NTHR + threadIdx.x;
   if (b >= B) return;
   const uint32_t c = cur[b];
@@ -1144,10 +1156,12 @@ __global__ __launch_bounds__(NTHR) void k_update_basins(uint32_t *cur, uint32_t 
 constexpr int RPT = 8;   // roots per thread: 2048 per block, so a round over 1e7 roots is 5e3 same-address atomics
 __global__ __launch_bounds__(NTHR) void k_compact_roots(const uint32_t *__restrict__ roots_in, uint32_t nroots,
                                                         const unsigned long long *__restrict__ link,
-                                                        uint32_t *roots_out, uint32_t *counter) {
+                                                        uint32_t *roots_out, uint32_t *counter,
+                                                        const uint32_t *__restrict__ dyn = nullptr) {
   __shared__ uint32_t wtot[NTHR / 64];
   __shared__ uint32_t bbase;
-  const uint32_t i0 = blockIdx.x * (NTHR * RPT);
+  if (dyn) nroots = *dyn;
+  for (uint32_t i0 = blockIdx.x * (NTHR * RPT); i0 < nroots; i0 += gridDim.x * (NTHR * RPT)) {
   uint32_t r[RPT];
   bool ok[RPT];
 #pragma unroll
@@ -1177,6 +1191,8 @@ __global__ __launch_bounds__(NTHR) void k_compact_roots(const uint32_t *__restri
   for (int q = 0; q < RPT; q++) {
     if (keep[q]) roots_out[off + (uint32_t)__popcll(bal[q] & ((1ull << lane) - 1ull))] = r[q];
     off += (uint32_t)__popcll(bal[q]);
+  }
+  __syncthreads();   // (the next chunk of the block reuses wtot / bbase)
   }
 }
 
@@ -3045,6 +3061,7 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
             dflags + 8);
   RD_HIP(hipMemcpyAsync(hw, dflags + 4, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
+  g_stats.host_syncs++;
   if (hw[1] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: node table overflow (nstripes %u rcap %u)\n", nstripes, fo.rcap); return false; }   // more nodes than a stripe's table holds: nothing was written to the DEM
   const uint32_t B = hw[4], NNmax = hw[6];   // basins; nodes of the fullest stripe
   g_stats.basins = B;
@@ -3080,6 +3097,7 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   if (sharded) {   // the frozen terminals are no roots: the list was compacted, its length comes back
     RD_HIP(hipMemcpyAsync(hw, dflags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
+    g_stats.host_syncs++;
     nroots0 = hw[0];
   }
   const char *env_pp = getenv("RDGPU_FILL_PAIRS");   // =0: k_scan<L16>, one block per tile (A/B and tests)
@@ -3107,9 +3125,8 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   EdgeOut eo{elist[0], elist[0] + ecap, elist[0] + 2 * ecap, segcount, segcap, nseg - 1, dflags + 5};
   eo.seglimit = env_cap ? (uint32_t)std::min<uint64_t>(segcap, std::max<uint64_t>(1, cdiv(cap, nseg))) : segcap;   // (the cap given on purpose is enforced to the record: the overflow tests)
   uint8_t *alive = ws.buf<uint8_t>("fill.alive", ntiles);
-  uint32_t nroots = nroots0, nedges = 0;
   int ein = 0;
-  bool first = true, eseg = true;
+  bool eseg = true;
   const char *env_dedup = getenv("RDGPU_FILL_DEDUP");
   const bool dedup = !(env_dedup && env_dedup[0] == '0');
   const char *env_pc = getenv("RDGPU_FILL_PRECHECK");
@@ -3127,10 +3144,31 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
   const char *env_ab = nullptr;
 #endif
   const int precheck = (!(env_pc && env_pc[0] == '0') ? 1 : 0) | (!(env_st && env_st[0] == '0') ? 2 : 0) | (env_ab ? (atoi(env_ab) & 124) : 0);
-  while (nroots > 0) {
-    const uint32_t rgrid = cdiv(nroots, NTHR);
-    RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
-    if (first) {   // round 1: the one raster pass (components gathered from the node table)
+  // r06: the rounds are enqueued WITHOUT a host read-back between them.  Every round kernel takes its counts from the device
+  // (rc[4 r] = live roots entering round r, rc[4 r + 1] = records of the list it contracts) and runs a grid-stride loop over
+  // a grid the host sizes from upper bounds: live roots at least halve per round (every one hooks into another component or
+  // the outside), the record list never grows.  After a batch of rounds -- as many as the halving bound and the measured
+  // shrink (a factor 4 - 9 per round) make plausible -- ONE synchronisation reads every round's counts and the error flags;
+  // only a fill that is not finished by then (never seen) enqueues more.  A fill has two synchronisations: after the
+  // descent (the basin count sizes the tables) and here.  (r05: one per round, 10 per fill at S3 -- on a busy host each is a
+  // scheduling quantum, profiles/README.md r05u.)
+  constexpr int MAXR = 48;
+  uint32_t *rc = ws.buf<uint32_t>("fused.round_counts", 4 * (MAXR + 2));
+  RD_HIP(hipMemsetAsync(rc, 0, 4 * (MAXR + 2) * sizeof(uint32_t), s));
+  hw[220] = nroots0;   // (pinned; beyond the words the read-backs use)
+  RD_HIP(hipMemcpyAsync(rc + 4, hw + 220, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  pcap[1] = ecap;   // (the second list is sized for whatever the first pass may leave: its count stays on the device)
+  elist[1] = ws.buf<uint32_t>("fill.edges1", 3 * pcap[1]);
+  const uint32_t gcap = 2048;   // blocks of a grid-stride launch: 8 per CU
+  int rdone = 0;                // rounds enqueued so far
+  uint32_t rounds_run = 0;
+  auto enqueue_round = [&](int r) {   // r = 1, 2, ...
+    const uint32_t bound = std::max(1u, r - 1 < 31 ? nroots0 >> (r - 1) : 1u);   // live roots at most halve... at least
+    const uint32_t rgrid = std::min(gcap, cdiv(bound, NTHR));
+    const uint32_t *nr = rc + 4 * r, *ne = rc + 4 * r + 1;
+    uint32_t *nr_next = rc + 4 * (r + 1), *ne_next = rc + 4 * (r + 1) + 1;
+    RD_LAUNCH("fill.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, best, nr);
+    if (r == 1) {   // round 1: the one raster pass (components gathered from the node table)
       const uint32_t nwork = listed ? lists->n[1] : ntiles;
       if (nwork == 0) {
         // (no tile holds a wet cell although basins exist: cannot happen -- a pit is a wet cell; kept safe)
@@ -3151,55 +3189,65 @@ static bool fill_fused(T *d_z, int w, int h, hipStream_t s, const uint8_t *outle
         RD_LAUNCH("fill.scan", (k_scan<T, TOPO, false, false, true, true>), dim3(xcd_grid(nwork)), dim3(NTHR), 0, s, (const T *)d_z,
                   reinterpret_cast<const uint32_t *>(fo.lab16), (const uint32_t *)curN, best, w, h, B, tilesX, ntiles,
                   sl_, nwork, alive, eo, (const uint32_t *)fo.tile_base, dtx, skip);
-      RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, dflags + 4);
+      RD_LAUNCH("fill.sum_segments", k_sum_segments, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)eo.segcount, nseg, rc + 4 * 1 + 1);
       g_stats.scan_tiles += ntiles;
     } else {
       const int eout = ein ^ 1;
-      RD_HIP(hipMemsetAsync(dflags + 4, 0, sizeof(uint32_t), s));
       const uint32_t *ia = elist[ein], *ib = elist[ein] + pcap[ein], *ik = elist[ein] + 2 * pcap[ein];
       uint32_t *oa = elist[eout], *ob = elist[eout] + pcap[eout], *ok = elist[eout] + 2 * pcap[eout];
-      if (eseg)
-        RD_LAUNCH("fill.edge_round", (k_edge_round<true, false>), dim3(cdiv(ecap, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik,
-                  (uint32_t)ecap, (const uint32_t *)segcount, segcap, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
-      else if (nedges > 0 && dedup)
-        RD_LAUNCH("fill.edge_round", (k_edge_round<false, true>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik, nedges,
-                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
-      else if (nedges > 0)
-        RD_LAUNCH("fill.edge_round", (k_edge_round<false, false>), dim3(cdiv(nedges, NTHR * EPT)), dim3(NTHR), 0, s, ia, ib, ik, nedges,
-                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, dflags + 4);
+      if (eseg)   // round 2 reads the segmented list of the raster pass: the segments' fill counts are on the device
+        RD_LAUNCH("fill.edge_round", (k_edge_round<true, false>), dim3(std::min<uint32_t>(4 * gcap, cdiv(ecap, NTHR * EPT))), dim3(NTHR), 0,
+                  s, ia, ib, ik, (uint32_t)ecap, (const uint32_t *)segcount, segcap, (const uint32_t *)cur, best, B, oa, ob, ok, ne_next);
+      else if (dedup)
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, true>), dim3(gcap), dim3(NTHR), 0, s, ia, ib, ik, 0u,
+                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, ne_next, ne);
+      else
+        RD_LAUNCH("fill.edge_round", (k_edge_round<false, false>), dim3(gcap), dim3(NTHR), 0, s, ia, ib, ik, 0u,
+                  (const uint32_t *)nullptr, 0u, (const uint32_t *)cur, best, B, oa, ob, ok, ne_next, ne);
       eseg = false;
       ein = eout;
     }
-    RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
+    RD_LAUNCH("fill.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, best, link, nr);
     // One pass: a thread follows its chain of hooks for up to 16384 steps (the chains of a round are a handful of hooks
-    // long; the classic path's 32 steps per pass and a host read-back after every pass cost nine round trips per fill).
-    // "A chain was left unfinished" is read back with the round's counts below and sends the raster to the classic path,
-    // whose loop repeats the pass: nothing has been written to the DEM yet.
-    RD_HIP(hipMemsetAsync(dflags, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("fill.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 1 << 14, dflags);
-    RD_LAUNCH("fill.update_basins", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
-    RD_HIP(hipMemsetAsync(dflags + 2, 0, sizeof(uint32_t), s));
-    RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
-              dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags, 14 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    if (first && getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair pass: %u records, overflow %u, %u tiles on the slow road\n", hw[4], hw[5], hw[12]);
-    if (hw[0] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: hook chain unfinished\n"); return false; }
-    const uint32_t next = hw[2];
-    if (first && (precheck & 124)) break;   // RDGPU_FILL_PAIRS_ABLATE (timing probes): the pair pass ran, its output is not used
-    if (next >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
-    if (first && hw[5] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair list overflow (B %u cap %llu nseg %u segcap %u nwork %u)\n", B, (unsigned long long)cap, nseg, segcap, nwork1); return false; }   // the pair list overflowed: the DEM is untouched, the classic path takes over
-    nroots = next;
-    nedges = hw[4];
-    if (first) {
-      g_stats.edge_records = nedges;
-      pcap[1] = std::max<size_t>(nedges, 1);
-      elist[1] = ws.buf<uint32_t>("fill.edges1", 3 * pcap[1]);
-    }
-    first = false;
+    // long).  "A chain was left unfinished" stays in dflags[0] for the read-back after the batch and sends the raster to
+    // the classic path, whose loop repeats the pass: nothing has been written to the DEM yet.
+    RD_LAUNCH("fill.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, link, 1 << 14, dflags, nr);
+    RD_LAUNCH("fill.update_basins", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B, nr);
+    RD_LAUNCH("fill.compact_roots", k_compact_roots, dim3(std::min(gcap, cdiv(bound, NTHR * RPT))), dim3(NTHR), 0, s, rootsA, 0u, link,
+              rootsB, nr_next, nr);
     std::swap(rootsA, rootsB);
-    g_stats.rounds++;
+  };
+  // round 1 writes the records' total where round 2 expects it
+  // (k_sum_segments above: rc[4 * 1 + 1] is unused by round 1 itself; round 2 reads the segmented list and needs no count)
+  uint32_t *hrc = ws.host_words() + 16;   // (pinned: the counts of every round, read once per batch)
+  {
+    uint32_t lg = 0;
+    while ((1ull << lg) < (unsigned long long)nroots0 + 1ull) lg++;
+    int batch = (precheck & 124) ? 1 : std::min(MAXR, std::max(4, (int)(2 * lg + 4) / 5 + 1));   // ~log5.7(roots) + 1: S3 enqueues 11, runs 9
+    const char *env_batch = getenv("RDGPU_FILL_ROUND_BATCH");
+    if (env_batch) batch = std::min(MAXR, std::max(1, atoi(env_batch)));   // (tests: several batches)
+    uint32_t last_live = 0xFFFFFFFFu;
+    for (;;) {
+      for (int k = 0; k < batch && rdone < MAXR; k++) enqueue_round(++rdone);
+      RD_HIP(hipMemcpyAsync(hrc, rc, 4 * (MAXR + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipMemcpyAsync(hw, dflags, 14 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+      g_stats.host_syncs++;
+      if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair pass: %u records, overflow %u, %u tiles on the slow road; %d rounds enqueued\n", hrc[4 + 1], hw[5], hw[12], rdone);
+      if (hw[0] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: hook chain unfinished\n"); return false; }
+      if (precheck & 124) break;   // RDGPU_FILL_PAIRS_ABLATE (timing probes): the pair pass ran, its output is not used
+      if (hw[5] != 0) { if (getenv("RDGPU_FILL_DEBUG")) fprintf(stderr, "fill_fused: pair list overflow (B %u cap %llu nseg %u segcap %u nwork %u)\n", B, (unsigned long long)cap, nseg, segcap, nwork1); return false; }   // the pair list overflowed: the DEM is untouched, the classic path takes over
+      rounds_run = 0;
+      for (int r = 1; r <= rdone; r++) rounds_run += hrc[4 * r] != 0;
+      g_stats.edge_records = hrc[4 + 1];
+      const uint32_t live = hrc[4 * (rdone + 1)];
+      if (live == 0) break;
+      if (live >= last_live || rdone >= MAXR) throw Error(RDGPU_ERR_HIP, "rdgpu_fill: contraction made no progress (internal error)");
+      last_live = live;
+      if (!env_batch) batch = 4;
+    }
   }
+  g_stats.rounds += rounds_run;
   uint32_t *lvl = fo.G;   // (the node table is dead: its storage holds the nodes' levels)
   RD_LAUNCH("fill.node_levels", k_node_levels, ngrid, dim3(NTHR), 0, s, (const uint32_t *)curN, (const uint32_t *)acc,
             (const unsigned long long *)fo.counters, fo.rcap, lvl);

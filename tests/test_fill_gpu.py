@@ -376,6 +376,23 @@ def _with_env(rd, env, dem, topo=8):
                 os.environ[k] = v
 
 
+def test_rounds_without_host_round_trips(rd, orc):
+    """r06: the contraction rounds take their counts from the device and are enqueued in one batch -- a fill synchronises its
+    stream twice (after the descent, after the rounds), not once per round.  RDGPU_FILL_ROUND_BATCH=1 / 2 enqueue the rounds
+    one / two at a time (one synchronisation per batch): same surface, same number of rounds with work."""
+    for dem in (fractal_dem(1500, 1100, seed=31), np.floor(fractal_dem(1200, 900, seed=32) * 0.05).astype(np.int32)):
+        exp = orc.port.fill(dem, 8)
+        got, st = _with_env(rd, {}, dem, 8)
+        assert np.array_equal(got, exp)
+        assert st["host_syncs"] == 2 and st["rounds"] >= 3 and st["edge_records"] > 0, st
+        for batch in ("1", "2"):
+            got, sb = _with_env(rd, {"RDGPU_FILL_ROUND_BATCH": batch}, dem, 8)
+            assert np.array_equal(got, exp)
+            # (the record count varies by a few per run: pairs that find no slot in a tile's table are appended on their own)
+            assert sb["rounds"] == st["rounds"] and abs(sb["edge_records"] - st["edge_records"]) <= st["edge_records"] // 50, (st, sb)
+            assert sb["host_syncs"] >= 1 + -(-st["rounds"] // int(batch)), (st, sb)
+
+
 @pytest.mark.parametrize("topo", [8, 4])
 def test_pair_list_rounds_equal_raster_rounds(rd, orc, topo):
     """Rounds 2.. run on the component-pair list the first raster pass records; RDGPU_FILL_EDGES=0 keeps them on
