@@ -330,9 +330,33 @@ def host_path(rd, torch, Z, reps: int = 2) -> dict:
         t0 = time.perf_counter()
         rd.FillDepressions(a, in_place=True)
         best = min(best, time.perf_counter() - t0)
-    return {"entry": "rdgpu_fill_f32 (host pointer: H2D + fill + D2H into the same buffer, pageable numpy array)",
-            "ms": round(best * 1e3, 1), "Mcells_s": round(Z.numel() / 1e6 / best, 1),
-            "GB_over_pcie": round(2 * host.nbytes / 1e9, 2)}
+    out = {"entry": "rdgpu_fill_f32 (host pointer: H2D + fill + D2H into the same buffer, pageable numpy array)",
+           "ms": round(best * 1e3, 1), "Mcells_s": round(Z.numel() / 1e6 / best, 1),
+           "GB_over_pcie": round(2 * host.nbytes / 1e9, 2)}
+    # the link's ceiling, measured here with a PINNED 1 GiB buffer (what hipHostRegister of the caller's array would buy --
+    # at 120 - 200 ms per call for 6.4 GB, tools/probes/pcie_probe.hip / profiles/r06d_pcie_probe.txt, more than it saves)
+    try:
+        pin = torch.empty(1 << 28, dtype=torch.float32).pin_memory()
+        dev = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        rates = {}
+        for name, dst, src in (("h2d", dev, pin), ("d2h", pin, dev)):
+            bt = 1e30
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize()
+                bt = min(bt, time.perf_counter() - t0)
+            rates[name] = pin.numel() * 4 / bt / 1e9
+        copies = host.nbytes / 1e9 / rates["h2d"] + host.nbytes / 1e9 / rates["d2h"]
+        out["pcie_pinned_GBps"] = {k: round(v, 1) for k, v in rates.items()}
+        out["pcie_floor_ms"] = round(copies * 1e3, 1)     # both copies at the pinned rate, nothing else
+        out["note"] = ("ms - pcie_floor_ms = the fill plus what pageable staging costs; registering the caller's buffer for the "
+                       "call costs more than the pinned rate saves (profiles/r06d_pcie_probe.txt)")
+        del pin, dev
+    except Exception as e:   # (no pinned memory on this box: the plain figure stands)
+        out["pcie_pinned_GBps"] = f"not measured: {e}"
+    return out
 
 
 def main():
