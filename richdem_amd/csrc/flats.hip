@@ -205,9 +205,19 @@ __device__ __forceinline__ uint8_t find_flats_cell(const T *sz, int zx, int zy, 
 // FINDFLATS (r05, ResolveFlatsEpsilon's lean path): the "directions" are FindFlats' pseudo raster and are NOT written -- nothing
 // but this classification reads them there: k_find_flats + k_flat_classify (two passes over the DEM, the pseudo raster
 // written and read back) in one.
-template <class T, bool NEARDIRS = false, bool FINDFLATS = false>
+// BITMAPS (r06, the plane engine): instead of a flag byte per cell, the rows of three bitmaps per 64 x 64 search tile -- the
+// cells without a direction (M), those of them next to a low edge (the towards seeds), the high edges (the away seeds) --
+// and the edge counts: what k_bits_prepare would make of the flags, without writing and re-reading them (1 B -> 3 bits per
+// cell; the start kernels of the two searches read 1.5 KB per tile instead of 4 KB, without byte loads).
+struct ClassBitmaps {
+  unsigned long long *rows = nullptr;   // three bitmaps of nrows = search tiles x 64 row words each: M, near, high
+  uint32_t *counts = nullptr;           // 256 stripes of (low edges, high edges, NO_FLOW cells)
+  uint32_t nrows = 0, tilesXb = 0;
+};
+template <class T, bool NEARDIRS = false, bool FINDFLATS = false, bool BITMAPS = false>
 __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z, T nodata, uint8_t *__restrict__ dirs,
-                                                        uint8_t *__restrict__ flags, int w, int h, uint32_t tilesX, uint32_t ntiles) {
+                                                        uint8_t *__restrict__ flags, int w, int h, uint32_t tilesX, uint32_t ntiles,
+                                                        ClassBitmaps bm = ClassBitmaps{}) {
   __shared__ T sz[FZH * FZW];
   __shared__ uint8_t sdir[KLLH * SLW];
   const uint32_t t = xcd_tile(blockIdx.x, ntiles);
@@ -295,6 +305,8 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
   T z0[3], z1[3], z2[3];
   uint8_t d0[3], d1[3], d2[3];
   bool v0[3], v1[3], v2[3], n0[3], n1[3], n2[3];
+  uint32_t nlow = 0;   // (BITMAPS: low edges, per lane)
+  unsigned long long keepM = 0, keepN = 0, keepH = 0;
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     z0[e] = sz[(yb + 1) * FZW + lx + 1 + e]; z1[e] = sz[(yb + 2) * FZW + lx + 1 + e];
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       v2[e] = d2[e] != 255; n2[e] = d2[e] == 0;
     }
     uint8_t f = 0;
+    bool b_noflow = false, b_high = false, b_near = false, b_low = false;   // (BITMAPS: the flags as lane masks, never a byte)
     const uint8_t d = d1[1];
     if (d != 255) {
       const bool noflow = d == 0;
@@ -330,6 +343,7 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
       nb(z2[0], v2[0], n2[0]); nb(z2[1], v2[1], n2[1]); nb(z2[2], v2[2], n2[2]);
       if (noflow ? higher : eq_noflow) f |= noflow ? F_HIGH : F_LOW;
       if (noflow && eq_flow) f |= F_NEAR;
+      if (BITMAPS) { b_noflow = noflow; b_high = noflow & higher; b_near = noflow & eq_flow; b_low = !noflow & eq_noflow; }
       if (NEARDIRS && noflow && eq_flow) {
         // neighbours 1..8 in the 234/105/876 numbering; le: an equal-elevation cell with a direction (a low edge of this flat)
         auto lowedge = [&](T zn, bool valid, bool nf) -> bool { return valid && zn == e && !nf; };
@@ -346,9 +360,31 @@ __global__ __launch_bounds__(NTHR) void k_dirs_classify(const T *__restrict__ z,
         if (gx < w && gy < h) dirs[(size_t)gy * w + gx] = (uint8_t)nd;   // (a NO_FLOW cell is interior: its window is complete)
       }
     }
-    if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
+    if (BITMAPS) {   // (a cell outside the raster has d == 255: f == 0)
+      const unsigned long long mb = __ballot(b_noflow), nb_ = __ballot(b_near), hb = __ballot(b_high);
+      // (the low edges are in no bitmap: counted here, per lane in a vector register -- as a wave-uniform sum it costs the kernel's
+      // scalar registers, 37 spilled; the high edges and NO_FLOW cells are counted from the bitmaps by k_planes_prepare_b)
+      nlow += b_low ? 1u : 0u;
+      if (lx == j) { keepM = mb; keepN = nb_; keepH = hb; }   // lane j keeps row j of the wavefront's band: one store of eight words per bitmap below
+    } else if (gx < w && gy < h) flags[(size_t)gy * w + gx] = f;
 #pragma unroll
     for (int e = 0; e < 3; e++) { z0[e] = z1[e]; z1[e] = z2[e]; d0[e] = d1[e]; d1[e] = d2[e]; v0[e] = v1[e]; v1[e] = v2[e]; n0[e] = n1[e]; n1[e] = n2[e]; }
+  }
+  if (BITMAPS) {
+    static_assert(SW == 64 && KLH / 4 == 8, "a classification tile is one search tile wide, a wavefront's band eight rows");
+    if (lx < KLH / 4) {   // rows y0 + yb .. + 7: consecutive words of one search tile
+      const int gy = y0 + yb + lx;
+      unsigned long long *const row = bm.rows + ((size_t)(gy >> 6) * bm.tilesXb + (size_t)(x0 >> 6)) * 64 + (size_t)(gy & 63);
+      row[0] = keepM; row[bm.nrows] = keepN; row[2 * (size_t)bm.nrows] = keepH;
+    }
+    // the counts, striped: same-address atomics serialise
+    const unsigned long long lowlanes = __ballot(nlow != 0);
+    if (lowlanes) {   // (rare: one wavefront in a few has a low edge)
+      uint32_t lo = nlow;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) lo += __shfl_xor(lo, o, 64);
+      if (lx == 0) atomicAdd(bm.counts + 3 * ((t * 4 + (threadIdx.x >> 6)) & 255u), lo);
+    }
   }
 }
 
@@ -1087,7 +1123,7 @@ struct BitsScratch {
   uint32_t *tlist, *ctr, *counts;
   uint32_t tilesX, tilesY, ntiles;
   PlaneField pf;               // P != nullptr: the search runs on planes
-  unsigned long long *near = nullptr;   // (planes, towards field) the seeds' rows: the cells next to a low edge
+  unsigned long long *near = nullptr, *high = nullptr;   // (planes) the two fields' seed rows: the cells next to a low edge, the high edges
 };
 
 __device__ __forceinline__ uint32_t dpp_up(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
@@ -1587,6 +1623,16 @@ __device__ __forceinline__ uint32_t relax_visit(const unsigned long long *__rest
 }
 
 #include "flat_planes.inc"
+
+// the cells of a bitmap, into a stripe of the edge counts
+__global__ __launch_bounds__(NTHR) void k_rows_count(const unsigned long long *__restrict__ rows, uint32_t ntiles, uint32_t *counts, int slot) {
+  const uint32_t t = blockIdx.x * (NTHR / 64) + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  uint32_t c = (uint32_t)__popcll(rows[(size_t)t * BT + (threadIdx.x & 63)]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(counts + 3 * (t & 255u) + slot, c);
+}
 
 template <int SEED_LEVEL, bool STATS = false>
 __global__ __launch_bounds__(NTHR, 5) void k_relax_bits(const unsigned long long *__restrict__ mbits, uint8_t *expanded, int32_t *D,
@@ -2342,7 +2388,7 @@ static BitsScratch bits_scratch(int w, int h, bool second = false, bool planes =
   Workspace &ws = Workspace::get();
   BitsScratch b;
   b.tilesX = (w + BT - 1) / BT; b.tilesY = (h + BT - 1) / BT; b.ntiles = b.tilesX * b.tilesY;
-  b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT);
+  b.mbits = ws.buf<unsigned long long>("flats.mbits", (size_t)b.ntiles * BT * (planes ? 3 : 1));   // (planes: M | near | high)
   b.expanded = ws.buf<uint8_t>(second ? "flats.bexp2" : "flats.bexp", b.ntiles);
   b.tflags = ws.buf<uint8_t>(second ? "flats.btflags2" : "flats.btflags", b.ntiles);
   b.tlist = ws.buf<uint32_t>(second ? "flats.btlist2" : "flats.btlist", b.ntiles);
@@ -2355,7 +2401,8 @@ static BitsScratch bits_scratch(int w, int h, bool second = false, bool planes =
     b.pf.overflow = ws.buf<uint32_t>("flats.poverflow", 4) + (second ? 1 : 0);
     b.pf.expanded = b.expanded;
     if (const char *e = getenv("RDGPU_FLAT_PLANES_MAX")) b.pf.max_level = std::min(0xFFF0, std::max(8, atoi(e)));   // (tests: the overflow path)
-    if (!second) b.near = ws.buf<unsigned long long>("flats.pnear", (size_t)b.ntiles * BT);
+    b.near = b.mbits + (size_t)b.ntiles * BT;
+    b.high = b.mbits + 2 * (size_t)b.ntiles * BT;
   }
   return b;
 }
@@ -2538,8 +2585,16 @@ static uint32_t run_bits_towards(const uint8_t *flags, int32_t *D, bool write_m,
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
   uint32_t *cnt = counts3 ? b.counts : nullptr;
-  if (cnt) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
-  if (planes) {
+  if (cnt && flags) RD_HIP(hipMemsetAsync(cnt, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
+  if (planes && !flags) {   // the classification made the bitmaps (mbits, near) and the counts: k_dirs_classify<BITMAPS>
+    RD_HIP(hipMemsetAsync(b.pf.overflow, 0, 2 * sizeof(uint32_t), s));
+    // (it also counts the NO_FLOW cells and the high edges from their bitmaps: the away search may start later, the counts
+    // are read with this search's)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare_b<true>), dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s,
+              (const unsigned long long *)b.near, b.pf, b.tflags, h, b.tilesX, b.tilesY, (const unsigned long long *)b.mbits, cnt, 2);
+    if (cnt) RD_LAUNCH("flats.bits_counts_high", k_rows_count, dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s,
+                       (const unsigned long long *)b.high, b.ntiles, cnt, 1);
+  } else if (planes) {
     RD_HIP(hipMemsetAsync(b.pf.overflow, 0, 2 * sizeof(uint32_t), s));   // (both fields' words)
     RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits, b.near,
               b.tflags, cnt, w, h, b.tilesX, b.tilesY);
@@ -2565,7 +2620,11 @@ static uint32_t run_bits_away(const uint8_t *flags, const uint32_t *L, const int
   const BitsScratch b = bits_scratch(w, h, planes, planes);   // (planes: the field's own planes, beside the towards field's)
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
-  if (planes)
+  if (planes && !flags)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare_b<false>), dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s,
+              (const unsigned long long *)b.high, b.pf, b.tflags, h,
+              b.tilesX, b.tilesY);
+  else if (planes)
     RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits,
               (unsigned long long *)nullptr, b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
   else if (write_m)
@@ -2598,7 +2657,11 @@ static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, i
   const RowWin win{0, h, nullptr, nullptr};
   RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
   RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
-  if (planes)
+  if (planes && !flags)
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare_b<false>), dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s,
+              (const unsigned long long *)b.high, b.pf, b.tflags, h,
+              b.tilesX, b.tilesY);
+  else if (planes)
     RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<false, false>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits,
               (unsigned long long *)nullptr, b.tflags, (uint32_t *)nullptr, w, h, b.tilesX, b.tilesY);
   else
@@ -2822,12 +2885,30 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   Workspace &ws = Workspace::get();
   g_fstats = rdgpu_flat_stats{0, 0, 0, 0, 0};
   g_async_info = AsyncInfo{0, 0, 0, 0};
-  uint8_t *flags = ws.buf<uint8_t>("flats.flags", n);
   // r05: the last pass from 4 bits per cell, without the DEM (k_flat_dirs_q; the cells next to a low edge get their direction
   // in the classification); RDGPU_FLAT_Q=0: k_flat_dirs_levels over the level planes and the DEM (r02-r04): A/B and tests
   const char *envq = getenv("RDGPU_FLAT_Q");
   const bool qpass = fused_classify && !(envq && envq[0] == '0');
-  if (fused_classify) {
+  // r06: the level fields as bit planes per tile (flat_planes.inc); RDGPU_FLAT_PLANES=0, a level beyond 16 bits (an open flat
+  // wider than 65 000 cells), or any of the A/B switches above: one int per cell (r02-r05).  The plane engine takes its
+  // bitmaps and counts from the flag bytes, or straight from the classification (RDGPU_FLAT_CLASS_BITMAPS=1).
+  const char *envp = getenv("RDGPU_FLAT_PLANES"), *envb = getenv("RDGPU_FLAT_CLASS_BITMAPS");
+  const bool planes = qpass && use_bits_engine() && !(envp && envp[0] == '0') && !g_planes_overflowed && !getenv("RDGPU_FLAT_TRACE");
+  // (measured r06: the start kernels drop from 2.9 to 0.4 ms and 4.8 GB of flag traffic go away, but the classification itself
+  // goes from 4.9 to 6.6 ms with the ballots and row words in it -- 22.7 ms either way at S3; so the flags stay the default and
+  // RDGPU_FLAT_CLASS_BITMAPS=1 selects the bitmaps: profiles/r06f_flats_class_bitmaps_ab.json)
+  const bool class_bitmaps = planes && envb && envb[0] == '1';
+  uint8_t *flags = class_bitmaps ? nullptr : ws.buf<uint8_t>("flats.flags", n);
+  if (class_bitmaps) {
+    const BitsScratch bt = bits_scratch(w, h, false, true);
+    ClassBitmaps bm;
+    bm.rows = bt.mbits; bm.nrows = bt.ntiles * BT;
+    bm.counts = bt.counts; bm.tilesXb = bt.tilesX;
+    RD_HIP(hipMemsetAsync(bt.counts, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
+    const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * 2u * (uint32_t)((h + BT - 1) / BT);   // whole search tiles: their rows past the raster read as empty
+    RD_LAUNCH("flats.dirs_classify", (k_dirs_classify<T, true, false, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, nodata,
+              d_dirs, (uint8_t *)nullptr, w, h, tilesX, ntiles, bm);
+  } else if (fused_classify) {
     const uint32_t tilesX = (w + SW - 1) / SW, ntiles = tilesX * ((h + KLH - 1) / KLH);
     if (qpass)
       RD_LAUNCH("flats.dirs_classify", (k_dirs_classify<T, true>), dim3(xcd_grid(ntiles)), dim3(NTHR), 0, s, d_z, nodata, d_dirs, flags,
@@ -2838,10 +2919,6 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
   } else {
     launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   }
-  // r06: the level fields as bit planes per tile (flat_planes.inc); RDGPU_FLAT_PLANES=0, a level beyond 16 bits (an open flat
-  // wider than 65 000 cells), or any of the A/B switches above: one int per cell (r02-r05)
-  const char *envp = getenv("RDGPU_FLAT_PLANES");
-  const bool planes = qpass && use_bits_engine() && !(envp && envp[0] == '0') && !g_planes_overflowed && !getenv("RDGPU_FLAT_TRACE");
   int32_t *TWd = planes ? nullptr : ws.buf<int32_t>("flats.mask", n), *A = nullptr;
   if (use_bits_engine()) {
     // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
