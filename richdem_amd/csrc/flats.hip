@@ -2649,6 +2649,45 @@ static bool away_beside() {
   const char *env = getenv("RDGPU_FLAT_AWAY_BESIDE");
   return !(env && env[0] == '0') && async_threshold() > 0 && getenv("RDGPU_FLAT_TRACE") == nullptr;
 }
+// r06 (plane engine): the TOWARDS search as one enqueue as well -- start levels (with the edge counts), TOWARDS_STATIC_ROUNDS
+// rounds over grids that follow the front's usual shrink (S3: 0.82, 0.44, 0.13, 0.05, 0.03, 0.02 of the tiles), the
+// asynchronous tail -- so that a directions-only flat resolution reads nothing back until everything is enqueued: one
+// synchronisation per call instead of one per batch of rounds, per tail and per check (on a busy host each is a scheduling
+// quantum: profiles/README.md r05u).
+constexpr int TOWARDS_STATIC_ROUNDS = 6;
+static StaticAway enqueue_towards_static(const uint8_t *flags, unsigned long long *d_counts3, int w, int h, hipStream_t s,
+                                         const Beside *beside) {
+  static_assert(TOWARDS_STATIC_ROUNDS < BITS_BATCH - 1, "the tail's own counter word is the last one");
+  StaticAway st;
+  st.b = bits_scratch(w, h, false, true);
+  const BitsScratch &b = st.b;
+  const RowWin win{0, h, nullptr, nullptr};
+  RD_HIP(hipMemsetAsync(b.tflags, 0, b.ntiles, s));
+  RD_HIP(hipMemsetAsync(b.expanded, 0, b.ntiles, s));
+  RD_HIP(hipMemsetAsync(b.pf.overflow, 0, 2 * sizeof(uint32_t), s));   // (both fields' words)
+  if (!flags) {   // the classification made the bitmaps and counted the low edges
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare_b<true>), dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s,
+              (const unsigned long long *)b.near, b.pf, b.tflags, h, b.tilesX, b.tilesY, (const unsigned long long *)b.mbits, b.counts, 2);
+    RD_LAUNCH("flats.bits_counts_high", k_rows_count, dim3((b.ntiles + 3) / 4), dim3(NTHR), 0, s, (const unsigned long long *)b.high,
+              b.ntiles, b.counts, 1);
+  } else {
+    RD_HIP(hipMemsetAsync(b.counts, 0, (3 * 256 + 8) * sizeof(uint32_t), s));
+    RD_LAUNCH("flats.bits_prepare", (k_planes_prepare<true, true>), dim3(b.ntiles), dim3(NTHR), 0, s, flags, b.pf, b.mbits, b.near,
+              b.tflags, b.counts, w, h, b.tilesX, b.tilesY);
+  }
+  RD_LAUNCH("flats.bits_counts", k_bits_counts, dim3(1), dim3(NTHR), 0, s, (const uint32_t *)b.counts, d_counts3);
+  RD_HIP(hipMemsetAsync(b.ctr, 0, BITS_BATCH * sizeof(uint32_t), s));
+  for (int k = 0; k < TOWARDS_STATIC_ROUNDS; k++) {
+    RD_LAUNCH("flats.tiles_compact", k_tiles_compact, dim3((b.ntiles + NTHR - 1) / NTHR), dim3(NTHR), 0, s, b.tflags, b.ntiles, b.tlist,
+              b.ctr + k);
+    const uint32_t full = (b.ntiles + 3) / 4, grid = k < 2 ? full : std::max<uint32_t>(256u, full >> (k - 1));
+    RD_LAUNCH("flats.relax_towards", (k_relax_planes<2>), dim3(grid), dim3(NTHR), 0, s, (const unsigned long long *)b.mbits, b.expanded,
+              b.pf, (const uint32_t *)b.tlist, (const uint32_t *)(b.ctr + k), b.tflags, w, h, b.tilesX, b.tilesY);
+  }
+  st.run = async_enqueue<2>(b, nullptr, w, h, "flats.relax_towards", s, win, false, beside);   // (mark() before the tail's launch, go() after)
+  return st;
+}
+
 static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, int h, hipStream_t s, bool planes = false) {
   static_assert(AWAY_STATIC_ROUNDS < BITS_BATCH - 1, "the tail's own counter word is the last one");
   StaticAway sa;
@@ -2685,15 +2724,32 @@ static StaticAway enqueue_away_static(const uint8_t *flags, int32_t *A, int w, i
   return sa;
 }
 // on a stream that has waited for the side stream: the end state of the tail, and the number of rounds that had work
-static uint32_t finish_away_static(const StaticAway &sa, int32_t *A, int w, int h, hipStream_t s) {
+// (the towards field of the static plane search: the same end-of-search check; *recovered: the tail had given up)
+static uint32_t finish_towards_static(const StaticAway &st, int w, int h, hipStream_t s, bool *recovered) {
+  uint32_t counts[TOWARDS_STATIC_ROUNDS];
+  RD_HIP(hipMemcpyAsync(counts, st.b.ctr, sizeof counts, hipMemcpyDeviceToHost, s));
+  const bool ok = async_check(st.run, "flats.relax_towards", s);   // (synchronises s)
+  uint32_t rounds = 1;
+  for (int k = 0; k < TOWARDS_STATIC_ROUNDS; k++) rounds += counts[k] != 0;
+  *recovered = false;
+  if (!ok || getenv("RDGPU_FLAT_ASYNC_FAIL")) {
+    RD_HIP(hipMemsetAsync(st.b.tflags, 1, st.b.ntiles, s));
+    rounds += relax_rounds_bits<2>(st.b, nullptr, w, h, "flats.relax_towards", s, RowWin{0, -1, nullptr, nullptr}, nullptr, false);
+    *recovered = true;
+  }
+  return rounds;
+}
+static uint32_t finish_away_static(const StaticAway &sa, int32_t *A, int w, int h, hipStream_t s, bool *recovered = nullptr) {
   uint32_t counts[AWAY_STATIC_ROUNDS];
   RD_HIP(hipMemcpyAsync(counts, sa.b.ctr, sizeof counts, hipMemcpyDeviceToHost, s));
   const bool ok = async_check(sa.run, "flats.relax_away", s);   // (synchronises s)
   uint32_t rounds = 1;
   for (int k = 0; k < AWAY_STATIC_ROUNDS; k++) rounds += counts[k] != 0;
+  if (recovered) *recovered = false;
   if (!ok || getenv("RDGPU_FLAT_ASYNC_FAIL")) {   // the tail gave up: rounds to the end, from every tile, on this stream
     RD_HIP(hipMemsetAsync(sa.b.tflags, 1, sa.b.ntiles, s));
     rounds += relax_rounds_bits<1>(sa.b, A, w, h, "flats.relax_away", s, RowWin{0, -1, nullptr, nullptr}, nullptr, false);
+    if (recovered) *recovered = true;
   }
   return rounds;
 }
@@ -2920,6 +2976,52 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
     launch_classify<T>(d_z, d_dirs, w, h, flags, s);
   }
   int32_t *TWd = planes ? nullptr : ws.buf<int32_t>("flats.mask", n), *A = nullptr;
+  const char *envs = getenv("RDGPU_FLAT_STATIC");   // =0: the towards search in batches of rounds decided on the host (r02-r05): A/B and tests
+  if (planes && away_beside() && !(envs && envs[0] == '0')) {
+    // Everything enqueued, nothing read back: towards search (start, rounds, tail), the away search beside its tail on a side
+    // stream, the last pass -- which looks at the overflow and abort words itself and leaves `dirs` alone when one is set.
+    // Then ONE synchronisation: the tails' end states, the overflow words, the counts.
+    Workspace::SideLane &lane = ws.side_lane(1);
+    unsigned long long *d_c3 = reinterpret_cast<unsigned long long *>(ws.buf<uint32_t>("flats.c3", 8));
+    StaticAway sa;
+    Beside bs;
+    bs.mark = [&]() { RD_HIP(hipEventRecord(lane.fork, s)); };   // (the rounds are done, the bitmaps made: before the tail's launch)
+    bs.go = [&]() {                                              // (the resident wavefronts have their places: the away search beside them)
+      RD_HIP(hipStreamWaitEvent(lane.stream, lane.fork, 0));
+      sa = enqueue_away_static(flags, nullptr, w, h, lane.stream, true);
+      RD_HIP(hipEventRecord(lane.join, lane.stream));
+    };
+    const StaticAway st = enqueue_towards_static(flags, d_c3, w, h, s, &bs);
+    RD_HIP(hipStreamWaitEvent(s, lane.join, 0));
+    const uint32_t *abT = st.run.Q.ctl + AQ_G_ABORT, *abA = sa.run.Q.ctl + AQ_G_ABORT;
+    RD_LAUNCH("flats.dirs_q", k_flat_dirs_qp, dim3(xcd_grid((st.b.ntiles + 3) / 4)), dim3(NTHR), 0, s, st.b.pf, sa.b.pf,
+              (const unsigned long long *)st.b.near, 1, d_dirs, w, h, st.b.tilesX, st.b.tilesY, (const uint32_t *)st.b.pf.overflow, abT, abA);
+    unsigned long long c3[3] = {0, 0, 0};
+    uint32_t over[2] = {0, 0};
+    RD_HIP(hipMemcpyAsync(c3, d_c3, sizeof c3, hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(over, st.b.pf.overflow, sizeof over, hipMemcpyDeviceToHost, s));
+    bool recT = false, recA = false;
+    g_fstats.towards_levels = finish_towards_static(st, w, h, s, &recT);   // (the synchronisation)
+    g_fstats.away_levels = finish_away_static(sa, nullptr, w, h, s, &recA);
+    g_fstats.low_edges = c3[0];
+    g_fstats.high_edges = c3[1];
+    g_fstats.noflow_cells = c3[2];
+    if (recT || recA) {   // a tail had given up and was finished in rounds (or the test switch says so): the last pass once more
+      RD_HIP(hipMemcpyAsync(over, st.b.pf.overflow, sizeof over, hipMemcpyDeviceToHost, s));
+      RD_HIP(hipStreamSynchronize(s));
+    }
+    if (over[0] | over[1]) {   // a level beyond 16 bits: once more, on ints (the last pass left dirs as the classification wrote it)
+      g_planes_overflowed = true;
+      struct Reset { ~Reset() { g_planes_overflowed = false; } } reset;
+      flat_resolution_device<T>(d_z, nodata, w, h, d_dirs, s);
+      return;
+    }
+    if (recT || recA)
+      RD_LAUNCH("flats.dirs_q", k_flat_dirs_qp, dim3(xcd_grid((st.b.ntiles + 3) / 4)), dim3(NTHR), 0, s, st.b.pf, sa.b.pf,
+                (const unsigned long long *)st.b.near, 1, d_dirs, w, h, st.b.tilesX, st.b.tilesY, (const uint32_t *)nullptr,
+                (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    return;
+  }
   if (use_bits_engine()) {
     // no edge lists at all: the seeds are bitmaps made from the flags, the counts come with them
     unsigned long long c3[3] = {0, 0, 0};
@@ -2965,7 +3067,8 @@ void flat_resolution_device(const T *d_z, T nodata, int w, int h, uint8_t *d_dir
         return;
       }
       RD_LAUNCH("flats.dirs_q", k_flat_dirs_qp, dim3(xcd_grid((bt.ntiles + 3) / 4)), dim3(NTHR), 0, s, bt.pf, ba.pf,
-                (const unsigned long long *)bt.near, have_away ? 1 : 0, d_dirs, w, h, bt.tilesX, bt.tilesY);
+                (const unsigned long long *)bt.near, have_away ? 1 : 0, d_dirs, w, h, bt.tilesX, bt.tilesY, (const uint32_t *)nullptr,
+                (const uint32_t *)nullptr, (const uint32_t *)nullptr);
       return;
     }
   } else {

@@ -144,7 +144,7 @@ def test_stencil_relaxation_engine_still_agrees(rd, orc, monkeypatch):
 
 @pytest.mark.parametrize("switch", ["RDGPU_FLAT_ASYNC=0", "RDGPU_FLAT_ASYNC=100000", "RDGPU_FLAT_AWAY_BESIDE=0", "RDGPU_FLAT_ASYNC_BLOCKS=3",
                                     "RDGPU_RFE_LEAN=0", "RDGPU_RFE_OVERLAP=0", "RDGPU_RFE_AWAY_BESIDE=1", "RDGPU_FLAT_ASYNC_FAIL=1",
-                                    "RDGPU_FLAT_Q=0", "RDGPU_FLAT_PLANES=0", "RDGPU_FLAT_PLANES_MAX=40", "RDGPU_FLAT_CLASS_BITMAPS=1"])
+                                    "RDGPU_FLAT_Q=0", "RDGPU_FLAT_PLANES=0", "RDGPU_FLAT_PLANES_MAX=40", "RDGPU_FLAT_CLASS_BITMAPS=1", "RDGPU_FLAT_STATIC=0"])
 def test_search_schedules_give_the_same_levels(rd, orc, monkeypatch, switch):
     """The bitmap search in rounds to the end, with its asynchronous tail from the first batch on (k_relax_bits_async),
     with the away search after instead of beside the towards tail, on three resident blocks; ResolveFlatsEpsilon with the
