@@ -2504,7 +2504,7 @@ static bool async_check(const AsyncRun &r, const char *name, hipStream_t s) {
   g_async_info.visits += all[AQ_G_VISITS];
   g_async_info.live_tiles += live;
   g_async_info.launches++;
-  if (getenv("RDGPU_FLAT_TRACE"))
+  if (getenv("RDGPU_FLAT_TRACE") || getenv("RDGPU_FLAT_ASYNC_STATS"))
     fprintf(stderr, "%s asynchronous tail: %u visits, %llu pushes, %u wavefronts on %d CUs, ticks (%d kHz): in visits %llu, longest wavefront %u\n",
             name, all[AQ_G_VISITS], (unsigned long long)pushes, r.blocks * 4u, r.cus, r.rate_khz,
             (unsigned long long)all[AQ_G_BUSY] | ((unsigned long long)all[AQ_G_BUSY + 1] << 32), all[AQ_G_SPAN]);
