@@ -207,7 +207,12 @@ def run_stages(rd, torch, W, nodata: float, reps: int = 2, Z=None, pf_flowdirs: 
     fs = rd.flat_stats()
     out["directions_plus_flat_resolution"].update({"noflow_cells": fs["noflow"], "rounds_towards": fs["towards"],
                                                    "rounds_away": fs["away"], "tail_visits": fs["tail_visits"],
-                                                   "tail_live_tiles": fs["tail_live_tiles"]})
+                                                   "tail_live_tiles": fs["tail_live_tiles"],
+                                                   "engine": "level fields as bit planes per 64 x 64 tile (csrc/flat_planes.inc)",
+                                                   "note": "tail_live_tiles = the active lists' lengths when the rounds hand over to the "
+                                                           "resident wavefronts, NOT the tiles the tails visit: the fronts move on through "
+                                                           "~3e5 tiles -- 2.3 working visits per tile and search over the whole call, 15 % of "
+                                                           "them ahead of their order (profiles/r06a_flat_visit_hist.json)"})
     area = torch.empty(W.shape, dtype=torch.float64, device="cuda")
     rd.d8_flow_accum_dev(dirs, area)
     out["d8_flow_accum"] = stage_entry(_best(lambda: rd.d8_flow_accum_dev(dirs, area), reps, sync), n_cells, 9)
@@ -486,6 +491,7 @@ def main():
             "boruvka_rounds": stats["rounds"],
             "pair_records": stats["edge_records"],
             "jump_passes": stats["jump_passes"],
+            "host_syncs_per_fill": stats.get("host_syncs"),
             "cells_raised_frac": round(changed, 4),
             "parallelism": "1 GPU",
         },

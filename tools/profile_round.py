@@ -51,7 +51,7 @@ def kernel_shas():
     """sha1 (first 12 hex digits) of every kernel source: the evidence names the engine state it was taken on"""
     import hashlib
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "richdem_amd", "csrc", "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "richdem_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "richdem_amd", "csrc", "*.inc"))):
         with open(f, "rb") as fh:
             out.append(os.path.basename(f) + ":" + hashlib.sha1(fh.read()).hexdigest()[:12])
     return " ".join(out)
