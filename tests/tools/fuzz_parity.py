@@ -114,6 +114,9 @@ def main():
             if np.issubdtype(dt, np.floating) and np.unique(dem).size == dem.size:   # (the epsilon fill: defined by the DEM only without ties)
                 chk(f"fill_epsilon{topo}", rd.FillDepressions(dem, epsilon=True, topology="D8" if topo == 8 else "D4", nodata=nd).tobytes()
                     == P.fill_epsilon(dem, nd, topo).tobytes())
+            # r06: the sweep's other names -- HasDepressions, Wei2018 with its NoData-as-outlet seeds
+            chk(f"has_depressions{topo}", rd.has_depressions(dem, "D8" if topo == 8 else "D4") == P.has_depressions(dem, topo))
+            chk("wei2018", rd.fill_wei2018(dem, nd).tobytes() == P.fill_wei2018(dem, nd).tobytes())
             if dt in (np.uint32,):
                 continue
             src = filled if rng.random() < 0.7 else dem
