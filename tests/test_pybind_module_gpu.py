@@ -37,6 +37,26 @@ def test_fill_in_place_every_type(R, orc):
             assert np.array_equal(a, orc.port.fill(dem, topo)), (dt, topo)   # the numpy array itself was filled
 
 
+def test_the_sweeps_other_names(R, orc):
+    """r06: PriorityFlood_Original<D8/D4>, PriorityFlood_Wei2018 (NoData holes drain) and HasDepressions<D8/D4> through the
+    module (the reference binds only the default fill; these are extras under `rd...` names)."""
+    dem = fractal_dem(260, 190, seed=8).copy()
+    for fn, topo in ((R.rdPriorityFloodOriginalD8, 8), (R.rdPriorityFloodOriginalD4, 4)):
+        a = dem.copy()
+        fn(wrap(R, a, -9999))
+        assert np.array_equal(a, orc.port.fill(dem, topo))
+    holes = dem.copy()
+    holes[70:80, 100:140] = -9999
+    a = holes.copy()
+    R.rdPriorityFloodWei2018(wrap(R, a, -9999))
+    assert np.array_equal(a, orc.port.fill_wei2018(holes, np.float32(-9999)))
+    assert not np.array_equal(a, orc.port.fill(holes, 8))
+    assert R.rdHasDepressionsD8(wrap(R, dem.copy(), -9999)) is True
+    assert R.rdHasDepressionsD4(wrap(R, orc.port.fill(dem, 4), -9999)) is False
+    i16 = np.floor((dem - dem.min()) * 0.1).astype(np.int16)
+    assert R.rdHasDepressionsD8(wrap(R, i16, -9999)) == orc.port.has_depressions(i16, 8)
+
+
 def test_accumulation_families(R, orc):
     raw = fractal_dem(240, 180, 77)
     nd = np.float32(-9999)
