@@ -277,7 +277,9 @@ RDGPU_DECL_WS(u64, uint64_t)
  *                              then rounds on the component-pair list it records)
  *   RDGPU_FILL_EDGE_CAP=<n>    capacity of that list in records (default min(12 per basin, cells/2)); a list
  *                              that does not fit falls back to raster passes
- *   RDGPU_FILL_DEDUP=0         do not merge the list's records per component pair between rounds */
+ *   RDGPU_FILL_DEDUP=0         do not merge the list's records per component pair between rounds
+ *   RDGPU_FILL_ROUND_BATCH=<n> contraction rounds enqueued per stream synchronisation (default: all of them at once --
+ *                              a fill synchronises twice, rdgpu_fill_stats::host_syncs) */
 /* Statistics of the last fill on this process (for DESIGN.md / bench.py reporting). */
 typedef struct rdgpu_fill_stats {
   uint64_t cells;       /* width*height                                   */
@@ -449,6 +451,16 @@ RDGPU_DECL_ALTER(i64, int64_t)
 RDGPU_DECL_ALTER(u64, uint64_t)
 #undef RDGPU_DECL_ALTER
 
+/* Environment switches of the directions-only flat resolution (read at every call; A/B timing and tests, results never change):
+ *   RDGPU_FLAT_PLANES=0         the two level fields as one int per cell instead of 16 bit planes per 64 x 64 tile (the plane
+ *                               engine also steps aside by itself when a level does not fit 16 bits: an open flat more than
+ *                               65 000 cells across; flat_mask / labels, alter = true, ResolveFlatsEpsilon and the row-block
+ *                               shards always use ints)
+ *   RDGPU_FLAT_STATIC=0         the towards search in batches of rounds decided on the host instead of one enqueue
+ *   RDGPU_FLAT_CLASS_BITMAPS=1  the classification writes the searches' bitmaps itself (no flag bytes)
+ *   RDGPU_FLAT_ASYNC=<n>        a search's rounds hand over to resident wavefronts once a round visits fewer than n tiles
+ *                               (default 20000; 0: rounds to the end), RDGPU_FLAT_ASYNC_BLOCKS / _NAP / _STATS tune and report them
+ *   RDGPU_FLAT_AWAY_BESIDE=0    the away search after the towards search instead of beside its tail */
 typedef struct rdgpu_flat_stats {
   uint64_t low_edges;      /* find_flat_edges: cells with flow next to an equal NO_FLOW cell */
   uint64_t high_edges;     /* NO_FLOW cells next to higher terrain                           */
