@@ -3619,28 +3619,46 @@ static void graph_solve_device(int S, int w, int topo, const uint32_t *d_keys_al
   RD_HIP(hipMemcpyAsync(hw, dflags + 2, 8, hipMemcpyDeviceToHost, s));
   RD_HIP(hipStreamSynchronize(s));
   if (hw[1] != 0) throw Error(RDGPU_ERR_CAPACITY, "rdgpu_fill_graph_solve_dev: a shard holds more edges than the gathered payload has room for");
-  uint32_t nroots = hw[0];
-  while (nroots > 0) {
-    const uint32_t rgrid = cdiv(nroots, NTHR);
-    RD_LAUNCH("graph.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best);
-    RD_LAUNCH("graph.scan", k_graph_scan, dim3(egrid), dim3(NTHR), 0, s, g, nslots, (const uint32_t *)cur, best);
-    RD_LAUNCH("graph.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, best, link);
-    for (;;) {
-      RD_HIP(hipMemsetAsync(dflags, 0, 4, s));
-      RD_LAUNCH("graph.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, nroots, link, 32, dflags);
-      RD_HIP(hipMemcpyAsync(hw, dflags, 4, hipMemcpyDeviceToHost, s));
-      RD_HIP(hipStreamSynchronize(s));
-      if (hw[0] == 0) break;
+  const uint32_t nroots0 = hw[0];
+  // r06: the rounds as in fill_fused -- counts on the device (rc[4 r] = live roots entering round r), grid-stride round kernels,
+  // a batch of rounds per synchronisation (r05: two to three synchronisations PER ROUND; every rank of a sharded fill runs this
+  // solve, so its host round trips are on every rank's critical path)
+  constexpr int MAXR = 40;
+  uint32_t *rc = ws.buf<uint32_t>("graph.round_counts", 4 * (MAXR + 2));
+  RD_HIP(hipMemsetAsync(rc, 0, 4 * (MAXR + 2) * sizeof(uint32_t), s));
+  hw[220] = nroots0;
+  RD_HIP(hipMemcpyAsync(rc + 4, hw + 220, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  uint32_t *hrc = hw + 16;
+  int rdone = 0;
+  uint32_t lg = 0;
+  while ((1ull << lg) < (unsigned long long)nroots0 + 1ull) lg++;
+  int batch = std::min(MAXR, std::max(4, (int)(2 * lg + 4) / 5 + 2));
+  uint32_t last_live = 0xFFFFFFFFu;
+  while (nroots0 > 0) {
+    for (int k = 0; k < batch && rdone < MAXR; k++) {
+      const int r = ++rdone;
+      const uint32_t bound = std::max(1u, r - 1 < 31 ? nroots0 >> (r - 1) : 1u);
+      const uint32_t rgrid = std::min(2048u, cdiv(bound, NTHR));
+      const uint32_t *nr = rc + 4 * r;
+      RD_LAUNCH("graph.best_reset", k_best_reset, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, best, nr);
+      RD_LAUNCH("graph.scan", k_graph_scan, dim3(egrid), dim3(NTHR), 0, s, g, nslots, (const uint32_t *)cur, best);
+      RD_LAUNCH("graph.hook", k_hook, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, best, link, nr);
+      RD_LAUNCH("graph.chase_links", k_chase_links, dim3(rgrid), dim3(NTHR), 0, s, rootsA, 0u, link, 1 << 14, dflags, nr);
+      RD_LAUNCH("graph.update", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B, nr);
+      RD_LAUNCH("graph.compact_roots", k_compact_roots, dim3(std::min(2048u, cdiv(bound, NTHR * RPT))), dim3(NTHR), 0, s, rootsA, 0u, link,
+                rootsB, rc + 4 * (r + 1), nr);
+      std::swap(rootsA, rootsB);
     }
-    RD_LAUNCH("graph.update", k_update_basins, dim3(cdiv(B, NTHR)), dim3(NTHR), 0, s, cur, acc, link, B);
-    RD_HIP(hipMemsetAsync(dflags + 2, 0, 4, s));
-    RD_LAUNCH("graph.compact_roots", k_compact_roots, dim3(cdiv(nroots, NTHR * RPT)), dim3(NTHR), 0, s, rootsA, nroots, link, rootsB,
-              dflags + 2);
-    RD_HIP(hipMemcpyAsync(hw, dflags + 2, 4, hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hrc, rc, 4 * (MAXR + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipMemcpyAsync(hw, dflags, 4, hipMemcpyDeviceToHost, s));
     RD_HIP(hipStreamSynchronize(s));
-    if (hw[0] >= nroots) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve_dev: a cut-row terminal is not connected to the outside");
-    nroots = hw[0];
-    std::swap(rootsA, rootsB);
+    if (hw[0] != 0) throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve_dev: a chain of hooks longer than 16384 (internal error)");
+    const uint32_t live = hrc[4 * (rdone + 1)];
+    if (live == 0) break;
+    if (live >= last_live || rdone >= MAXR)
+      throw Error(RDGPU_ERR_HIP, "rdgpu_fill_graph_solve_dev: a cut-row terminal is not connected to the outside");
+    last_live = live;
+    batch = 4;
   }
   RD_LAUNCH("graph.levels", k_graph_levels, dim3(cdiv(NOUT, NTHR)), dim3(NTHR), 0, s, (const uint32_t *)cur,
             (const uint32_t *)acc, (const uint32_t *)closed, d_levels_all, NOUT);
