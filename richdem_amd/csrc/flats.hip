@@ -1728,8 +1728,11 @@ __device__ __forceinline__ bool aq_terminated(const AsyncQ &Q, int lane) {
   return e == d;
 }
 
+// (r06, the plane visits: 168 registers -- the resident wavefronts share their SIMDs' register files with the other search's
+// rounds, which is how the two searches slow each other down: at 128 registers the tail spills and loses 2 ms while the away
+// rounds gain 2.4, at 187 the reverse; 22.6 / 23.7 / 22.8 ms for the stage at 168 / 128 / 187)
 template <int SEED_LEVEL, bool PL = false>
-__global__ __launch_bounds__(NTHR, PL ? 2 : 4) void k_relax_bits_async(const unsigned long long *__restrict__ mbits, int32_t *D, AsyncQ Q, int w,
+__global__ __launch_bounds__(NTHR, PL ? 3 : 4) void k_relax_bits_async(const unsigned long long *__restrict__ mbits, int32_t *D, AsyncQ Q, int w,
                                                            int h, RowWin win, uint32_t tilesX, uint32_t tilesY,
                                                            unsigned long long tick_budget, int nap, PlaneField pf = PlaneField{}) {
   static_assert(AQ_NQ == 64, "one lane per queue in the termination test");
